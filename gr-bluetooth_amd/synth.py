@@ -1,0 +1,195 @@
+"""Synthetic wideband Bluetooth captures (SURVEY.md section 8(d) "Synthetic inputs").
+
+The reference's IQ captures (samples/headset*.cfile) are not in the checkout
+(/root/reference/.MISSING_LARGE_BLOBS), so tests and bench.py drive the hot path
+with captures generated here: AWGN floor + N piconets hopping pseudo-randomly
+over the visible channels, each transmitting GFSK bursts (1 Msym/s, BT 0.5,
+modulation index 0.32) that start with a valid 72-bit access code for the
+piconet's LAP.  The generator is independent of both the oracle and the HIP
+path: the access code comes from its own BCH(64,30) encoder below.
+
+numpy version: tests (small captures).  torch version: bench.py (built on the
+GPU so that a 1e8-sample capture does not cost minutes of host time).
+"""
+import math
+
+import numpy as np
+
+SYMBOL_RATE = 1e6
+BASE_FREQUENCY = 2402e6
+_PN = 0x83848D96BBCC54FC
+_GEN = 0o260534236651          # BCH(64,30) generator, degree 34
+
+
+def sync_word(lap):
+    """64-bit Bluetooth sync word, bit i = i-th transmitted bit."""
+    lap &= 0xFFFFFF
+    barker = 0b110010 if (lap >> 23) & 1 else 0b001101   # a24..a29, a24 = MSB of this literal
+    # information polynomial: LAP bits a0..a23 then Barker bits, placed at bit 34..63
+    info = lap
+    for i in range(6):
+        info |= ((barker >> (5 - i)) & 1) << (24 + i)
+    x = (info ^ (_PN >> 34)) & ((1 << 30) - 1)
+    # parity = x(D) * D^34 mod g(D)
+    rem = x << 34
+    for bit in range(63, 33, -1):
+        if (rem >> bit) & 1:
+            rem ^= _GEN << (bit - 34)
+    cw = (x << 34) | (rem & ((1 << 34) - 1))
+    return cw ^ _PN
+
+
+def access_code_bits(lap):
+    """72 air-order bits: 4 preamble, 64 sync word, 4 trailer."""
+    sw = sync_word(lap)
+    sync = [(sw >> i) & 1 for i in range(64)]
+    pre = [1, 0, 1, 0] if sync[0] else [0, 1, 0, 1]
+    tr = [0, 1, 0, 1] if sync[63] else [1, 0, 1, 0]
+    return np.array(pre + sync + tr, dtype=np.uint8)
+
+
+def visible_channels(sample_rate, center_freq):
+    """Channel range rule of multi_block::set_channels (lib/multi_block.cc:306-324)."""
+    center = (center_freq - BASE_FREQUENCY) / 1e6
+    bw = sample_rate / 1e6
+    lo = int(center - bw / 2 + 0.45 + 1)
+    hi = int(center + bw / 2 - 0.45)
+    return max(lo, 0), min(hi, 78)
+
+
+def gaussian_pulse(sps, bt=0.5, span=3):
+    """Gaussian frequency pulse, unit area, `span` symbols long."""
+    n = int(span * sps) | 1
+    t = (np.arange(n) - (n - 1) / 2) / sps
+    sigma = math.sqrt(math.log(2)) / (2 * math.pi * bt)
+    g = np.exp(-t * t / (2 * sigma * sigma))
+    return g / g.sum()
+
+
+def gfsk_baseband(bits, sps, h=0.32, bt=0.5):
+    """Complex baseband GFSK at `sps` samples per symbol (unit amplitude)."""
+    nrz = np.repeat(2.0 * np.asarray(bits, dtype=np.float64) - 1.0, sps)
+    f = np.convolve(nrz, gaussian_pulse(sps, bt), mode="same")
+    phase = np.pi * h * np.cumsum(f) / sps
+    return np.exp(1j * phase)
+
+
+def packet_bits(lap, rng, payload_bits):
+    hdr = np.repeat(rng.integers(0, 2, 18, dtype=np.uint8), 3)        # FEC 1/3 shaped header
+    pay = rng.integers(0, 2, payload_bits, dtype=np.uint8)
+    return np.concatenate([access_code_bits(lap), hdr, pay])
+
+
+def make_capture(sample_rate, center_freq, n_slots, laps=(0x24D952,), seed=1, snr_db=25.0,
+                 occupancy=0.3, cfo_hz=10e3, max_payload_bits=240, extra_slots=0.0,
+                 channels=None, noise=True, amplitude=1.0):
+    """Return (iq complex64 [n_slots*slot], truth list of dicts).
+
+    snr_db is signal power over the noise power in 1 MHz.  Each piconet (LAP)
+    transmits in a slot with probability `occupancy` on a pseudo-random visible
+    channel; bursts start 5-15 us into the slot."""
+    rng = np.random.default_rng(seed)
+    sps = int(round(sample_rate / SYMBOL_RATE))
+    assert abs(sps * SYMBOL_RATE - sample_rate) < 1e-6, "integer samples per symbol only"
+    slot = 625 * sps
+    n = int(n_slots * slot + extra_slots * slot)
+    lo, hi = visible_channels(sample_rate, center_freq)
+    chans = list(range(lo, hi + 1)) if channels is None else list(channels)
+    if noise:
+        sigma2 = (sample_rate / 1e6) / (10.0 ** (snr_db / 10.0)) * amplitude ** 2
+        s = math.sqrt(sigma2 / 2)
+        iq = (rng.standard_normal(n) * s + 1j * rng.standard_normal(n) * s).astype(np.complex64)
+    else:
+        iq = np.zeros(n, np.complex64)
+    truth = []
+    for k in range(n_slots):
+        used = set()
+        for lap in laps:
+            if rng.random() >= occupancy:
+                continue
+            ch = int(rng.choice(chans))
+            if ch in used:
+                continue
+            used.add(ch)
+            nb = int(rng.integers(0, max_payload_bits + 1))
+            bits = packet_bits(lap, rng, nb)
+            start = k * slot + int(rng.integers(5 * sps, 15 * sps))
+            bb = gfsk_baseband(bits, sps) * amplitude
+            f = (BASE_FREQUENCY + ch * 1e6 - center_freq) + float(rng.uniform(-cfo_hz, cfo_hz))
+            ph0 = rng.uniform(0, 2 * np.pi)
+            m = np.arange(len(bb))
+            bb = bb * np.exp(1j * (2 * np.pi * f / sample_rate * m + ph0))
+            end = min(start + len(bb), n)
+            if end > start:
+                iq[start:end] += bb[:end - start].astype(np.complex64)
+            truth.append(dict(slot=k, channel=ch, lap=lap, start=start, nbits=len(bits)))
+    return iq, truth
+
+
+def make_capture_torch(sample_rate, center_freq, n_slots, device, laps=(0x24D952,), seed=1,
+                       snr_db=25.0, occupancy=0.3, cfo_hz=10e3, max_payload_bits=240,
+                       burst_batch=256):
+    """Same capture model, built with torch on `device` (bench-scale sizes).
+
+    Returns (iq float32 tensor [n, 2] interleaved I/Q on device, truth list)."""
+    import torch
+
+    rng = np.random.default_rng(seed)
+    sps = int(round(sample_rate / SYMBOL_RATE))
+    slot = 625 * sps
+    n = int(n_slots) * slot
+    lo, hi = visible_channels(sample_rate, center_freq)
+    chans = list(range(lo, hi + 1))
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    sigma2 = (sample_rate / 1e6) / (10.0 ** (snr_db / 10.0))
+    iq = torch.randn((n, 2), generator=gen, device=device, dtype=torch.float32)
+    iq.mul_(math.sqrt(sigma2 / 2))
+    # schedule bursts on the host (cheap), modulate in batches on the device
+    truth, sched = [], []
+    for k in range(n_slots):
+        used = set()
+        for lap in laps:
+            if rng.random() >= occupancy:
+                continue
+            ch = int(rng.choice(chans))
+            if ch in used:
+                continue
+            used.add(ch)
+            nb = int(rng.integers(0, max_payload_bits + 1))
+            bits = packet_bits(lap, rng, nb)
+            start = k * slot + int(rng.integers(5 * sps, 15 * sps))
+            f = (BASE_FREQUENCY + ch * 1e6 - center_freq) + float(rng.uniform(-cfo_hz, cfo_hz))
+            ph0 = float(rng.uniform(0, 2 * np.pi))
+            truth.append(dict(slot=k, channel=ch, lap=lap, start=start, nbits=len(bits)))
+            sched.append((bits, start, f, ph0))
+    max_bits = 72 + 54 + max_payload_bits
+    L = max_bits * sps
+    g = torch.tensor(gaussian_pulse(sps), device=device, dtype=torch.float64)
+    pad = (len(g) - 1) // 2
+    flat = iq.view(-1)
+    for b0 in range(0, len(sched), burst_batch):
+        batch = sched[b0:b0 + burst_batch]
+        B = len(batch)
+        nrz = torch.zeros((B, max_bits), dtype=torch.float64)
+        lens = []
+        for i, (bits, _, _, _) in enumerate(batch):
+            nrz[i, :len(bits)] = torch.from_numpy(2.0 * bits.astype(np.float64) - 1.0)
+            lens.append(len(bits) * sps)
+        nrz = nrz.to(device).repeat_interleave(sps, dim=1)                       # [B, L]
+        f = torch.nn.functional.conv1d(nrz[:, None, :], g[None, None, :], padding=pad)[:, 0, :]
+        phase = math.pi * 0.32 * torch.cumsum(f, dim=1) / sps
+        m = torch.arange(L, device=device, dtype=torch.float64)
+        fo = torch.tensor([b[2] for b in batch], device=device, dtype=torch.float64)
+        p0 = torch.tensor([b[3] for b in batch], device=device, dtype=torch.float64)
+        phase = phase + (2 * math.pi / sample_rate) * fo[:, None] * m[None, :] + p0[:, None]
+        re = torch.cos(phase).to(torch.float32)
+        im = torch.sin(phase).to(torch.float32)
+        for i, (_, start, _, _) in enumerate(batch):
+            ln = min(lens[i], n - start)
+            if ln <= 0:
+                continue
+            seg = flat[2 * start: 2 * (start + ln)].view(ln, 2)
+            seg[:, 0] += re[i, :ln]
+            seg[:, 1] += im[i, :ln]
+    return iq, truth

@@ -1,0 +1,260 @@
+"""ctypes binding of the CPU oracle (oracle/libbt_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbt_oracle.so")
+
+MODE_LAP, MODE_SNIFFER = 0, 1
+MM_WINDOWED_RESET, MM_REF_FAITHFUL = 0, 1
+KIND_AC, KIND_AA = 0, 1
+
+
+class Hit(ctypes.Structure):
+    _fields_ = [("slot", ctypes.c_uint32), ("channel", ctypes.c_int32),
+                ("offset", ctypes.c_int32), ("lap", ctypes.c_uint32),
+                ("ac_errors", ctypes.c_int32), ("kind", ctypes.c_int32),
+                ("nsym", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("snr", ctypes.c_double)]
+
+    def key(self):
+        return (self.slot, self.channel, self.kind, self.offset, self.lap, self.ac_errors, self.nsym)
+
+
+def build(force=False):
+    """Compile the oracle with gcc if the shared object is missing or stale."""
+    src = os.path.join(_HERE, "bt_oracle.c")
+    hdr = os.path.join(_HERE, "bt_oracle.h")
+    stale = (not os.path.exists(_SO)
+             or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = ctypes.CDLL(_SO)
+    c_fp = ctypes.POINTER(ctypes.c_float)
+    c_dp = ctypes.POINTER(ctypes.c_double)
+    vp = ctypes.c_void_p
+    L.bto_create.restype = vp
+    L.bto_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+    L.bto_destroy.argtypes = [vp]
+    L.bto_set_mm_policy.argtypes = [vp, ctypes.c_int]
+    L.bto_set_le.argtypes = [vp, ctypes.c_int]
+    for name in ("history", "samples_per_slot", "decimation", "low_channel", "high_channel",
+                 "first_channel_sample", "first_noise_sample", "ntaps_channel", "ntaps_noise",
+                 "ddc_out", "noise_out"):
+        f = getattr(L, "bto_" + name)
+        f.restype = ctypes.c_int
+        f.argtypes = [vp]
+    for name in ("channel_taps", "noise_taps", "mmse_taps", "atan_table"):
+        f = getattr(L, "bto_" + name)
+        f.restype = c_fp
+        f.argtypes = [vp]
+    L.bto_firdes_ntaps.restype = ctypes.c_int
+    L.bto_firdes_ntaps.argtypes = [ctypes.c_double, ctypes.c_double]
+    L.bto_firdes_low_pass.restype = ctypes.c_int
+    L.bto_firdes_low_pass.argtypes = [ctypes.c_double] * 4 + [c_fp, ctypes.c_int]
+    L.bto_fast_atan2f.restype = ctypes.c_float
+    L.bto_fast_atan2f.argtypes = [vp, ctypes.c_float, ctypes.c_float]
+    L.bto_mmse_interpolate.restype = ctypes.c_float
+    L.bto_mmse_interpolate.argtypes = [vp, c_fp, ctypes.c_float]
+    L.bto_channel_samples.restype = ctypes.c_int
+    L.bto_channel_samples.argtypes = [vp, ctypes.c_int, c_fp, c_fp, c_dp]
+    L.bto_check_snr.restype = ctypes.c_int
+    L.bto_check_snr.argtypes = [vp, ctypes.c_int, ctypes.c_double, c_fp, c_dp, c_dp]
+    L.bto_demod.argtypes = [vp, c_fp, c_fp, ctypes.c_int]
+    L.bto_mm_cr.restype = ctypes.c_int
+    L.bto_mm_cr.argtypes = [vp, c_fp, ctypes.c_int, c_fp, ctypes.c_int]
+    L.bto_channel_symbols.restype = ctypes.c_int
+    L.bto_channel_symbols.argtypes = [vp, c_fp, ctypes.c_int, ctypes.c_char_p, c_fp]
+    L.bto_acgen.argtypes = [ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8)]
+    L.bto_ac_errors.restype = ctypes.c_int
+    L.bto_ac_errors.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
+    L.bto_check_ac.restype = ctypes.c_int
+    L.bto_check_ac.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
+    L.bto_sniff_ac.restype = ctypes.c_int
+    L.bto_sniff_ac.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.bto_sniff_aa.restype = ctypes.c_int
+    L.bto_sniff_aa.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_double]
+    L.bto_le_freq2index.restype = ctypes.c_int
+    L.bto_le_freq2index.argtypes = [ctypes.c_double]
+    L.bto_work.restype = ctypes.c_int
+    L.bto_work.argtypes = [vp, c_fp, ctypes.c_uint32, ctypes.POINTER(Hit), ctypes.c_int]
+    L.bto_run_stream.restype = ctypes.c_int
+    L.bto_run_stream.argtypes = [vp, c_fp, ctypes.c_size_t, ctypes.POINTER(Hit), ctypes.c_int,
+                                 ctypes.POINTER(ctypes.c_int)]
+    L.bto_run_stream_mt.restype = ctypes.c_int
+    L.bto_run_stream_mt.argtypes = [vp, c_fp, ctypes.c_size_t, ctypes.POINTER(Hit), ctypes.c_int,
+                                    ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    L.bto_scan_symbols.restype = ctypes.c_int
+    L.bto_scan_symbols.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(Hit),
+                                   ctypes.c_int]
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _iq_as_f32(iq):
+    """complex64 array or interleaved float32 array -> contiguous float32 view."""
+    a = np.ascontiguousarray(iq)
+    if a.dtype == np.complex64:
+        a = a.view(np.float32)
+    assert a.dtype == np.float32
+    return a
+
+
+def acgen(lap):
+    ac = (ctypes.c_uint8 * 9)()
+    lib().bto_acgen(lap, ac)
+    return bytes(ac)
+
+
+def ac_bits(lap):
+    """72 air-order bits (uint8 0/1) of the access code."""
+    return np.unpackbits(np.frombuffer(acgen(lap), dtype=np.uint8))
+
+
+def sniff_ac(symbols, limit=None):
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    if limit is None:
+        limit = len(s) - 67
+    pad = np.concatenate([s, np.zeros(80, np.uint8)])
+    return lib().bto_sniff_ac(pad.tobytes(), int(limit))
+
+
+def sniff_aa(symbols, limit, freq):
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    pad = np.concatenate([s, np.zeros(80, np.uint8)])
+    return lib().bto_sniff_aa(pad.tobytes(), int(limit), float(freq))
+
+
+def scan_symbols(symbols, max_hits=4096):
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    hits = (Hit * max_hits)()
+    n = lib().bto_scan_symbols(s.tobytes(), len(s), hits, max_hits)
+    return [(hits[i].offset, hits[i].lap, hits[i].ac_errors) for i in range(n)]
+
+
+class Oracle:
+    """One reference block instance (multi_LAP or multi_sniffer)."""
+
+    def __init__(self, sample_rate, center_freq, squelch_db=10.0, mode=MODE_SNIFFER,
+                 mm_policy=MM_WINDOWED_RESET, le=False):
+        self.L = lib()
+        self.h = self.L.bto_create(sample_rate, center_freq, squelch_db, mode)
+        if not self.h:
+            raise MemoryError("bto_create")
+        self.L.bto_set_mm_policy(self.h, mm_policy)
+        self.L.bto_set_le(self.h, 1 if le else 0)
+        g = lambda n: getattr(self.L, "bto_" + n)(self.h)
+        self.history = g("history")
+        self.slot = g("samples_per_slot")
+        self.decim = g("decimation")
+        self.low_ch = g("low_channel")
+        self.high_ch = g("high_channel")
+        self.first_ch = g("first_channel_sample")
+        self.first_noise = g("first_noise_sample")
+        self.ntaps_ch = g("ntaps_channel")
+        self.ntaps_noise = g("ntaps_noise")
+        self.ddc_out = g("ddc_out")
+        self.noise_out = g("noise_out")
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.bto_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def channel_taps(self):
+        return np.ctypeslib.as_array(self.L.bto_channel_taps(self.h), (self.ntaps_ch,)).copy()
+
+    def noise_taps(self):
+        return np.ctypeslib.as_array(self.L.bto_noise_taps(self.h), (self.ntaps_noise,)).copy()
+
+    def mmse_taps(self):
+        return np.ctypeslib.as_array(self.L.bto_mmse_taps(self.h), (129, 8)).copy()
+
+    def atan_table(self):
+        return np.ctypeslib.as_array(self.L.bto_atan_table(self.h), (257,)).copy()
+
+    def fast_atan2f(self, y, x):
+        return self.L.bto_fast_atan2f(self.h, y, x)
+
+    def window(self, iq, k):
+        """Window of history() samples the reference sees at work() call k."""
+        a = np.ascontiguousarray(iq).astype(np.complex64, copy=False)
+        H, slot = self.history, self.slot
+        a0 = k * slot - (H - 1)
+        win = np.zeros(H, np.complex64)
+        lo, hi = max(a0, 0), min(a0 + H, len(a))
+        if hi > lo:
+            win[lo - a0:hi - a0] = a[lo:hi]
+        return win
+
+    def channel_samples(self, win, channel):
+        w = _iq_as_f32(win)
+        out = np.zeros(2 * (self.ddc_out + 1), np.float32)
+        e = ctypes.c_double()
+        n = self.L.bto_channel_samples(self.h, channel, _fp(w), _fp(out), ctypes.byref(e))
+        return out[:2 * n].view(np.complex64).copy(), e.value
+
+    def check_snr(self, win, channel, on_energy):
+        w = _iq_as_f32(win)
+        snr, off = ctypes.c_double(), ctypes.c_double()
+        ok = self.L.bto_check_snr(self.h, channel, on_energy, _fp(w), ctypes.byref(snr),
+                                  ctypes.byref(off))
+        return bool(ok), snr.value, off.value
+
+    def demod(self, ch_iq):
+        a = _iq_as_f32(ch_iq)
+        n = len(a) // 2 - 1
+        out = np.zeros(max(n, 1), np.float32)
+        self.L.bto_demod(self.h, _fp(a), _fp(out), n)
+        return out[:n]
+
+    def channel_symbols(self, ch_iq):
+        a = _iq_as_f32(ch_iq)
+        n = len(a) // 2
+        sym = ctypes.create_string_buffer(n + 64)
+        soft = np.zeros(n + 8, np.float32)
+        k = self.L.bto_channel_symbols(self.h, _fp(a), n, sym, _fp(soft))
+        return np.frombuffer(sym.raw[:k], dtype=np.uint8).copy(), soft[:k].copy()
+
+    def work(self, win, slot, max_hits=256):
+        w = _iq_as_f32(win)
+        hits = (Hit * max_hits)()
+        n = self.L.bto_work(self.h, _fp(w), slot, hits, max_hits)
+        return [hits[i] for i in range(n)]
+
+    def run_stream(self, iq, max_hits=65536, threads=0):
+        a = _iq_as_f32(iq)
+        hits = (Hit * max_hits)()
+        done = ctypes.c_int()
+        if threads and threads > 0:
+            n = self.L.bto_run_stream_mt(self.h, _fp(a), len(a) // 2, hits, max_hits,
+                                         ctypes.byref(done), threads)
+        else:
+            n = self.L.bto_run_stream(self.h, _fp(a), len(a) // 2, hits, max_hits,
+                                      ctypes.byref(done))
+        return [hits[i] for i in range(n)], done.value
