@@ -1,0 +1,529 @@
+// btgpu.hip -- host runtime and C ABI (include/btgpu.h) over the gfx950 kernels.
+// No CPU fallback exists: every entry point that needs the GPU fails with
+// BTGPU_ENODEVICE / BTGPU_EDEVICE when the device or the code object is unusable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "btgpu.h"
+#include "design.h"
+#include "kernels.hip.h"
+
+using namespace btgpu;
+
+#define HIPCHK(h, expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            (h)->set_error(std::string(#expr) + ": " + hipGetErrorString(e__));              \
+            return BTGPU_EDEVICE;                                                             \
+        }                                                                                     \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct LaunchShape {
+    int T = 0;        // lanes (= outputs) per workgroup
+    int JC = 0;       // taps per LDS chunk
+    size_t lds = 0;
+};
+
+bool pick_shape(int D, int ntp, LaunchShape &s)
+{
+    const size_t budget = 64 * 1024;
+    for (int T : {256, 128, 64}) {
+        size_t fixed = (size_t)(T - 1) * D * sizeof(float2);
+        if (fixed + 64 * sizeof(float2) > budget) continue;
+        long long room = (long long)((budget - fixed) / sizeof(float2));
+        int jc = (int)std::min<long long>(ntp, room / 8 * 8);
+        if (jc < 8) continue;
+        s.T = T;
+        s.JC = jc;
+        s.lds = (size_t)((T - 1) * D + jc) * sizeof(float2);
+        return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+struct btgpu_handle {
+    Design des;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+    int sticky = BTGPU_OK;
+
+    // batch geometry
+    int max_slots = 0, max_hits = 0;
+    long long ystride = 0, ystride_n = 0;
+    int nb_max = 0;
+    size_t in_cap = 0;           // complex samples the staging buffer holds
+
+    // device memory
+    DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
+    DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
+    DevBuf d_eon, d_eoff, d_snr, d_winlen, d_hits, d_hitcount;
+    LaunchShape shape_ch, shape_n;
+
+    // last-batch bookkeeping (debug fetch)
+    int last_S = 0;
+    long long last_G = 0;
+
+    // host side
+    std::vector<btgpu_hit> queue;
+    std::vector<float> carry;    // btgpu_push history carry (interleaved)
+    uint64_t push_slot = 0;
+    btgpu_timing timing{};
+
+    void set_error(const std::string &s) { err = s; }
+
+    int alloc(DevBuf &b, size_t bytes)
+    {
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&b.p, bytes);
+        if (e != hipSuccess) {
+            set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+            return BTGPU_ENOMEM;
+        }
+        b.bytes = bytes;
+        return BTGPU_OK;
+    }
+    int upload(DevBuf &b, const void *src, size_t bytes)
+    {
+        int rc = alloc(b, bytes);
+        if (rc) return rc;
+        if (bytes) {
+            hipError_t e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { set_error(std::string("hipMemcpy: ") + hipGetErrorString(e)); return BTGPU_EDEVICE; }
+        }
+        return BTGPU_OK;
+    }
+    void release()
+    {
+        DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
+                         &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
+                         &d_eon, &d_eoff, &d_snr, &d_winlen, &d_hits, &d_hitcount};
+        for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
+        for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    }
+
+    int process_batch(const float2 *d_x, size_t x_len, uint64_t abs_first_slot, int S, hipStream_t st);
+};
+
+// ---------------------------------------------------------------------------------------
+// one batch of S slots; d_x[0] = first sample of window 0 of the batch
+// ---------------------------------------------------------------------------------------
+int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, uint64_t abs_first_slot, int S,
+                                hipStream_t st)
+{
+    const btgpu_design &d = des.d;
+    const int nch = d.high_channel - d.low_channel + 1;
+    const int ops = des.outs_per_slot;
+    const long long G = (long long)ops * (S - 1) + d.ddc_out;
+    const long long Gn = (long long)ops * S;
+    const int nb = (int)((G + ops - 1) / ops);
+    last_S = S;
+    last_G = G;
+
+    HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, sizeof(unsigned int), st));
+    HIPCHK(this, hipEventRecord(ev[0], st));
+
+    // ---- K1 + K2: channel bank, demod, block energies ----
+    {
+        const LaunchShape &s = shape_ch;
+        dim3 grid((unsigned)((G + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
+        hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len,
+                           (long long)d.first_channel_sample, d.decimation, des.channel.ntp, s.JC,
+                           (const float2 *)d_taps_ch.p, (const float2 *)d_rot_ch.p, des.channel.rot_period,
+                           (const double *)d_rotstep_ch.p, (float2 *)d_Y.p, G, ystride, nch);
+        dim3 g2((unsigned)nb, (unsigned)nch);
+        hipLaunchKernelGGL(demod_energy_kernel<true>, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
+                           ystride, ops, des.tail, (const float *)d_atan.p, des.demod_gain,
+                           (float *)d_d.p, (double *)d_P.p, (double *)d_Pt.p, nb);
+    }
+    HIPCHK(this, hipEventRecord(ev[1], st));
+
+    // ---- noise bank + per-slot energies ----
+    {
+        const LaunchShape &s = shape_n;
+        dim3 grid((unsigned)((Gn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
+        hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len,
+                           (long long)d.first_noise_sample, d.decimation, des.noise.ntp, s.JC,
+                           (const float2 *)d_taps_n.p, (const float2 *)d_rot_n.p, des.noise.rot_period,
+                           (const double *)d_rotstep_n.p, (float2 *)d_Yn.p, Gn, ystride_n, nch);
+        dim3 g2((unsigned)S, (unsigned)nch);
+        hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, st, (const float2 *)d_Yn.p, Gn,
+                           ystride_n, ops, 0, (const float *)nullptr, 0.f, (float *)nullptr,
+                           (double *)d_Q.p, (double *)nullptr, S);
+    }
+    HIPCHK(this, hipEventRecord(ev[2], st));
+
+    // ---- K3: squelch + M&M + slicer + access-code search ----
+    {
+        WindowParams p{};
+        p.nch = nch; p.S = S; p.outs_per_slot = ops; p.ddc_out = d.ddc_out; p.noise_out = d.noise_out;
+        p.blocks_per_window = des.blocks_per_window; p.tail = des.tail; p.nb = nb; p.ystride = ystride;
+        p.target_snr = des.cfg.squelch_db;
+        p.gain_mu = des.gain_mu; p.mu0 = des.mu0; p.omega_relative_limit = des.omega_relative_limit;
+        p.omega0 = des.omega0; p.gain_omega = des.gain_omega; p.omega_mid = des.omega_mid;
+        p.mode = des.cfg.mode; p.max_hits = max_hits;
+        p.a0_lo = des.ac.a0_lo; p.a0_hi = des.ac.a0_hi;
+        const long long nwin = (long long)S * nch;
+        dim3 grid((unsigned)((nwin + 63) / 64));
+        hipLaunchKernelGGL(window_kernel, grid, dim3(64), 0, st, p, (const float *)d_d.p,
+                           (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
+                           (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
+                           (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
+                           (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p);
+    }
+    HIPCHK(this, hipEventRecord(ev[3], st));
+    HIPCHK(this, hipGetLastError());
+
+    // ---- collect hits ----
+    unsigned int count = 0;
+    HIPCHK(this, hipMemcpyAsync(&count, d_hitcount.p, sizeof count, hipMemcpyDeviceToHost, st));
+    HIPCHK(this, hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(this, hipEventElapsedTime(&ms, ev[0], ev[1])); timing.channelizer_ms += ms;
+    HIPCHK(this, hipEventElapsedTime(&ms, ev[1], ev[2])); timing.noise_ms += ms;
+    HIPCHK(this, hipEventElapsedTime(&ms, ev[2], ev[3])); timing.window_ms += ms;
+    HIPCHK(this, hipEventElapsedTime(&ms, ev[0], ev[3])); timing.total_ms += ms;
+    timing.launches_channelizer += 2; timing.launches_noise += 2; timing.launches_window += 1;
+    timing.slots += (uint64_t)S;
+    timing.samples += (uint64_t)S * (uint64_t)d.samples_per_slot;
+
+    int rc = BTGPU_OK;
+    if (count > (unsigned)max_hits) { count = (unsigned)max_hits; rc = BTGPU_EOVERFLOW; sticky = rc; set_error("hit buffer overflow"); }
+    if (count) {
+        std::vector<DeviceHit> hh(count);
+        HIPCHK(this, hipMemcpy(hh.data(), d_hits.p, sizeof(DeviceHit) * count, hipMemcpyDeviceToHost));
+        std::vector<int> wl((size_t)S * nch);
+        HIPCHK(this, hipMemcpy(wl.data(), d_winlen.p, sizeof(int) * wl.size(), hipMemcpyDeviceToHost));
+        size_t q0 = queue.size();
+        for (const DeviceHit &x : hh) {
+            btgpu_hit o{};
+            o.slot = abs_first_slot + x.slot;
+            o.channel = d.low_channel + x.channel_idx;
+            o.offset = x.offset;
+            o.lap = x.lap;
+            o.ac_errors = x.ac_errors;
+            o.kind = x.kind;
+            o.nsym = wl[(size_t)x.slot * nch + x.channel_idx] - x.offset;
+            o.snr_db = x.snr;
+            queue.push_back(o);
+        }
+        std::sort(queue.begin() + q0, queue.end(), [](const btgpu_hit &a, const btgpu_hit &b) {
+            if (a.slot != b.slot) return a.slot < b.slot;
+            if (a.channel != b.channel) return a.channel < b.channel;
+            if (a.kind != b.kind) return a.kind < b.kind;
+            return a.offset < b.offset;
+        });
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char *btgpu_version(void) { return "btgpu 0.1 (gfx950)"; }
+
+const char *btgpu_strerror(int code)
+{
+    switch (code) {
+        case BTGPU_OK: return "ok";
+        case BTGPU_EINVAL: return "invalid argument or unsupported configuration";
+        case BTGPU_ENOMEM: return "out of memory";
+        case BTGPU_EDEVICE: return "HIP runtime error";
+        case BTGPU_ENODEVICE: return "no gfx950 device available";
+        case BTGPU_EOVERFLOW: return "hit buffer overflow";
+        case BTGPU_EUNSUPPORTED: return "configuration not supported by the GPU path";
+        default: return "unknown error";
+    }
+}
+
+int btgpu_design_query(const btgpu_config *cfg, btgpu_design *out)
+{
+    if (!cfg || !out) return BTGPU_EINVAL;
+    Design *d = new (std::nothrow) Design();
+    if (!d) return BTGPU_ENOMEM;
+    int rc = make_design(*cfg, *d);
+    if (rc == BTGPU_OK) *out = d->d;
+    delete d;
+    return rc;
+}
+
+int btgpu_acgen(uint32_t lap, uint8_t ac[9])
+{
+    if (!ac) return BTGPU_EINVAL;
+    access_code_bytes(lap, ac);
+    return BTGPU_OK;
+}
+
+int btgpu_filter_taps(const btgpu_config *cfg, int which, float *taps, int cap)
+{
+    if (!cfg) return BTGPU_EINVAL;
+    std::vector<float> h = which == 0 ? firdes_low_pass_hann(1.0, cfg->sample_rate, 500000.0, 300000.0)
+                                      : firdes_low_pass_hann(1.0, cfg->sample_rate, 22500.0, 10000.0);
+    if (!taps) return (int)h.size();
+    if (cap < (int)h.size()) return BTGPU_EINVAL;
+    std::memcpy(taps, h.data(), h.size() * sizeof(float));
+    return (int)h.size();
+}
+
+/* host-side view of the constant tables the kernels use (CPU tests) */
+int btgpu_debug_tables(const btgpu_config *cfg, float *mmse /*129*8*/, float *atan_tab /*257*/,
+                       uint32_t lap, uint64_t *ac_lo, uint32_t *ac_hi)
+{
+    if (!cfg) return BTGPU_EINVAL;
+    Design *d = new (std::nothrow) Design();
+    if (!d) return BTGPU_ENOMEM;
+    int rc = make_design(*cfg, *d);
+    if (rc == BTGPU_OK) {
+        if (mmse) std::memcpy(mmse, d->mmse, sizeof d->mmse);
+        if (atan_tab) std::memcpy(atan_tab, d->atan_tab, sizeof d->atan_tab);
+        lap &= 0xffffff;
+        if (ac_lo) *ac_lo = d->ac.a0_lo ^ d->ac.byte_lo[0][lap & 0xff] ^ d->ac.byte_lo[1][(lap >> 8) & 0xff] ^
+                            d->ac.byte_lo[2][lap >> 16];
+        if (ac_hi) *ac_hi = d->ac.a0_hi ^ d->ac.byte_hi[0][lap & 0xff] ^ d->ac.byte_hi[1][(lap >> 8) & 0xff] ^
+                            d->ac.byte_hi[2][lap >> 16];
+    }
+    delete d;
+    return rc;
+}
+
+int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
+{
+    if (!cfg || !out) return BTGPU_EINVAL;
+    *out = nullptr;
+    btgpu_handle *h = new (std::nothrow) btgpu_handle();
+    if (!h) return BTGPU_ENOMEM;
+    int rc = make_design(*cfg, h->des);
+    if (rc != BTGPU_OK) { delete h; return rc; }
+    if (h->des.d.channelizer != BTGPU_CHANNELIZER_DIRECT) { delete h; return BTGPU_EUNSUPPORTED; }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete h; return BTGPU_ENODEVICE; }
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { delete h; return BTGPU_EINVAL; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete h; return BTGPU_ENODEVICE; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete h; return BTGPU_ENODEVICE; }
+    if (hipSetDevice(dev) != hipSuccess) { delete h; return BTGPU_ENODEVICE; }
+    h->device = dev;
+
+    const Design &des = h->des;
+    const btgpu_design &d = des.d;
+    const int nch = d.high_channel - d.low_channel + 1;
+    const int ops = des.outs_per_slot;
+
+    auto fail = [&](int code) { h->release(); delete h; return code; };
+
+    if (!pick_shape(d.decimation, des.channel.ntp, h->shape_ch) ||
+        !pick_shape(d.decimation, des.noise.ntp, h->shape_n))
+        return fail(BTGPU_EUNSUPPORTED);
+
+    // batch size: bounded by ~3 GiB of intermediates
+    size_t per_slot = (size_t)nch * ops * (sizeof(float2) * 2 + sizeof(float)) + (size_t)d.samples_per_slot * 8;
+    int S = cfg->max_batch_slots > 0 ? cfg->max_batch_slots : 512;
+    size_t cap = (size_t)3 << 30;
+    if ((size_t)S * per_slot > cap) S = (int)std::max<size_t>(8, cap / per_slot);
+    h->max_slots = S;
+    h->max_hits = cfg->max_hits > 0 ? cfg->max_hits : std::max(4096, S * nch * 2);
+
+    const long long G = (long long)ops * (S - 1) + d.ddc_out;
+    h->ystride = (G + 63) / 64 * 64;
+    h->ystride_n = ((long long)ops * S + 63) / 64 * 64;
+    h->nb_max = (int)((G + ops - 1) / ops);
+    h->in_cap = (size_t)d.history + (size_t)(S - 1) * d.samples_per_slot;
+
+    if (hipStreamCreate(&h->stream) != hipSuccess) return fail(BTGPU_EDEVICE);
+    for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
+
+#define TRY(x) do { int rc__ = (x); if (rc__ != BTGPU_OK) { int c__ = rc__; std::string m__ = h->err; \
+        if (getenv("BTGPU_VERBOSE")) fprintf(stderr, "btgpu_create: %s\n", m__.c_str()); return fail(c__); } } while (0)
+    TRY(h->alloc(h->d_in, (h->in_cap + 64) * sizeof(float2)));
+    TRY(h->upload(h->d_taps_ch, des.channel.taps.data(), des.channel.taps.size() * sizeof(float)));
+    TRY(h->upload(h->d_taps_n, des.noise.taps.data(), des.noise.taps.size() * sizeof(float)));
+    TRY(h->upload(h->d_rot_ch, des.channel.rot.data(), des.channel.rot.size() * sizeof(float)));
+    TRY(h->upload(h->d_rot_n, des.noise.rot.data(), des.noise.rot.size() * sizeof(float)));
+    {
+        std::vector<double> st(nch), sn(nch);
+        for (int c = 0; c < nch; c++) {
+            st[c] = -des.channel.foff[c] * d.decimation / cfg->sample_rate;
+            sn[c] = -des.noise.foff[c] * d.decimation / cfg->sample_rate;
+        }
+        TRY(h->upload(h->d_rotstep_ch, st.data(), st.size() * sizeof(double)));
+        TRY(h->upload(h->d_rotstep_n, sn.data(), sn.size() * sizeof(double)));
+    }
+    TRY(h->alloc(h->d_Y, (size_t)nch * h->ystride * sizeof(float2)));
+    TRY(h->alloc(h->d_Yn, (size_t)nch * h->ystride_n * sizeof(float2)));
+    TRY(h->alloc(h->d_d, (size_t)nch * h->ystride * sizeof(float)));
+    TRY(h->alloc(h->d_P, (size_t)nch * h->nb_max * sizeof(double)));
+    TRY(h->alloc(h->d_Pt, (size_t)nch * h->nb_max * sizeof(double)));
+    TRY(h->alloc(h->d_Q, (size_t)nch * S * sizeof(double)));
+    TRY(h->upload(h->d_mmse, des.mmse, sizeof des.mmse));
+    TRY(h->upload(h->d_atan, des.atan_tab, sizeof des.atan_tab));
+    TRY(h->upload(h->d_aclo, des.ac.byte_lo, sizeof des.ac.byte_lo));
+    TRY(h->upload(h->d_achi, des.ac.byte_hi, sizeof des.ac.byte_hi));
+    TRY(h->alloc(h->d_eon, (size_t)S * nch * sizeof(double)));
+    TRY(h->alloc(h->d_eoff, (size_t)S * nch * sizeof(double)));
+    TRY(h->alloc(h->d_snr, (size_t)S * nch * sizeof(double)));
+    TRY(h->alloc(h->d_winlen, (size_t)S * nch * sizeof(int)));
+    TRY(h->alloc(h->d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
+    TRY(h->alloc(h->d_hitcount, sizeof(unsigned int)));
+#undef TRY
+    // allow > 48 KiB of dynamic LDS for the FIR tiles
+    (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+
+    h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]
+    *out = h;
+    return BTGPU_OK;
+}
+
+void btgpu_destroy(btgpu_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->release();
+    delete h;
+}
+
+int btgpu_get_design(const btgpu_handle *h, btgpu_design *out)
+{
+    if (!h || !out) return BTGPU_EINVAL;
+    *out = h->des.d;
+    return BTGPU_OK;
+}
+
+int btgpu_history(const btgpu_handle *h) { return h ? h->des.d.history : BTGPU_EINVAL; }
+const char *btgpu_last_error(const btgpu_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, uint64_t first_slot,
+                         uint64_t n_slots, void *hip_stream)
+{
+    if (!h || !d_iq) return BTGPU_EINVAL;
+    const btgpu_design &d = h->des.d;
+    if (n_slots == 0) return BTGPU_OK;
+    const size_t need = (size_t)d.history + (size_t)(n_slots - 1) * d.samples_per_slot;
+    if (n_complex < need) return BTGPU_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    std::memset(&h->timing, 0, sizeof h->timing);
+    int rc_all = BTGPU_OK;
+    for (uint64_t s0 = 0; s0 < n_slots; s0 += (uint64_t)h->max_slots) {
+        const int S = (int)std::min<uint64_t>((uint64_t)h->max_slots, n_slots - s0);
+        const float2 *x = (const float2 *)d_iq + (size_t)s0 * d.samples_per_slot;
+        const size_t xlen = n_complex - (size_t)s0 * d.samples_per_slot;
+        int rc = h->process_batch(x, xlen, first_slot + s0, S, st);
+        if (rc == BTGPU_EOVERFLOW) rc_all = rc;
+        else if (rc != BTGPU_OK) return rc;
+    }
+    return rc_all;
+}
+
+int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *consumed)
+{
+    if (!h || !items) return BTGPU_EINVAL;
+    const btgpu_design &d = h->des.d;
+    if (consumed) *consumed = 0;
+    const size_t H = (size_t)d.history, slot = (size_t)d.samples_per_slot;
+    if (n_items < H - 1 + slot) return BTGPU_OK;                 // not a whole slot of new items yet
+    const uint64_t n_slots = (n_items - (H - 1)) / slot;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::memset(&h->timing, 0, sizeof h->timing);
+    int rc_all = BTGPU_OK;
+    for (uint64_t s0 = 0; s0 < n_slots; s0 += (uint64_t)h->max_slots) {
+        const int S = (int)std::min<uint64_t>((uint64_t)h->max_slots, n_slots - s0);
+        const size_t seg = H + (size_t)(S - 1) * slot;
+        HIPCHK(h, hipMemcpyAsync(h->d_in.p, items + 2 * (size_t)s0 * slot, seg * sizeof(float2),
+                                 hipMemcpyHostToDevice, h->stream));
+        int rc = h->process_batch((const float2 *)h->d_in.p, seg, h->push_slot + s0, S, h->stream);
+        if (rc == BTGPU_EOVERFLOW) rc_all = rc;
+        else if (rc != BTGPU_OK) return rc;
+    }
+    h->push_slot += n_slots;
+    if (consumed) *consumed = (size_t)n_slots * slot;
+    return rc_all;
+}
+
+int btgpu_push(btgpu_handle *h, const float *iq, size_t n_complex)
+{
+    if (!h || (!iq && n_complex)) return BTGPU_EINVAL;
+    h->carry.insert(h->carry.end(), iq, iq + 2 * n_complex);
+    size_t consumed = 0;
+    int rc = btgpu_work(h, h->carry.data(), h->carry.size() / 2, &consumed);
+    if (rc != BTGPU_OK && rc != BTGPU_EOVERFLOW) return rc;
+    if (consumed) h->carry.erase(h->carry.begin(), h->carry.begin() + 2 * consumed);
+    return rc;
+}
+
+int btgpu_pending(const btgpu_handle *h) { return h ? (int)h->queue.size() : BTGPU_EINVAL; }
+
+int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits)
+{
+    if (!h || (!out && max_hits > 0) || max_hits < 0) return BTGPU_EINVAL;
+    int n = (int)std::min<size_t>((size_t)max_hits, h->queue.size());
+    if (n > 0) {
+        std::memcpy(out, h->queue.data(), sizeof(btgpu_hit) * n);
+        h->queue.erase(h->queue.begin(), h->queue.begin() + n);
+    }
+    return n;
+}
+
+int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out)
+{
+    if (!h || !out) return BTGPU_EINVAL;
+    *out = h->timing;
+    return BTGPU_OK;
+}
+
+long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, size_t count, void *out)
+{
+    if (!h || !out) return BTGPU_EINVAL;
+    const btgpu_design &d = h->des.d;
+    const int nch = d.high_channel - d.low_channel + 1;
+    const int c = channel - d.low_channel;
+    const void *src = nullptr;
+    size_t elem = 0, avail = 0;
+    switch (what) {
+        case 0:
+            if (c < 0 || c >= nch) return BTGPU_EINVAL;
+            src = (const float2 *)h->d_Y.p + (size_t)c * h->ystride; elem = sizeof(float2); avail = (size_t)h->last_G; break;
+        case 1:
+            if (c < 0 || c >= nch) return BTGPU_EINVAL;
+            src = (const float *)h->d_d.p + (size_t)c * h->ystride; elem = sizeof(float); avail = (size_t)h->last_G; break;
+        case 2: src = h->d_eon.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
+        case 3: src = h->d_eoff.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
+        case 4: src = h->d_snr.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
+        case 5:
+            if (c < 0 || c >= nch) return BTGPU_EINVAL;
+            src = (const float2 *)h->d_Yn.p + (size_t)c * h->ystride_n; elem = sizeof(float2);
+            avail = (size_t)h->last_S * h->des.outs_per_slot; break;
+        default: return BTGPU_EINVAL;
+    }
+    if (first >= avail) return 0;
+    count = std::min(count, avail - first);
+    if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
+    if (hipMemcpy(out, (const char *)src + first * elem, count * elem, hipMemcpyDeviceToHost) != hipSuccess)
+        return BTGPU_EDEVICE;
+    return (long)count;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// design.h -- host-side derivation of everything the reference's multi_block constructor
+// computes (lib/multi_block.cc:40-120, :299-342) plus the constant tables the HIP kernels
+// need.  Pure host C++ (no HIP), shared by the C ABI and the GNU Radio block mirror.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "btgpu.h"
+
+namespace btgpu {
+
+constexpr int kFirLanes = 8;             // FIR summation order: 8 strided partial sums
+constexpr int kMmseTaps = 8;
+constexpr int kMmseSteps = 128;
+constexpr int kSymbolsPerSlot = 625;
+constexpr int kSymbolsShortAC = 68;      // SYMBOLS_PER_BASIC_RATE_SHORTENED_ACCESS_CODE
+constexpr int kSymbolsLeAA = 40;         // SYMBOLS_PER_LOW_ENERGY_PREAMBLE_AA
+constexpr int kSymbolsHistorySniffer = 3125;
+
+struct FilterBank {
+    int ntaps = 0;                       // true filter length
+    int ntp = 0;                         // padded to a multiple of kFirLanes
+    int nch = 0;
+    std::vector<float> taps;             // [nch][ntp][2] (re, im), time-reversed, zero padded
+    std::vector<double> foff;            // [nch] centre offset in Hz
+    int rot_period = 0;                  // 0: not periodic (device computes the phase)
+    std::vector<float> rot;              // [nch][rot_period][2] derotation factors per output index
+};
+
+struct AcTables {
+    uint64_t a0_lo;                      // AC(LAP=0) bits 0..63 (bit i = i-th symbol on air)
+    uint32_t a0_hi;                      //            bits 64..67
+    uint64_t byte_lo[3][256];            // XOR of the affine columns selected by LAP byte b
+    uint32_t byte_hi[3][256];
+};
+
+struct Design {
+    btgpu_config cfg{};
+    btgpu_design d{};
+    double samples_per_slot_d = 0;       // d_samples_per_slot (double in the reference)
+    std::vector<float> h_channel, h_noise;
+    FilterBank channel, noise;
+    float demod_gain = 0;
+    float gain_mu = 0, mu0 = 0, omega_relative_limit = 0, omega0 = 0, gain_omega = 0, omega_mid = 0;
+    float mmse[(kMmseSteps + 1) * kMmseTaps];
+    float atan_tab[257];
+    AcTables ac;
+    int blocks_per_window = 0;           // ddc_out / (slot/decim)
+    int tail = 0;                        // ddc_out % (slot/decim)
+    int outs_per_slot = 0;               // slot / decim
+};
+
+// returns BTGPU_OK or a negative error code; never throws
+int make_design(const btgpu_config &cfg, Design &out);
+
+// own implementation of the Bluetooth access code (classic_packet::acgen equivalent)
+uint64_t sync_word(uint32_t lap);
+void access_code_68(uint32_t lap, uint64_t &lo, uint32_t &hi);   // bits 0..67, air order
+void access_code_bytes(uint32_t lap, uint8_t ac[9]);             // 72 bits, MSB-first packing
+
+int firdes_ntaps(double fs, double transition_width);
+std::vector<float> firdes_low_pass_hann(double gain, double fs, double cutoff, double transition_width);
+
+}  // namespace btgpu

@@ -1,0 +1,364 @@
+// kernels.hip.h -- CDNA4 (gfx950) kernels of the sniffer hot path.  Wave = 64 lanes.
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit
+// fmaf(), mirroring oracle/bt_oracle.c so that the DIRECT path is bit-exact against it.
+//
+// Data layout in HBM:
+//   x      interleaved complex64 input stream segment, [n] float2
+//   taps   [nch][ntp] float2, time-reversed complex band-pass taps, zero padded to 8
+//   Y      [nch][ystride] float2   channel / noise DDC output on the shared output grid
+//   d      [nch][ystride] float    quadrature-demodulated stream (gain * atan2)
+//   P, Pt  [nch][nb]      double   |Y|^2 sums per slot-block / per block head (`tail` outs)
+//   Q      [nch][S]       double   noise |Y|^2 sums per slot
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace btgpu {
+
+struct DeviceHit {            // 32 bytes, written by the window kernel
+    uint32_t slot;            // batch-relative slot index
+    int32_t  channel_idx;     // index into the visible channel range
+    int32_t  offset;
+    uint32_t lap;
+    int32_t  ac_errors;
+    int32_t  kind;
+    double   snr;
+};
+
+// ------------------------------------------------------------------------------------
+// K1: direct-form decimating complex band-pass FIR bank (channel bank and noise bank).
+//   y[c][g] = ( sum_j taps[c][j] * x[first + g*D + j] ) * rot[c][g]
+// Summation order (bit-exact contract with the oracle): 8 partial sums, partial l takes
+// j = l, l+8, l+16, ... ascending, four fmaf per complex MAC; combined as
+// ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)).
+// One lane = one output instant, CPB channels per workgroup; the input span of the
+// workgroup's tile is staged through LDS once per tap chunk and shared by the CPB
+// channels; taps are wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------
+template <int CPB>
+__global__ __launch_bounds__(256) void ddc_direct_kernel(
+    const float2 *__restrict__ x, long long x_len, long long first, int D, int ntp, int JC,
+    const float2 *__restrict__ taps, const float2 *__restrict__ rot, int Q,
+    const double *__restrict__ rot_step_turns,   // used when Q == 0
+    float2 *__restrict__ Y, long long G, long long ystride, int nch)
+{
+    extern __shared__ float2 tile[];
+    const int T = blockDim.x;
+    const long long g0 = (long long)blockIdx.x * T;
+    const int c0 = blockIdx.y * CPB;
+    const int o = threadIdx.x;
+
+    float ar[CPB][8], ai[CPB][8];
+#pragma unroll
+    for (int cc = 0; cc < CPB; cc++)
+#pragma unroll
+        for (int l = 0; l < 8; l++) { ar[cc][l] = 0.f; ai[cc][l] = 0.f; }
+
+    const float2 *tp[CPB];
+#pragma unroll
+    for (int cc = 0; cc < CPB; cc++) {
+        int c = c0 + cc < nch ? c0 + cc : nch - 1;
+        tp[cc] = taps + (size_t)c * ntp;
+    }
+
+    for (int j0 = 0; j0 < ntp; j0 += JC) {
+        const int jc = (ntp - j0) < JC ? (ntp - j0) : JC;
+        const int need = (T - 1) * D + jc;
+        const long long base = first + g0 * D + j0;
+        __syncthreads();
+        for (int s = o; s < need; s += T) {
+            long long a = base + s;
+            float2 v = make_float2(0.f, 0.f);
+            if (a >= 0 && a < x_len) v = x[a];
+            tile[s] = v;
+        }
+        __syncthreads();
+        const float2 *px = tile + o * D;
+        for (int j = 0; j < jc; j += 8) {
+#pragma unroll
+            for (int l = 0; l < 8; l++) {
+                const float2 v = px[j + l];
+#pragma unroll
+                for (int cc = 0; cc < CPB; cc++) {
+                    const float2 t = tp[cc][j0 + j + l];
+                    ar[cc][l] = fmaf(t.x, v.x, ar[cc][l]);
+                    ar[cc][l] = fmaf(-t.y, v.y, ar[cc][l]);
+                    ai[cc][l] = fmaf(t.x, v.y, ai[cc][l]);
+                    ai[cc][l] = fmaf(t.y, v.x, ai[cc][l]);
+                }
+            }
+        }
+    }
+
+    const long long g = g0 + o;
+    if (g >= G) return;
+#pragma unroll
+    for (int cc = 0; cc < CPB; cc++) {
+        const int c = c0 + cc;
+        if (c >= nch) break;
+        float yr = ((ar[cc][0] + ar[cc][1]) + (ar[cc][2] + ar[cc][3])) +
+                   ((ar[cc][4] + ar[cc][5]) + (ar[cc][6] + ar[cc][7]));
+        float yi = ((ai[cc][0] + ai[cc][1]) + (ai[cc][2] + ai[cc][3])) +
+                   ((ai[cc][4] + ai[cc][5]) + (ai[cc][6] + ai[cc][7]));
+        float rr, ri;
+        if (Q > 0) {
+            const float2 r = rot[(size_t)c * Q + (int)(g % Q)];
+            rr = r.x; ri = r.y;
+        } else {
+            double t = rot_step_turns[c] * (double)g;
+            t -= floor(t);
+            double s, co;
+            sincospi(2.0 * t, &s, &co);
+            rr = (float)co; ri = (float)s;
+        }
+        float2 out;
+        out.x = fmaf(-yi, ri, yr * rr);
+        out.y = fmaf(yi, rr, yr * ri);
+        Y[(size_t)c * ystride + g] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// gr::fast_atan2f [EXT GNU Radio 3.7], table in LDS/global (257 floats)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2f_dev(const float *__restrict__ tab, float y, float x)
+{
+    const float TAN_MAP_RES = 0.003921569f;
+    const float TAN_MAP_SIZE = 255.0f;
+    float y_abs = fabsf(y), x_abs = fabsf(x), z, base_angle, angle;
+    if (!((y_abs > 0.0f) || (x_abs > 0.0f))) return 0.0f;
+    if (y_abs < x_abs) z = __fdiv_rn(y_abs, x_abs); else z = __fdiv_rn(x_abs, y_abs);
+    if (z < TAN_MAP_RES) {
+        base_angle = z;
+    } else {
+        float alpha = z * TAN_MAP_SIZE;
+        int index = ((int)alpha) & 0xff;
+        alpha -= (float)index;
+        base_angle = tab[index];
+        base_angle = base_angle + ((tab[index + 1] - tab[index]) * alpha);
+    }
+    if (x_abs > y_abs) {
+        if (x >= 0.0f) angle = (y >= 0.0f) ? base_angle : -base_angle;
+        else {
+            angle = 3.14159265358979323846f;
+            angle = (y >= 0.0f) ? (angle - base_angle) : (base_angle - angle);
+        }
+    } else {
+        if (y >= 0.0f) {
+            angle = 1.57079632679489661923f;
+            angle = (x >= 0.0f) ? (angle - base_angle) : (angle + base_angle);
+        } else {
+            angle = -1.57079632679489661923f;
+            angle = (x >= 0.0f) ? (angle + base_angle) : (angle - base_angle);
+        }
+    }
+    return angle;
+}
+
+__device__ __forceinline__ float demod_one(const float *__restrict__ atab, float gain, float2 a, float2 b)
+{
+    // a * conj(b)  (multi_block.cc:165-166)
+    float pr = fmaf(a.y, b.y, a.x * b.x);
+    float pi = fmaf(a.y, b.x, -(a.x * b.y));
+    return gain * fast_atan2f_dev(atab, pi, pr);
+}
+
+// ------------------------------------------------------------------------------------
+// K2: demodulate the channel stream and reduce |Y|^2 per slot-block.
+// One workgroup per (block b of `bs` outputs, channel).  DEMOD=false: energy only
+// (noise bank).  Sums are float mag^2 accumulated in double like multi_block.cc:206-218.
+// ------------------------------------------------------------------------------------
+template <bool DEMOD>
+__global__ __launch_bounds__(256) void demod_energy_kernel(
+    const float2 *__restrict__ Y, long long G, long long ystride, int bs, int tail,
+    const float *__restrict__ atan_tab, float gain, float *__restrict__ d,
+    double *__restrict__ P, double *__restrict__ Pt, int nb)
+{
+    __shared__ float atab[257];
+    __shared__ double red[2][4];
+    const int c = blockIdx.y;
+    const int b = blockIdx.x;
+    if (DEMOD) {
+        for (int i = threadIdx.x; i < 257; i += blockDim.x) atab[i] = atan_tab[i];
+        __syncthreads();
+    }
+    const float2 *y = Y + (size_t)c * ystride;
+    const long long gb = (long long)b * bs;
+    double s_full = 0.0, s_tail = 0.0;
+    for (int i = threadIdx.x; i < bs; i += blockDim.x) {
+        const long long g = gb + i;
+        if (g >= G) break;
+        const float2 v = y[g];
+        const float m = (v.x * v.x) + (v.y * v.y);
+        s_full += (double)m;
+        if (i < tail) s_tail += (double)m;
+        if (DEMOD) {
+            float dv = 0.f;
+            if (g > 0) dv = demod_one(atab, gain, v, y[g - 1]);
+            d[(size_t)c * ystride + g] = dv;
+        }
+    }
+    // wave reduce (64 lanes) then across the 4 waves
+    for (int off = 32; off > 0; off >>= 1) {
+        s_full += __shfl_down(s_full, off, 64);
+        s_tail += __shfl_down(s_tail, off, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = s_full; red[1][wave] = s_tail; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        double a = 0.0, t = 0.0;
+        for (int w = 0; w < nw; w++) { a += red[0][w]; t += red[1][w]; }
+        P[(size_t)c * nb + b] = a;
+        if (Pt) Pt[(size_t)c * nb + b] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3: per (slot, channel) window: squelch decision, M&M clock recovery, slicer and the
+// access-code search, fused.  One lane per window (windows are independent under the
+// windowed-reset policy).  Symbols are never stored: the 68-symbol correlator window is
+// a shift register updated as each symbol is sliced, and offset c = s - 67 is tested the
+// moment symbol s exists (classic_packet::sniff_ac, lib/packet_impl.cc:247-268).  A
+// candidate is committed when one more symbol exists (c < len - 68) and c < 625
+// (lib/multi_sniffer_impl.cc:108-127); the next search resumes at c + 68.
+// ------------------------------------------------------------------------------------
+struct WindowParams {
+    int nch, S;
+    int outs_per_slot;          // grid points per slot (slot / decim)
+    int ddc_out, noise_out;
+    int blocks_per_window, tail;
+    int nb;                     // number of energy blocks per channel
+    long long ystride;
+    double target_snr;
+    float gain_mu, mu0, omega_relative_limit, omega0, gain_omega, omega_mid;
+    int mode;                   // BTGPU_MODE_*
+    int max_hits;
+    uint64_t a0_lo; uint32_t a0_hi;
+};
+
+__device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
+{
+    int da = __popc(v ^ a), db = __popc(v ^ b);
+    return da < db ? da : db;
+}
+
+__global__ __launch_bounds__(64) void window_kernel(
+    WindowParams p, const float *__restrict__ d, const double *__restrict__ P,
+    const double *__restrict__ Pt, const double *__restrict__ Qn,
+    const float *__restrict__ mmse_g, const uint64_t *__restrict__ ac_lo_g,
+    const uint32_t *__restrict__ ac_hi_g,
+    double *__restrict__ e_on_out, double *__restrict__ e_off_out, double *__restrict__ snr_out,
+    int *__restrict__ win_len, DeviceHit *__restrict__ hits, unsigned int *__restrict__ hit_count)
+{
+    __shared__ float mmse[129 * 8];
+    __shared__ uint64_t ac_lo[3 * 256];
+    __shared__ uint32_t ac_hi[3 * 256];
+    for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) { ac_lo[i] = ac_lo_g[i]; ac_hi[i] = ac_hi_g[i]; }
+    __syncthreads();
+
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nwin = (long long)p.S * p.nch;
+    if (w >= nwin) return;
+    // channel-fastest ordering: neighbouring lanes = neighbouring channels of one slot
+    const int k = (int)(w / p.nch);
+    const int c = (int)(w % p.nch);
+
+    // ---- squelch: multi_block::channel_samples energy + check_snr (multi_block.cc:206-293) ----
+    double e_on = 0.0;
+    for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)c * p.nb + k + j];
+    if (p.tail > 0) e_on += Pt[(size_t)c * p.nb + k + p.blocks_per_window];
+    e_on /= (double)p.ddc_out;
+    const double e_off = Qn[(size_t)c * p.S + k] / (double)p.noise_out;
+    const double snr = 10.0 * log10(e_on / e_off);
+    e_on_out[w] = e_on; e_off_out[w] = e_off; snr_out[w] = snr;
+    win_len[w] = -1;
+    if (!(snr >= p.target_snr)) return;
+
+    // ---- M&M (multi_block.cc:128-155), windowed reset ----
+    const float *dw = d + (size_t)c * p.ystride + (long long)k * p.outs_per_slot;
+    const int demod_n = p.ddc_out - 1;
+    const unsigned int ni = (unsigned int)(demod_n - 8);
+    float mu = p.mu0, omega = p.omega0, last = 0.f;
+    unsigned int ii = 0;
+    int oo = 0;
+    uint64_t wlo = 0; uint32_t whi = 0;      // correlator window: bit i = symbol (s-67+i)
+    int pending = -1, resume = 0, nhits = 0;
+    uint32_t pend_lap = 0; int pend_err = 0;
+    bool searching = true;
+    while (ii < ni && oo < demod_n) {
+        // interpolate: sum_k T[imu][7-k] * in[ii+k], k ascending
+        int imu = (int)rintf(mu * 128.0f);
+        imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
+        const float *t = &mmse[imu * 8];
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned int idx = ii + q;
+            const float v = idx == 0 ? 0.0f : dw[idx];
+            acc = fmaf(t[7 - q], v, acc);
+        }
+        const float out = acc;
+        const float s_last = (last < 0) ? -1.0f : 1.0f;
+        const float s_out = (out < 0) ? -1.0f : 1.0f;
+        const float mm_val = s_last * out - s_out * last;
+        last = out;
+        omega = omega + (p.gain_omega * mm_val);
+        {
+            const float xx = omega - p.omega_mid;
+            float x1 = fabsf(xx + p.omega_relative_limit);
+            const float x2 = fabsf(xx - p.omega_relative_limit);
+            x1 -= x2;
+            omega = p.omega_mid + 0.5f * x1;
+        }
+        mu = mu + (omega + (p.gain_mu * mm_val));
+        const float fl = floorf(mu);
+        ii += (unsigned int)(int)fl;
+        mu = mu - fl;
+
+        // ---- slicer + streaming access-code search ----
+        const uint32_t sym = (out < 0) ? 0u : 1u;
+        const int s = oo;
+        oo++;
+        if (searching) {
+            wlo = (wlo >> 1) | ((uint64_t)(whi & 1u) << 63);
+            whi = (whi >> 1) | (sym << 3);
+            if (pending >= 0) {          // one more symbol exists: pending < len - 68
+                const unsigned int slot_h = atomicAdd(hit_count, 1u);
+                if (slot_h < (unsigned int)p.max_hits) {
+                    DeviceHit h;
+                    h.slot = (uint32_t)k; h.channel_idx = c; h.offset = pending;
+                    h.lap = pend_lap; h.ac_errors = pend_err; h.kind = 0; h.snr = snr;
+                    hits[slot_h] = h;
+                }
+                nhits++;
+                resume = pending + 68;
+                pending = -1;
+                if (p.mode == 0) searching = false;      // multi_LAP: first hit only
+            }
+            const int cpos = s - 67;
+            if (searching && cpos >= resume && cpos < 625) {
+                const uint32_t pre = (uint32_t)wlo & 0x1f;
+                const uint32_t bar = ((uint32_t)(wlo >> 61) | (whi << 3)) & 0x7f;
+                const int gate = popc5min(pre, 0x0a, 0x15) + popc5min(bar, 0x27, 0x58);
+                if (gate <= 2) {
+                    const uint32_t lap = (uint32_t)(wlo >> 38) & 0xffffff;
+                    const uint64_t elo = p.a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^
+                                         ac_lo[512 + (lap >> 16)];
+                    const uint32_t ehi = p.a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^
+                                         ac_hi[512 + (lap >> 16)];
+                    const int err = __popcll(elo ^ wlo) + __popc((ehi ^ whi) & 0xf);
+                    if (err < 7) { pending = cpos; pend_lap = lap; pend_err = err; }
+                }
+            }
+            if (cpos >= 625 && pending < 0) searching = false;
+        }
+        if (!searching && nhits == 0) break;      // search range exhausted without a hit
+    }
+    if (nhits > 0) win_len[w] = oo;       // len: only needed (and only exact) for windows with hits
+}
+
+}  // namespace btgpu

@@ -1,0 +1,158 @@
+/*
+ * btgpu.h -- C ABI of the MI355X-native gr-bluetooth multi-channel sniffer hot path.
+ *
+ * This is the drop-in boundary: a GNU Radio block (gr::bluetooth::multi_LAP /
+ * gr::bluetooth::multi_sniffer, see gr-bluetooth_amd/host/ and INTEGRATION.md) keeps
+ * the reference's make()/work() surface and forwards to these entry points.  Plain
+ * pointers and sizes only; no C++ or torch types; no exceptions cross this boundary
+ * (every function returns BTGPU_OK or a negative BTGPU_E* code).
+ *
+ * Reference interfaces replaced (paths relative to the gr-bluetooth checkout):
+ *   btgpu_design_query   multi_block::multi_block + set_symbol_history + set_channels
+ *                        (lib/multi_block.cc:40-120, :299-342): pure host arithmetic
+ *   btgpu_create         multi_LAP::make / multi_sniffer::make
+ *                        (lib/multi_LAP_impl.cc:39-56, lib/multi_sniffer_impl.cc:42-72)
+ *   btgpu_work           multi_LAP_impl::work / multi_sniffer_impl::work
+ *                        (lib/multi_LAP_impl.cc:65-114, lib/multi_sniffer_impl.cc:82-166):
+ *                        same input contract (history()-1 old items followed by the new
+ *                        ones), but consumes every whole slot in the buffer at once
+ *   btgpu_process_device same work on a device-resident stream segment (time-partitioned
+ *                        multi-GPU and bench entry; no reference counterpart)
+ *   btgpu_poll           replaces the printf side effect of work(): hit records in the
+ *                        order the reference's loops print them (slot, channel, offset)
+ *   btgpu_acgen          classic_packet::acgen (lib/packet_impl.cc:309-364)
+ */
+#ifndef BTGPU_H
+#define BTGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTGPU_OK            0
+#define BTGPU_EINVAL       -1   /* bad argument / unsupported configuration */
+#define BTGPU_ENOMEM       -2
+#define BTGPU_EDEVICE      -3   /* HIP runtime error (see btgpu_last_error)  */
+#define BTGPU_ENODEVICE    -4   /* no gfx950 device visible                  */
+#define BTGPU_EOVERFLOW    -5   /* hit buffer overflow (hits were dropped)   */
+#define BTGPU_EUNSUPPORTED -6
+
+#define BTGPU_MODE_LAP      0   /* gr::bluetooth::multi_LAP     (+68 symbols of history)   */
+#define BTGPU_MODE_SNIFFER  1   /* gr::bluetooth::multi_sniffer (+3125 symbols of history) */
+
+#define BTGPU_CHANNELIZER_AUTO      0
+#define BTGPU_CHANNELIZER_DIRECT    1   /* per-channel direct-form DDC; bit-exact vs the oracle */
+#define BTGPU_CHANNELIZER_POLYPHASE 2   /* polyphase filter bank; equal within float tolerance   */
+
+#define BTGPU_SQUELCH_DIRECT    0       /* exact direct-form noise DDC                          */
+#define BTGPU_SQUELCH_AUTO      1
+
+#define BTGPU_FLAG_LE        0x1        /* also run the le_packet::sniff_aa pass (sniffer mode)  */
+
+#define BTGPU_KIND_AC 0
+#define BTGPU_KIND_AA 1
+
+typedef struct btgpu_handle btgpu_handle;
+
+typedef struct btgpu_config {
+    double  sample_rate;      /* multi_*::make(sample_rate, ...)            */
+    double  center_freq;      /* multi_*::make(..., center_freq, ...)       */
+    double  squelch_db;       /* multi_*::make(..., squelch_threshold)      */
+    int32_t mode;             /* BTGPU_MODE_*                               */
+    int32_t device;           /* HIP device ordinal, -1 = current device    */
+    int32_t channelizer;      /* BTGPU_CHANNELIZER_*                        */
+    int32_t squelch;          /* BTGPU_SQUELCH_*                            */
+    int32_t flags;            /* BTGPU_FLAG_*                               */
+    int32_t max_batch_slots;  /* slots per internal batch, 0 = default      */
+    int32_t max_hits;         /* hit-buffer capacity per batch, 0 = default */
+    int32_t reserved;
+} btgpu_config;
+
+/* Everything the multi_block constructor derives (lib/multi_block.cc:56-119). */
+typedef struct btgpu_design {
+    double  samples_per_symbol;
+    int32_t samples_per_slot;
+    int32_t decimation;
+    int32_t ntaps_channel, ntaps_noise;
+    int32_t low_channel, high_channel;       /* classic channel numbers, inclusive */
+    int32_t first_channel_sample, first_noise_sample;
+    int32_t history;                          /* history() incl. symbol history     */
+    int32_t ddc_out;                          /* channel DDC outputs per window     */
+    int32_t noise_out;                        /* noise DDC outputs per window       */
+    int32_t channelizer;                      /* resolved BTGPU_CHANNELIZER_*       */
+    int32_t reserved[3];
+} btgpu_design;
+
+typedef struct btgpu_hit {
+    uint64_t slot;        /* work() call index == "time slot" the reference prints          */
+    int32_t  channel;     /* classic channel 0..78                                          */
+    int32_t  offset;      /* symbol offset in the window's symbol array (sniff_ac result)    */
+    uint32_t lap;         /* LAP (kind AC) / access address (kind AA)                       */
+    int32_t  ac_errors;   /* mismatches over the 68 checked access-code bits               */
+    int32_t  kind;        /* BTGPU_KIND_*                                                   */
+    int32_t  nsym;        /* symbols available to the packet handler from `offset` on       */
+    double   snr_db;      /* 10 log10(E_on / E_off) of the (slot, channel) window           */
+} btgpu_hit;
+
+/* Per-stage GPU time of the most recent btgpu_work/btgpu_process_device call,
+ * measured with HIP events on the handle's stream. */
+typedef struct btgpu_timing {
+    float channelizer_ms;     /* channel bank (+ fused demod/energy)     */
+    float noise_ms;           /* noise bank + squelch energies           */
+    float window_ms;          /* squelch decision + M&M + slicer + search */
+    float total_ms;
+    uint64_t samples;         /* new complex samples consumed             */
+    uint64_t slots;
+    uint32_t launches_channelizer, launches_noise, launches_window, reserved;
+} btgpu_timing;
+
+/* ---- host-only helpers (no GPU needed) ---- */
+int  btgpu_design_query(const btgpu_config *cfg, btgpu_design *out);
+int  btgpu_acgen(uint32_t lap, uint8_t ac[9]);
+int  btgpu_filter_taps(const btgpu_config *cfg, int which /*0 channel, 1 noise*/, float *taps, int cap);
+const char *btgpu_strerror(int code);
+const char *btgpu_version(void);
+
+/* ---- block lifetime ---- */
+int  btgpu_create(const btgpu_config *cfg, btgpu_handle **out);
+void btgpu_destroy(btgpu_handle *h);
+int  btgpu_get_design(const btgpu_handle *h, btgpu_design *out);
+int  btgpu_history(const btgpu_handle *h);
+const char *btgpu_last_error(const btgpu_handle *h);
+
+/* ---- work() ----
+ * `items` is what GNU Radio hands to work(): interleaved float32 I/Q, history()-1 old
+ * samples followed by the new ones, `n_items` complex samples in total.  Processes
+ * S = (n_items - history()) / samples_per_slot + 1 slots (0 if n_items < history()),
+ * queues their hits, stores S*samples_per_slot in *consumed.  Returns BTGPU_OK or <0. */
+int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *consumed);
+
+/* Streaming convenience: keeps history internally (zero pre-filled like the GNU Radio
+ * scheduler) so arbitrary chunks can be pushed. */
+int btgpu_push(btgpu_handle *h, const float *iq, size_t n_complex);
+
+/* Device-resident segment: d_iq[0] is absolute sample first_slot*samples_per_slot-(history()-1);
+ * the segment must hold history() + (n_slots-1)*samples_per_slot complex samples.
+ * `hip_stream` is a hipStream_t (NULL = the handle's own stream). */
+int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex,
+                         uint64_t first_slot, uint64_t n_slots, void *hip_stream);
+
+/* Drain queued hits, ordered by (slot, channel, kind, offset). Returns count (>=0) or <0. */
+int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits);
+int btgpu_pending(const btgpu_handle *h);
+
+int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out);
+
+/* ---- introspection for parity tests: copies an intermediate of the LAST batch ----
+ * what: 0 channel-DDC output Y (complex64, needs DIRECT channelizer or debug build),
+ *       1 demodulated stream d (float32), 2 E_on per window (float64, [slot][channel]),
+ *       3 E_off per window (float64), 4 snr per window (float64).
+ * channel is a classic channel number (ignored for 2..4); returns elements copied. */
+long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, size_t count, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTGPU_H */
