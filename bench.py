@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- complex-IQ Msamples/s of the multi_sniffer hot path on MI355X.
+
+One "step" = one pass of the hot path (channel bank -> squelch -> demod -> M&M -> slicer ->
+access-code search -> hit records on the host) over one batch of synthetic wideband IQ that
+is already resident in HBM.  Workload = BASELINE.json configs[2]: multi_sniffer, 79 channels,
+100 Msps, centre 2441 MHz (C79).  N > 1: the stream is time-partitioned, each rank gets its
+own slot range plus a history()-1 halo and the hit records are gathered over RCCL (weak
+scaling: per-rank slots fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects added.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from conftest import load_pkg  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    "c79": dict(sample_rate=100e6, center_freq=2441e6, name="multi_sniffer 79-channel classic BT, 100 Msps synthetic wideband IQ"),
+    "c8": dict(sample_rate=8e6, center_freq=2476.5e6, name="multi_sniffer 8-channel (8 MHz span) synthetic IQ"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c79", choices=sorted(WORKLOADS))
+    ap.add_argument("--slots", type=int, default=0, help="slots per rank per step (0 = workload default)")
+    ap.add_argument("--squelch", type=float, default=10.0, help="SNR squelch threshold in dB (btrx -t default 10.0)")
+    ap.add_argument("--snr", type=float, default=25.0, help="burst SNR in 1 MHz (dB) of the synthetic capture")
+    ap.add_argument("--piconets", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--channelizer", type=int, default=0)
+    ap.add_argument("--squelch-mode", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    pkg = load_pkg()
+    import importlib
+    synth = importlib.import_module("gr_bluetooth_amd.synth")
+    bdist = importlib.import_module("gr_bluetooth_amd.dist")
+
+    wl = WORKLOADS[args.workload]
+    fs, fc = wl["sample_rate"], wl["center_freq"]
+    S = args.slots or (128 if args.workload == "c79" else 1600)
+    laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(args.piconets))
+
+    blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
+                            channelizer=args.channelizer, squelch=args.squelch_mode)
+    des = blk.design
+    H, slot = des.history, des.samples_per_slot
+    nch = des.high_channel - des.low_channel + 1
+
+    first = rank * S
+    seg, truth = synth.make_segment_torch(fs, fc, first, first + S, device, laps=laps, seed=args.seed,
+                                          snr_db=args.snr, left_pad=H - 1)
+    seg = seg.contiguous()
+    n_complex = seg.shape[0]
+    torch.cuda.synchronize()
+
+    def step():
+        blk.process_device(seg.data_ptr(), n_complex, first, S)
+        hits = blk.poll()
+        ints, snr = bdist.hits_to_arrays(hits)
+        if world > 1:
+            ints, snr = bdist.gather_hits(ints, snr, device=device)
+        return ints, snr
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = np.zeros(8)
+    kernel_launches = np.zeros(8)
+    for _ in range(args.steps):
+        ints, snr = step()
+        tm = blk.timing()
+        kernel_ms += np.array(list(tm.kernel_ms))
+        kernel_launches += np.array(list(tm.kernel_launches))
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = float(world) * S * slot * args.steps
+    value = total_samples / elapsed / 1e6
+
+    # ---- correctness gate 1: every detectable ground-truth burst is reported ----
+    got = set((int(r[0]), int(r[1]), int(r[4])) for r in ints)           # (slot, channel, lap)
+    lo_slot, hi_slot = (0 if world > 1 else first), (world * S if world > 1 else first + S)
+    if world > 1:                                   # rank 0 only knows its own truth; regenerate all
+        truth, _ = synth.burst_schedule(fs, fc, 0, world * S, laps, args.seed, 0.3, 10e3, 240)
+    expected = found = 0
+    for tr in truth:
+        det = tr["slot"] + 6                        # sniffer window lag: (history()-1)/slot = 6.3
+        if det + 1 >= hi_slot or tr["slot"] < lo_slot:
+            continue
+        expected += 1
+        if any((det + d, tr["channel"], tr["lap"]) in got for d in (-1, 0, 1)):
+            found += 1
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (HIP events inside libbtgpu, same stream) ----
+        names = pkg.KERNEL_NAMES
+        avg = [kernel_ms[i] / kernel_launches[i] if kernel_launches[i] else 0.0 for i in range(5)]
+        dom = int(np.argmax(avg))
+        bytes_per_launch = 8.0 * S * slot                      # 8 B per complex input sample, read once
+        ach = bytes_per_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
+        # algorithmic FMA per input sample of the direct-form banks
+        fma_ch = nch * des.ntaps_channel * 2.0 / des.decimation * 2
+        fma_noise = nch * des.ntaps_noise * 2.0 / des.decimation * 2
+        roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(ach, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_ms": round(avg[dom], 4),
+                "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(5)}}
+        if names[dom] in ("ddc_noise", "ddc_channel"):
+            fl = (fma_noise if names[dom] == "ddc_noise" else fma_ch) * 2.0 * S * slot
+            roof["fp32_tflops"] = round(fl / (avg[dom] * 1e-3) / 1e12, 3)
+            roof["fp32_frac"] = round(roof["fp32_tflops"] / FP32_PEAK_TFLOPS, 4)
+
+        # ---- cpu_baseline: the oracle (a port, NOT the upstream binary) on a bounded sample ----
+        cpu = None
+        oracle_ok = None
+        if not args.no_cpu:
+            import pyoracle as po
+            o = po.Oracle(fs, fc, args.squelch, po.MODE_SNIFFER)
+            probe = 2
+            host = seg[H - 1:H - 1 + 64 * slot].cpu().numpy().reshape(-1) if S >= 64 else \
+                seg[H - 1:].cpu().numpy().reshape(-1)
+            t1 = time.perf_counter()
+            o.run_stream(host[:2 * probe * slot])
+            per_slot = (time.perf_counter() - t1) / probe
+            cs = int(max(2, min(len(host) // (2 * slot), args.cpu_seconds / max(per_slot, 1e-6))))
+            t1 = time.perf_counter()
+            ohits, done = o.run_stream(host[:2 * cs * slot])
+            dt = time.perf_counter() - t1
+            cpu = {"value": round(cs * slot / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+                   "kind": "port",
+                   "sample": "first %d slots (%d samples) of the same capture, oracle/bt_oracle.c single thread" % (cs, cs * slot)}
+            okeys = [h.key() for h in ohits]
+            gkeys = [tuple(int(v) for v in r) for r in ints if r[0] < cs]
+            gkeys = [(k[0], k[1], k[2], k[3], k[4], k[5], k[6]) for k in gkeys]
+            oracle_ok = okeys == gkeys
+            ncores = os.cpu_count() or 1
+            if ncores > 1:
+                cs2 = min(len(host) // (2 * slot), cs * min(ncores, 8))
+                t1 = time.perf_counter()
+                o.run_stream(host[:2 * cs2 * slot], threads=ncores)
+                dt2 = time.perf_counter() - t1
+                cpu["all_cores"] = {"value": round(cs2 * slot / dt2 / 1e6, 4), "cores": ncores, "slots": cs2}
+
+        out = {
+            "metric": "complex-IQ Msamples/s @ 79 ch" if args.workload == "c79" else "complex-IQ Msamples/s @ 8 ch",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "sample_rate": fs, "center_freq": fc, "channels": nch,
+                       "slots_per_rank_per_step": S, "samples_per_rank_per_step": S * slot,
+                       "squelch_db": args.squelch, "burst_snr_db": args.snr, "piconets": args.piconets,
+                       "mode": "multi_sniffer", "partition": "time x%d, halo %d samples" % (world, H - 1),
+                       "channelizer": int(des.channelizer)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "parity": {"truth_detected": found, "truth_expected": expected, "hits": int(len(ints)),
+                       "hits_equal_oracle_on_sample": oracle_ok},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    blk.close()
+
+
+if __name__ == "__main__":
+    main()

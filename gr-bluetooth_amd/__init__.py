@@ -61,12 +61,14 @@ class Hit(ctypes.Structure):
         return (self.slot, self.channel, self.kind, self.offset, self.lap, self.ac_errors, self.nsym)
 
 
+K_DDC_CHANNEL, K_DEMOD_ENERGY, K_DDC_NOISE, K_NOISE_ENERGY, K_WINDOW = 0, 1, 2, 3, 4
+KERNEL_NAMES = ["ddc_channel", "demod_energy", "ddc_noise", "noise_energy", "window"]
+
+
 class Timing(ctypes.Structure):
-    _fields_ = [("channelizer_ms", ctypes.c_float), ("noise_ms", ctypes.c_float),
-                ("window_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("samples", ctypes.c_uint64), ("slots", ctypes.c_uint64),
-                ("launches_channelizer", ctypes.c_uint32), ("launches_noise", ctypes.c_uint32),
-                ("launches_window", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+    _fields_ = [("kernel_ms", ctypes.c_float * 8), ("kernel_launches", ctypes.c_uint32 * 8),
+                ("total_ms", ctypes.c_float), ("batches", ctypes.c_uint32),
+                ("samples", ctypes.c_uint64), ("slots", ctypes.c_uint64)]
 
 
 EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_strerror",

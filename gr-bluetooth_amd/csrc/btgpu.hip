@@ -62,7 +62,7 @@ struct btgpu_handle {
     Design des;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
     int sticky = BTGPU_OK;
 
@@ -150,12 +150,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, uint64_t abs_fi
                            (long long)d.first_channel_sample, d.decimation, des.channel.ntp, s.JC,
                            (const float2 *)d_taps_ch.p, (const float2 *)d_rot_ch.p, des.channel.rot_period,
                            (const double *)d_rotstep_ch.p, (float2 *)d_Y.p, G, ystride, nch);
+        HIPCHK(this, hipEventRecord(ev[1], st));
         dim3 g2((unsigned)nb, (unsigned)nch);
         hipLaunchKernelGGL(demod_energy_kernel<true>, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
                            ystride, ops, des.tail, (const float *)d_atan.p, des.demod_gain,
                            (float *)d_d.p, (double *)d_P.p, (double *)d_Pt.p, nb);
     }
-    HIPCHK(this, hipEventRecord(ev[1], st));
+    HIPCHK(this, hipEventRecord(ev[2], st));
 
     // ---- noise bank + per-slot energies ----
     {
@@ -165,12 +166,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, uint64_t abs_fi
                            (long long)d.first_noise_sample, d.decimation, des.noise.ntp, s.JC,
                            (const float2 *)d_taps_n.p, (const float2 *)d_rot_n.p, des.noise.rot_period,
                            (const double *)d_rotstep_n.p, (float2 *)d_Yn.p, Gn, ystride_n, nch);
+        HIPCHK(this, hipEventRecord(ev[3], st));
         dim3 g2((unsigned)S, (unsigned)nch);
         hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, st, (const float2 *)d_Yn.p, Gn,
                            ystride_n, ops, 0, (const float *)nullptr, 0.f, (float *)nullptr,
                            (double *)d_Q.p, (double *)nullptr, S);
     }
-    HIPCHK(this, hipEventRecord(ev[2], st));
+    HIPCHK(this, hipEventRecord(ev[4], st));
 
     // ---- K3: squelch + M&M + slicer + access-code search ----
     {
@@ -190,7 +192,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, uint64_t abs_fi
                            (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
                            (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p);
     }
-    HIPCHK(this, hipEventRecord(ev[3], st));
+    HIPCHK(this, hipEventRecord(ev[5], st));
     HIPCHK(this, hipGetLastError());
 
     // ---- collect hits ----
@@ -198,11 +200,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, uint64_t abs_fi
     HIPCHK(this, hipMemcpyAsync(&count, d_hitcount.p, sizeof count, hipMemcpyDeviceToHost, st));
     HIPCHK(this, hipStreamSynchronize(st));
     float ms = 0;
-    HIPCHK(this, hipEventElapsedTime(&ms, ev[0], ev[1])); timing.channelizer_ms += ms;
-    HIPCHK(this, hipEventElapsedTime(&ms, ev[1], ev[2])); timing.noise_ms += ms;
-    HIPCHK(this, hipEventElapsedTime(&ms, ev[2], ev[3])); timing.window_ms += ms;
-    HIPCHK(this, hipEventElapsedTime(&ms, ev[0], ev[3])); timing.total_ms += ms;
-    timing.launches_channelizer += 2; timing.launches_noise += 2; timing.launches_window += 1;
+    for (int i = 0; i < 5; i++) {
+        HIPCHK(this, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        timing.kernel_ms[i] += ms;
+        timing.kernel_launches[i] += 1;
+    }
+    HIPCHK(this, hipEventElapsedTime(&ms, ev[0], ev[5])); timing.total_ms += ms;
+    timing.batches += 1;
     timing.slots += (uint64_t)S;
     timing.samples += (uint64_t)S * (uint64_t)d.samples_per_slot;
 

@@ -1,7 +1,8 @@
 // kernels.hip.h -- CDNA4 (gfx950) kernels of the sniffer hot path.  Wave = 64 lanes.
 //
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit
-// fmaf(), mirroring oracle/bt_oracle.c so that the DIRECT path is bit-exact against it.
+// fmaf(), in the order DESIGN.md fixes, so that the DIRECT path is bit-exact against the
+// CPU oracle kept under oracle/ (test infrastructure; never linked here).
 //
 // Data layout in HBM:
 //   x      interleaved complex64 input stream segment, [n] float2

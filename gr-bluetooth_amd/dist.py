@@ -1,0 +1,78 @@
+"""Time-partitioned multi-GPU layer.
+
+The IQ stream is split into contiguous slot ranges, one per rank, each with a left halo of
+history()-1 samples (exactly what the reference's GNU Radio history provides at a window
+start: lib/multi_block.cc:102-119).  No collective touches the data path; the only
+exchange is one gather of the fixed-size hit records per batch (RCCL over xGMI on the
+GPU box via backend "nccl", gloo in the CPU tests).
+"""
+import numpy as np
+
+HIT_INT_FIELDS = ("slot", "channel", "kind", "offset", "lap", "ac_errors", "nsym")
+
+
+def partition_slots(total_slots, world_size, rank):
+    """Contiguous, balanced slot ranges: returns (first_slot, n_slots) of `rank`."""
+    base, rem = divmod(int(total_slots), int(world_size))
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def segment_bounds(first_slot, n_slots, history, samples_per_slot):
+    """Absolute sample range [start, start+n) a rank needs for its slots, halo included.
+    start may be negative (the zeros GNU Radio pre-fills before the stream)."""
+    if n_slots <= 0:
+        return first_slot * samples_per_slot, 0
+    start = first_slot * samples_per_slot - (history - 1)
+    return start, history + (n_slots - 1) * samples_per_slot
+
+
+def hits_to_arrays(hits):
+    """List of hit records (btgpu Hit or oracle Hit) -> (int64 [n,7], float64 [n])."""
+    n = len(hits)
+    ints = np.zeros((n, len(HIT_INT_FIELDS)), np.int64)
+    snr = np.zeros(n, np.float64)
+    for i, h in enumerate(hits):
+        for j, f in enumerate(HIT_INT_FIELDS):
+            ints[i, j] = getattr(h, f)
+        snr[i] = getattr(h, "snr_db", getattr(h, "snr", 0.0))
+    return ints, snr
+
+
+def sort_hits(ints, snr):
+    """Order the reference's loops print in: slot, channel, kind, offset."""
+    if len(ints) == 0:
+        return ints, snr
+    order = np.lexsort((ints[:, 3], ints[:, 2], ints[:, 1], ints[:, 0]))
+    return ints[order], snr[order]
+
+
+def gather_hits(ints, snr, group=None, device="cpu"):
+    """Gather every rank's hit records; every rank returns the globally sorted (ints, snr).
+
+    Uses two all_gathers (counts, then records padded to the maximum count): fixed-size,
+    latency-bound traffic of tens of bytes per detected packet."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sort_hits(ints, snr)
+    world = dist.get_world_size(group)
+    n = torch.tensor([len(ints)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+    nf = len(HIT_INT_FIELDS)
+    pad_i = torch.zeros((m, nf), dtype=torch.int64, device=device)
+    pad_s = torch.zeros((m,), dtype=torch.float64, device=device)
+    if len(ints):
+        pad_i[:len(ints)] = torch.from_numpy(np.ascontiguousarray(ints)).to(device)
+        pad_s[:len(ints)] = torch.from_numpy(np.ascontiguousarray(snr)).to(device)
+    all_i = [torch.zeros_like(pad_i) for _ in range(world)]
+    all_s = [torch.zeros_like(pad_s) for _ in range(world)]
+    dist.all_gather(all_i, pad_i, group=group)
+    dist.all_gather(all_s, pad_s, group=group)
+    gi = np.concatenate([all_i[r][:counts[r]].cpu().numpy() for r in range(world)], axis=0)
+    gs = np.concatenate([all_s[r][:counts[r]].cpu().numpy() for r in range(world)], axis=0)
+    return sort_hits(gi, gs)

@@ -126,28 +126,17 @@ def make_capture(sample_rate, center_freq, n_slots, laps=(0x24D952,), seed=1, sn
     return iq, truth
 
 
-def make_capture_torch(sample_rate, center_freq, n_slots, device, laps=(0x24D952,), seed=1,
-                       snr_db=25.0, occupancy=0.3, cfo_hz=10e3, max_payload_bits=240,
-                       burst_batch=256):
-    """Same capture model, built with torch on `device` (bench-scale sizes).
-
-    Returns (iq float32 tensor [n, 2] interleaved I/Q on device, truth list)."""
-    import torch
-
-    rng = np.random.default_rng(seed)
+def burst_schedule(sample_rate, center_freq, slot_begin, slot_end, laps, seed, occupancy, cfo_hz,
+                   max_payload_bits):
+    """Position-deterministic burst schedule: slot k's bursts depend only on (seed, k), so any
+    rank can regenerate any part of one long stream (time-partitioned multi-GPU runs)."""
     sps = int(round(sample_rate / SYMBOL_RATE))
     slot = 625 * sps
-    n = int(n_slots) * slot
     lo, hi = visible_channels(sample_rate, center_freq)
     chans = list(range(lo, hi + 1))
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
-    sigma2 = (sample_rate / 1e6) / (10.0 ** (snr_db / 10.0))
-    iq = torch.randn((n, 2), generator=gen, device=device, dtype=torch.float32)
-    iq.mul_(math.sqrt(sigma2 / 2))
-    # schedule bursts on the host (cheap), modulate in batches on the device
     truth, sched = [], []
-    for k in range(n_slots):
+    for k in range(max(slot_begin, 0), slot_end):
+        rng = np.random.default_rng([seed, k])
         used = set()
         for lap in laps:
             if rng.random() >= occupancy:
@@ -163,8 +152,41 @@ def make_capture_torch(sample_rate, center_freq, n_slots, device, laps=(0x24D952
             ph0 = float(rng.uniform(0, 2 * np.pi))
             truth.append(dict(slot=k, channel=ch, lap=lap, start=start, nbits=len(bits)))
             sched.append((bits, start, f, ph0))
+    return truth, sched
+
+
+def make_segment_torch(sample_rate, center_freq, slot_begin, slot_end, device, laps=(0x24D952,),
+                       seed=1, snr_db=25.0, occupancy=0.3, cfo_hz=10e3, max_payload_bits=240,
+                       burst_batch=128, left_pad=0):
+    """Samples [slot_begin*slot - left_pad, slot_end*slot) of the synthetic stream `seed`, built
+    with torch on `device`.  Samples at negative absolute index are zero (GNU Radio history
+    pre-fill).  Noise of slot k is seeded by (seed, k); bursts by burst_schedule().
+
+    Returns (iq float32 tensor [n, 2] interleaved I/Q on device, truth list)."""
+    import torch
+
+    sps = int(round(sample_rate / SYMBOL_RATE))
+    slot = 625 * sps
+    pad_slots = (left_pad + slot - 1) // slot
+    k0 = slot_begin - pad_slots
+    a0 = slot_begin * slot - left_pad                 # absolute index of iq[0]
+    n = slot_end * slot - a0
+    iq = torch.zeros((n, 2), device=device, dtype=torch.float32)
+    sigma2 = (sample_rate / 1e6) / (10.0 ** (snr_db / 10.0))
+    gen = torch.Generator(device=device)
+    for k in range(max(k0, 0), slot_end):
+        gen.manual_seed((seed * 1000003 + k) & 0x7FFFFFFFFFFFFFFF)
+        blk = torch.randn((slot, 2), generator=gen, device=device, dtype=torch.float32)
+        blk.mul_(math.sqrt(sigma2 / 2))
+        lo_a, hi_a = max(k * slot, a0), (k + 1) * slot
+        if hi_a > lo_a:
+            iq[lo_a - a0:hi_a - a0] = blk[lo_a - k * slot:]
+    # bursts that can overlap the segment: those starting up to one max-burst earlier
     max_bits = 72 + 54 + max_payload_bits
     L = max_bits * sps
+    back = (L + slot - 1) // slot
+    truth, sched = burst_schedule(sample_rate, center_freq, k0 - back, slot_end, laps, seed, occupancy,
+                                  cfo_hz, max_payload_bits)
     g = torch.tensor(gaussian_pulse(sps), device=device, dtype=torch.float64)
     pad = (len(g) - 1) // 2
     flat = iq.view(-1)
@@ -186,10 +208,12 @@ def make_capture_torch(sample_rate, center_freq, n_slots, device, laps=(0x24D952
         re = torch.cos(phase).to(torch.float32)
         im = torch.sin(phase).to(torch.float32)
         for i, (_, start, _, _) in enumerate(batch):
-            ln = min(lens[i], n - start)
-            if ln <= 0:
+            lo_a = max(start, a0)
+            hi_a = min(start + lens[i], a0 + n)
+            if hi_a <= lo_a:
                 continue
-            seg = flat[2 * start: 2 * (start + ln)].view(ln, 2)
-            seg[:, 0] += re[i, :ln]
-            seg[:, 1] += im[i, :ln]
+            seg = flat[2 * (lo_a - a0): 2 * (hi_a - a0)].view(hi_a - lo_a, 2)
+            seg[:, 0] += re[i, lo_a - start:hi_a - start]
+            seg[:, 1] += im[i, lo_a - start:hi_a - start]
+    truth = [t for t in truth if t["slot"] >= 0]
     return iq, truth

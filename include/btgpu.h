@@ -96,16 +96,21 @@ typedef struct btgpu_hit {
     double   snr_db;      /* 10 log10(E_on / E_off) of the (slot, channel) window           */
 } btgpu_hit;
 
-/* Per-stage GPU time of the most recent btgpu_work/btgpu_process_device call,
- * measured with HIP events on the handle's stream. */
+/* Per-kernel GPU time of the most recent btgpu_work/btgpu_process_device call, measured
+ * with HIP events recorded on the stream the kernels are launched on. */
+#define BTGPU_K_DDC_CHANNEL   0   /* channel bank (direct DDC or polyphase channelizer) */
+#define BTGPU_K_DEMOD_ENERGY  1   /* quadrature demod + |Y|^2 block sums (0 when fused)  */
+#define BTGPU_K_DDC_NOISE     2   /* noise bank                                          */
+#define BTGPU_K_NOISE_ENERGY  3   /* noise |Y|^2 per-slot sums                           */
+#define BTGPU_K_WINDOW        4   /* squelch + M&M + slicer + access-code search         */
+#define BTGPU_K_COUNT         8
 typedef struct btgpu_timing {
-    float channelizer_ms;     /* channel bank (+ fused demod/energy)     */
-    float noise_ms;           /* noise bank + squelch energies           */
-    float window_ms;          /* squelch decision + M&M + slicer + search */
-    float total_ms;
-    uint64_t samples;         /* new complex samples consumed             */
+    float    kernel_ms[BTGPU_K_COUNT];        /* summed over launches                  */
+    uint32_t kernel_launches[BTGPU_K_COUNT];
+    float    total_ms;                        /* first kernel start to last kernel end */
+    uint32_t batches;
+    uint64_t samples;                         /* new complex samples consumed          */
     uint64_t slots;
-    uint32_t launches_channelizer, launches_noise, launches_window, reserved;
 } btgpu_timing;
 
 /* ---- host-only helpers (no GPU needed) ---- */
@@ -124,8 +129,10 @@ const char *btgpu_last_error(const btgpu_handle *h);
 
 /* ---- work() ----
  * `items` is what GNU Radio hands to work(): interleaved float32 I/Q, history()-1 old
- * samples followed by the new ones, `n_items` complex samples in total.  Processes
- * S = (n_items - history()) / samples_per_slot + 1 slots (0 if n_items < history()),
+ * samples followed by the new ones, `n_items` complex samples in total (so GNU Radio's
+ * noutput_items = n_items - (history()-1)).  Processes S = noutput_items / samples_per_slot
+ * whole slots -- the reference processes exactly one per call and returns samples_per_slot
+ * (lib/multi_sniffer_impl.cc:165); S consecutive reference calls give the same records --
  * queues their hits, stores S*samples_per_slot in *consumed.  Returns BTGPU_OK or <0. */
 int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *consumed);
 

@@ -23,7 +23,7 @@ print("HIT LIST IDENTICAL:", ok)
 if not ok:
     for h in ohits: print("O", h.key(), h.snr)
     for h in ghits: print("G", h.key(), h.snr_db)
-tm = b.timing(); print("timing ms", tm.channelizer_ms, tm.noise_ms, tm.window_ms, tm.total_ms, tm.slots)
+tm = b.timing(); print("timing ms", list(tm.kernel_ms)[:5], tm.total_ms, tm.slots)
 # intermediates of the last batch: Y / d for one channel, window 0..
 S = done
 for ch in (71, 75, 78):

@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the time partition + hit gather
+(gr_bluetooth_amd/dist.py).  The per-rank processor here is the oracle (checker standing in
+for the GPU, which does not exist in this container); the partition, halo and gather logic is
+the product's and must reproduce the single-process hit list."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_and_segment_bounds(pkg):
+    import importlib
+    d = importlib.import_module("gr_bluetooth_amd.dist")
+    for total, world in ((20, 2), (1600, 8), (7, 3), (3, 8)):
+        parts = [d.partition_slots(total, world, r) for r in range(world)]
+        assert sum(n for _, n in parts) == total
+        pos = 0
+        for first, n in parts:
+            assert first == pos
+            pos += n
+    start, n = d.segment_bounds(10, 5, 31601, 5000)
+    assert (start, n) == (10 * 5000 - 31600, 31601 + 4 * 5000)
+    assert d.segment_bounds(0, 0, 31601, 5000)[1] == 0
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import importlib
+    import torch.distributed as dist
+    from conftest import load_pkg
+    load_pkg()
+    bd = importlib.import_module("gr_bluetooth_amd.dist")
+    synth = importlib.import_module("gr_bluetooth_amd.synth")
+    import pyoracle as po
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fs, fc, total = 8e6, 2476.5e6, 18
+    iq, _ = synth.make_capture(fs, fc, total, laps=(0x24D952, 0x4831DD), seed=21, snr_db=24, occupancy=0.5)
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    H, slot = o.history, o.slot
+    first, n = bd.partition_slots(total, world, rank)
+    start, cnt = bd.segment_bounds(first, n, H, slot)
+    full = np.concatenate([np.zeros(H - 1, np.complex64), iq])       # GNU Radio pre-fill
+    seg = full[start + (H - 1): start + (H - 1) + cnt]               # this rank's samples incl. halo
+    hits = []
+    for k in range(n):                                               # one work() per slot on the segment
+        for h in o.work(seg[k * slot: k * slot + H], first + k):
+            hits.append(h)
+    ints, snr = bd.hits_to_arrays(hits)
+    gi, gs = bd.gather_hits(ints, snr, device="cpu")
+    if rank == 0:
+        np.save(os.path.join(tmp, "gathered.npy"), gi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_time_partition_matches_single_process(pkg, po, synth, tmp_path):
+    import importlib
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    gi = np.load(os.path.join(str(tmp_path), "gathered.npy"))
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 18, laps=(0x24D952, 0x4831DD), seed=21, snr_db=24, occupancy=0.5)
+    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq)
+    bd = importlib.import_module("gr_bluetooth_amd.dist")
+    wi, _ = bd.sort_hits(*bd.hits_to_arrays(want))
+    assert len(want) > 0
+    assert np.array_equal(gi, wi)
