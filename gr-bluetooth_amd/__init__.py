@@ -112,6 +112,13 @@ def lib():
     if not os.path.exists(_SO):
         raise ImportError("libbtgpu.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C gr-bluetooth_amd/csrc` (no CPU fallback exists)")
+    try:
+        # The PyTorch ROCm wheel bundles its own libamdhip64/libhsa-runtime64.  Two HIP runtimes
+        # in one process cannot both own the GPU, so when torch is installed it is imported
+        # first and libbtgpu.so then binds to the runtime torch already loaded (same SONAME).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(_SO)
     vp = ctypes.c_void_p
     L.btgpu_design_query.restype = ctypes.c_int
