@@ -28,8 +28,8 @@ _SO = os.path.join(_HERE, "libbtgpu.so")
 OK, EINVAL, ENOMEM, EDEVICE, ENODEVICE, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 MODE_LAP, MODE_SNIFFER = 0, 1
 CHANNELIZER_AUTO, CHANNELIZER_DIRECT, CHANNELIZER_POLYPHASE = 0, 1, 2
-SQUELCH_DIRECT, SQUELCH_AUTO = 0, 1
-FLAG_LE = 1
+SQUELCH_AUTO, SQUELCH_DIRECT, SQUELCH_STAGED = 0, 1, 2
+FLAG_LE, FLAG_DEBUG_Y = 1, 2
 KIND_AC, KIND_AA = 0, 1
 
 
@@ -49,7 +49,8 @@ class Design(ctypes.Structure):
                 ("high_channel", ctypes.c_int32), ("first_channel_sample", ctypes.c_int32),
                 ("first_noise_sample", ctypes.c_int32), ("history", ctypes.c_int32),
                 ("ddc_out", ctypes.c_int32), ("noise_out", ctypes.c_int32),
-                ("channelizer", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("channelizer", ctypes.c_int32), ("squelch", ctypes.c_int32),
+                ("left_margin", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
 
 
 class Hit(ctypes.Structure):
@@ -144,7 +145,7 @@ def lib():
     L.btgpu_push.restype = ctypes.c_int
     L.btgpu_push.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t]
     L.btgpu_process_device.restype = ctypes.c_int
-    L.btgpu_process_device.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64, vp]
+    L.btgpu_process_device.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64, vp]
     L.btgpu_poll.restype = ctypes.c_int
     L.btgpu_poll.argtypes = [vp, ctypes.POINTER(Hit), ctypes.c_int]
     L.btgpu_pending.restype = ctypes.c_int
@@ -162,7 +163,7 @@ def lib():
 
 
 def make_config(sample_rate, center_freq, squelch_db=10.0, mode=MODE_SNIFFER, device=-1,
-                channelizer=CHANNELIZER_AUTO, squelch=SQUELCH_DIRECT, flags=0, max_batch_slots=0,
+                channelizer=CHANNELIZER_AUTO, squelch=SQUELCH_AUTO, flags=0, max_batch_slots=0,
                 max_hits=0):
     return Config(float(sample_rate), float(center_freq), float(squelch_db), mode, device,
                   channelizer, squelch, flags, max_batch_slots, max_hits, 0)
@@ -272,9 +273,10 @@ class _MultiBlock:
         rc = self._L.btgpu_push(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(a) // 2)
         self._check(rc, "btgpu_push")
 
-    def process_device(self, dev_ptr, n_complex, first_slot, n_slots, stream=None):
-        rc = self._L.btgpu_process_device(self._h, ctypes.c_void_p(dev_ptr), n_complex, first_slot,
-                                          n_slots, ctypes.c_void_p(stream or 0))
+    def process_device(self, dev_ptr, n_complex, first_slot, n_slots, left_margin=0, stream=None):
+        """dev_ptr[left_margin] = absolute sample first_slot*slot-(history()-1)."""
+        rc = self._L.btgpu_process_device(self._h, ctypes.c_void_p(dev_ptr), n_complex, left_margin,
+                                          first_slot, n_slots, ctypes.c_void_p(stream or 0))
         self._check(rc, "btgpu_process_device")
 
     def poll(self, max_hits=1 << 16):

@@ -14,6 +14,7 @@
 #include "btgpu.h"
 #include "design.h"
 #include "kernels.hip.h"
+#include "pfb100.hip.h"
 
 using namespace btgpu;
 
@@ -60,6 +61,10 @@ bool pick_shape(int D, int ntp, LaunchShape &s)
 
 struct btgpu_handle {
     Design des;
+    FastPath fp;
+    bool use_pfb = false, use_staged = false, keep_Y = false;
+    int margin = 0;                  // samples in front of window 0 the kernels may read
+    std::vector<float> pre;          // the `margin` samples preceding the next work() buffer
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -76,6 +81,10 @@ struct btgpu_handle {
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_winlen, d_hits, d_hitcount;
+    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile;
+    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w;
+    long long zstride = 0;
+    int ntiles_max = 0;
     LaunchShape shape_ch, shape_n;
 
     // last-batch bookkeeping (debug fetch)
@@ -115,20 +124,22 @@ struct btgpu_handle {
     {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
-                         &d_eon, &d_eoff, &d_snr, &d_winlen, &d_hits, &d_hitcount};
+                         &d_eon, &d_eoff, &d_snr, &d_winlen, &d_hits, &d_hitcount,
+                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile,
+                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     }
 
-    int process_batch(const float2 *d_x, size_t x_len, uint64_t abs_first_slot, int S, hipStream_t st);
+    int process_batch(const float2 *d_x, size_t x_len, long long w0, uint64_t abs_first_slot, int S, hipStream_t st);
 };
 
 // ---------------------------------------------------------------------------------------
-// one batch of S slots; d_x[0] = first sample of window 0 of the batch
+// one batch of S slots; d_x[w0] = first sample of window 0 of the batch, d_x[0..w0) = margin
 // ---------------------------------------------------------------------------------------
-int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, uint64_t abs_first_slot, int S,
-                                hipStream_t st)
+int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, uint64_t abs_first_slot,
+                                int S, hipStream_t st)
 {
     const btgpu_design &d = des.d;
     const int nch = d.high_channel - d.low_channel + 1;
@@ -142,35 +153,81 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, uint64_t abs_fi
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, sizeof(unsigned int), st));
     HIPCHK(this, hipEventRecord(ev[0], st));
 
-    // ---- K1 + K2: channel bank, demod, block energies ----
-    {
+    // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 block sums P, Pt ----
+    if (use_pfb) {
+        const PfbBank &b = fp.channel;
+        constexpr int NT = 26, TT = NT - 1;
+        PfbParams p{};
+        p.x = d_x; p.x_len = (long long)x_len; p.x0 = w0 + d.first_channel_sample;
+        p.D = b.D; p.T = G;
+        p.taps = (const float2 *)d_pfb_taps_ch.p; p.twiddle = (const float2 *)d_pfb_tw.p;
+        p.nsel = nch; p.binpos = (const int *)d_binpos_ch.p; p.krot = (const float2 *)d_krot_ch.p;
+        p.rot_period = b.rot_period;
+        p.ntiles = (int)((G + TT - 1) / TT);
+        p.d = (float *)d_d.p; p.ptile = (double *)d_ptile.p; p.phead = (double *)d_Pt.p;
+        p.tiles_per_block = ops / TT; p.tail = des.tail; p.nb = nb;
+        p.atan_tab = (const float *)d_atan.p; p.gain = des.demod_gain;
+        p.Z = keep_Y ? (float2 *)d_Y.p : nullptr; p.zstride = ystride;
+        const int span = b.D * (NT - 1) + b.Q * 100, wsz = nch * NT;
+        const int asz = ((span > wsz ? span : wsz) + 1) & ~1;
+        const size_t lds = (size_t)(asz + NT * 100) * sizeof(float2) + (size_t)(nch * NT + 257) * sizeof(float);
+        if (b.real_taps)
+            hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true>), dim3(p.ntiles), dim3(256), lds, st, p);
+        else
+            hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true>), dim3(p.ntiles), dim3(256), lds, st, p);
+        HIPCHK(this, hipEventRecord(ev[1], st));
+        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 255) / 256), dim3(256), 0, st,
+                           (const double *)d_ptile.p, p.ntiles, p.tiles_per_block, (double *)d_P.p, nb, nch);
+    } else {
         const LaunchShape &s = shape_ch;
         dim3 grid((unsigned)((G + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
         hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len,
-                           (long long)d.first_channel_sample, d.decimation, des.channel.ntp, s.JC,
+                           w0 + (long long)d.first_channel_sample, d.decimation, des.channel.ntp, s.JC,
                            (const float2 *)d_taps_ch.p, (const float2 *)d_rot_ch.p, des.channel.rot_period,
                            (const double *)d_rotstep_ch.p, (float2 *)d_Y.p, G, ystride, nch);
         HIPCHK(this, hipEventRecord(ev[1], st));
         dim3 g2((unsigned)nb, (unsigned)nch);
         hipLaunchKernelGGL(demod_energy_kernel<true>, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
                            ystride, ops, des.tail, (const float *)d_atan.p, des.demod_gain,
-                           (float *)d_d.p, (double *)d_P.p, (double *)d_Pt.p, nb);
+                           (float *)d_d.p, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     }
     HIPCHK(this, hipEventRecord(ev[2], st));
 
-    // ---- noise bank + per-slot energies ----
-    {
+    // ---- noise bank -> Qn[c][k] = noise_out * E_off ----
+    if (use_staged) {
+        const NoiseStage &ns = fp.noise;
+        const PfbBank &b = ns.pfb;
+        constexpr int NT = 10;
+        const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+        PfbParams p{};
+        p.x = d_x; p.x_len = (long long)x_len;
+        p.x0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
+        p.D = b.D; p.T = Tn;
+        p.taps = (const float2 *)d_pfb_taps_n.p; p.twiddle = (const float2 *)d_pfb_tw.p;
+        p.nsel = nch; p.binpos = (const int *)d_binpos_n.p; p.krot = (const float2 *)d_krot_n.p;
+        p.rot_period = b.rot_period;
+        p.ntiles = (int)((Tn + NT - 1) / NT);
+        p.Z = (float2 *)d_Z.p; p.zstride = zstride;
+        const int span = b.D * (NT - 1) + b.Q * 100;
+        const size_t lds = (size_t)(((span + 1) & ~1) + NT * 100) * sizeof(float2);
+        hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false>), dim3(p.ntiles), dim3(256), lds, st, p);
+        HIPCHK(this, hipEventRecord(ev[3], st));
+        const size_t lds2 = (size_t)((ns.nw + ns.L3 + 1) & ~1) * sizeof(float2) + ns.L3 * sizeof(float);
+        hipLaunchKernelGGL(noise_stage2_kernel, dim3(S, nch), dim3(256), lds2, st, (const float2 *)d_Z.p,
+                           zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p, (const double *)d_w.p,
+                           (double *)d_Q.p, S);
+    } else {
         const LaunchShape &s = shape_n;
         dim3 grid((unsigned)((Gn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
         hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len,
-                           (long long)d.first_noise_sample, d.decimation, des.noise.ntp, s.JC,
+                           w0 + (long long)d.first_noise_sample, d.decimation, des.noise.ntp, s.JC,
                            (const float2 *)d_taps_n.p, (const float2 *)d_rot_n.p, des.noise.rot_period,
                            (const double *)d_rotstep_n.p, (float2 *)d_Yn.p, Gn, ystride_n, nch);
         HIPCHK(this, hipEventRecord(ev[3], st));
         dim3 g2((unsigned)S, (unsigned)nch);
         hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, st, (const float2 *)d_Yn.p, Gn,
                            ystride_n, ops, 0, (const float *)nullptr, 0.f, (float *)nullptr,
-                           (double *)d_Q.p, (double *)nullptr, S);
+                           (double *)d_Q.p, (double *)nullptr, S, nch);
     }
     HIPCHK(this, hipEventRecord(ev[4], st));
 
@@ -319,8 +376,26 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     if (!h) return BTGPU_ENOMEM;
     int rc = make_design(*cfg, h->des);
     if (rc != BTGPU_OK) { delete h; return rc; }
-    if (h->des.d.channelizer != BTGPU_CHANNELIZER_DIRECT) { delete h; return BTGPU_EUNSUPPORTED; }
-
+    {
+        FastPath *fp = &h->fp;
+        int frc = make_fast_path(h->des, *fp);
+        const bool pfb_ok = frc == BTGPU_OK && fp->channel.available && fp->channel.Q == 7 && fp->channel.S == 1 &&
+                            h->des.outs_per_slot % 25 == 0;
+        const bool staged_ok = pfb_ok && fp->noise.available && fp->noise.pfb.Q == 15 && fp->noise.pfb.S == 5;
+        int ch = cfg->channelizer, sq = cfg->squelch;
+        if (ch == BTGPU_CHANNELIZER_AUTO) ch = pfb_ok ? BTGPU_CHANNELIZER_POLYPHASE : BTGPU_CHANNELIZER_DIRECT;
+        if (sq == BTGPU_SQUELCH_AUTO) sq = staged_ok ? BTGPU_SQUELCH_STAGED : BTGPU_SQUELCH_DIRECT;
+        if ((ch == BTGPU_CHANNELIZER_POLYPHASE && !pfb_ok) || (sq == BTGPU_SQUELCH_STAGED && !staged_ok) ||
+            (ch != BTGPU_CHANNELIZER_POLYPHASE && ch != BTGPU_CHANNELIZER_DIRECT) ||
+            (sq != BTGPU_SQUELCH_STAGED && sq != BTGPU_SQUELCH_DIRECT)) { delete h; return BTGPU_EUNSUPPORTED; }
+        h->use_pfb = ch == BTGPU_CHANNELIZER_POLYPHASE;
+        h->use_staged = sq == BTGPU_SQUELCH_STAGED;
+        h->keep_Y = !h->use_pfb || (cfg->flags & BTGPU_FLAG_DEBUG_Y);
+        h->margin = h->use_staged ? kNoiseMargin : 0;
+        h->des.d.channelizer = ch;
+        h->des.d.squelch = sq;
+        h->des.d.left_margin = h->margin;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete h; return BTGPU_ENODEVICE; }
     int dev = cfg->device;
@@ -344,7 +419,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         return fail(BTGPU_EUNSUPPORTED);
 
     // batch size: bounded by ~3 GiB of intermediates
-    size_t per_slot = (size_t)nch * ops * (sizeof(float2) * 2 + sizeof(float)) + (size_t)d.samples_per_slot * 8;
+    size_t per_slot = (size_t)nch * ops * ((h->keep_Y ? sizeof(float2) : 0) + (h->use_staged ? 2 : sizeof(float2)) + sizeof(float)) + (size_t)d.samples_per_slot * 8;
     int S = cfg->max_batch_slots > 0 ? cfg->max_batch_slots : 512;
     size_t cap = (size_t)3 << 30;
     if ((size_t)S * per_slot > cap) S = (int)std::max<size_t>(8, cap / per_slot);
@@ -362,7 +437,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != BTGPU_OK) { int c__ = rc__; std::string m__ = h->err; \
         if (getenv("BTGPU_VERBOSE")) fprintf(stderr, "btgpu_create: %s\n", m__.c_str()); return fail(c__); } } while (0)
-    TRY(h->alloc(h->d_in, (h->in_cap + 64) * sizeof(float2)));
+    TRY(h->alloc(h->d_in, (h->in_cap + h->margin + 64) * sizeof(float2)));
     TRY(h->upload(h->d_taps_ch, des.channel.taps.data(), des.channel.taps.size() * sizeof(float)));
     TRY(h->upload(h->d_taps_n, des.noise.taps.data(), des.noise.taps.size() * sizeof(float)));
     TRY(h->upload(h->d_rot_ch, des.channel.rot.data(), des.channel.rot.size() * sizeof(float)));
@@ -376,9 +451,30 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_rotstep_ch, st.data(), st.size() * sizeof(double)));
         TRY(h->upload(h->d_rotstep_n, sn.data(), sn.size() * sizeof(double)));
     }
-    TRY(h->alloc(h->d_Y, (size_t)nch * h->ystride * sizeof(float2)));
-    TRY(h->alloc(h->d_Yn, (size_t)nch * h->ystride_n * sizeof(float2)));
-    TRY(h->alloc(h->d_d, (size_t)nch * h->ystride * sizeof(float)));
+    if (h->keep_Y) TRY(h->alloc(h->d_Y, (size_t)nch * h->ystride * sizeof(float2)));
+    if (!h->use_staged) TRY(h->alloc(h->d_Yn, (size_t)nch * h->ystride_n * sizeof(float2)));
+    if (h->use_pfb) {
+        const PfbBank &b = h->fp.channel;
+        h->ntiles_max = (int)((G + 24) / 25);
+        TRY(h->upload(h->d_pfb_taps_ch, b.taps.data(), b.taps.size() * sizeof(float)));
+        TRY(h->upload(h->d_pfb_tw, b.twiddle.data(), b.twiddle.size() * sizeof(float)));
+        TRY(h->upload(h->d_binpos_ch, b.binpos.data(), b.binpos.size() * sizeof(int)));
+        TRY(h->upload(h->d_krot_ch, b.krot.data(), b.krot.size() * sizeof(float)));
+        TRY(h->alloc(h->d_ptile, (size_t)nch * h->ntiles_max * sizeof(double)));
+    }
+    if (h->use_staged) {
+        const NoiseStage &ns = h->fp.noise;
+        const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+        h->zstride = (Tn + 10 + 63) / 64 * 64;
+        TRY(h->upload(h->d_pfb_taps_n, ns.pfb.taps.data(), ns.pfb.taps.size() * sizeof(float)));
+        if (!h->d_pfb_tw.p) TRY(h->upload(h->d_pfb_tw, ns.pfb.twiddle.data(), ns.pfb.twiddle.size() * sizeof(float)));
+        TRY(h->upload(h->d_binpos_n, ns.pfb.binpos.data(), ns.pfb.binpos.size() * sizeof(int)));
+        TRY(h->upload(h->d_krot_n, ns.pfb.krot.data(), ns.pfb.krot.size() * sizeof(float)));
+        TRY(h->alloc(h->d_Z, (size_t)nch * h->zstride * sizeof(float2)));
+        TRY(h->upload(h->d_h3, ns.h3.data(), ns.h3.size() * sizeof(float)));
+        TRY(h->upload(h->d_w, ns.weights.data(), ns.weights.size() * sizeof(double)));
+    }
+    TRY(h->alloc(h->d_d, (size_t)nch * (h->ystride + 64) * sizeof(float)));
     TRY(h->alloc(h->d_P, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Pt, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Q, (size_t)nch * S * sizeof(double)));
@@ -395,6 +491,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    h->pre.assign((size_t)h->margin * 2, 0.f);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]
     *out = h;
@@ -419,13 +519,13 @@ int btgpu_get_design(const btgpu_handle *h, btgpu_design *out)
 int btgpu_history(const btgpu_handle *h) { return h ? h->des.d.history : BTGPU_EINVAL; }
 const char *btgpu_last_error(const btgpu_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
-int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, uint64_t first_slot,
-                         uint64_t n_slots, void *hip_stream)
+int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, size_t left_margin,
+                         uint64_t first_slot, uint64_t n_slots, void *hip_stream)
 {
     if (!h || !d_iq) return BTGPU_EINVAL;
     const btgpu_design &d = h->des.d;
     if (n_slots == 0) return BTGPU_OK;
-    const size_t need = (size_t)d.history + (size_t)(n_slots - 1) * d.samples_per_slot;
+    const size_t need = left_margin + (size_t)d.history + (size_t)(n_slots - 1) * d.samples_per_slot;
     if (n_complex < need) return BTGPU_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
@@ -433,9 +533,8 @@ int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, ui
     int rc_all = BTGPU_OK;
     for (uint64_t s0 = 0; s0 < n_slots; s0 += (uint64_t)h->max_slots) {
         const int S = (int)std::min<uint64_t>((uint64_t)h->max_slots, n_slots - s0);
-        const float2 *x = (const float2 *)d_iq + (size_t)s0 * d.samples_per_slot;
-        const size_t xlen = n_complex - (size_t)s0 * d.samples_per_slot;
-        int rc = h->process_batch(x, xlen, first_slot + s0, S, st);
+        const long long w0 = (long long)left_margin + (long long)s0 * d.samples_per_slot;
+        int rc = h->process_batch((const float2 *)d_iq, n_complex, w0, first_slot + s0, S, st);
         if (rc == BTGPU_EOVERFLOW) rc_all = rc;
         else if (rc != BTGPU_OK) return rc;
     }
@@ -447,7 +546,7 @@ int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *cons
     if (!h || !items) return BTGPU_EINVAL;
     const btgpu_design &d = h->des.d;
     if (consumed) *consumed = 0;
-    const size_t H = (size_t)d.history, slot = (size_t)d.samples_per_slot;
+    const size_t H = (size_t)d.history, slot = (size_t)d.samples_per_slot, mg = (size_t)h->margin;
     if (n_items < H - 1 + slot) return BTGPU_OK;                 // not a whole slot of new items yet
     const uint64_t n_slots = (n_items - (H - 1)) / slot;
     HIPCHK(h, hipSetDevice(h->device));
@@ -456,14 +555,32 @@ int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *cons
     for (uint64_t s0 = 0; s0 < n_slots; s0 += (uint64_t)h->max_slots) {
         const int S = (int)std::min<uint64_t>((uint64_t)h->max_slots, n_slots - s0);
         const size_t seg = H + (size_t)(S - 1) * slot;
-        HIPCHK(h, hipMemcpyAsync(h->d_in.p, items + 2 * (size_t)s0 * slot, seg * sizeof(float2),
-                                 hipMemcpyHostToDevice, h->stream));
-        int rc = h->process_batch((const float2 *)h->d_in.p, seg, h->push_slot + s0, S, h->stream);
+        const size_t i0 = (size_t)s0 * slot;                     // item index of window 0 of this batch
+        // staging buffer = [margin samples preceding items[i0] | items[i0 .. i0+seg)]
+        size_t from_items = std::min(mg, i0), from_pre = mg - from_items;
+        if (from_pre) {
+            // pre holds the mg samples before items[0]; we need its last from_pre samples
+            HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->pre.data() + 2 * (mg - from_pre), from_pre * sizeof(float2),
+                                     hipMemcpyHostToDevice, h->stream));
+        }
+        HIPCHK(h, hipMemcpyAsync((float2 *)h->d_in.p + from_pre, items + 2 * (i0 - from_items),
+                                 (from_items + seg) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        int rc = h->process_batch((const float2 *)h->d_in.p, mg + seg, (long long)mg, h->push_slot + s0, S, h->stream);
         if (rc == BTGPU_EOVERFLOW) rc_all = rc;
         else if (rc != BTGPU_OK) return rc;
     }
     h->push_slot += n_slots;
-    if (consumed) *consumed = (size_t)n_slots * slot;
+    const size_t used = (size_t)n_slots * slot;
+    if (mg) {                                                    // margin for the next call: samples before items[used]
+        std::vector<float> np(2 * mg);
+        for (size_t i = 0; i < mg; i++) {
+            long long src = (long long)used - (long long)mg + (long long)i;      // item index, may be < 0 -> old pre
+            const float *pp = src >= 0 ? items + 2 * src : h->pre.data() + 2 * (mg + src);
+            np[2 * i] = pp[0]; np[2 * i + 1] = pp[1];
+        }
+        h->pre.swap(np);
+    }
+    if (consumed) *consumed = used;
     return rc_all;
 }
 
@@ -508,16 +625,23 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
     size_t elem = 0, avail = 0;
     switch (what) {
         case 0:
-            if (c < 0 || c >= nch) return BTGPU_EINVAL;
+            if (c < 0 || c >= nch || !h->keep_Y) return BTGPU_EINVAL;
             src = (const float2 *)h->d_Y.p + (size_t)c * h->ystride; elem = sizeof(float2); avail = (size_t)h->last_G; break;
-        case 1:
+        case 1: {
             if (c < 0 || c >= nch) return BTGPU_EINVAL;
-            src = (const float *)h->d_d.p + (size_t)c * h->ystride; elem = sizeof(float); avail = (size_t)h->last_G; break;
+            avail = (size_t)h->last_G;
+            if (first >= avail) return 0;
+            count = std::min(count, avail - first);
+            if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
+            if (hipMemcpy2D(out, sizeof(float), (const float *)h->d_d.p + first * nch + c, (size_t)nch * sizeof(float),
+                            sizeof(float), count, hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
+            return (long)count;
+        }
         case 2: src = h->d_eon.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 3: src = h->d_eoff.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 4: src = h->d_snr.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 5:
-            if (c < 0 || c >= nch) return BTGPU_EINVAL;
+            if (c < 0 || c >= nch || h->use_staged) return BTGPU_EINVAL;
             src = (const float2 *)h->d_Yn.p + (size_t)c * h->ystride_n; elem = sizeof(float2);
             avail = (size_t)h->last_S * h->des.outs_per_slot; break;
         default: return BTGPU_EINVAL;

@@ -62,3 +62,47 @@ int firdes_ntaps(double fs, double transition_width);
 std::vector<float> firdes_low_pass_hann(double gain, double fs, double cutoff, double transition_width);
 
 }  // namespace btgpu
+
+// ---- polyphase (M = 100 bins of 1 MHz) fast path -----------------------------------------
+namespace btgpu {
+
+constexpr int kPfbM = 100;
+constexpr int kNoiseMargin = 4096;      // samples before a segment the staged noise path may read
+
+struct PfbBank {
+    bool available = false;
+    int D = 0;                          // hop (input samples per output instant)
+    int L = 0;                          // prototype length
+    int Q = 0;                          // taps per polyphase branch, ceil(L / 100)
+    int S = 0;                          // 2*D / 100: branch-window slide per two output instants
+    bool real_taps = false;
+    std::vector<float> taps;            // [Q*100][2]  a[j] = proto[L-1-j] * exp(-j 2 pi delta j / 100)
+    std::vector<float> twiddle;         // [100][2]    exp(-j 2 pi m1 p2 / 100) at index m1*10 + p2
+    std::vector<int> binpos;            // [nch] position of the channel's bin in the 10x10 FFT output
+    int rot_period = 0;
+    std::vector<float> krot;            // [nch][rot_period][2]  C_m * exp(-j 2 pi f D t / fs)
+};
+
+struct NoiseStage {
+    bool available = false;
+    int R = 0;                          // stage-1 hop = 5 * decimation
+    int L1 = 0;                         // B-spline prototype length
+    int L3 = 0;                         // stage-2 taps at the stage-1 output rate
+    int Jm = 0;                         // quadrature edge half-width (stage-2 outputs)
+    int pad = 0;                        // composite length excess / 2
+    int nw = 0;                         // quadrature weights per slot = outs + 2*Jm
+    int outs = 0;                       // stage-2 outputs per slot (slot / R)
+    std::vector<float> h3;              // [L3]
+    std::vector<double> weights;        // [nw]
+    double fit_l1_error = 0;            // ||composite - h_noise||_1 / ||h_noise||_1
+    PfbBank pfb;                        // stage 1
+};
+
+struct FastPath {
+    PfbBank channel;
+    NoiseStage noise;
+};
+
+int make_fast_path(const Design &des, FastPath &fp);
+
+}  // namespace btgpu

@@ -1,0 +1,256 @@
+// design_fast.cc -- host design of the polyphase fast path (DESIGN.md "Fast path"):
+//  * channel bank: the SAME 667-tap prototype as the direct form, evaluated as a 100-branch
+//    polyphase filter + 100-point DFT (exact restructuring; float rounding differs);
+//  * noise bank: the reference's 20001-tap 22.5 kHz low-pass is replaced by an equivalent
+//    two-stage cascade -- stage 1: polyphase bank with an order-6 B-spline prototype at hop
+//    R = 5*decim (deep nulls at every alias of the noise band), stage 2: an L3-tap FIR at
+//    the stage-1 rate whose coefficients are the least-squares fit that makes the COMPOSITE
+//    impulse response equal the reference filter (fit error ~1e-6 of the DC gain) -- and the
+//    per-slot mean |y|^2 is taken with band-limited quadrature weights on the stage-2 grid.
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "design.h"
+
+namespace btgpu {
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+void phasor_turns(double turns, float &re, float &im)
+{
+    double t = turns - std::floor(turns);
+    double q4 = t * 4.0;
+    double qr = std::round(q4);
+    if (std::fabs(q4 - qr) < 1e-12) {
+        switch (((int)qr) & 3) {
+            case 0: re = 1.f; im = 0.f; return;
+            case 1: re = 0.f; im = 1.f; return;
+            case 2: re = -1.f; im = 0.f; return;
+            default: re = 0.f; im = -1.f; return;
+        }
+    }
+    re = (float)std::cos(2.0 * kPi * t);
+    im = (float)std::sin(2.0 * kPi * t);
+}
+
+long long gcdll(long long a, long long b)
+{
+    a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+    while (b) { long long t = a % b; a = b; b = t; }
+    return a;
+}
+
+// bins are 1 MHz apart: channel offset = (m + delta) MHz with integer m, delta in [0,1)
+bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::vector<double> &foff_hz,
+               double fs)
+{
+    const int M = kPfbM;
+    if (std::fabs(fs - 100e6) > 1e-3) return false;
+    if ((2 * D) % M != 0) return false;
+    const int nch = (int)foff_hz.size();
+    const double lowoff = foff_hz[0] / 1e6;
+    const double delta = lowoff - std::floor(lowoff);
+    b.D = D;
+    b.L = (int)proto.size();
+    b.Q = (b.L + M - 1) / M;
+    b.S = 2 * D / M;
+    b.real_taps = std::fabs(delta) < 1e-12;
+    b.taps.assign((size_t)b.Q * M * 2, 0.f);
+    for (int j = 0; j < b.L; j++) {
+        float wr, wi;
+        phasor_turns(-delta * j / M, wr, wi);
+        const double h = proto[b.L - 1 - j];
+        b.taps[2 * j + 0] = (float)(h * wr);
+        b.taps[2 * j + 1] = (float)(h * wi);
+    }
+    b.twiddle.resize(200);
+    for (int m1 = 0; m1 < 10; m1++)
+        for (int p2 = 0; p2 < 10; p2++) {
+            float wr, wi;
+            phasor_turns(-(double)(m1 * p2) / 100.0, wr, wi);
+            b.twiddle[2 * (m1 * 10 + p2) + 0] = wr;
+            b.twiddle[2 * (m1 * 10 + p2) + 1] = wi;
+        }
+    // derotation period
+    long long period = 1;
+    for (int c = 0; c < nch; c++) {
+        // turns per output = -foff * D / fs ; foff in Hz integer
+        long long num = (long long)std::llround(foff_hz[c]) * D;
+        long long den = (long long)std::llround(fs);
+        long long r = ((num % den) + den) % den;
+        long long q = den / gcdll(r, den);
+        period = period / gcdll(period, q) * q;
+        if (period > 4096) return false;
+    }
+    b.rot_period = (int)period;
+    b.binpos.resize(nch);
+    b.krot.resize((size_t)nch * period * 2);
+    for (int c = 0; c < nch; c++) {
+        const double off = foff_hz[c] / 1e6;             // (m + delta)
+        const long long m = (long long)std::floor(off - delta + 0.5);
+        if (std::fabs(off - (m + delta)) > 1e-9) return false;
+        const int mm = (int)(((m % M) + M) % M);
+        b.binpos[c] = 10 * (mm % 10) + mm / 10;
+        // C_m = exp(+j 2 pi (m+delta)(L-1)/M)
+        const double cturn = off * (b.L - 1) / M;
+        for (long long t = 0; t < period; t++) {
+            // exact rational rotation: -(foff*D*t mod fs)/fs
+            long long num = (long long)std::llround(foff_hz[c]) * D;
+            long long den = (long long)std::llround(fs);
+            __int128 r = ((__int128)num * t) % den;
+            double rturn = -(double)(long long)r / (double)den;
+            double cr = std::cos(2 * kPi * (cturn - std::floor(cturn))), ci = std::sin(2 * kPi * (cturn - std::floor(cturn)));
+            float rr, ri;
+            phasor_turns(rturn, rr, ri);
+            // (cr + j ci) * (rr + j ri); C_m on a quarter-turn grid is handled by phasor_turns too
+            float c_r, c_i;
+            phasor_turns(cturn, c_r, c_i);
+            (void)cr; (void)ci;
+            b.krot[((size_t)c * period + t) * 2 + 0] = c_r * rr - c_i * ri;
+            b.krot[((size_t)c * period + t) * 2 + 1] = c_r * ri + c_i * rr;
+        }
+    }
+    b.available = true;
+    return true;
+}
+
+double bessel_i0(double x)
+{
+    double s = 1.0, t = 1.0;
+    for (int k = 1; k < 60; k++) {
+        t *= (x / (2.0 * k)) * (x / (2.0 * k));
+        s += t;
+        if (t < 1e-18 * s) break;
+    }
+    return s;
+}
+
+bool solve_dense(std::vector<double> &A, std::vector<double> &b, int n)
+{
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++)
+            if (std::fabs(A[(size_t)r * n + c]) > std::fabs(A[(size_t)p * n + c])) p = r;
+        if (std::fabs(A[(size_t)p * n + c]) < 1e-300) return false;
+        if (p != c) {
+            for (int k = 0; k < n; k++) std::swap(A[(size_t)c * n + k], A[(size_t)p * n + k]);
+            std::swap(b[c], b[p]);
+        }
+        for (int r = c + 1; r < n; r++) {
+            double f = A[(size_t)r * n + c] / A[(size_t)c * n + c];
+            if (f == 0.0) continue;
+            for (int k = c; k < n; k++) A[(size_t)r * n + k] -= f * A[(size_t)c * n + k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        double s = b[r];
+        for (int k = r + 1; k < n; k++) s -= A[(size_t)r * n + k] * b[k];
+        b[r] = s / A[(size_t)r * n + r];
+    }
+    return true;
+}
+
+}  // namespace
+
+int make_fast_path(const Design &des, FastPath &fp)
+{
+    const btgpu_design &d = des.d;
+    const double fs = des.cfg.sample_rate;
+    const int nch = d.high_channel - d.low_channel + 1;
+    fp = FastPath();
+
+    // ---- channel bank: same prototype, polyphase evaluation ----
+    {
+        std::vector<double> proto(des.h_channel.begin(), des.h_channel.end());
+        build_pfb(fp.channel, proto, d.decimation, des.channel.foff, fs);
+    }
+    if (!fp.channel.available) return BTGPU_EUNSUPPORTED;
+
+    // ---- noise bank ----
+    NoiseStage &ns = fp.noise;
+    ns.R = 5 * d.decimation;
+    if (d.samples_per_slot % ns.R != 0) return BTGPU_OK;
+    ns.outs = d.samples_per_slot / ns.R;
+    const int order = 6;
+    std::vector<double> p(1, 1.0);
+    for (int o = 0; o < order; o++) {
+        std::vector<double> q(p.size() + ns.R - 1, 0.0);
+        for (size_t i = 0; i < p.size(); i++)
+            for (int k = 0; k < ns.R; k++) q[i + k] += p[i] / ns.R;
+        p.swap(q);
+    }
+    ns.L1 = (int)p.size();
+    ns.L3 = 80;
+    const int clen = ns.L1 + ns.R * (ns.L3 - 1);
+    const int nh = d.ntaps_noise;
+    if (clen < nh) return BTGPU_OK;
+    ns.pad = (clen - nh) / 2;
+    std::vector<double> tgt(clen, 0.0);
+    for (int i = 0; i < nh; i++) tgt[ns.pad + i] = des.h_noise[i];
+    // normal equations (Toeplitz autocorrelation of the prototype at lags of R)
+    std::vector<double> ac(ns.L3, 0.0);
+    for (int lag = 0; lag < ns.L3; lag++) {
+        double s = 0.0;
+        long long sh = (long long)lag * ns.R;
+        for (long long k = sh; k < ns.L1; k++) s += p[k] * p[k - sh];
+        ac[lag] = s;
+    }
+    std::vector<double> N((size_t)ns.L3 * ns.L3), rhs(ns.L3);
+    for (int i = 0; i < ns.L3; i++) {
+        for (int j = 0; j < ns.L3; j++) N[(size_t)i * ns.L3 + j] = ac[std::abs(i - j)];
+        double s = 0.0;
+        for (int k = 0; k < ns.L1; k++) s += p[k] * tgt[(size_t)ns.R * i + k];
+        rhs[i] = s;
+    }
+    if (!solve_dense(N, rhs, ns.L3)) return BTGPU_OK;
+    ns.h3.resize(ns.L3);
+    for (int i = 0; i < ns.L3; i++) ns.h3[i] = (float)rhs[i];
+    {
+        std::vector<double> comp(clen, 0.0);
+        for (int i = 0; i < ns.L3; i++)
+            for (int k = 0; k < ns.L1; k++) comp[(size_t)ns.R * i + k] += (double)ns.h3[i] * p[k];
+        double e = 0, nrm = 0;
+        for (int k = 0; k < clen; k++) e += std::fabs(comp[k] - tgt[k]);
+        for (int k = 0; k < nh; k++) nrm += std::fabs((double)des.h_noise[k]);
+        ns.fit_l1_error = e / nrm;
+    }
+    // quadrature weights: sum_{i=0}^{noise_out-1} f[i] from samples f[U*J], U = R / decim = 5
+    const int U = ns.R / d.decimation;
+    ns.Jm = 6;
+    const int half = ns.Jm * U;
+    std::vector<double> phi(2 * half + 1);
+    {
+        const double beta = 10.0, fcut = 0.8 / (2.0 * U);   // cycles/sample at the fine rate
+        double sum = 0;
+        for (int n = 0; n <= 2 * half; n++) {
+            double x = n - half;
+            double s = x == 0 ? 2 * fcut : std::sin(2 * kPi * fcut * x) / (kPi * x);
+            double r = x / half;
+            double w = bessel_i0(beta * std::sqrt(std::max(0.0, 1 - r * r))) / bessel_i0(beta);
+            phi[n] = s * w;
+            sum += phi[n];
+        }
+        for (double &v : phi) v *= U / sum;
+    }
+    ns.nw = ns.outs + 2 * ns.Jm;
+    ns.weights.assign(ns.nw, 0.0);
+    for (int a = 0; a < ns.nw; a++) {
+        const int J = a - ns.Jm;
+        double s = 0;
+        for (int i = 0; i < d.noise_out; i++) {
+            int idx = i - U * J + half;
+            if (idx >= 0 && idx <= 2 * half) s += phi[idx];
+        }
+        ns.weights[a] = s;
+    }
+    // stage-1 polyphase bank on the noise offsets (+790 kHz)
+    if (!build_pfb(ns.pfb, p, ns.R, des.noise.foff, fs)) return BTGPU_OK;
+    ns.available = true;
+    (void)nch;
+    return BTGPU_OK;
+}
+
+}  // namespace btgpu

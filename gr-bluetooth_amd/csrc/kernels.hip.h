@@ -8,7 +8,8 @@
 //   x      interleaved complex64 input stream segment, [n] float2
 //   taps   [nch][ntp] float2, time-reversed complex band-pass taps, zero padded to 8
 //   Y      [nch][ystride] float2   channel / noise DDC output on the shared output grid
-//   d      [nch][ystride] float    quadrature-demodulated stream (gain * atan2)
+//   d      [G][nch] float          quadrature-demodulated stream (gain * atan2), TIME-major:
+//                                  the window kernel's lanes are channels -> coalesced reads
 //   P, Pt  [nch][nb]      double   |Y|^2 sums per slot-block / per block head (`tail` outs)
 //   Q      [nch][S]       double   noise |Y|^2 sums per slot
 #pragma once
@@ -174,7 +175,7 @@ template <bool DEMOD>
 __global__ __launch_bounds__(256) void demod_energy_kernel(
     const float2 *__restrict__ Y, long long G, long long ystride, int bs, int tail,
     const float *__restrict__ atan_tab, float gain, float *__restrict__ d,
-    double *__restrict__ P, double *__restrict__ Pt, int nb)
+    double *__restrict__ P, double *__restrict__ Pt, int nb, int nch)
 {
     __shared__ float atab[257];
     __shared__ double red[2][4];
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void demod_energy_kernel(
         if (DEMOD) {
             float dv = 0.f;
             if (g > 0) dv = demod_one(atab, gain, v, y[g - 1]);
-            d[(size_t)c * ystride + g] = dv;
+            d[(size_t)g * nch + c] = dv;
         }
     }
     // wave reduce (64 lanes) then across the 4 waves
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(64) void window_kernel(
     if (!(snr >= p.target_snr)) return;
 
     // ---- M&M (multi_block.cc:128-155), windowed reset ----
-    const float *dw = d + (size_t)c * p.ystride + (long long)k * p.outs_per_slot;
+    const float *dw = d + ((size_t)k * p.outs_per_slot) * p.nch + c;      // time-major, stride nch
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
     float mu = p.mu0, omega = p.omega0, last = 0.f;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(64) void window_kernel(
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const unsigned int idx = ii + q;
-            const float v = idx == 0 ? 0.0f : dw[idx];
+            const float v = idx == 0 ? 0.0f : dw[(size_t)idx * p.nch];
             acc = fmaf(t[7 - q], v, acc);
         }
         const float out = acc;

@@ -1,0 +1,317 @@
+// pfb100.hip.h -- 100-bin (1 MHz spacing at 100 Msps) polyphase channelizer for gfx950.
+//
+// For every output instant t the bank needs, for each of the 100 polyphase branches p,
+//   u_p[t] = sum_q a[100 q + p] * x[x0 + D t + 100 q + p]               (Q taps per branch)
+// followed by a 100-point DFT over p (10 x 10 Cooley-Tukey) and, per selected channel,
+// one complex multiply by C_m * rot(t).  This is algebraically the reference's per-channel
+// "complex band-pass FIR, decimate, de-rotate" (freq_xlating_fir_filter_ccf [EXT], called
+// from lib/multi_block.cc:204,275) for all channels at once: ~27 FMA + ~70 flop per input
+// sample instead of ~2100 FMA.
+//
+// Work decomposition (one workgroup = NT consecutive output instants, 256 lanes):
+//   A  lanes (p, r): branch p, instants of parity r.  Because 2 D is a multiple of 100 the
+//      samples a branch needs for instant t+2 are the ones of instant t shifted by S = 2D/100
+//      taps: each lane keeps a Q-deep register window and reads every input sample from LDS
+//      exactly once.  Input tile staged with coalesced 16-byte global loads.
+//   B  two passes of 10-point DFTs over the LDS matrix U[t][100], twiddle in between.
+//   C  epilogue.  CHANNEL bank: quadrature demod against the previous instant
+//      (multi_block::demod), |y|^2 tile sums in double, d written time-major [g][nch] so the
+//      window kernel's lanes (= channels) read it coalesced.  NOISE bank: stage-1 output Z.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hip.h"
+
+namespace btgpu {
+
+struct PfbParams {
+    const float2 *x; long long x_len; long long x0;   // x index of tap 0 for output instant 0
+    int D;
+    long long T;                 // output instants in total
+    const float2 *taps;          // [Q*100]
+    const float2 *twiddle;       // [100]
+    int nsel;
+    const int *binpos;           // [nsel]
+    const float2 *krot;          // [nsel][rot_period]
+    int rot_period;
+    int ntiles;
+    // channel epilogue
+    float *d;                    // [T][nsel] time-major
+    double *ptile;               // [nsel][ntiles]
+    double *phead;               // [nsel][nb]
+    int tiles_per_block, tail, nb;
+    const float *atan_tab; float gain;
+    // noise epilogue
+    float2 *Z; long long zstride;   // [nsel][zstride]
+};
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// forward 5-point DFT (kernel e^{-j 2 pi k n / 5})
+__device__ __forceinline__ void dft5(const float2 x0, const float2 x1, const float2 x2, const float2 x3,
+                                     const float2 x4, float2 *X)
+{
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const float2 a1 = caddf(x1, x4), a2 = caddf(x2, x3), b1 = csubf(x1, x4), b2 = csubf(x2, x3);
+    X[0] = caddf(x0, caddf(a1, a2));
+    const float2 t1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y);
+    const float2 t2 = make_float2(x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y);
+    const float2 u1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const float2 u2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    X[1] = make_float2(t1.x + u1.y, t1.y - u1.x);
+    X[4] = make_float2(t1.x - u1.y, t1.y + u1.x);
+    X[2] = make_float2(t2.x + u2.y, t2.y - u2.x);
+    X[3] = make_float2(t2.x - u2.y, t2.y + u2.x);
+}
+
+// forward 10-point DFT, in place on v[0..9]
+__device__ __forceinline__ void dft10(float2 *v)
+{
+    float2 E[5], O[5];
+    dft5(v[0], v[2], v[4], v[6], v[8], E);
+    dft5(v[1], v[3], v[5], v[7], v[9], O);
+    const float2 w1 = make_float2(0.80901699437494742f, -0.58778525229247313f);
+    const float2 w2 = make_float2(0.30901699437494742f, -0.95105651629515357f);
+    const float2 w3 = make_float2(-0.30901699437494742f, -0.95105651629515357f);
+    const float2 w4 = make_float2(-0.80901699437494742f, -0.58778525229247313f);
+    const float2 o0 = O[0], o1 = cmulf(O[1], w1), o2 = cmulf(O[2], w2), o3 = cmulf(O[3], w3),
+                 o4 = cmulf(O[4], w4);
+    v[0] = caddf(E[0], o0); v[5] = csubf(E[0], o0);
+    v[1] = caddf(E[1], o1); v[6] = csubf(E[1], o1);
+    v[2] = caddf(E[2], o2); v[7] = csubf(E[2], o2);
+    v[3] = caddf(E[3], o3); v[8] = csubf(E[3], o3);
+    v[4] = caddf(E[4], o4); v[9] = csubf(E[4], o4);
+}
+
+// XCD-aware tile order: consecutive tiles (which share the filter-length halo of their input
+// span) run on the same XCD so the overlap is an L2 hit.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+    const int q = n / 8, r = n % 8, xcd = b % 8, idx = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int Q, int S, int NT, bool REAL, bool CHAN>
+__global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
+{
+    constexpr int M = 100;
+    constexpr int UST = 100;
+    constexpr int TT = CHAN ? NT - 1 : NT;      // new output instants per tile
+    static_assert(NT % 2 == 0, "NT must be even");
+    extern __shared__ float4 lds4[];
+    float2 *lds = (float2 *)lds4;
+    const int span = p.D * (NT - 1) + Q * M;                 // input samples staged per tile
+    const int wsz = CHAN ? p.nsel * NT : 0;
+    const int asz = span > wsz ? span : wsz;                 // xs is dead after phase A -> reuse for W
+    float2 *xs = lds;                                        // [span]  (aliased by Wb[nsel][NT])
+    float2 *U = lds + ((asz + 1) & ~1);                      // [NT][UST]
+    float *Mb = (float *)(U + NT * UST);                     // [nsel][NT] |y|^2     (CHAN)
+    float *atab = Mb + (CHAN ? p.nsel * NT : 0);             // [257]               (CHAN)
+
+    const int tile = xcd_remap(blockIdx.x, p.ntiles);
+    const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
+    const int l = threadIdx.x;
+
+    // ---- stage the input span: x[x0 + D*t0 + s], s < span; 16-byte loads where aligned ----
+    {
+        const long long gs = p.x0 + (long long)p.D * t0;
+        const int lead = (int)((2 - (gs & 1)) & 1);          // make (gs + lead) even -> 16 B aligned
+        for (int s = l; s < lead; s += 256) {
+            long long a = gs + s;
+            xs[s] = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
+        }
+        const int npair = (span - lead) >> 1;
+        for (int i = l; i < npair; i += 256) {
+            const int s = lead + 2 * i;
+            const long long a = gs + s;
+            float4 v;
+            if (a >= 0 && a + 1 < p.x_len) v = *(const float4 *)(p.x + a);
+            else {
+                float2 v0 = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
+                float2 v1 = (a + 1 >= 0 && a + 1 < p.x_len) ? p.x[a + 1] : make_float2(0.f, 0.f);
+                v = make_float4(v0.x, v0.y, v1.x, v1.y);
+            }
+            xs[s] = make_float2(v.x, v.y);
+            xs[s + 1] = make_float2(v.z, v.w);
+        }
+        if (((span - lead) & 1) && l == 0) {
+            const int s = span - 1;
+            long long a = gs + s;
+            xs[s] = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
+        }
+        if (CHAN) for (int i = l; i < 257; i += 256) atab[i] = p.atan_tab[i];
+    }
+    __syncthreads();
+
+    // ---- phase A: polyphase branch filters ----
+    {
+        const int pp = l & 127, r = l >> 7;
+        if (pp < M) {
+            float2 a[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) a[q] = p.taps[q * M + pp];
+            const float2 *z = xs + p.D * r + pp;
+            float2 zw[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) zw[q] = z[q * M];
+#pragma unroll
+            for (int tau = 0; tau < NT / 2; tau++) {
+                float ur = 0.f, ui = 0.f;
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    if (REAL) {
+                        ur = fmaf(a[q].x, zw[q].x, ur);
+                        ui = fmaf(a[q].x, zw[q].y, ui);
+                    } else {
+                        ur = fmaf(a[q].x, zw[q].x, ur);
+                        ur = fmaf(-a[q].y, zw[q].y, ur);
+                        ui = fmaf(a[q].x, zw[q].y, ui);
+                        ui = fmaf(a[q].y, zw[q].x, ui);
+                    }
+                }
+                U[(2 * tau + r) * UST + pp] = make_float2(ur, ui);
+                if (tau + 1 < NT / 2) {
+#pragma unroll
+                    for (int q = 0; q + S < Q; q++) zw[q] = zw[q + S];
+#pragma unroll
+                    for (int q = (Q - S > 0 ? Q - S : 0); q < Q; q++) zw[q] = z[(q + S * (tau + 1)) * M];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100} ----
+    for (int i = l; i < NT * 10; i += 256) {
+        const int tl = i / 10, p2 = i % 10;
+        float2 v[10];
+        float2 *row = U + tl * UST + p2;
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k] = row[10 * k];
+        dft10(v);
+#pragma unroll
+        for (int k = 0; k < 10; k++) row[10 * k] = cmulf(v[k], p.twiddle[k * 10 + p2]);
+    }
+    __syncthreads();
+    // ---- phase B2: DFT over p2; bin m = m1 + 10 m2 ends up at position 10 m1 + m2 ----
+    for (int i = l; i < NT * 10; i += 256) {
+        const int tl = i / 10, m1 = i % 10;
+        float2 v[10];
+        float2 *row = U + tl * UST + 10 * m1;
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k] = row[k];
+        dft10(v);
+#pragma unroll
+        for (int k = 0; k < 10; k++) row[k] = v[k];
+    }
+    __syncthreads();
+
+    // ---- phase C ----
+    if (!CHAN) {
+        for (int i = l; i < p.nsel * NT; i += 256) {
+            const int c = i / NT, tl = i % NT;
+            const long long t = t0 + tl;
+            if (t >= p.T) continue;
+            const int ph = (int)(t % p.rot_period);
+            const float2 y = cmulf(U[tl * UST + p.binpos[c]], p.krot[(size_t)c * p.rot_period + ph]);
+            p.Z[(size_t)c * p.zstride + t] = y;
+        }
+        return;
+    }
+    float2 *Wb = xs;                                         // [nsel][NT]
+    for (int i = l; i < p.nsel * NT; i += 256) {
+        const int c = i / NT, tl = i % NT;
+        const long long t = t0 + tl;
+        const int ph = (int)(((t % p.rot_period) + p.rot_period) % p.rot_period);
+        const float2 y = cmulf(U[tl * UST + p.binpos[c]], p.krot[(size_t)c * p.rot_period + ph]);
+        Wb[c * NT + tl] = y;
+        if (p.Z && tl >= 1 && t < p.T) p.Z[(size_t)c * p.zstride + t] = y;     // BTGPU_FLAG_DEBUG_Y
+    }
+    __syncthreads();
+    for (int i = l; i < p.nsel * TT; i += 256) {
+        const int c = i % p.nsel, tl = 1 + i / p.nsel;       // channel fastest: coalesced d store
+        const long long t = t0 + tl;
+        const float2 a = Wb[c * NT + tl], b = Wb[c * NT + tl - 1];
+        float m = 0.f;
+        if (t < p.T) {
+            m = (a.x * a.x) + (a.y * a.y);
+            p.d[(size_t)t * p.nsel + c] = demod_one(atab, p.gain, a, b);
+        }
+        Mb[c * NT + tl] = m;
+    }
+    __syncthreads();
+    if (l < p.nsel) {
+        double s = 0.0, h = 0.0;
+        for (int tl = 1; tl < NT; tl++) {
+            const double m = (double)Mb[l * NT + tl];
+            s += m;
+            if (tl - 1 < p.tail) h += m;
+        }
+        p.ptile[(size_t)l * p.ntiles + tile] = s;
+        if (tile % p.tiles_per_block == 0) p.phead[(size_t)l * p.nb + tile / p.tiles_per_block] = h;
+    }
+}
+
+// tile sums -> per-slot-block sums P[c][b] (same layout the direct path produces)
+__global__ void block_sum_kernel(const double *__restrict__ ptile, int ntiles, int tiles_per_block,
+                                 double *__restrict__ P, int nb, int nch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * nch) return;
+    const int c = i / nb, b = i % nb;
+    double s = 0.0;
+    for (int k = 0; k < tiles_per_block; k++) {
+        const int t = b * tiles_per_block + k;
+        if (t < ntiles) s += ptile[(size_t)c * ntiles + t];
+    }
+    P[(size_t)c * nb + b] = s;
+}
+
+// ------------------------------------------------------------------------------------
+// Noise stage 2: y^[J] = sum_i h3[i] Z[c][J + i]; E_off * noise_out = sum_J w[J] |y^[J]|^2
+// over the slot's nw stage-2 outputs (quadrature weights incl. the band-limited edge
+// correction).  One workgroup per (slot k, channel c).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void noise_stage2_kernel(
+    const float2 *__restrict__ Z, long long zstride, int outs, int nw, int L3,
+    const float *__restrict__ h3, const double *__restrict__ w, double *__restrict__ Qn, int S)
+{
+    extern __shared__ float4 lds4[];
+    float2 *zs = (float2 *)lds4;                 // [nw + L3 - 1]
+    float *hs = (float *)(zs + ((nw + L3 + 1) & ~1));   // [L3]
+    __shared__ double red[4];
+    const int k = blockIdx.x, c = blockIdx.y;
+    const float2 *z = Z + (size_t)c * zstride + (long long)k * outs;
+    const int need = nw + L3 - 1;
+    for (int i = threadIdx.x; i < need; i += blockDim.x) zs[i] = z[i];
+    for (int i = threadIdx.x; i < L3; i += blockDim.x) hs[i] = h3[i];
+    __syncthreads();
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < nw; j += blockDim.x) {
+        float yr = 0.f, yi = 0.f;
+        for (int i = 0; i < L3; i++) {
+            const float2 v = zs[j + i];
+            yr = fmaf(hs[i], v.x, yr);
+            yi = fmaf(hs[i], v.y, yi);
+        }
+        const float m = (yr * yr) + (yi * yi);
+        acc += w[j] * (double)m;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) s += red[wv];
+        Qn[(size_t)c * S + k] = s;
+    }
+}
+
+}  // namespace btgpu

@@ -46,10 +46,12 @@ extern "C" {
 #define BTGPU_CHANNELIZER_DIRECT    1   /* per-channel direct-form DDC; bit-exact vs the oracle */
 #define BTGPU_CHANNELIZER_POLYPHASE 2   /* polyphase filter bank; equal within float tolerance   */
 
-#define BTGPU_SQUELCH_DIRECT    0       /* exact direct-form noise DDC                          */
-#define BTGPU_SQUELCH_AUTO      1
+#define BTGPU_SQUELCH_AUTO      0
+#define BTGPU_SQUELCH_DIRECT    1       /* exact direct-form 20001-tap-class noise DDC           */
+#define BTGPU_SQUELCH_STAGED    2       /* two-stage equivalent filter + quadrature (tolerance)  */
 
 #define BTGPU_FLAG_LE        0x1        /* also run the le_packet::sniff_aa pass (sniffer mode)  */
+#define BTGPU_FLAG_DEBUG_Y   0x2        /* keep the channel-bank output Y for btgpu_debug_fetch  */
 
 #define BTGPU_KIND_AC 0
 #define BTGPU_KIND_AA 1
@@ -82,7 +84,10 @@ typedef struct btgpu_design {
     int32_t ddc_out;                          /* channel DDC outputs per window     */
     int32_t noise_out;                        /* noise DDC outputs per window       */
     int32_t channelizer;                      /* resolved BTGPU_CHANNELIZER_*       */
-    int32_t reserved[3];
+    int32_t squelch;                          /* resolved BTGPU_SQUELCH_*           */
+    int32_t left_margin;                      /* samples before a device segment the staged
+                                                 squelch may read (0 for DIRECT)     */
+    int32_t reserved[1];
 } btgpu_design;
 
 typedef struct btgpu_hit {
@@ -140,10 +145,14 @@ int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *cons
  * scheduler) so arbitrary chunks can be pushed. */
 int btgpu_push(btgpu_handle *h, const float *iq, size_t n_complex);
 
-/* Device-resident segment: d_iq[0] is absolute sample first_slot*samples_per_slot-(history()-1);
- * the segment must hold history() + (n_slots-1)*samples_per_slot complex samples.
+/* Device-resident segment: d_iq[left_margin] is absolute sample
+ * first_slot*samples_per_slot-(history()-1); from there the segment must hold
+ * history() + (n_slots-1)*samples_per_slot complex samples.  The `left_margin` samples in
+ * front (real stream data when the segment is cut out of a longer stream; 0 at the stream
+ * start, where GNU Radio's pre-filled zeros are implied) let the staged squelch filter see
+ * the same samples the reference's noise filter would; btgpu_design.left_margin is enough.
  * `hip_stream` is a hipStream_t (NULL = the handle's own stream). */
-int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex,
+int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, size_t left_margin,
                          uint64_t first_slot, uint64_t n_slots, void *hip_stream);
 
 /* Drain queued hits, ordered by (slot, channel, kind, offset). Returns count (>=0) or <0. */
@@ -153,9 +162,10 @@ int btgpu_pending(const btgpu_handle *h);
 int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out);
 
 /* ---- introspection for parity tests: copies an intermediate of the LAST batch ----
- * what: 0 channel-DDC output Y (complex64, needs DIRECT channelizer or debug build),
- *       1 demodulated stream d (float32), 2 E_on per window (float64, [slot][channel]),
- *       3 E_off per window (float64), 4 snr per window (float64).
+ * what: 0 channel-bank output Y (complex64 [channel][g]; DIRECT channelizer or BTGPU_FLAG_DEBUG_Y),
+ *       1 demodulated stream d (float32, time-major [g][nch]: pass channel to get a strided copy),
+ *       2 E_on per window (float64, [slot][channel]), 3 E_off per window, 4 snr per window,
+ *       5 noise-bank output (complex64; DIRECT squelch only).
  * channel is a classic channel number (ignored for 2..4); returns elements copied. */
 long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, size_t count, void *out);
 

@@ -19,6 +19,8 @@ def _keys(hits):
 
 
 def _run_gpu(pkg, cls, fs, fc, iq, squelch=10.0, **kw):
+    kw.setdefault("channelizer", pkg.CHANNELIZER_DIRECT)       # bit-exact contract = DIRECT path
+    kw.setdefault("squelch", pkg.SQUELCH_DIRECT)
     blk = cls(fs, fc, squelch, **kw) if cls is pkg.multi_LAP else cls(fs, fc, squelch, False, **kw)
     blk.push(iq)
     hits = blk.poll()
@@ -57,6 +59,55 @@ def test_c79_small_hit_list_bit_exact(pkg, po, synth):
     assert done == 9 and len(want) > 0
     assert _keys(got) == _keys(want)
     blk.close()
+
+
+def test_fast_path_c79_vs_oracle_and_direct(pkg, po, synth):
+    """Polyphase channel bank + staged squelch (the bench path) against the oracle and the
+    DIRECT path.  Stated tolerances: channel-bank output rel-L2 <= 1e-5, E_on / E_off relative
+    <= 1e-5, SNR <= 1e-4 dB; hit records identical on (slot, channel, kind, offset, LAP,
+    ac_errors); nsym (M&M run length over the noise after the packet) within +-8 symbols."""
+    fs, fc = 100e6, 2441e6
+    laps = tuple(0x24D952 + 0x10101 * i for i in range(6))
+    S, nch = 9, 79
+    iq, truth = synth.make_capture(fs, fc, S, laps=laps, seed=79, snr_db=25, occupancy=0.6)
+    want, done = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq, threads=16)
+    out = {}
+    for name, ch, sq in (("direct", pkg.CHANNELIZER_DIRECT, pkg.SQUELCH_DIRECT),
+                         ("fast", pkg.CHANNELIZER_POLYPHASE, pkg.SQUELCH_STAGED)):
+        b = pkg.multi_sniffer(fs, fc, 10.0, False, channelizer=ch, squelch=sq, flags=pkg.FLAG_DEBUG_Y)
+        assert (b.design.channelizer, b.design.squelch) == (ch, sq)
+        b.push(iq)
+        out[name] = dict(hits=b.poll(), Y={c: b.debug_fetch(0, c, 0, 1 << 22) for c in (0, 40, 78)},
+                         eon=b.debug_fetch(2, 0, 0, S * nch), eoff=b.debug_fetch(3, 0, 0, S * nch),
+                         snr=b.debug_fetch(4, 0, 0, S * nch))
+        b.close()
+    assert len(want) > 5
+    assert _keys(out["direct"]["hits"]) == _keys(want)
+    fk, wk = _keys(out["fast"]["hits"]), _keys(want)
+    assert [k[:6] for k in fk] == [k[:6] for k in wk]
+    assert max(abs(a[6] - b[6]) for a, b in zip(fk, wk)) <= 8
+    for c in (0, 40, 78):
+        a, r = out["fast"]["Y"][c], out["direct"]["Y"][c]
+        n = min(len(a), len(r))
+        assert np.linalg.norm(a[1:n] - r[1:n]) / np.linalg.norm(r[1:n]) <= 1e-5
+    m = np.isfinite(out["direct"]["snr"]) & (out["direct"]["eoff"] > 0)
+    assert m.sum() > 100
+    for key, tol in (("eon", 1e-5), ("eoff", 1e-5)):
+        assert np.max(np.abs(out["fast"][key][m] - out["direct"][key][m]) / out["direct"][key][m]) <= tol
+    assert np.max(np.abs(out["fast"]["snr"][m] - out["direct"]["snr"][m])) <= 1e-4
+
+
+def test_fast_path_is_default_at_100msps_and_margin_is_reported(pkg):
+    b = pkg.multi_sniffer(100e6, 2441e6, 10.0, False)
+    assert b.design.channelizer == pkg.CHANNELIZER_POLYPHASE and b.design.squelch == pkg.SQUELCH_STAGED
+    assert b.design.left_margin >= 2200
+    b.close()
+    b = pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False)             # no 100-bin bank at 8 Msps: direct
+    assert b.design.channelizer == pkg.CHANNELIZER_DIRECT and b.design.squelch == pkg.SQUELCH_DIRECT
+    assert b.design.left_margin == 0
+    b.close()
+    with pytest.raises(pkg.BtgpuError):
+        pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False, channelizer=pkg.CHANNELIZER_POLYPHASE)
 
 
 def test_golden_fixture(pkg):
@@ -134,7 +185,8 @@ def test_ragged_pushes_and_small_batches_equal_one_shot(pkg, po, synth):
     iq, _ = synth.make_capture(fs, fc, 23, laps=(0x24D952, 0x4831DD), seed=8, snr_db=24, occupancy=0.5,
                                extra_slots=0.37)
     want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq, threads=8)
-    blk = pkg.multi_sniffer(fs, fc, 10.0, False, max_batch_slots=5)      # forces 5 internal batches
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, max_batch_slots=5, channelizer=pkg.CHANNELIZER_DIRECT,
+                            squelch=pkg.SQUELCH_DIRECT)      # forces 5 internal batches
     rng = np.random.default_rng(0)
     pos = 0
     while pos < len(iq):
@@ -210,17 +262,18 @@ def test_full_size_properties_c79(pkg, synth):
     blk = pkg.multi_sniffer(fs, fc, 10.0, False, max_batch_slots=48)
     H, slot = blk.history(), blk.output_multiple()
     S = 48
-    seg, truth = synth.make_segment_torch(fs, fc, 0, S, "cuda", laps=laps, seed=3, left_pad=H - 1)
+    mg = blk.design.left_margin
+    seg, truth = synth.make_segment_torch(fs, fc, 0, S, "cuda", laps=laps, seed=3, left_pad=H - 1 + mg)
     n = seg.shape[0]
-    blk.process_device(seg.data_ptr(), n, 0, S)
+    blk.process_device(seg.data_ptr(), n, 0, S, left_margin=mg)
     a = _keys(blk.poll())
-    blk.process_device(seg.data_ptr(), n, 0, S)
+    blk.process_device(seg.data_ptr(), n, 0, S, left_margin=mg)
     assert _keys(blk.poll()) == a                                  # deterministic
-    blk.process_device(seg.data_ptr(), n, 1000, S)
+    blk.process_device(seg.data_ptr(), n, 1000, S, left_margin=mg)
     b = _keys(blk.poll())
     assert [(k[0] - 1000,) + k[1:] for k in b] == a                 # slot index is just a label
     seg2 = (seg * 4.0).contiguous()                                # power-of-two scale: exact in float
-    blk.process_device(seg2.data_ptr(), n, 0, S)
+    blk.process_device(seg2.data_ptr(), n, 0, S, left_margin=mg)
     assert _keys(blk.poll()) == a
     got = {(k[0], k[1], k[4]) for k in a}
     exp = [t for t in truth if t["slot"] + 7 < S]
