@@ -241,9 +241,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.omega0 = des.omega0; p.gain_omega = des.gain_omega; p.omega_mid = des.omega_mid;
         p.mode = des.cfg.mode; p.max_hits = max_hits;
         p.a0_lo = des.ac.a0_lo; p.a0_hi = des.ac.a0_hi;
-        const long long nwin = (long long)S * nch;
-        dim3 grid((unsigned)((nwin + 63) / 64));
-        hipLaunchKernelGGL(window_kernel, grid, dim3(64), 0, st, p, (const float *)d_d.p,
+        hipLaunchKernelGGL(window_kernel, dim3(S), dim3(kWinThreads), 0, st, p, (const float *)d_d.p, G,
                            (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
                            (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
                            (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
@@ -474,7 +472,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_h3, ns.h3.data(), ns.h3.size() * sizeof(float)));
         TRY(h->upload(h->d_w, ns.weights.data(), ns.weights.size() * sizeof(double)));
     }
-    TRY(h->alloc(h->d_d, (size_t)nch * (h->ystride + 64) * sizeof(float)));
+    TRY(h->alloc(h->d_d, (size_t)80 * (h->ystride + 64) * sizeof(float)));
+    if (nch > 80) return fail(BTGPU_EUNSUPPORTED);
     TRY(h->alloc(h->d_P, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Pt, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Q, (size_t)nch * S * sizeof(double)));
@@ -633,7 +632,7 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
             if (first >= avail) return 0;
             count = std::min(count, avail - first);
             if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
-            if (hipMemcpy2D(out, sizeof(float), (const float *)h->d_d.p + first * nch + c, (size_t)nch * sizeof(float),
+            if (hipMemcpy2D(out, sizeof(float), (const float *)h->d_d.p + first * 80 + c, (size_t)80 * sizeof(float),
                             sizeof(float), count, hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
             return (long)count;
         }

@@ -8,7 +8,7 @@
 //   x      interleaved complex64 input stream segment, [n] float2
 //   taps   [nch][ntp] float2, time-reversed complex band-pass taps, zero padded to 8
 //   Y      [nch][ystride] float2   channel / noise DDC output on the shared output grid
-//   d      [G][nch] float          quadrature-demodulated stream (gain * atan2), TIME-major:
+//   d      [G][80] float           quadrature-demodulated stream (gain * atan2), TIME-major:
 //                                  the window kernel's lanes are channels -> coalesced reads
 //   P, Pt  [nch][nb]      double   |Y|^2 sums per slot-block / per block head (`tail` outs)
 //   Q      [nch][S]       double   noise |Y|^2 sums per slot
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void demod_energy_kernel(
         if (DEMOD) {
             float dv = 0.f;
             if (g > 0) dv = demod_one(atab, gain, v, y[g - 1]);
-            d[(size_t)g * nch + c] = dv;
+            d[(size_t)g * 80 + c] = dv;
         }
     }
     // wave reduce (64 lanes) then across the 4 waves
@@ -234,6 +234,7 @@ struct WindowParams {
     int blocks_per_window, tail;
     int nb;                     // number of energy blocks per channel
     long long ystride;
+    int dstride;                // row stride of d in floats (nch padded to a multiple of 4)
     double target_snr;
     float gain_mu, mu0, omega_relative_limit, omega0, gain_omega, omega_mid;
     int mode;                   // BTGPU_MODE_*
@@ -247,8 +248,19 @@ __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
     return da < db ? da : db;
 }
 
-__global__ __launch_bounds__(64) void window_kernel(
-    WindowParams p, const float *__restrict__ d, const double *__restrict__ P,
+constexpr int kWinThreads = 128;     // >= 79 visible channels; lane = channel
+constexpr int kWinRows = 64;         // demod rows staged per chunk
+
+// One workgroup per slot k, one lane per channel c (nch <= 79 < 128).  The demodulated stream
+// is time-major [g][nch], so the rows a slot's windows need are shared by all its lanes: they
+// are staged through LDS in chunks of kWinRows rows with fully coalesced loads, and the
+// strictly sequential M&M recursion of each lane then runs out of LDS instead of paying a
+// global-memory round trip per symbol.  Lanes drift apart by a few samples only (omega is
+// clipped to 2 +- 0.005), so a chunk starts at the minimum input index over the live lanes.
+// Lanes stop after the 625-offset search range unless they committed a hit; those continue
+// to the end of the window to obtain `len` (the handlers' symbol count, nsym = len - offset).
+__global__ __launch_bounds__(kWinThreads) void window_kernel(
+    WindowParams p, const float *__restrict__ d, long long d_rows, const double *__restrict__ P,
     const double *__restrict__ Pt, const double *__restrict__ Qn,
     const float *__restrict__ mmse_g, const uint64_t *__restrict__ ac_lo_g,
     const uint32_t *__restrict__ ac_hi_g,
@@ -258,32 +270,35 @@ __global__ __launch_bounds__(64) void window_kernel(
     __shared__ float mmse[129 * 8];
     __shared__ uint64_t ac_lo[3 * 256];
     __shared__ uint32_t ac_hi[3 * 256];
+    __shared__ __attribute__((aligned(16))) float tile[kWinRows * 80];
+    __shared__ int s_min;
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) { ac_lo[i] = ac_lo_g[i]; ac_hi[i] = ac_hi_g[i]; }
-    __syncthreads();
 
-    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long nwin = (long long)p.S * p.nch;
-    if (w >= nwin) return;
-    // channel-fastest ordering: neighbouring lanes = neighbouring channels of one slot
-    const int k = (int)(w / p.nch);
-    const int c = (int)(w % p.nch);
+    const int k = blockIdx.x;
+    const int c = threadIdx.x;
+    const int nch = p.nch;
+    const long long w = (long long)k * nch + c;
+    bool active = c < nch;
+    double snr = 0.0;
 
     // ---- squelch: multi_block::channel_samples energy + check_snr (multi_block.cc:206-293) ----
-    double e_on = 0.0;
-    for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)c * p.nb + k + j];
-    if (p.tail > 0) e_on += Pt[(size_t)c * p.nb + k + p.blocks_per_window];
-    e_on /= (double)p.ddc_out;
-    const double e_off = Qn[(size_t)c * p.S + k] / (double)p.noise_out;
-    const double snr = 10.0 * log10(e_on / e_off);
-    e_on_out[w] = e_on; e_off_out[w] = e_off; snr_out[w] = snr;
-    win_len[w] = -1;
-    if (!(snr >= p.target_snr)) return;
+    if (active) {
+        double e_on = 0.0;
+        for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)c * p.nb + k + j];
+        if (p.tail > 0) e_on += Pt[(size_t)c * p.nb + k + p.blocks_per_window];
+        e_on /= (double)p.ddc_out;
+        const double e_off = Qn[(size_t)c * p.S + k] / (double)p.noise_out;
+        snr = 10.0 * log10(e_on / e_off);
+        e_on_out[w] = e_on; e_off_out[w] = e_off; snr_out[w] = snr;
+        win_len[w] = -1;
+        if (!(snr >= p.target_snr)) active = false;
+    }
 
     // ---- M&M (multi_block.cc:128-155), windowed reset ----
-    const float *dw = d + ((size_t)k * p.outs_per_slot) * p.nch + c;      // time-major, stride nch
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
+    const long long row0 = (long long)k * p.outs_per_slot;       // global row of window index 0
     float mu = p.mu0, omega = p.omega0, last = 0.f;
     unsigned int ii = 0;
     int oo = 0;
@@ -291,76 +306,114 @@ __global__ __launch_bounds__(64) void window_kernel(
     int pending = -1, resume = 0, nhits = 0;
     uint32_t pend_lap = 0; int pend_err = 0;
     bool searching = true;
-    while (ii < ni && oo < demod_n) {
-        // interpolate: sum_k T[imu][7-k] * in[ii+k], k ascending
-        int imu = (int)rintf(mu * 128.0f);
-        imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
-        const float *t = &mmse[imu * 8];
-        float acc = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const unsigned int idx = ii + q;
-            const float v = idx == 0 ? 0.0f : dw[(size_t)idx * p.nch];
-            acc = fmaf(t[7 - q], v, acc);
-        }
-        const float out = acc;
-        const float s_last = (last < 0) ? -1.0f : 1.0f;
-        const float s_out = (out < 0) ? -1.0f : 1.0f;
-        const float mm_val = s_last * out - s_out * last;
-        last = out;
-        omega = omega + (p.gain_omega * mm_val);
-        {
-            const float xx = omega - p.omega_mid;
-            float x1 = fabsf(xx + p.omega_relative_limit);
-            const float x2 = fabsf(xx - p.omega_relative_limit);
-            x1 -= x2;
-            omega = p.omega_mid + 0.5f * x1;
-        }
-        mu = mu + (omega + (p.gain_mu * mm_val));
-        const float fl = floorf(mu);
-        ii += (unsigned int)(int)fl;
-        mu = mu - fl;
 
-        // ---- slicer + streaming access-code search ----
-        const uint32_t sym = (out < 0) ? 0u : 1u;
-        const int s = oo;
-        oo++;
-        if (searching) {
-            wlo = (wlo >> 1) | ((uint64_t)(whi & 1u) << 63);
-            whi = (whi >> 1) | (sym << 3);
-            if (pending >= 0) {          // one more symbol exists: pending < len - 68
-                const unsigned int slot_h = atomicAdd(hit_count, 1u);
-                if (slot_h < (unsigned int)p.max_hits) {
-                    DeviceHit h;
-                    h.slot = (uint32_t)k; h.channel_idx = c; h.offset = pending;
-                    h.lap = pend_lap; h.ac_errors = pend_err; h.kind = 0; h.snr = snr;
-                    hits[slot_h] = h;
-                }
-                nhits++;
-                resume = pending + 68;
-                pending = -1;
-                if (p.mode == 0) searching = false;      // multi_LAP: first hit only
+    for (;;) {
+        // chunk base = min input index over the live lanes
+        if (threadIdx.x == 0) s_min = 0x7fffffff;
+        __syncthreads();
+        if (active) atomicMin(&s_min, (int)ii);
+        __syncthreads();
+        const int base = s_min;
+        if (base == 0x7fffffff) break;                           // no live lane left (uniform)
+        {
+            // rows [base, base + kWinRows) of this slot's windows are one contiguous range of the
+            // time-major stream (row stride dstride = 80 floats): straight 16-byte copy, all
+            // loads of a lane issued before the first LDS store.
+            constexpr int kVec = kWinRows * 80 / 4;              // float4 per chunk
+            constexpr int kPer = (kVec + kWinThreads - 1) / kWinThreads;
+            const long long r_first = row0 + base;
+            const float4 *src = (const float4 *)(d + (size_t)r_first * 80);
+            long long rows_ok = d_rows - r_first;                // rows that exist in the buffer
+            const long long win_ok = (long long)p.ddc_out - base;
+            if (win_ok < rows_ok) rows_ok = win_ok;
+            const int vec_ok = rows_ok <= 0 ? 0 : (rows_ok >= kWinRows ? kVec : (int)rows_ok * 20);
+            float4 v[kPer];
+#pragma unroll
+            for (int j = 0; j < kPer; j++) {
+                const int i = threadIdx.x + j * kWinThreads;
+                v[j] = (i < vec_ok) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            const int cpos = s - 67;
-            if (searching && cpos >= resume && cpos < 625) {
-                const uint32_t pre = (uint32_t)wlo & 0x1f;
-                const uint32_t bar = ((uint32_t)(wlo >> 61) | (whi << 3)) & 0x7f;
-                const int gate = popc5min(pre, 0x0a, 0x15) + popc5min(bar, 0x27, 0x58);
-                if (gate <= 2) {
-                    const uint32_t lap = (uint32_t)(wlo >> 38) & 0xffffff;
-                    const uint64_t elo = p.a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^
-                                         ac_lo[512 + (lap >> 16)];
-                    const uint32_t ehi = p.a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^
-                                         ac_hi[512 + (lap >> 16)];
-                    const int err = __popcll(elo ^ wlo) + __popc((ehi ^ whi) & 0xf);
-                    if (err < 7) { pending = cpos; pend_lap = lap; pend_err = err; }
-                }
+#pragma unroll
+            for (int j = 0; j < kPer; j++) {
+                const int i = threadIdx.x + j * kWinThreads;
+                if (i < kVec) ((float4 *)tile)[i] = v[j];
             }
-            if (cpos >= 625 && pending < 0) searching = false;
+            if (base == 0 && threadIdx.x < 80) tile[threadIdx.x] = 0.f;   // policy Q1: demod_out[0] = 0
         }
-        if (!searching && nhits == 0) break;      // search range exhausted without a hit
+        __syncthreads();
+        const unsigned int lim = (unsigned int)(base + kWinRows - 8);
+        while (active && ii <= lim) {
+            if (!(ii < ni && oo < demod_n)) {                    // input exhausted: window done
+                if (nhits > 0) win_len[w] = oo;
+                active = false;
+                break;
+            }
+            // interpolate: sum_q T[imu][7-q] * in[ii+q], q ascending
+            int imu = (int)rintf(mu * 128.0f);
+            imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
+            const float *t = &mmse[imu * 8];
+            const float *in = &tile[(ii - (unsigned int)base) * 80 + c];
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc = fmaf(t[7 - q], in[q * 80], acc);
+            const float out = acc;
+            const float s_last = (last < 0) ? -1.0f : 1.0f;
+            const float s_out = (out < 0) ? -1.0f : 1.0f;
+            const float mm_val = s_last * out - s_out * last;
+            last = out;
+            omega = omega + (p.gain_omega * mm_val);
+            {
+                const float xx = omega - p.omega_mid;
+                float x1 = fabsf(xx + p.omega_relative_limit);
+                const float x2 = fabsf(xx - p.omega_relative_limit);
+                x1 -= x2;
+                omega = p.omega_mid + 0.5f * x1;
+            }
+            mu = mu + (omega + (p.gain_mu * mm_val));
+            const float fl = floorf(mu);
+            ii += (unsigned int)(int)fl;
+            mu = mu - fl;
+
+            // ---- slicer + streaming access-code search ----
+            const uint32_t sym = (out < 0) ? 0u : 1u;
+            const int s = oo;
+            oo++;
+            if (searching) {
+                wlo = (wlo >> 1) | ((uint64_t)(whi & 1u) << 63);
+                whi = (whi >> 1) | (sym << 3);
+                if (pending >= 0) {          // one more symbol exists: pending < len - 68
+                    const unsigned int slot_h = atomicAdd(hit_count, 1u);
+                    if (slot_h < (unsigned int)p.max_hits) {
+                        DeviceHit h;
+                        h.slot = (uint32_t)k; h.channel_idx = c; h.offset = pending;
+                        h.lap = pend_lap; h.ac_errors = pend_err; h.kind = 0; h.snr = snr;
+                        hits[slot_h] = h;
+                    }
+                    nhits++;
+                    resume = pending + 68;
+                    pending = -1;
+                    if (p.mode == 0) searching = false;      // multi_LAP: first hit only
+                }
+                const int cpos = s - 67;
+                if (searching && cpos >= resume && cpos < 625) {
+                    const uint32_t pre = (uint32_t)wlo & 0x1f;
+                    const uint32_t bar = ((uint32_t)(wlo >> 61) | (whi << 3)) & 0x7f;
+                    const int gate = popc5min(pre, 0x0a, 0x15) + popc5min(bar, 0x27, 0x58);
+                    if (gate <= 2) {
+                        const uint32_t lap = (uint32_t)(wlo >> 38) & 0xffffff;
+                        const uint64_t elo = p.a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^
+                                             ac_lo[512 + (lap >> 16)];
+                        const uint32_t ehi = p.a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^
+                                             ac_hi[512 + (lap >> 16)];
+                        const int err = __popcll(elo ^ wlo) + __popc((ehi ^ whi) & 0xf);
+                        if (err < 7) { pending = cpos; pend_lap = lap; pend_err = err; }
+                    }
+                }
+                if (cpos >= 625 && pending < 0) searching = false;
+            }
+            if (!searching && nhits == 0) active = false;    // search range exhausted without a hit
+        }
     }
-    if (nhits > 0) win_len[w] = oo;       // len: only needed (and only exact) for windows with hits
 }
 
 }  // namespace btgpu

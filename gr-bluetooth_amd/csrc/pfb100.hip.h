@@ -37,7 +37,7 @@ struct PfbParams {
     int rot_period;
     int ntiles;
     // channel epilogue
-    float *d;                    // [T][nsel] time-major
+    float *d;                    // [T][80] time-major (row stride 80 floats)
     double *ptile;               // [nsel][ntiles]
     double *phead;               // [nsel][nb]
     int tiles_per_block, tail, nb;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
         float m = 0.f;
         if (t < p.T) {
             m = (a.x * a.x) + (a.y * a.y);
-            p.d[(size_t)t * p.nsel + c] = demod_one(atab, p.gain, a, b);
+            p.d[(size_t)t * 80 + c] = demod_one(atab, p.gain, a, b);
         }
         Mb[c * NT + tl] = m;
     }
