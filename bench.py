@@ -91,8 +91,7 @@ def main():
 
     def step():
         blk.process_device(seg.data_ptr(), n_complex, first, S, left_margin=margin)
-        hits = blk.poll()
-        ints, snr = bdist.hits_to_arrays(hits)
+        ints, snr = bdist.struct_to_arrays(blk.poll_arrays())
         if world > 1:
             ints, snr = bdist.gather_hits(ints, snr, device=device)
         return ints, snr
@@ -142,7 +141,8 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events inside libbtgpu, same stream) ----
         names = pkg.KERNEL_NAMES
-        avg = [kernel_ms[i] / kernel_launches[i] if kernel_launches[i] else 0.0 for i in range(5)]
+        NK = len(names)
+        avg = [kernel_ms[i] / kernel_launches[i] if kernel_launches[i] else 0.0 for i in range(NK)]
         dom = int(np.argmax(avg))
         bytes_per_launch = 8.0 * S * slot                      # 8 B per complex input sample, read once
         ach = bytes_per_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
@@ -152,7 +152,7 @@ def main():
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(ach, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                 "avg_launch_ms": round(avg[dom], 4),
-                "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(5)}}
+                "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(NK)}}
         if names[dom] in ("ddc_noise", "ddc_channel"):
             fl = (fma_noise if names[dom] == "ddc_noise" else fma_ch) * 2.0 * S * slot
             roof["fp32_tflops"] = round(fl / (avg[dom] * 1e-3) / 1e12, 3)

@@ -63,7 +63,7 @@ class Hit(ctypes.Structure):
 
 
 K_DDC_CHANNEL, K_DEMOD_ENERGY, K_DDC_NOISE, K_NOISE_ENERGY, K_WINDOW = 0, 1, 2, 3, 4
-KERNEL_NAMES = ["ddc_channel", "demod_energy", "ddc_noise", "noise_energy", "window"]
+KERNEL_NAMES = ["ddc_channel", "demod_energy", "ddc_noise", "noise_energy", "window", "finish"]
 
 
 class Timing(ctypes.Structure):
@@ -285,6 +285,21 @@ class _MultiBlock:
         if n < 0:
             raise BtgpuError(n, "btgpu_poll")
         return [buf[i] for i in range(n)]
+
+    HIT_DTYPE = np.dtype([("slot", "<u8"), ("channel", "<i4"), ("offset", "<i4"), ("lap", "<u4"),
+                          ("ac_errors", "<i4"), ("kind", "<i4"), ("nsym", "<i4"), ("snr_db", "<f8")])
+
+    def poll_arrays(self, max_hits=1 << 20):
+        """Drain the hit queue into a numpy structured array (no per-record Python objects)."""
+        n = self._L.btgpu_pending(self._h)
+        n = min(max(n, 0), max_hits)
+        buf = np.zeros(n, self.HIT_DTYPE)
+        if n:
+            got = self._L.btgpu_poll(self._h, buf.ctypes.data_as(ctypes.POINTER(Hit)), n)
+            if got < 0:
+                raise BtgpuError(got, "btgpu_poll")
+            buf = buf[:got]
+        return buf
 
     def timing(self):
         t = Timing()

@@ -67,7 +67,7 @@ struct btgpu_handle {
     std::vector<float> pre;          // the `margin` samples preceding the next work() buffer
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
     int sticky = BTGPU_OK;
 
@@ -80,7 +80,7 @@ struct btgpu_handle {
     // device memory
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
-    DevBuf d_eon, d_eoff, d_snr, d_winlen, d_hits, d_hitcount;
+    DevBuf d_eon, d_eoff, d_snr, d_winlen, d_hits, d_hitcount, d_fin;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w;
     long long zstride = 0;
@@ -124,7 +124,7 @@ struct btgpu_handle {
     {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
-                         &d_eon, &d_eoff, &d_snr, &d_winlen, &d_hits, &d_hitcount,
+                         &d_eon, &d_eoff, &d_snr, &d_winlen, &d_hits, &d_hitcount, &d_fin,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -150,7 +150,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     last_S = S;
     last_G = G;
 
-    HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, sizeof(unsigned int), st));
+    HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
     HIPCHK(this, hipEventRecord(ev[0], st));
 
     // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 block sums P, Pt ----
@@ -212,8 +212,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         const size_t lds = (size_t)(((span + 1) & ~1) + NT * 100) * sizeof(float2);
         hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false>), dim3(p.ntiles), dim3(256), lds, st, p);
         HIPCHK(this, hipEventRecord(ev[3], st));
-        const size_t lds2 = (size_t)((ns.nw + ns.L3 + 1) & ~1) * sizeof(float2) + ns.L3 * sizeof(float);
-        hipLaunchKernelGGL(noise_stage2_kernel, dim3(S, nch), dim3(256), lds2, st, (const float2 *)d_Z.p,
+        const size_t lds2 = (size_t)((ns.nw + ns.L3 + 2) & ~1) * sizeof(float2);
+        hipLaunchKernelGGL(noise_stage2_kernel, dim3(S, nch), dim3(128), lds2, st, (const float2 *)d_Z.p,
                            zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p, (const double *)d_w.p,
                            (double *)d_Q.p, S);
     } else {
@@ -245,9 +245,20 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
                            (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
                            (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
-                           (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p);
+                           (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
+                           (unsigned int *)d_hitcount.p + 1);
+        HIPCHK(this, hipEventRecord(ev[5], st));
+        if (des.cfg.mode == BTGPU_MODE_SNIFFER) {
+            // windows with hits: at most one FinishRec per window; grid sized for the worst case
+            // that can actually occur (bounded by the hit capacity), lanes beyond fin_count exit.
+            const long long cap = std::min<long long>((long long)S * nch, (long long)max_hits);
+            const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
+            hipLaunchKernelGGL(finish_kernel, dim3(nblk), dim3(64), 0, st, p, (const float *)d_d.p, G,
+                               (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
+                               (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p);
+        }
     }
-    HIPCHK(this, hipEventRecord(ev[5], st));
+    HIPCHK(this, hipEventRecord(ev[6], st));
     HIPCHK(this, hipGetLastError());
 
     // ---- collect hits ----
@@ -255,12 +266,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     HIPCHK(this, hipMemcpyAsync(&count, d_hitcount.p, sizeof count, hipMemcpyDeviceToHost, st));
     HIPCHK(this, hipStreamSynchronize(st));
     float ms = 0;
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 6; i++) {
         HIPCHK(this, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
         timing.kernel_ms[i] += ms;
         timing.kernel_launches[i] += 1;
     }
-    HIPCHK(this, hipEventElapsedTime(&ms, ev[0], ev[5])); timing.total_ms += ms;
+    HIPCHK(this, hipEventElapsedTime(&ms, ev[0], ev[6])); timing.total_ms += ms;
     timing.batches += 1;
     timing.slots += (uint64_t)S;
     timing.samples += (uint64_t)S * (uint64_t)d.samples_per_slot;
@@ -486,7 +497,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_snr, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_winlen, (size_t)S * nch * sizeof(int)));
     TRY(h->alloc(h->d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
-    TRY(h->alloc(h->d_hitcount, sizeof(unsigned int)));
+    TRY(h->alloc(h->d_hitcount, 2 * sizeof(unsigned int)));
+    TRY(h->alloc(h->d_fin, (size_t)S * nch * sizeof(FinishRec)));
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

@@ -28,6 +28,13 @@ struct DeviceHit {            // 32 bytes, written by the window kernel
     double   snr;
 };
 
+struct FinishRec {            // M&M state of a window that reported hits, handed to finish_kernel
+    int32_t  w;               // window index k * nch + c
+    uint32_t ii;
+    int32_t  oo;
+    float    mu, omega, last;
+};
+
 // ------------------------------------------------------------------------------------
 // K1: direct-form decimating complex band-pass FIR bank (channel bank and noise bank).
 //   y[c][g] = ( sum_j taps[c][j] * x[first + g*D + j] ) * rot[c][g]
@@ -265,7 +272,8 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const float *__restrict__ mmse_g, const uint64_t *__restrict__ ac_lo_g,
     const uint32_t *__restrict__ ac_hi_g,
     double *__restrict__ e_on_out, double *__restrict__ e_off_out, double *__restrict__ snr_out,
-    int *__restrict__ win_len, DeviceHit *__restrict__ hits, unsigned int *__restrict__ hit_count)
+    int *__restrict__ win_len, DeviceHit *__restrict__ hits, unsigned int *__restrict__ hit_count,
+    FinishRec *__restrict__ fin, unsigned int *__restrict__ fin_count)
 {
     __shared__ float mmse[129 * 8];
     __shared__ uint64_t ac_lo[3 * 256];
@@ -412,8 +420,88 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                 if (cpos >= 625 && pending < 0) searching = false;
             }
             if (!searching && nhits == 0) active = false;    // search range exhausted without a hit
+            if (!searching && nhits > 0 && p.mode != 0) {
+                // multi_sniffer: the handlers need len = symbols in the whole window.  Hand the
+                // M&M state to finish_kernel (dense waves of hit windows) instead of keeping this
+                // slot's workgroup alive for 5x longer with one or two live lanes.
+                const unsigned int f = atomicAdd(fin_count, 1u);
+                FinishRec r;
+                r.w = (int32_t)w; r.ii = ii; r.oo = oo; r.mu = mu; r.omega = omega; r.last = last;
+                fin[f] = r;
+                active = false;
+            }
         }
     }
+}
+
+// Continue the M&M recursion of the windows that reported hits to the end of their window and
+// store len.  One lane per window; each lane stages its own column of the time-major stream
+// (row stride 80 floats) into a private LDS slab, kFinRows rows at a time, all loads of a chunk
+// in flight together.  No cross-lane data => no barriers.
+constexpr int kFinRows = 32;
+__global__ __launch_bounds__(64) void finish_kernel(
+    WindowParams p, const float *__restrict__ d, long long d_rows, const float *__restrict__ mmse_g,
+    const FinishRec *__restrict__ fin, const unsigned int *__restrict__ fin_count,
+    int *__restrict__ win_len)
+{
+    __shared__ float mmse[129 * 8];
+    __shared__ float slab[64 * (kFinRows + 1)];
+    const unsigned int n = *fin_count;
+    if (blockIdx.x * blockDim.x >= n) return;                    // uniform: nothing for this workgroup
+    for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
+    __syncthreads();
+    const unsigned int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const FinishRec r = fin[f];
+    const int k = r.w / p.nch, c = r.w - k * p.nch;
+    const int demod_n = p.ddc_out - 1;
+    const unsigned int ni = (unsigned int)(demod_n - 8);
+    const float *col = d + ((size_t)k * p.outs_per_slot) * 80 + c;
+    const long long row0 = (long long)k * p.outs_per_slot;
+    float mu = r.mu, omega = r.omega, last = r.last;
+    unsigned int ii = r.ii;
+    int oo = r.oo;
+    float *my = slab + threadIdx.x * (kFinRows + 1);
+    while (ii < ni && oo < demod_n) {
+        const unsigned int base = ii;
+        float v[kFinRows];
+#pragma unroll
+        for (int j = 0; j < kFinRows; j++) {
+            const unsigned int idx = base + j;
+            v[j] = (idx < (unsigned int)p.ddc_out && row0 + idx < d_rows) ? col[(size_t)idx * 80] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < kFinRows; j++) my[j] = v[j];
+        const unsigned int lim = base + kFinRows - 8;
+        while (ii <= lim && ii < ni && oo < demod_n) {
+            int imu = (int)rintf(mu * 128.0f);
+            imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
+            const float *t = &mmse[imu * 8];
+            const float *in = my + (ii - base);
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc = fmaf(t[7 - q], in[q], acc);
+            const float out = acc;
+            const float s_last = (last < 0) ? -1.0f : 1.0f;
+            const float s_out = (out < 0) ? -1.0f : 1.0f;
+            const float mm_val = s_last * out - s_out * last;
+            last = out;
+            omega = omega + (p.gain_omega * mm_val);
+            {
+                const float xx = omega - p.omega_mid;
+                float x1 = fabsf(xx + p.omega_relative_limit);
+                const float x2 = fabsf(xx - p.omega_relative_limit);
+                x1 -= x2;
+                omega = p.omega_mid + 0.5f * x1;
+            }
+            mu = mu + (omega + (p.gain_mu * mm_val));
+            const float fl = floorf(mu);
+            ii += (unsigned int)(int)fl;
+            mu = mu - fl;
+            oo++;
+        }
+    }
+    win_len[r.w] = oo;
 }
 
 }  // namespace btgpu

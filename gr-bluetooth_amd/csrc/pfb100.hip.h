@@ -279,39 +279,38 @@ __global__ void block_sum_kernel(const double *__restrict__ ptile, int ntiles, i
 // over the slot's nw stage-2 outputs (quadrature weights incl. the band-limited edge
 // correction).  One workgroup per (slot k, channel c).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void noise_stage2_kernel(
+__global__ __launch_bounds__(128) void noise_stage2_kernel(
     const float2 *__restrict__ Z, long long zstride, int outs, int nw, int L3,
     const float *__restrict__ h3, const double *__restrict__ w, double *__restrict__ Qn, int S)
 {
     extern __shared__ float4 lds4[];
-    float2 *zs = (float2 *)lds4;                 // [nw + L3 - 1]
-    float *hs = (float *)(zs + ((nw + L3 + 1) & ~1));   // [L3]
-    __shared__ double red[4];
+    float2 *zs = (float2 *)lds4;                 // [nw + L3]
+    __shared__ double red[2];
     const int k = blockIdx.x, c = blockIdx.y;
     const float2 *z = Z + (size_t)c * zstride + (long long)k * outs;
     const int need = nw + L3 - 1;
-    for (int i = threadIdx.x; i < need; i += blockDim.x) zs[i] = z[i];
-    for (int i = threadIdx.x; i < L3; i += blockDim.x) hs[i] = h3[i];
+    for (int i = threadIdx.x; i < need + 1; i += blockDim.x) zs[i] = i < need ? z[i] : make_float2(0.f, 0.f);
     __syncthreads();
     double acc = 0.0;
-    for (int j = threadIdx.x; j < nw; j += blockDim.x) {
-        float yr = 0.f, yi = 0.f;
+    // each lane produces two adjacent outputs j, j+1: every staged sample is read once and used
+    // for both; the taps are wave-uniform (scalar loads)
+    for (int j = 2 * threadIdx.x; j < nw; j += 2 * blockDim.x) {
+        float y0r = 0.f, y0i = 0.f, y1r = 0.f, y1i = 0.f;
+        float2 prev = zs[j];
         for (int i = 0; i < L3; i++) {
-            const float2 v = zs[j + i];
-            yr = fmaf(hs[i], v.x, yr);
-            yi = fmaf(hs[i], v.y, yi);
+            const float2 nxt = zs[j + i + 1];
+            const float hh = h3[i];
+            y0r = fmaf(hh, prev.x, y0r); y0i = fmaf(hh, prev.y, y0i);
+            y1r = fmaf(hh, nxt.x, y1r);  y1i = fmaf(hh, nxt.y, y1i);
+            prev = nxt;
         }
-        const float m = (yr * yr) + (yi * yi);
-        acc += w[j] * (double)m;
+        acc += w[j] * (double)((y0r * y0r) + (y0i * y0i));
+        if (j + 1 < nw) acc += w[j + 1] * (double)((y1r * y1r) + (y1i * y1i));
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) s += red[wv];
-        Qn[(size_t)c * S + k] = s;
-    }
+    if (threadIdx.x == 0) Qn[(size_t)c * S + k] = red[0] + red[1];
 }
 
 }  // namespace btgpu

@@ -39,6 +39,13 @@ def hits_to_arrays(hits):
     return ints, snr
 
 
+def struct_to_arrays(rec):
+    """numpy structured hit array (multi_*.poll_arrays) -> (int64 [n,7], float64 [n])."""
+    ints = np.stack([rec[f].astype(np.int64) for f in HIT_INT_FIELDS], axis=1) if len(rec) else \
+        np.zeros((0, len(HIT_INT_FIELDS)), np.int64)
+    return ints, rec["snr_db"].astype(np.float64)
+
+
 def sort_hits(ints, snr):
     """Order the reference's loops print in: slot, channel, kind, offset."""
     if len(ints) == 0:

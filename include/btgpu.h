@@ -108,6 +108,7 @@ typedef struct btgpu_hit {
 #define BTGPU_K_DDC_NOISE     2   /* noise bank                                          */
 #define BTGPU_K_NOISE_ENERGY  3   /* noise |Y|^2 per-slot sums                           */
 #define BTGPU_K_WINDOW        4   /* squelch + M&M + slicer + access-code search         */
+#define BTGPU_K_FINISH        5   /* M&M continuation of the windows that reported hits  */
 #define BTGPU_K_COUNT         8
 typedef struct btgpu_timing {
     float    kernel_ms[BTGPU_K_COUNT];        /* summed over launches                  */
