@@ -80,8 +80,8 @@ struct btgpu_handle {
     // device memory
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
-    DevBuf d_eon, d_eoff, d_snr, d_winlen, d_hits, d_hitcount, d_fin;
-    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile;
+    DevBuf d_eon, d_eoff, d_snr, d_winlen, d_hits, d_hitcount, d_fin, d_d2;
+    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w;
     long long zstride = 0;
     int ntiles_max = 0;
@@ -124,8 +124,8 @@ struct btgpu_handle {
     {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
-                         &d_eon, &d_eoff, &d_snr, &d_winlen, &d_hits, &d_hitcount, &d_fin,
-                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile,
+                         &d_eon, &d_eoff, &d_snr, &d_winlen, &d_hits, &d_hitcount, &d_fin, &d_d2,
+                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -164,20 +164,23 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.nsel = nch; p.binpos = (const int *)d_binpos_ch.p; p.krot = (const float2 *)d_krot_ch.p;
         p.rot_period = b.rot_period;
         p.ntiles = (int)((G + TT - 1) / TT);
-        p.d = (float *)d_d.p; p.ptile = (double *)d_ptile.p; p.phead = (double *)d_Pt.p;
+        p.d = (float *)d_d.p; p.ptile = (double *)d_ptile.p; p.phead = (double *)d_phead.p;
+        p.d2 = (float *)d_d2.p; p.d2stride = ystride;
         p.tiles_per_block = ops / TT; p.tail = des.tail; p.nb = nb;
         p.atan_tab = (const float *)d_atan.p; p.gain = des.demod_gain;
         p.Z = keep_Y ? (float2 *)d_Y.p : nullptr; p.zstride = ystride;
         const int span = b.D * (NT - 1) + b.Q * 100, wsz = nch * NT;
         const int asz = ((span > wsz ? span : wsz) + 1) & ~1;
         const size_t lds = (size_t)(asz + NT * 100) * sizeof(float2) + (size_t)(nch * NT + 257) * sizeof(float);
+        static_assert(NT * 79 + 2 + 3 * 80 * 2 * 2 <= 2 * (50 * 25 + 700), "epilogue scratch must fit the dead input tile");
         if (b.real_taps)
             hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true>), dim3(p.ntiles), dim3(256), lds, st, p);
         else
             hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true>), dim3(p.ntiles), dim3(256), lds, st, p);
         HIPCHK(this, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 255) / 256), dim3(256), 0, st,
-                           (const double *)d_ptile.p, p.ntiles, p.tiles_per_block, (double *)d_P.p, nb, nch);
+                           (const double *)d_ptile.p, (const double *)d_phead.p, p.ntiles, p.tiles_per_block,
+                           des.tail / TT, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     } else {
         const LaunchShape &s = shape_ch;
         dim3 grid((unsigned)((G + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
@@ -189,7 +192,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         dim3 g2((unsigned)nb, (unsigned)nch);
         hipLaunchKernelGGL(demod_energy_kernel<true>, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
                            ystride, ops, des.tail, (const float *)d_atan.p, des.demod_gain,
-                           (float *)d_d.p, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
+                           (float *)d_d.p, (double *)d_P.p, (double *)d_Pt.p, nb, nch, (float *)d_d2.p, ystride);
     }
     HIPCHK(this, hipEventRecord(ev[2], st));
 
@@ -227,7 +230,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         dim3 g2((unsigned)S, (unsigned)nch);
         hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, st, (const float2 *)d_Yn.p, Gn,
                            ystride_n, ops, 0, (const float *)nullptr, 0.f, (float *)nullptr,
-                           (double *)d_Q.p, (double *)nullptr, S, nch);
+                           (double *)d_Q.p, (double *)nullptr, S, nch, (float *)nullptr, 0LL);
     }
     HIPCHK(this, hipEventRecord(ev[4], st));
 
@@ -253,7 +256,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             // that can actually occur (bounded by the hit capacity), lanes beyond fin_count exit.
             const long long cap = std::min<long long>((long long)S * nch, (long long)max_hits);
             const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
-            hipLaunchKernelGGL(finish_kernel, dim3(nblk), dim3(64), 0, st, p, (const float *)d_d.p, G,
+            hipLaunchKernelGGL(finish_kernel, dim3(nblk), dim3(64), 0, st, p, (const float *)d_d2.p, ystride, G,
                                (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p);
         }
@@ -470,6 +473,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_binpos_ch, b.binpos.data(), b.binpos.size() * sizeof(int)));
         TRY(h->upload(h->d_krot_ch, b.krot.data(), b.krot.size() * sizeof(float)));
         TRY(h->alloc(h->d_ptile, (size_t)nch * h->ntiles_max * sizeof(double)));
+        TRY(h->alloc(h->d_phead, (size_t)nch * h->ntiles_max * sizeof(double)));
     }
     if (h->use_staged) {
         const NoiseStage &ns = h->fp.noise;
@@ -499,6 +503,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
     TRY(h->alloc(h->d_hitcount, 2 * sizeof(unsigned int)));
     TRY(h->alloc(h->d_fin, (size_t)S * nch * sizeof(FinishRec)));
+    if (cfg->mode == BTGPU_MODE_SNIFFER) TRY(h->alloc(h->d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

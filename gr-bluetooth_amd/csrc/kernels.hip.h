@@ -182,7 +182,8 @@ template <bool DEMOD>
 __global__ __launch_bounds__(256) void demod_energy_kernel(
     const float2 *__restrict__ Y, long long G, long long ystride, int bs, int tail,
     const float *__restrict__ atan_tab, float gain, float *__restrict__ d,
-    double *__restrict__ P, double *__restrict__ Pt, int nb, int nch)
+    double *__restrict__ P, double *__restrict__ Pt, int nb, int nch, float *__restrict__ d2,
+    long long d2stride)
 {
     __shared__ float atab[257];
     __shared__ double red[2][4];
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void demod_energy_kernel(
             float dv = 0.f;
             if (g > 0) dv = demod_one(atab, gain, v, y[g - 1]);
             d[(size_t)g * 80 + c] = dv;
+            if (d2) d2[(size_t)c * d2stride + g] = dv;
         }
     }
     // wave reduce (64 lanes) then across the 4 waves
@@ -440,12 +442,12 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 // in flight together.  No cross-lane data => no barriers.
 constexpr int kFinRows = 32;
 __global__ __launch_bounds__(64) void finish_kernel(
-    WindowParams p, const float *__restrict__ d, long long d_rows, const float *__restrict__ mmse_g,
-    const FinishRec *__restrict__ fin, const unsigned int *__restrict__ fin_count,
-    int *__restrict__ win_len)
+    WindowParams p, const float *__restrict__ d2, long long d2stride, long long d_rows,
+    const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
+    const unsigned int *__restrict__ fin_count, int *__restrict__ win_len)
 {
     __shared__ float mmse[129 * 8];
-    __shared__ float slab[64 * (kFinRows + 1)];
+    __shared__ float slab[64 * (2 * kFinRows + 1)];
     const unsigned int n = *fin_count;
     if (blockIdx.x * blockDim.x >= n) return;                    // uniform: nothing for this workgroup
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
@@ -456,31 +458,37 @@ __global__ __launch_bounds__(64) void finish_kernel(
     const int k = r.w / p.nch, c = r.w - k * p.nch;
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
-    const float *col = d + ((size_t)k * p.outs_per_slot) * 80 + c;
     const long long row0 = (long long)k * p.outs_per_slot;
+    const float *col = d2 + (size_t)c * d2stride + row0;         // this window's demod samples, contiguous
+    const unsigned int nvalid = (unsigned int)((d_rows - row0) < p.ddc_out ? (d_rows - row0) : p.ddc_out);
     float mu = r.mu, omega = r.omega, last = r.last;
     unsigned int ii = r.ii;
     int oo = r.oo;
-    float *my = slab + threadIdx.x * (kFinRows + 1);
+    // private ring of 2*kFinRows samples: rows [lo, lo + 2*kFinRows) live at my[row & (2*kFinRows-1)]
+    float *my = slab + threadIdx.x * (2 * kFinRows + 1);
+    constexpr unsigned int RING = 2 * kFinRows, MASK = RING - 1;
+    unsigned int hi = ii;                                        // rows [.., hi) are resident
+    {
+        float v[RING];
+#pragma unroll
+        for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = idx < nvalid ? col[idx] : 0.f; }
+#pragma unroll
+        for (unsigned int j = 0; j < RING; j++) my[(hi + j) & MASK] = v[j];
+        hi += RING;
+    }
     while (ii < ni && oo < demod_n) {
-        const unsigned int base = ii;
+        // issue the loads of the next kFinRows rows now; they land while the steps below run
         float v[kFinRows];
 #pragma unroll
-        for (int j = 0; j < kFinRows; j++) {
-            const unsigned int idx = base + j;
-            v[j] = (idx < (unsigned int)p.ddc_out && row0 + idx < d_rows) ? col[(size_t)idx * 80] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < kFinRows; j++) my[j] = v[j];
-        const unsigned int lim = base + kFinRows - 8;
-        while (ii <= lim && ii < ni && oo < demod_n) {
+        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = idx < nvalid ? col[idx] : 0.f; }
+        // consume every step whose 8-tap window lies inside the resident rows [.., hi)
+        while (ii + 8 <= hi && ii < ni && oo < demod_n) {
             int imu = (int)rintf(mu * 128.0f);
             imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
             const float *t = &mmse[imu * 8];
-            const float *in = my + (ii - base);
             float acc = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; q++) acc = fmaf(t[7 - q], in[q], acc);
+            for (int q = 0; q < 8; q++) acc = fmaf(t[7 - q], my[(ii + q) & MASK], acc);
             const float out = acc;
             const float s_last = (last < 0) ? -1.0f : 1.0f;
             const float s_out = (out < 0) ? -1.0f : 1.0f;
@@ -500,6 +508,11 @@ __global__ __launch_bounds__(64) void finish_kernel(
             mu = mu - fl;
             oo++;
         }
+        // here ii + 8 > hi (or the window is done): the ring slots of rows [hi-RING, hi-RING+kFinRows)
+        // are all below ii and can take rows [hi, hi + kFinRows)
+#pragma unroll
+        for (int j = 0; j < kFinRows; j++) my[(hi + j) & MASK] = v[j];
+        hi += kFinRows;
     }
     win_len[r.w] = oo;
 }

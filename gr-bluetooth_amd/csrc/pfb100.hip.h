@@ -23,6 +23,9 @@
 
 #include "kernels.hip.h"
 
+// The polyphase path is a tolerance path: let the compiler fuse a*b+c here.
+#pragma clang fp contract(fast)
+
 namespace btgpu {
 
 struct PfbParams {
@@ -38,8 +41,9 @@ struct PfbParams {
     int ntiles;
     // channel epilogue
     float *d;                    // [T][80] time-major (row stride 80 floats)
+    float *d2; long long d2stride;  // optional channel-major copy [nsel][d2stride] for finish_kernel
     double *ptile;               // [nsel][ntiles]
-    double *phead;               // [nsel][nb]
+    double *phead;               // [nsel][ntiles]  sum of the first (tail % TT) instants of each tile
     int tiles_per_block, tail, nb;
     const float *atan_tab; float gain;
     // noise epilogue
@@ -90,6 +94,35 @@ __device__ __forceinline__ void dft10(float2 *v)
     v[4] = caddf(E[4], o4); v[9] = csubf(E[4], o4);
 }
 
+// fast_atan2f with v_rcp_f32 instead of the IEEE divide (1 ulp on the ratio; tolerance path only)
+__device__ __forceinline__ float demod_fast(const float *__restrict__ tab, float gain, float2 a, float2 b)
+{
+    const float pr = a.x * b.x + a.y * b.y;
+    const float pi = a.y * b.x - a.x * b.y;
+    const float ya = fabsf(pi), xa = fabsf(pr);
+    const float mx = fmaxf(xa, ya), mn = fminf(xa, ya);
+    if (!(mx > 0.0f)) return 0.0f;
+    const float z = mn * __builtin_amdgcn_rcpf(mx);
+    float base;
+    if (z < 0.003921569f) base = z;
+    else {
+        float alpha = z * 255.0f;
+        const int index = ((int)alpha) & 0xff;
+        alpha -= (float)index;
+        const float t0 = tab[index];
+        base = t0 + (tab[index + 1] - t0) * alpha;
+    }
+    float ang;
+    if (xa > ya) {
+        ang = pr >= 0.0f ? base : 3.14159265358979323846f - base;
+        ang = pi >= 0.0f ? ang : -ang;
+    } else {
+        ang = pr >= 0.0f ? 1.57079632679489661923f - base : 1.57079632679489661923f + base;
+        ang = pi >= 0.0f ? ang : -ang;
+    }
+    return gain * ang;
+}
+
 // XCD-aware tile order: consecutive tiles (which share the filter-length halo of their input
 // span) run on the same XCD so the overlap is an L2 hit.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int b, int n)
@@ -114,6 +147,10 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
     float2 *U = lds + ((asz + 1) & ~1);                      // [NT][UST]
     float *Mb = (float *)(U + NT * UST);                     // [nsel][NT] |y|^2     (CHAN)
     float *atab = Mb + (CHAN ? p.nsel * NT : 0);             // [257]               (CHAN)
+    __shared__ float2 s_tw[100];
+    __shared__ float2 s_krot[80 * 4];
+    __shared__ int s_binpos[80];
+    const bool krot_lds = p.rot_period <= 4 && p.nsel <= 80;
 
     const int tile = xcd_remap(blockIdx.x, p.ntiles);
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
@@ -147,6 +184,9 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
             xs[s] = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
         }
         if (CHAN) for (int i = l; i < 257; i += 256) atab[i] = p.atan_tab[i];
+        if (l < 100) s_tw[l] = p.twiddle[l];
+        if (l < p.nsel && l < 80) s_binpos[l] = p.binpos[l];
+        if (krot_lds) for (int i = l; i < p.nsel * p.rot_period; i += 256) s_krot[i] = p.krot[i];
     }
     __syncthreads();
 
@@ -197,7 +237,7 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
         for (int k = 0; k < 10; k++) v[k] = row[10 * k];
         dft10(v);
 #pragma unroll
-        for (int k = 0; k < 10; k++) row[10 * k] = cmulf(v[k], p.twiddle[k * 10 + p2]);
+        for (int k = 0; k < 10; k++) row[10 * k] = cmulf(v[k], s_tw[k * 10 + p2]);
     }
     __syncthreads();
     // ---- phase B2: DFT over p2; bin m = m1 + 10 m2 ends up at position 10 m1 + m2 ----
@@ -220,58 +260,88 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
             const long long t = t0 + tl;
             if (t >= p.T) continue;
             const int ph = (int)(t % p.rot_period);
-            const float2 y = cmulf(U[tl * UST + p.binpos[c]], p.krot[(size_t)c * p.rot_period + ph]);
+            const float2 kr = krot_lds ? s_krot[c * p.rot_period + ph] : p.krot[(size_t)c * p.rot_period + ph];
+            const float2 y = cmulf(U[tl * UST + s_binpos[c]], kr);
             p.Z[(size_t)c * p.zstride + t] = y;
         }
         return;
     }
-    float2 *Wb = xs;                                         // [nsel][NT]
-    for (int i = l; i < p.nsel * NT; i += 256) {
-        const int c = i / NT, tl = i % NT;
-        const long long t = t0 + tl;
-        const int ph = (int)(((t % p.rot_period) + p.rot_period) % p.rot_period);
-        const float2 y = cmulf(U[tl * UST + p.binpos[c]], p.krot[(size_t)c * p.rot_period + ph]);
-        Wb[c * NT + tl] = y;
-        if (p.Z && tl >= 1 && t < p.T) p.Z[(size_t)c * p.zstride + t] = y;     // BTGPU_FLAG_DEBUG_Y
-    }
-    __syncthreads();
-    for (int i = l; i < p.nsel * TT; i += 256) {
-        const int c = i % p.nsel, tl = 1 + i / p.nsel;       // channel fastest: coalesced d store
-        const long long t = t0 + tl;
-        const float2 a = Wb[c * NT + tl], b = Wb[c * NT + tl - 1];
-        float m = 0.f;
-        if (t < p.T) {
-            m = (a.x * a.x) + (a.y * a.y);
-            p.d[(size_t)t * 80 + c] = demod_one(atab, p.gain, a, b);
+    // Channel epilogue.  Lane (chunk, c): channel c, a run of <= 9 consecutive instants, walking
+    // forward in time with the previous instant's Y in registers: de-rotate, demodulate against
+    // the previous instant (multi_block::demod), |Y|^2 partial sums in double (fixed order).
+    {
+        constexpr int CH = 3, RUN = (TT + CH - 1) / CH;          // 3 runs of 9, 9, 7 instants
+        float *Db = (float *)xs;                                 // [nsel][NT] demod values for the d2 copy
+        double *part = (double *)(Db + ((p.nsel * NT + 1) & ~1)); // [CH][80][2] (sum, head)
+        const int chunk = l / 80, c = l % 80;
+        if (chunk < CH && c < p.nsel) {
+            const int pos = s_binpos[c];
+            const int tl0 = 1 + chunk * RUN;
+            const int tl1 = tl0 + RUN < NT ? tl0 + RUN : NT;
+            const int hr = p.tail % TT;                          // head length inside a tile
+            double sum = 0.0, head = 0.0;
+            long long t = t0 + tl0 - 1;
+            int ph = (int)(((t % p.rot_period) + p.rot_period) % p.rot_period);
+            float2 kr = krot_lds ? s_krot[c * p.rot_period + ph] : p.krot[(size_t)c * p.rot_period + ph];
+            float2 prev = cmulf(U[(tl0 - 1) * UST + pos], kr);
+            for (int tl = tl0; tl < tl1; tl++) {
+                t = t0 + tl;
+                ph = ph + 1 == p.rot_period ? 0 : ph + 1;
+                kr = krot_lds ? s_krot[c * p.rot_period + ph] : p.krot[(size_t)c * p.rot_period + ph];
+                const float2 y = cmulf(U[tl * UST + pos], kr);
+                float dv = 0.f;
+                if (t < p.T) {
+                    const float m = y.x * y.x + y.y * y.y;
+                    sum += (double)m;
+                    if (tl - 1 < hr) head += (double)m;
+                    dv = demod_fast(atab, p.gain, y, prev);
+                    p.d[(size_t)t * 80 + c] = dv;
+                    if (p.Z) p.Z[(size_t)c * p.zstride + t] = y;               // BTGPU_FLAG_DEBUG_Y
+                }
+                Db[c * NT + tl] = dv;
+                prev = y;
+            }
+            part[(chunk * 80 + c) * 2 + 0] = sum;
+            part[(chunk * 80 + c) * 2 + 1] = head;
         }
-        Mb[c * NT + tl] = m;
-    }
-    __syncthreads();
-    if (l < p.nsel) {
-        double s = 0.0, h = 0.0;
-        for (int tl = 1; tl < NT; tl++) {
-            const double m = (double)Mb[l * NT + tl];
-            s += m;
-            if (tl - 1 < p.tail) h += m;
+        __syncthreads();
+        if (l < p.nsel) {
+            double sum = 0.0, head = 0.0;
+            for (int k = 0; k < CH; k++) { sum += part[(k * 80 + l) * 2]; head += part[(k * 80 + l) * 2 + 1]; }
+            p.ptile[(size_t)l * p.ntiles + tile] = sum;
+            p.phead[(size_t)l * p.ntiles + tile] = head;         // first (tail % TT) instants of this tile
         }
-        p.ptile[(size_t)l * p.ntiles + tile] = s;
-        if (tile % p.tiles_per_block == 0) p.phead[(size_t)l * p.nb + tile / p.tiles_per_block] = h;
+        if (p.d2) {                                              // channel-major copy, time fastest
+            for (int i = l; i < p.nsel * TT; i += 256) {
+                const int cc = i / TT, tl = 1 + i % TT;
+                const long long t = t0 + tl;
+                if (t < p.T) p.d2[(size_t)cc * p.d2stride + t] = Db[cc * NT + tl];
+            }
+        }
     }
 }
 
-// tile sums -> per-slot-block sums P[c][b] (same layout the direct path produces)
-__global__ void block_sum_kernel(const double *__restrict__ ptile, int ntiles, int tiles_per_block,
-                                 double *__restrict__ P, int nb, int nch)
+// tile sums -> per-slot-block sums P[c][b] and block-head sums Pt[c][b] (first `tail` instants of
+// block b), the layout the direct path produces.  tail may span several tiles (multi_LAP: 144).
+__global__ void block_sum_kernel(const double *__restrict__ ptile, const double *__restrict__ phead,
+                                 int ntiles, int tiles_per_block, int tail_tiles,
+                                 double *__restrict__ P, double *__restrict__ Pt, int nb, int nch)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb * nch) return;
     const int c = i / nb, b = i % nb;
-    double s = 0.0;
+    double s = 0.0, h = 0.0;
     for (int k = 0; k < tiles_per_block; k++) {
         const int t = b * tiles_per_block + k;
-        if (t < ntiles) s += ptile[(size_t)c * ntiles + t];
+        if (t < ntiles) {
+            const double v = ptile[(size_t)c * ntiles + t];
+            s += v;
+            if (k < tail_tiles) h += v;
+            else if (k == tail_tiles) h += phead[(size_t)c * ntiles + t];
+        }
     }
     P[(size_t)c * nb + b] = s;
+    Pt[(size_t)c * nb + b] = h;
 }
 
 // ------------------------------------------------------------------------------------

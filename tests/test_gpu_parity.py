@@ -97,6 +97,27 @@ def test_fast_path_c79_vs_oracle_and_direct(pkg, po, synth):
     assert np.max(np.abs(out["fast"]["snr"][m] - out["direct"]["snr"][m])) <= 1e-4
 
 
+def test_fast_path_lap_mode_c79(pkg, po, synth):
+    """multi_LAP at 100 Msps on the fast path (window = 1250 + 144 outputs: the block-head energy
+    sum spans several channelizer tiles)."""
+    fs, fc = 100e6, 2441e6
+    laps = tuple(0x24D952 + 0x10101 * i for i in range(6))
+    iq, truth = synth.make_capture(fs, fc, 6, laps=laps, seed=80, snr_db=25, occupancy=0.7)
+    want, done = po.Oracle(fs, fc, 10.0, po.MODE_LAP).run_stream(iq, threads=16)
+    b = pkg.multi_LAP(fs, fc, 10.0)
+    assert b.design.channelizer == pkg.CHANNELIZER_POLYPHASE
+    b.push(iq)
+    got = b.poll()
+    eon = b.debug_fetch(2, 0, 0, 6 * 79)
+    b.close()
+    assert len(want) > 5
+    assert [k[:6] for k in _keys(got)] == [k[:6] for k in _keys(want)]
+    o = po.Oracle(fs, fc, 10.0, po.MODE_LAP)
+    for k, ch in ((2, 5), (4, 60)):
+        _, e = o.channel_samples(o.window(iq, k), ch)
+        assert abs(eon[k * 79 + ch] - e) <= 1e-5 * e
+
+
 def test_fast_path_is_default_at_100msps_and_margin_is_reported(pkg):
     b = pkg.multi_sniffer(100e6, 2441e6, 10.0, False)
     assert b.design.channelizer == pkg.CHANNELIZER_POLYPHASE and b.design.squelch == pkg.SQUELCH_STAGED
