@@ -251,7 +251,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
                            (unsigned int *)d_hitcount.p + 1);
         HIPCHK(this, hipEventRecord(ev[5], st));
-        if (des.cfg.mode == BTGPU_MODE_SNIFFER) {
+        {
             // windows with hits: at most one FinishRec per window; grid sized for the worst case
             // that can actually occur (bounded by the hit capacity), lanes beyond fin_count exit.
             const long long cap = std::min<long long>((long long)S * nch, (long long)max_hits);
@@ -503,7 +503,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
     TRY(h->alloc(h->d_hitcount, 2 * sizeof(unsigned int)));
     TRY(h->alloc(h->d_fin, (size_t)S * nch * sizeof(FinishRec)));
-    if (cfg->mode == BTGPU_MODE_SNIFFER) TRY(h->alloc(h->d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
+    TRY(h->alloc(h->d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

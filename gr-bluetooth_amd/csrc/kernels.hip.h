@@ -259,15 +259,30 @@ __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
 
 constexpr int kWinThreads = 128;     // >= 79 visible channels; lane = channel
 constexpr int kWinRows = 64;         // demod rows staged per chunk
+constexpr int kDetectSyms = 693;     // 625 search offsets + 68-symbol access code
+constexpr int kBitWords = 24;        // 32-bit words of sliced symbols kept per lane (>= 693 + 99 bits)
 
-// One workgroup per slot k, one lane per channel c (nch <= 79 < 128).  The demodulated stream
-// is time-major [g][nch], so the rows a slot's windows need are shared by all its lanes: they
-// are staged through LDS in chunks of kWinRows rows with fully coalesced loads, and the
-// strictly sequential M&M recursion of each lane then runs out of LDS instead of paying a
-// global-memory round trip per symbol.  Lanes drift apart by a few samples only (omega is
-// clipped to 2 +- 0.005), so a chunk starts at the minimum input index over the live lanes.
-// Lanes stop after the 625-offset search range unless they committed a hit; those continue
-// to the end of the window to obtain `len` (the handlers' symbol count, nsym = len - offset).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | (c & (a | b)); }
+
+// One workgroup per slot k, one lane per channel c (nch <= 79 < 128).
+//
+// Phase 1 -- clock recovery.  The demodulated stream is time-major [g][80], so the rows a slot's
+// windows need are shared by all its lanes: they are staged through LDS in chunks of kWinRows
+// rows with contiguous 16-byte copies and the strictly sequential M&M recursion of each lane
+// (multi_block::mm_cr, lib/multi_block.cc:128-155; windowed reset) runs out of LDS.  Lanes drift
+// apart by a few samples only (omega is clipped to 2 +- 0.005), so a chunk starts at the minimum
+// input index over the live lanes.  Only the first 693 symbols can hold a reportable access code
+// (lib/multi_sniffer_impl.cc:108-126), so the recursion stops there; sliced symbols are packed
+// one bit each into a per-lane LDS bit buffer.
+//
+// Phase 2 -- access-code search (classic_packet::sniff_ac, lib/packet_impl.cc:247-268) on the
+// packed bits, 32 offsets at a time: the 5-bit preamble and 7-bit Barker distance LUTs are
+// "min Hamming distance to a pattern or its complement", evaluated bit-sliced with full adders
+// over shifted copies of the stream; surviving candidates (7.7 % on noise) get the 68-bit
+// compare against the affine access code AC(0) ^ cols(LAP) with popcount < 7
+// (check_ac, lib/packet_impl.cc:471-510).  Hits are taken greedily with resume at c + 68 and
+// limit = min(len - 68, 625), which is what the reference's while (limit >= 0) loop does.
 __global__ __launch_bounds__(kWinThreads) void window_kernel(
     WindowParams p, const float *__restrict__ d, long long d_rows, const double *__restrict__ P,
     const double *__restrict__ Pt, const double *__restrict__ Qn,
@@ -277,23 +292,25 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     int *__restrict__ win_len, DeviceHit *__restrict__ hits, unsigned int *__restrict__ hit_count,
     FinishRec *__restrict__ fin, unsigned int *__restrict__ fin_count)
 {
-    __shared__ float mmse[129 * 8];
+    __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
     __shared__ uint64_t ac_lo[3 * 256];
     __shared__ uint32_t ac_hi[3 * 256];
     __shared__ __attribute__((aligned(16))) float tile[kWinRows * 80];
+    __shared__ uint32_t bits[kBitWords * kWinThreads];
     __shared__ int s_min;
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) { ac_lo[i] = ac_lo_g[i]; ac_hi[i] = ac_hi_g[i]; }
+    for (int i = threadIdx.x; i < kBitWords * kWinThreads; i += blockDim.x) bits[i] = 0u;
 
     const int k = blockIdx.x;
     const int c = threadIdx.x;
     const int nch = p.nch;
     const long long w = (long long)k * nch + c;
-    bool active = c < nch;
+    int nmax = 0;                                    // symbols this lane will produce in phase 1
     double snr = 0.0;
 
     // ---- squelch: multi_block::channel_samples energy + check_snr (multi_block.cc:206-293) ----
-    if (active) {
+    if (c < nch) {
         double e_on = 0.0;
         for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)c * p.nb + k + j];
         if (p.tail > 0) e_on += Pt[(size_t)c * p.nb + k + p.blocks_per_window];
@@ -302,38 +319,33 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         snr = 10.0 * log10(e_on / e_off);
         e_on_out[w] = e_on; e_off_out[w] = e_off; snr_out[w] = snr;
         win_len[w] = -1;
-        if (!(snr >= p.target_snr)) active = false;
+        if (snr >= p.target_snr) nmax = kDetectSyms;
     }
 
-    // ---- M&M (multi_block.cc:128-155), windowed reset ----
+    // ---- phase 1: M&M ----
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
+    if (nmax > demod_n) nmax = demod_n;
     const long long row0 = (long long)k * p.outs_per_slot;       // global row of window index 0
     float mu = p.mu0, omega = p.omega0, last = 0.f;
     unsigned int ii = 0;
     int oo = 0;
-    uint64_t wlo = 0; uint32_t whi = 0;      // correlator window: bit i = symbol (s-67+i)
-    int pending = -1, resume = 0, nhits = 0;
-    uint32_t pend_lap = 0; int pend_err = 0;
-    bool searching = true;
+    uint32_t cur = 0;
+    uint32_t *mybits = bits + threadIdx.x;
 
     for (;;) {
-        // chunk base = min input index over the live lanes
         if (threadIdx.x == 0) s_min = 0x7fffffff;
         __syncthreads();
-        if (active) atomicMin(&s_min, (int)ii);
+        if (oo < nmax && ii < ni) atomicMin(&s_min, (int)ii);
         __syncthreads();
         const int base = s_min;
         if (base == 0x7fffffff) break;                           // no live lane left (uniform)
         {
-            // rows [base, base + kWinRows) of this slot's windows are one contiguous range of the
-            // time-major stream (row stride dstride = 80 floats): straight 16-byte copy, all
-            // loads of a lane issued before the first LDS store.
             constexpr int kVec = kWinRows * 80 / 4;              // float4 per chunk
             constexpr int kPer = (kVec + kWinThreads - 1) / kWinThreads;
             const long long r_first = row0 + base;
             const float4 *src = (const float4 *)(d + (size_t)r_first * 80);
-            long long rows_ok = d_rows - r_first;                // rows that exist in the buffer
+            long long rows_ok = d_rows - r_first;
             const long long win_ok = (long long)p.ddc_out - base;
             if (win_ok < rows_ok) rows_ok = win_ok;
             const int vec_ok = rows_ok <= 0 ? 0 : (rows_ok >= kWinRows ? kVec : (int)rows_ok * 20);
@@ -351,87 +363,123 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             if (base == 0 && threadIdx.x < 80) tile[threadIdx.x] = 0.f;   // policy Q1: demod_out[0] = 0
         }
         __syncthreads();
-        const unsigned int lim = (unsigned int)(base + kWinRows - 8);
-        while (active && ii <= lim) {
-            if (!(ii < ni && oo < demod_n)) {                    // input exhausted: window done
-                if (nhits > 0) win_len[w] = oo;
-                active = false;
-                break;
-            }
+        unsigned int lim = (unsigned int)(base + kWinRows - 8);
+        if (lim > ni - 1) lim = ni - 1;                          // while (ii < ni) of the reference
+        const float *col = tile + c - base * 80;
+        while (ii <= lim && oo < nmax) {
             // interpolate: sum_q T[imu][7-q] * in[ii+q], q ascending
             int imu = (int)rintf(mu * 128.0f);
             imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
-            const float *t = &mmse[imu * 8];
-            const float *in = &tile[(ii - (unsigned int)base) * 80 + c];
+            const float4 ta = *(const float4 *)&mmse[imu * 8 + 4];   // T[7], T[6], T[5], T[4] reversed below
+            const float4 tb = *(const float4 *)&mmse[imu * 8];
+            const float *in = col + ii * 80;
             float acc = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; q++) acc = fmaf(t[7 - q], in[q * 80], acc);
+            acc = fmaf(ta.w, in[0 * 80], acc);
+            acc = fmaf(ta.z, in[1 * 80], acc);
+            acc = fmaf(ta.y, in[2 * 80], acc);
+            acc = fmaf(ta.x, in[3 * 80], acc);
+            acc = fmaf(tb.w, in[4 * 80], acc);
+            acc = fmaf(tb.z, in[5 * 80], acc);
+            acc = fmaf(tb.y, in[6 * 80], acc);
+            acc = fmaf(tb.x, in[7 * 80], acc);
             const float out = acc;
-            const float s_last = (last < 0) ? -1.0f : 1.0f;
-            const float s_out = (out < 0) ? -1.0f : 1.0f;
-            const float mm_val = s_last * out - s_out * last;
+            // slice(x) = (x < 0) ? -1 : +1; neither operand can be -0.0 (sums starting from +0)
+            const float s_last = __builtin_copysignf(1.0f, last);
+            const float s_out = __builtin_copysignf(1.0f, out);
+            const float mm_val = fmaf(s_last, out, -(s_out * last));     // both products exact
             last = out;
             omega = omega + (p.gain_omega * mm_val);
             {
                 const float xx = omega - p.omega_mid;
-                float x1 = fabsf(xx + p.omega_relative_limit);
-                const float x2 = fabsf(xx - p.omega_relative_limit);
-                x1 -= x2;
-                omega = p.omega_mid + 0.5f * x1;
+                const float x1 = fabsf(xx + p.omega_relative_limit) - fabsf(xx - p.omega_relative_limit);
+                omega = fmaf(0.5f, x1, p.omega_mid);                     // 0.5 * x1 is exact
             }
             mu = mu + (omega + (p.gain_mu * mm_val));
             const float fl = floorf(mu);
             ii += (unsigned int)(int)fl;
             mu = mu - fl;
-
-            // ---- slicer + streaming access-code search ----
-            const uint32_t sym = (out < 0) ? 0u : 1u;
-            const int s = oo;
+            // slicer: one bit per symbol
+            cur |= (out < 0.f ? 0u : 1u) << (oo & 31);
+            if ((oo & 31) == 31) { mybits[(oo >> 5) * kWinThreads] = cur; cur = 0u; }
             oo++;
-            if (searching) {
-                wlo = (wlo >> 1) | ((uint64_t)(whi & 1u) << 63);
-                whi = (whi >> 1) | (sym << 3);
-                if (pending >= 0) {          // one more symbol exists: pending < len - 68
-                    const unsigned int slot_h = atomicAdd(hit_count, 1u);
-                    if (slot_h < (unsigned int)p.max_hits) {
-                        DeviceHit h;
-                        h.slot = (uint32_t)k; h.channel_idx = c; h.offset = pending;
-                        h.lap = pend_lap; h.ac_errors = pend_err; h.kind = 0; h.snr = snr;
-                        hits[slot_h] = h;
-                    }
-                    nhits++;
-                    resume = pending + 68;
-                    pending = -1;
-                    if (p.mode == 0) searching = false;      // multi_LAP: first hit only
+        }
+    }
+    if (nmax == 0) return;
+    if (oo & 31) mybits[(oo >> 5) * kWinThreads] = cur;
+    // all symbols of this lane are in LDS; the search below is lane-private (no barrier needed:
+    // every lane reads only the words it wrote)
+
+    // ---- phase 2: access-code search over offsets [0, limit) ----
+    const int len1 = oo;                                         // 693, or the whole window if shorter
+    int limit = len1 - 68 < 625 ? len1 - 68 : 625;
+    int resume = 0, nhits = 0;
+    uint32_t r0 = mybits[0], r1 = mybits[kWinThreads], r2 = mybits[2 * kWinThreads], r3;
+    for (int b = 0; b * 32 < limit; b++) {
+        r3 = mybits[(b + 3) * kWinThreads];
+        // W_k: bit j = symbol (32 b + j + k)
+        const uint32_t w0 = r0;
+        const uint32_t w1 = __funnelshift_r(r0, r1, 1), w2 = __funnelshift_r(r0, r1, 2);
+        const uint32_t w3 = __funnelshift_r(r0, r1, 3), w4 = __funnelshift_r(r0, r1, 4);
+        const uint32_t v61 = __funnelshift_r(r1, r2, 29), v62 = __funnelshift_r(r1, r2, 30);
+        const uint32_t v63 = __funnelshift_r(r1, r2, 31), v64 = r2;
+        const uint32_t v65 = __funnelshift_r(r2, r3, 1), v66 = __funnelshift_r(r2, r3, 2);
+        const uint32_t v67 = __funnelshift_r(r2, r3, 3);
+        // preamble: distance to 0x0a (symbols 0,1,0,1,0) or its complement
+        const uint32_t m0 = w0, m1 = ~w1, m2 = w2, m3 = ~w3, m4 = w4;
+        const uint32_t s1 = xor3(m0, m1, m2), c1 = maj3(m0, m1, m2);
+        const uint32_t s2 = m3 ^ m4, c2 = m3 & m4;
+        const uint32_t a0 = s1 ^ s2, c3 = s1 & s2;
+        const uint32_t a1 = xor3(c1, c2, c3), a2 = maj3(c1, c2, c3);
+        const uint32_t p1 = ~a2 & a1;                                  // min(d, 5 - d), bit 1
+        const uint32_t p0 = (~a2 & ~a1 & a0) | (a2 & ~a0);             //               bit 0
+        // Barker + LAP msb: distance to 0x27 (symbols 1,1,1,0,0,1,0) or its complement
+        const uint32_t n0 = ~v61, n1 = ~v62, n2 = ~v63, n3 = v64, n4 = v65, n5 = ~v66, n6 = v67;
+        const uint32_t t1 = xor3(n0, n1, n2), u1 = maj3(n0, n1, n2);
+        const uint32_t t2 = xor3(n3, n4, n5), u2 = maj3(n3, n4, n5);
+        const uint32_t d0 = xor3(t1, t2, n6), u3 = maj3(t1, t2, n6);
+        const uint32_t d1 = xor3(u1, u2, u3), d2 = maj3(u1, u2, u3);
+        const uint32_t b0 = d0 ^ d2, b1 = d1 ^ d2;                     // min(d, 7 - d) in 0..3
+        // PREAMBLE_DISTANCE + BARKER_DISTANCE <= 2
+        uint32_t ok = (~p1 & ~p0 & ~(b1 & b0)) | (~p1 & p0 & ~b1) | (p1 & ~p0 & ~b1 & ~b0);
+        while (ok) {
+            const int j = __ffs(ok) - 1;
+            ok &= ok - 1;
+            const int cpos = 32 * b + j;
+            if (cpos < resume || cpos >= limit) continue;
+            // 68-bit window at offset cpos
+            const uint32_t x0 = j ? ((r0 >> j) | (r1 << (32 - j))) : r0;
+            const uint32_t x1 = j ? ((r1 >> j) | (r2 << (32 - j))) : r1;
+            const uint32_t x2 = j ? ((r2 >> j) | (r3 << (32 - j))) : r2;
+            const uint64_t wlo = ((uint64_t)x1 << 32) | x0;
+            const uint32_t whi = x2 & 0xf;
+            const uint32_t lap = (uint32_t)(wlo >> 38) & 0xffffff;
+            const uint64_t elo = p.a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^ ac_lo[512 + (lap >> 16)];
+            const uint32_t ehi = p.a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^ ac_hi[512 + (lap >> 16)];
+            const int err = __popcll(elo ^ wlo) + __popc((ehi ^ whi) & 0xf);
+            if (err < 7) {
+                const unsigned int slot_h = atomicAdd(hit_count, 1u);
+                if (slot_h < (unsigned int)p.max_hits) {
+                    DeviceHit h;
+                    h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
+                    h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr;
+                    hits[slot_h] = h;
                 }
-                const int cpos = s - 67;
-                if (searching && cpos >= resume && cpos < 625) {
-                    const uint32_t pre = (uint32_t)wlo & 0x1f;
-                    const uint32_t bar = ((uint32_t)(wlo >> 61) | (whi << 3)) & 0x7f;
-                    const int gate = popc5min(pre, 0x0a, 0x15) + popc5min(bar, 0x27, 0x58);
-                    if (gate <= 2) {
-                        const uint32_t lap = (uint32_t)(wlo >> 38) & 0xffffff;
-                        const uint64_t elo = p.a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^
-                                             ac_lo[512 + (lap >> 16)];
-                        const uint32_t ehi = p.a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^
-                                             ac_hi[512 + (lap >> 16)];
-                        const int err = __popcll(elo ^ wlo) + __popc((ehi ^ whi) & 0xf);
-                        if (err < 7) { pending = cpos; pend_lap = lap; pend_err = err; }
-                    }
-                }
-                if (cpos >= 625 && pending < 0) searching = false;
+                nhits++;
+                resume = cpos + 68;
+                if (p.mode == 0) limit = 0;                            // multi_LAP: first hit only
             }
-            if (!searching && nhits == 0) active = false;    // search range exhausted without a hit
-            if (!searching && nhits > 0 && p.mode != 0) {
-                // multi_sniffer: the handlers need len = symbols in the whole window.  Hand the
-                // M&M state to finish_kernel (dense waves of hit windows) instead of keeping this
-                // slot's workgroup alive for 5x longer with one or two live lanes.
-                const unsigned int f = atomicAdd(fin_count, 1u);
-                FinishRec r;
-                r.w = (int32_t)w; r.ii = ii; r.oo = oo; r.mu = mu; r.omega = omega; r.last = last;
-                fin[f] = r;
-                active = false;
-            }
+        }
+        r0 = r1; r1 = r2; r2 = r3;
+    }
+    if (nhits > 0) {
+        if (ii >= ni || oo >= demod_n) win_len[w] = oo;                // the window ended inside phase 1
+        else {
+            // the handlers need len = symbols in the whole window: hand the M&M state to
+            // finish_kernel (dense waves of hit windows)
+            const unsigned int f = atomicAdd(fin_count, 1u);
+            FinishRec r;
+            r.w = (int32_t)w; r.ii = ii; r.oo = oo; r.mu = mu; r.omega = omega; r.last = last;
+            fin[f] = r;
         }
     }
 }
