@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--sync", action="store_true", help="harvest every batch before the next one is enqueued (no tail overlap)")
     ap.add_argument("--channelizer", type=int, default=0)
     ap.add_argument("--squelch-mode", type=int, default=0, help="0 auto, 1 direct, 2 staged")
     args = ap.parse_args()
@@ -76,7 +77,8 @@ def main():
     laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(args.piconets))
 
     blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
-                            channelizer=args.channelizer, squelch=args.squelch_mode)
+                            channelizer=args.channelizer, squelch=args.squelch_mode,
+                            flags=0 if args.sync else pkg.FLAG_ASYNC)
     des = blk.design
     H, slot = des.history, des.samples_per_slot
     nch = des.high_channel - des.low_channel + 1
@@ -89,12 +91,21 @@ def main():
     n_complex = seg.shape[0]
     torch.cuda.synchronize()
 
-    def step():
+    def step(last=False):
+        """One pass of the hot path over the rank's batch.  In the (default) pipelined mode the
+        records of a batch are harvested while the next batch runs; the last step of a timed
+        region flushes, so every record of every step is on the host inside the timed region."""
         blk.process_device(seg.data_ptr(), n_complex, first, S, left_margin=margin)
+        if last:
+            blk.flush()
         ints, snr = bdist.struct_to_arrays(blk.poll_arrays())
-        if world > 1:
+        if world > 1:                               # RCCL gather of whatever records are ready
             ints, snr = bdist.gather_hits(ints, snr, device=device)
         return ints, snr
+
+    def tdiff(a, b):
+        return np.array(list(b.kernel_ms)) - np.array(list(a.kernel_ms)), \
+            np.array(list(b.kernel_launches), dtype=np.float64) - np.array(list(a.kernel_launches), dtype=np.float64)
 
     def fence():
         torch.cuda.synchronize()
@@ -102,23 +113,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(last=(i == args.warmup - 1))
     fence()
+    tm0 = blk.timing()
     t0 = time.perf_counter()
-    kernel_ms = np.zeros(8)
-    kernel_launches = np.zeros(8)
-    for _ in range(args.steps):
-        ints, snr = step()
-        tm = blk.timing()
-        kernel_ms += np.array(list(tm.kernel_ms))
-        kernel_launches += np.array(list(tm.kernel_launches))
+    got_i, got_s = [], []
+    for i in range(args.steps):
+        ints, snr = step(last=(i == args.steps - 1))
+        got_i.append(ints); got_s.append(snr)
+    ints = np.concatenate(got_i, axis=0)
+    snr = np.concatenate(got_s, axis=0)
     fence()
     elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_launches = tdiff(tm0, blk.timing())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # every step processes the same resident batch: keep one copy of the (identical) record set
+    if args.steps > 1 and len(ints):
+        ints_u, idx = np.unique(ints, axis=0, return_index=True)
+        assert len(ints_u) * args.steps == len(ints), "steps produced different record sets"
+        ints, snr = bdist.sort_hits(ints_u, snr[idx])
 
     total_samples = float(world) * S * slot * args.steps
     value = total_samples / elapsed / 1e6

@@ -29,7 +29,7 @@ OK, EINVAL, ENOMEM, EDEVICE, ENODEVICE, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3,
 MODE_LAP, MODE_SNIFFER = 0, 1
 CHANNELIZER_AUTO, CHANNELIZER_DIRECT, CHANNELIZER_POLYPHASE = 0, 1, 2
 SQUELCH_AUTO, SQUELCH_DIRECT, SQUELCH_STAGED = 0, 1, 2
-FLAG_LE, FLAG_DEBUG_Y = 1, 2
+FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC = 1, 2, 4
 KIND_AC, KIND_AA = 0, 1
 
 
@@ -75,7 +75,7 @@ class Timing(ctypes.Structure):
 EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_strerror",
            "btgpu_version", "btgpu_create", "btgpu_destroy", "btgpu_get_design", "btgpu_history",
            "btgpu_last_error", "btgpu_work", "btgpu_push", "btgpu_process_device", "btgpu_poll",
-           "btgpu_pending", "btgpu_last_timing", "btgpu_debug_fetch"]
+           "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch"]
 
 
 class BtgpuError(RuntimeError):
@@ -150,6 +150,8 @@ def lib():
     L.btgpu_poll.argtypes = [vp, ctypes.POINTER(Hit), ctypes.c_int]
     L.btgpu_pending.restype = ctypes.c_int
     L.btgpu_pending.argtypes = [vp]
+    L.btgpu_flush.restype = ctypes.c_int
+    L.btgpu_flush.argtypes = [vp]
     L.btgpu_last_timing.restype = ctypes.c_int
     L.btgpu_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
     L.btgpu_debug_fetch.restype = ctypes.c_long
@@ -279,6 +281,11 @@ class _MultiBlock:
                                           first_slot, n_slots, ctypes.c_void_p(stream or 0))
         self._check(rc, "btgpu_process_device")
 
+    def flush(self):
+        rc = self._L.btgpu_flush(self._h)
+        if rc not in (OK, EOVERFLOW):
+            raise BtgpuError(rc, "btgpu_flush")
+
     def poll(self, max_hits=1 << 16):
         buf = (Hit * max_hits)()
         n = self._L.btgpu_poll(self._h, buf, max_hits)
@@ -307,7 +314,9 @@ class _MultiBlock:
         return t
 
     def debug_fetch(self, what, channel=0, first=0, count=0):
-        dt = {0: np.complex64, 1: np.float32, 2: np.float64, 3: np.float64, 4: np.float64, 5: np.complex64}[what]
+        dt = {0: np.complex64, 1: np.float32, 2: np.float64, 3: np.float64, 4: np.float64, 5: np.complex64,
+              6: np.float32, 7: np.int32,
+              8: np.dtype([('w', '<i4'), ('ii', '<u4'), ('oo', '<i4'), ('mu', '<f4'), ('omega', '<f4'), ('last', '<f4')])}[what]
         out = np.zeros(count, dt)
         n = self._L.btgpu_debug_fetch(self._h, what, channel, first, count, out.ctypes.data_as(ctypes.c_void_p))
         if n < 0:

@@ -67,7 +67,21 @@ struct btgpu_handle {
     std::vector<float> pre;          // the `margin` samples preceding the next work() buffer
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t tail_stream = nullptr;
+    struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
+        DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_d2;
+        unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
+        DeviceHit *h_hits = nullptr;          // pinned: first kEagerHits records, copied by the tail stream
+        hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t detect_done = nullptr, tail_done = nullptr;
+        int S = 0;
+        uint64_t abs_first_slot = 0;
+        bool pending = false;
+    } tc[2];
+    int cur = 0;
+    bool async = false;
+    hipStream_t copy_stream = nullptr;
+    static constexpr unsigned kEagerHits = 65536;
     std::string err;
     int sticky = BTGPU_OK;
 
@@ -80,7 +94,7 @@ struct btgpu_handle {
     // device memory
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
-    DevBuf d_eon, d_eoff, d_snr, d_winlen, d_hits, d_hitcount, d_fin, d_d2;
+    DevBuf d_eon, d_eoff, d_snr;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w;
     long long zstride = 0;
@@ -124,15 +138,28 @@ struct btgpu_handle {
     {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
-                         &d_eon, &d_eoff, &d_snr, &d_winlen, &d_hits, &d_hitcount, &d_fin, &d_d2,
+                         &d_eon, &d_eoff, &d_snr,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
-        for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d2.p = nullptr; }
+        for (TailCtx &t : tc) {
+            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_d2};
+            for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
+            for (auto &e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            if (t.detect_done) { (void)hipEventDestroy(t.detect_done); t.detect_done = nullptr; }
+            if (t.tail_done) { (void)hipEventDestroy(t.tail_done); t.tail_done = nullptr; }
+            if (t.h_count) { (void)hipHostFree(t.h_count); t.h_count = nullptr; }
+            if (t.h_hits) { (void)hipHostFree(t.h_hits); t.h_hits = nullptr; }
+        }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (tail_stream) { (void)hipStreamDestroy(tail_stream); tail_stream = nullptr; }
+        if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
     }
 
     int process_batch(const float2 *d_x, size_t x_len, long long w0, uint64_t abs_first_slot, int S, hipStream_t st);
+    int harvest(TailCtx &t);
+    int harvest_all(bool block);
 };
 
 // ---------------------------------------------------------------------------------------
@@ -149,6 +176,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     const int nb = (int)((G + ops - 1) / ops);
     last_S = S;
     last_G = G;
+    TailCtx &t = tc[cur];
+    if (t.pending) { int hrc = harvest(t); if (hrc != BTGPU_OK && hrc != BTGPU_EOVERFLOW) return hrc; }
+    hipEvent_t *ev = t.ev;
+    DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin, &d_d2 = t.d_d2;
+    t.S = S; t.abs_first_slot = abs_first_slot;
 
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
     HIPCHK(this, hipEventRecord(ev[0], st));
@@ -251,51 +283,73 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
                            (unsigned int *)d_hitcount.p + 1);
         HIPCHK(this, hipEventRecord(ev[5], st));
+        // ---- tail: finish + nsym on the tail stream, overlapping the next batch's banks ----
+        HIPCHK(this, hipEventRecord(t.detect_done, st));
+        HIPCHK(this, hipStreamWaitEvent(tail_stream, t.detect_done, 0));
         {
-            // windows with hits: at most one FinishRec per window; grid sized for the worst case
-            // that can actually occur (bounded by the hit capacity), lanes beyond fin_count exit.
+            // windows with hits: at most one FinishRec per window; lanes beyond fin_count exit
             const long long cap = std::min<long long>((long long)S * nch, (long long)max_hits);
             const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
-            hipLaunchKernelGGL(finish_kernel, dim3(nblk), dim3(64), 0, st, p, (const float *)d_d2.p, ystride, G,
-                               (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
+            hipLaunchKernelGGL(finish_kernel, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d2.p,
+                               ystride, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p);
+            hipLaunchKernelGGL(nsym_patch_kernel, dim3(32), dim3(256), 0, tail_stream, (DeviceHit *)d_hits.p,
+                               (const unsigned int *)d_hitcount.p, max_hits, (const int *)d_winlen.p, nch);
+            // records travel to pinned host memory on the tail stream too: harvesting a batch is
+            // then pure host work and never waits on the other stream
+            HIPCHK(this, hipMemcpyAsync(t.h_count, d_hitcount.p, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
+            const size_t eager = std::min<size_t>((size_t)max_hits, (size_t)kEagerHits);
+            HIPCHK(this, hipMemcpyAsync(t.h_hits, d_hits.p, eager * sizeof(DeviceHit), hipMemcpyDeviceToHost, tail_stream));
         }
     }
-    HIPCHK(this, hipEventRecord(ev[6], st));
+    HIPCHK(this, hipEventRecord(ev[6], tail_stream));
+    HIPCHK(this, hipEventRecord(t.tail_done, tail_stream));
     HIPCHK(this, hipGetLastError());
+    t.pending = true;
+    cur ^= 1;
+    if (!async) return harvest(t);
+    return BTGPU_OK;
+}
 
-    // ---- collect hits ----
-    unsigned int count = 0;
-    HIPCHK(this, hipMemcpyAsync(&count, d_hitcount.p, sizeof count, hipMemcpyDeviceToHost, st));
-    HIPCHK(this, hipStreamSynchronize(st));
+// wait for a batch's tail, move its hit records to the host queue, account its kernel times
+int btgpu_handle::harvest(TailCtx &t)
+{
+    if (!t.pending) return BTGPU_OK;
+    const btgpu_design &d = des.d;
+    HIPCHK(this, hipEventSynchronize(t.tail_done));
+    t.pending = false;
     float ms = 0;
     for (int i = 0; i < 6; i++) {
-        HIPCHK(this, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        HIPCHK(this, hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
         timing.kernel_ms[i] += ms;
         timing.kernel_launches[i] += 1;
     }
-    HIPCHK(this, hipEventElapsedTime(&ms, ev[0], ev[6])); timing.total_ms += ms;
+    HIPCHK(this, hipEventElapsedTime(&ms, t.ev[0], t.ev[6])); timing.total_ms += ms;
     timing.batches += 1;
-    timing.slots += (uint64_t)S;
-    timing.samples += (uint64_t)S * (uint64_t)d.samples_per_slot;
+    timing.slots += (uint64_t)t.S;
+    timing.samples += (uint64_t)t.S * (uint64_t)d.samples_per_slot;
 
+    unsigned int count = t.h_count[0];
     int rc = BTGPU_OK;
     if (count > (unsigned)max_hits) { count = (unsigned)max_hits; rc = BTGPU_EOVERFLOW; sticky = rc; set_error("hit buffer overflow"); }
     if (count) {
-        std::vector<DeviceHit> hh(count);
-        HIPCHK(this, hipMemcpy(hh.data(), d_hits.p, sizeof(DeviceHit) * count, hipMemcpyDeviceToHost));
-        std::vector<int> wl((size_t)S * nch);
-        HIPCHK(this, hipMemcpy(wl.data(), d_winlen.p, sizeof(int) * wl.size(), hipMemcpyDeviceToHost));
+        std::vector<DeviceHit> hh(t.h_hits, t.h_hits + std::min<unsigned>(count, kEagerHits));
+        if (count > kEagerHits) {             // rare: more records than the eager copy carries
+            hh.resize(count);
+            HIPCHK(this, hipMemcpyAsync(hh.data() + kEagerHits, (const DeviceHit *)t.d_hits.p + kEagerHits,
+                                     sizeof(DeviceHit) * (count - kEagerHits), hipMemcpyDeviceToHost, copy_stream));
+            HIPCHK(this, hipStreamSynchronize(copy_stream));
+        }
         size_t q0 = queue.size();
         for (const DeviceHit &x : hh) {
             btgpu_hit o{};
-            o.slot = abs_first_slot + x.slot;
+            o.slot = t.abs_first_slot + x.slot;
             o.channel = d.low_channel + x.channel_idx;
             o.offset = x.offset;
             o.lap = x.lap;
             o.ac_errors = x.ac_errors;
             o.kind = x.kind;
-            o.nsym = wl[(size_t)x.slot * nch + x.channel_idx] - x.offset;
+            o.nsym = x.nsym;
             o.snr_db = x.snr;
             queue.push_back(o);
         }
@@ -307,6 +361,21 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         });
     }
     return rc;
+}
+
+// harvest pending batches in submission order; block = false takes only the finished ones
+int btgpu_handle::harvest_all(bool block)
+{
+    int rc_all = BTGPU_OK;
+    for (int i = 0; i < 2; i++) {
+        TailCtx &t = tc[(cur + i) & 1];             // tc[cur] is the older one
+        if (!t.pending) continue;
+        if (!block && hipEventQuery(t.tail_done) != hipSuccess) break;
+        int rc = harvest(t);
+        if (rc == BTGPU_EOVERFLOW) rc_all = rc;
+        else if (rc != BTGPU_OK) return rc;
+    }
+    return rc_all;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -444,8 +513,15 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     h->nb_max = (int)((G + ops - 1) / ops);
     h->in_cap = (size_t)d.history + (size_t)(S - 1) * d.samples_per_slot;
 
-    if (hipStreamCreate(&h->stream) != hipSuccess) return fail(BTGPU_EDEVICE);
-    for (auto &e : h->ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
+    if (hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
+    for (auto &t : h->tc) {
+        for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
+        if (hipEventCreateWithFlags(&t.detect_done, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
+        if (hipEventCreateWithFlags(&t.tail_done, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
+    }
+    h->async = (cfg->flags & BTGPU_FLAG_ASYNC) != 0;
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != BTGPU_OK) { int c__ = rc__; std::string m__ = h->err; \
         if (getenv("BTGPU_VERBOSE")) fprintf(stderr, "btgpu_create: %s\n", m__.c_str()); return fail(c__); } } while (0)
@@ -499,11 +575,22 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_eon, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_eoff, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_snr, (size_t)S * nch * sizeof(double)));
-    TRY(h->alloc(h->d_winlen, (size_t)S * nch * sizeof(int)));
-    TRY(h->alloc(h->d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
-    TRY(h->alloc(h->d_hitcount, 2 * sizeof(unsigned int)));
-    TRY(h->alloc(h->d_fin, (size_t)S * nch * sizeof(FinishRec)));
-    TRY(h->alloc(h->d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
+    for (int i = 0; i < (h->async ? 2 : 1); i++) {
+        auto &t = h->tc[i];
+        TRY(h->alloc(t.d_winlen, (size_t)S * nch * sizeof(int)));
+        TRY(h->alloc(t.d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
+        TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
+        TRY(h->alloc(t.d_fin, (size_t)S * nch * sizeof(FinishRec)));
+        TRY(h->alloc(t.d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
+    }
+    for (auto &t : h->tc) {
+        if (hipHostMalloc((void **)&t.h_count, 2 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
+        if (hipHostMalloc((void **)&t.h_hits, (size_t)btgpu_handle::kEagerHits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
+    }
+    if (!h->async) {                      // synchronous mode: one context, used for every batch
+        h->tc[1].d_winlen = h->tc[0].d_winlen; h->tc[1].d_hits = h->tc[0].d_hits;
+        h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d2 = h->tc[0].d_d2;
+    }
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -521,6 +608,7 @@ void btgpu_destroy(btgpu_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
     h->release();
     delete h;
 }
@@ -545,7 +633,6 @@ int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, si
     if (n_complex < need) return BTGPU_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
-    std::memset(&h->timing, 0, sizeof h->timing);
     int rc_all = BTGPU_OK;
     for (uint64_t s0 = 0; s0 < n_slots; s0 += (uint64_t)h->max_slots) {
         const int S = (int)std::min<uint64_t>((uint64_t)h->max_slots, n_slots - s0);
@@ -566,7 +653,6 @@ int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *cons
     if (n_items < H - 1 + slot) return BTGPU_OK;                 // not a whole slot of new items yet
     const uint64_t n_slots = (n_items - (H - 1)) / slot;
     HIPCHK(h, hipSetDevice(h->device));
-    std::memset(&h->timing, 0, sizeof h->timing);
     int rc_all = BTGPU_OK;
     for (uint64_t s0 = 0; s0 < n_slots; s0 += (uint64_t)h->max_slots) {
         const int S = (int)std::min<uint64_t>((uint64_t)h->max_slots, n_slots - s0);
@@ -611,11 +697,24 @@ int btgpu_push(btgpu_handle *h, const float *iq, size_t n_complex)
     return rc;
 }
 
-int btgpu_pending(const btgpu_handle *h) { return h ? (int)h->queue.size() : BTGPU_EINVAL; }
+int btgpu_pending(const btgpu_handle *h)
+{
+    if (!h) return BTGPU_EINVAL;
+    (void)const_cast<btgpu_handle *>(h)->harvest_all(false);      // take batches whose tail has finished
+    return (int)h->queue.size();
+}
+
+int btgpu_flush(btgpu_handle *h)
+{
+    if (!h) return BTGPU_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
+    return h->harvest_all(true);
+}
 
 int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits)
 {
     if (!h || (!out && max_hits > 0) || max_hits < 0) return BTGPU_EINVAL;
+    (void)h->harvest_all(false);
     int n = (int)std::min<size_t>((size_t)max_hits, h->queue.size());
     if (n > 0) {
         std::memcpy(out, h->queue.data(), sizeof(btgpu_hit) * n);
@@ -634,6 +733,7 @@ int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out)
 long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, size_t count, void *out)
 {
     if (!h || !out) return BTGPU_EINVAL;
+    (void)h->harvest_all(true);
     const btgpu_design &d = h->des.d;
     const int nch = d.high_channel - d.low_channel + 1;
     const int c = channel - d.low_channel;
@@ -653,6 +753,11 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
                             sizeof(float), count, hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
             return (long)count;
         }
+        case 6:
+            if (c < 0 || c >= nch) return BTGPU_EINVAL;
+            src = (const float *)h->tc[h->cur ^ 1].d_d2.p + (size_t)c * h->ystride; elem = sizeof(float); avail = (size_t)h->last_G; break;
+        case 7: src = h->tc[h->cur ^ 1].d_winlen.p; elem = sizeof(int); avail = (size_t)h->last_S * nch; break;
+        case 8: src = h->tc[h->cur ^ 1].d_fin.p; elem = sizeof(FinishRec); avail = (size_t)h->last_S * nch; break;
         case 2: src = h->d_eon.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 3: src = h->d_eoff.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 4: src = h->d_snr.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;

@@ -18,7 +18,7 @@
 
 namespace btgpu {
 
-struct DeviceHit {            // 32 bytes, written by the window kernel
+struct DeviceHit {            // 40 bytes, written by the window kernel
     uint32_t slot;            // batch-relative slot index
     int32_t  channel_idx;     // index into the visible channel range
     int32_t  offset;
@@ -26,6 +26,8 @@ struct DeviceHit {            // 32 bytes, written by the window kernel
     int32_t  ac_errors;
     int32_t  kind;
     double   snr;
+    int32_t  nsym;            // len - offset, filled by nsym_patch_kernel once len is known
+    int32_t  pad_;
 };
 
 struct FinishRec {            // M&M state of a window that reported hits, handed to finish_kernel
@@ -358,9 +360,10 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 #pragma unroll
             for (int j = 0; j < kPer; j++) {
                 const int i = threadIdx.x + j * kWinThreads;
+                // policy Q1: demod_out[0] = 0 -- row 0 of the window is float4 index 0..19 of chunk 0
+                if (base == 0 && i < 20) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (i < kVec) ((float4 *)tile)[i] = v[j];
             }
-            if (base == 0 && threadIdx.x < 80) tile[threadIdx.x] = 0.f;   // policy Q1: demod_out[0] = 0
         }
         __syncthreads();
         unsigned int lim = (unsigned int)(base + kWinRows - 8);
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                 if (slot_h < (unsigned int)p.max_hits) {
                     DeviceHit h;
                     h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
-                    h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr;
+                    h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.pad_ = 0;
                     hits[slot_h] = h;
                 }
                 nhits++;
@@ -563,6 +566,16 @@ __global__ __launch_bounds__(64) void finish_kernel(
         hi += kFinRows;
     }
     win_len[r.w] = oo;
+}
+
+// nsym = len - offset for every hit record, once finish_kernel has produced the window lengths
+__global__ void nsym_patch_kernel(DeviceHit *__restrict__ hits, const unsigned int *__restrict__ hit_count,
+                                  int max_hits, const int *__restrict__ win_len, int nch)
+{
+    unsigned int n = *hit_count;
+    if (n > (unsigned int)max_hits) n = (unsigned int)max_hits;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        hits[i].nsym = win_len[(size_t)hits[i].slot * nch + hits[i].channel_idx] - hits[i].offset;
 }
 
 }  // namespace btgpu

@@ -52,6 +52,10 @@ extern "C" {
 
 #define BTGPU_FLAG_LE        0x1        /* also run the le_packet::sniff_aa pass (sniffer mode)  */
 #define BTGPU_FLAG_DEBUG_Y   0x2        /* keep the channel-bank output Y for btgpu_debug_fetch  */
+#define BTGPU_FLAG_ASYNC     0x4        /* work/process_device return once a batch is enqueued;
+                                           its records appear in a later btgpu_poll (always in
+                                           stream order) or after btgpu_flush.  The tail of batch
+                                           n (finish_kernel, record copy) overlaps batch n+1.    */
 
 #define BTGPU_KIND_AC 0
 #define BTGPU_KIND_AA 1
@@ -101,8 +105,9 @@ typedef struct btgpu_hit {
     double   snr_db;      /* 10 log10(E_on / E_off) of the (slot, channel) window           */
 } btgpu_hit;
 
-/* Per-kernel GPU time of the most recent btgpu_work/btgpu_process_device call, measured
- * with HIP events recorded on the stream the kernels are launched on. */
+/* Per-kernel GPU time, cumulative since btgpu_create (callers take differences), measured with
+ * HIP events recorded on the streams the kernels are launched on; a batch is accounted when
+ * its records are harvested. */
 #define BTGPU_K_DDC_CHANNEL   0   /* channel bank (direct DDC or polyphase channelizer) */
 #define BTGPU_K_DEMOD_ENERGY  1   /* quadrature demod + |Y|^2 block sums (0 when fused)  */
 #define BTGPU_K_DDC_NOISE     2   /* noise bank                                          */
@@ -159,6 +164,8 @@ int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, si
 /* Drain queued hits, ordered by (slot, channel, kind, offset). Returns count (>=0) or <0. */
 int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits);
 int btgpu_pending(const btgpu_handle *h);
+/* Wait for every enqueued batch and move its records to the poll queue (BTGPU_FLAG_ASYNC). */
+int btgpu_flush(btgpu_handle *h);
 
 int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out);
 

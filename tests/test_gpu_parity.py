@@ -219,6 +219,24 @@ def test_ragged_pushes_and_small_batches_equal_one_shot(pkg, po, synth):
     blk.close()
 
 
+def test_async_pipeline_equals_sync(pkg, po, synth):
+    """BTGPU_FLAG_ASYNC: batches are enqueued without waiting; records arrive later, in stream
+    order, and are the same records."""
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 30, laps=(0x24D952, 0x4831DD), seed=14, snr_db=24, occupancy=0.5)
+    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq, threads=8)
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, max_batch_slots=4, flags=pkg.FLAG_ASYNC,
+                            channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT)
+    got = []
+    for i in range(0, len(iq), 7 * 5000 + 11):
+        blk.push(iq[i:i + 7 * 5000 + 11])
+        got += blk.poll()                      # whatever is ready
+    blk.flush()
+    got += blk.poll()
+    assert _keys(got) == _keys(want)
+    blk.close()
+
+
 def test_work_contract(pkg, po, synth):
     """work(): history()-1 old items + new ones; consumes whole slots only."""
     fs, fc = 8e6, 2476.5e6
