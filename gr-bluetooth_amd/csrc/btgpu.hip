@@ -203,12 +203,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.Z = keep_Y ? (float2 *)d_Y.p : nullptr; p.zstride = ystride;
         const int span = b.D * (NT - 1) + b.Q * 100, wsz = nch * NT;
         const int asz = ((span > wsz ? span : wsz) + 1) & ~1;
-        const size_t lds = (size_t)(asz + NT * 100) * sizeof(float2) + (size_t)(nch * NT + 257) * sizeof(float);
+        const size_t lds = (size_t)(asz + NT * 100) * sizeof(float2) + (size_t)257 * sizeof(float);
         static_assert(NT * 79 + 2 + 3 * 80 * 2 * 2 <= 2 * (50 * 25 + 700), "epilogue scratch must fit the dead input tile");
         if (b.real_taps)
-            hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true>), dim3(p.ntiles), dim3(256), lds, st, p);
+            hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
         else
-            hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true>), dim3(p.ntiles), dim3(256), lds, st, p);
+            hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
         HIPCHK(this, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 255) / 256), dim3(256), 0, st,
                            (const double *)d_ptile.p, (const double *)d_phead.p, p.ntiles, p.tiles_per_block,
@@ -245,12 +245,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.Z = (float2 *)d_Z.p; p.zstride = zstride;
         const int span = b.D * (NT - 1) + b.Q * 100;
         const size_t lds = (size_t)(((span + 1) & ~1) + NT * 100) * sizeof(float2);
-        hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false>), dim3(p.ntiles), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
         HIPCHK(this, hipEventRecord(ev[3], st));
-        const size_t lds2 = (size_t)((ns.nw + ns.L3 + 2) & ~1) * sizeof(float2);
-        hipLaunchKernelGGL(noise_stage2_kernel, dim3(S, nch), dim3(128), lds2, st, (const float2 *)d_Z.p,
-                           zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p, (const double *)d_w.p,
-                           (double *)d_Q.p, S);
+        const int run = ns.outs * (kS2Slots - 1) + ns.nw;
+        const size_t lds2 = (size_t)((run + ns.L3 + 4) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
+        hipLaunchKernelGGL(noise_stage2_kernel, dim3((S + kS2Slots - 1) / kS2Slots, nch), dim3(256), lds2, st,
+                           (const float2 *)d_Z.p, zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p,
+                           (const double *)d_w.p, (double *)d_Q.p, S);
     } else {
         const LaunchShape &s = shape_n;
         dim3 grid((unsigned)((Gn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
@@ -514,7 +515,13 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     h->in_cap = (size_t)d.history + (size_t)(S - 1) * d.samples_per_slot;
 
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
-    if (hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
+    {
+        // the tail (a few dozen latency-bound waves) gets the highest stream priority so that it is
+        // not starved of issue slots by the throughput kernels of the next batch
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
+    }
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
     for (auto &t : h->tc) {
         for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
@@ -594,9 +601,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]

@@ -131,9 +131,11 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int Q, int S, int NT, bool REAL, bool CHAN>
-__global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
+template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH>
+__global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
 {
+    // NTH lanes: NT*10 DFT tasks per pass must fit in one sweep (260 tasks -> 320 lanes), otherwise
+    // one wave runs the whole DFT body twice for a handful of tasks and the workgroup waits for it
     constexpr int M = 100;
     constexpr int UST = 100;
     constexpr int TT = CHAN ? NT - 1 : NT;      // new output instants per tile
@@ -145,8 +147,7 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
     const int asz = span > wsz ? span : wsz;                 // xs is dead after phase A -> reuse for W
     float2 *xs = lds;                                        // [span]  (aliased by Wb[nsel][NT])
     float2 *U = lds + ((asz + 1) & ~1);                      // [NT][UST]
-    float *Mb = (float *)(U + NT * UST);                     // [nsel][NT] |y|^2     (CHAN)
-    float *atab = Mb + (CHAN ? p.nsel * NT : 0);             // [257]               (CHAN)
+    float *atab = (float *)(U + NT * UST);                   // [257]               (CHAN)
     __shared__ float2 s_tw[100];
     __shared__ float2 s_krot[80 * 4];
     __shared__ int s_binpos[80];
@@ -160,12 +161,12 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
     {
         const long long gs = p.x0 + (long long)p.D * t0;
         const int lead = (int)((2 - (gs & 1)) & 1);          // make (gs + lead) even -> 16 B aligned
-        for (int s = l; s < lead; s += 256) {
+        for (int s = l; s < lead; s += NTH) {
             long long a = gs + s;
             xs[s] = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
         }
         const int npair = (span - lead) >> 1;
-        for (int i = l; i < npair; i += 256) {
+        for (int i = l; i < npair; i += NTH) {
             const int s = lead + 2 * i;
             const long long a = gs + s;
             float4 v;
@@ -183,17 +184,17 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
             long long a = gs + s;
             xs[s] = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
         }
-        if (CHAN) for (int i = l; i < 257; i += 256) atab[i] = p.atan_tab[i];
+        if (CHAN) for (int i = l; i < 257; i += NTH) atab[i] = p.atan_tab[i];
         if (l < 100) s_tw[l] = p.twiddle[l];
         if (l < p.nsel && l < 80) s_binpos[l] = p.binpos[l];
-        if (krot_lds) for (int i = l; i < p.nsel * p.rot_period; i += 256) s_krot[i] = p.krot[i];
+        if (krot_lds) for (int i = l; i < p.nsel * p.rot_period; i += NTH) s_krot[i] = p.krot[i];
     }
     __syncthreads();
 
     // ---- phase A: polyphase branch filters ----
     {
         const int pp = l & 127, r = l >> 7;
-        if (pp < M) {
+        if (pp < M && r < 2) {
             float2 a[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) a[q] = p.taps[q * M + pp];
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
     __syncthreads();
 
     // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100} ----
-    for (int i = l; i < NT * 10; i += 256) {
+    for (int i = l; i < NT * 10; i += NTH) {
         const int tl = i / 10, p2 = i % 10;
         float2 v[10];
         float2 *row = U + tl * UST + p2;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
     }
     __syncthreads();
     // ---- phase B2: DFT over p2; bin m = m1 + 10 m2 ends up at position 10 m1 + m2 ----
-    for (int i = l; i < NT * 10; i += 256) {
+    for (int i = l; i < NT * 10; i += NTH) {
         const int tl = i / 10, m1 = i % 10;
         float2 v[10];
         float2 *row = U + tl * UST + 10 * m1;
@@ -254,12 +255,16 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
     __syncthreads();
 
     // ---- phase C ----
+    const uint32_t period = (uint32_t)p.rot_period;
+    // phase index of local instant 0: (t0 mod period) in 32-bit arithmetic (t0 >= -1)
+    const uint32_t ph_t0 = (uint32_t)(((uint32_t)tile * (uint32_t)TT % period + period - (CHAN ? 1u : 0u)) % period);
     if (!CHAN) {
-        for (int i = l; i < p.nsel * NT; i += 256) {
+        for (int i = l; i < p.nsel * NT; i += NTH) {
             const int c = i / NT, tl = i % NT;
             const long long t = t0 + tl;
             if (t >= p.T) continue;
-            const int ph = (int)(t % p.rot_period);
+            uint32_t ph = ph_t0 + (uint32_t)tl;
+            ph = ph >= period ? ph % period : ph;
             const float2 kr = krot_lds ? s_krot[c * p.rot_period + ph] : p.krot[(size_t)c * p.rot_period + ph];
             const float2 y = cmulf(U[tl * UST + s_binpos[c]], kr);
             p.Z[(size_t)c * p.zstride + t] = y;
@@ -279,30 +284,31 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
             const int tl0 = 1 + chunk * RUN;
             const int tl1 = tl0 + RUN < NT ? tl0 + RUN : NT;
             const int hr = p.tail % TT;                          // head length inside a tile
-            double sum = 0.0, head = 0.0;
-            long long t = t0 + tl0 - 1;
-            int ph = (int)(((t % p.rot_period) + p.rot_period) % p.rot_period);
-            float2 kr = krot_lds ? s_krot[c * p.rot_period + ph] : p.krot[(size_t)c * p.rot_period + ph];
-            float2 prev = cmulf(U[(tl0 - 1) * UST + pos], kr);
+            float sum = 0.f, head = 0.f;                         // <= 9 terms per run; combined in double below
+            uint32_t ph = ph_t0 + (uint32_t)(tl0 - 1);
+            ph = ph >= period ? ph % period : ph;
+            const float2 *krc = krot_lds ? &s_krot[c * p.rot_period] : &p.krot[(size_t)c * p.rot_period];
+            float2 prev = cmulf(U[(tl0 - 1) * UST + pos], krc[ph]);
+            const bool full = t0 + NT <= p.T;                    // every instant of the tile exists
+            float *drow = p.d + (size_t)(t0 + tl0) * 80 + c;
             for (int tl = tl0; tl < tl1; tl++) {
-                t = t0 + tl;
-                ph = ph + 1 == p.rot_period ? 0 : ph + 1;
-                kr = krot_lds ? s_krot[c * p.rot_period + ph] : p.krot[(size_t)c * p.rot_period + ph];
-                const float2 y = cmulf(U[tl * UST + pos], kr);
+                ph = ph + 1 == period ? 0 : ph + 1;
+                const float2 y = cmulf(U[tl * UST + pos], krc[ph]);
                 float dv = 0.f;
-                if (t < p.T) {
+                if (full || t0 + tl < p.T) {
                     const float m = y.x * y.x + y.y * y.y;
-                    sum += (double)m;
-                    if (tl - 1 < hr) head += (double)m;
+                    sum += m;
+                    if (tl - 1 < hr) head += m;
                     dv = demod_fast(atab, p.gain, y, prev);
-                    p.d[(size_t)t * 80 + c] = dv;
-                    if (p.Z) p.Z[(size_t)c * p.zstride + t] = y;               // BTGPU_FLAG_DEBUG_Y
+                    *drow = dv;
+                    if (p.Z) p.Z[(size_t)c * p.zstride + (t0 + tl)] = y;          // BTGPU_FLAG_DEBUG_Y
                 }
+                drow += 80;
                 Db[c * NT + tl] = dv;
                 prev = y;
             }
-            part[(chunk * 80 + c) * 2 + 0] = sum;
-            part[(chunk * 80 + c) * 2 + 1] = head;
+            part[(chunk * 80 + c) * 2 + 0] = (double)sum;
+            part[(chunk * 80 + c) * 2 + 1] = (double)head;
         }
         __syncthreads();
         if (l < p.nsel) {
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(256) void pfb100_kernel(PfbParams p)
             p.phead[(size_t)l * p.ntiles + tile] = head;         // first (tail % TT) instants of this tile
         }
         if (p.d2) {                                              // channel-major copy, time fastest
-            for (int i = l; i < p.nsel * TT; i += 256) {
+            for (int i = l; i < p.nsel * TT; i += NTH) {
                 const int cc = i / TT, tl = 1 + i % TT;
                 const long long t = t0 + tl;
                 if (t < p.T) p.d2[(size_t)cc * p.d2stride + t] = Db[cc * NT + tl];
@@ -345,42 +351,54 @@ __global__ void block_sum_kernel(const double *__restrict__ ptile, const double 
 }
 
 // ------------------------------------------------------------------------------------
-// Noise stage 2: y^[J] = sum_i h3[i] Z[c][J + i]; E_off * noise_out = sum_J w[J] |y^[J]|^2
-// over the slot's nw stage-2 outputs (quadrature weights incl. the band-limited edge
-// correction).  One workgroup per (slot k, channel c).
+// Noise stage 2: y^[J] = sum_i h3[i] Z[c][J + i]; E_off * noise_out = sum_J w[J - outs k] |y^[J]|^2
+// over slot k's nw stage-2 outputs (quadrature weights incl. the band-limited edge correction;
+// neighbouring slots share 2 Jm outputs).  One workgroup = one channel, KS consecutive slots:
+// the stage-1 samples of the run are staged once, every y^ is computed once (two adjacent
+// outputs per lane, 16-byte LDS reads, wave-uniform taps), |y^|^2 goes to LDS and lane s<KS
+// forms slot s's weighted sum in double.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void noise_stage2_kernel(
+constexpr int kS2Slots = 8;
+__global__ __launch_bounds__(256) void noise_stage2_kernel(
     const float2 *__restrict__ Z, long long zstride, int outs, int nw, int L3,
     const float *__restrict__ h3, const double *__restrict__ w, double *__restrict__ Qn, int S)
 {
     extern __shared__ float4 lds4[];
-    float2 *zs = (float2 *)lds4;                 // [nw + L3]
-    __shared__ double red[2];
-    const int k = blockIdx.x, c = blockIdx.y;
-    const float2 *z = Z + (size_t)c * zstride + (long long)k * outs;
-    const int need = nw + L3 - 1;
-    for (int i = threadIdx.x; i < need + 1; i += blockDim.x) zs[i] = i < need ? z[i] : make_float2(0.f, 0.f);
+    const int k0 = blockIdx.x * kS2Slots, c = blockIdx.y;
+    const int ks = (S - k0) < kS2Slots ? (S - k0) : kS2Slots;        // slots in this run
+    const int nout = outs * (ks - 1) + nw;                            // y^ needed
+    const int need = nout + L3 - 1;                                   // stage-1 samples needed
+    float2 *zs = (float2 *)lds4;                                      // [need + 3]
+    float *m2 = (float *)(zs + ((outs * (kS2Slots - 1) + nw + L3 + 4) & ~1));   // [nout]
+    const float2 *z = Z + (size_t)c * zstride + (long long)k0 * outs;
+    for (int i = threadIdx.x; i < need + 3; i += blockDim.x) zs[i] = i < need ? z[i] : make_float2(0.f, 0.f);
     __syncthreads();
-    double acc = 0.0;
-    // each lane produces two adjacent outputs j, j+1: every staged sample is read once and used
-    // for both; the taps are wave-uniform (scalar loads)
-    for (int j = 2 * threadIdx.x; j < nw; j += 2 * blockDim.x) {
+    const float4 *zq = (const float4 *)zs;                           // zq[n] = (z[2n], z[2n+1])
+    for (int j = 2 * threadIdx.x; j < nout; j += 2 * blockDim.x) {
         float y0r = 0.f, y0i = 0.f, y1r = 0.f, y1i = 0.f;
-        float2 prev = zs[j];
-        for (int i = 0; i < L3; i++) {
-            const float2 nxt = zs[j + i + 1];
-            const float hh = h3[i];
-            y0r = fmaf(hh, prev.x, y0r); y0i = fmaf(hh, prev.y, y0i);
-            y1r = fmaf(hh, nxt.x, y1r);  y1i = fmaf(hh, nxt.y, y1i);
-            prev = nxt;
+        float4 q = zq[j >> 1];
+        for (int m = 0; m < L3 / 2; m++) {                           // taps 2m, 2m+1 (L3 is even)
+            const float4 qn = zq[(j >> 1) + m + 1];
+            const float ha = h3[2 * m], hb = h3[2 * m + 1];
+            y0r = fmaf(ha, q.x, y0r);  y0i = fmaf(ha, q.y, y0i);
+            y0r = fmaf(hb, q.z, y0r);  y0i = fmaf(hb, q.w, y0i);
+            y1r = fmaf(ha, q.z, y1r);  y1i = fmaf(ha, q.w, y1i);
+            y1r = fmaf(hb, qn.x, y1r); y1i = fmaf(hb, qn.y, y1i);
+            q = qn;
         }
-        acc += w[j] * (double)((y0r * y0r) + (y0i * y0i));
-        if (j + 1 < nw) acc += w[j + 1] * (double)((y1r * y1r) + (y1i * y1i));
+        m2[j] = (y0r * y0r) + (y0i * y0i);
+        if (j + 1 < nout) m2[j + 1] = (y1r * y1r) + (y1i * y1i);
     }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) Qn[(size_t)c * S + k] = red[0] + red[1];
+    // slot sums: 32 lanes per slot, fixed order (lane partial sums combined by shuffles)
+    const int s = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    if (s < ks) {
+        double acc = 0.0;
+        const float *mm = m2 + s * outs;
+        for (int j = lane; j < nw; j += 32) acc += w[j] * (double)mm[j];
+        for (int off = 16; off > 0; off >>= 1) acc += __shfl_down(acc, off, 32);
+        if (lane == 0) Qn[(size_t)c * S + k0 + s] = acc;
+    }
 }
 
 }  // namespace btgpu
