@@ -73,7 +73,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     fs, fc = wl["sample_rate"], wl["center_freq"]
-    S = args.slots or (128 if args.workload == "c79" else 1600)
+    S = args.slots or (1600 if args.workload == "c79" else 1600)      # 1 s of signal per step at C79
     laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(args.piconets))
 
     blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
@@ -170,10 +170,23 @@ def main():
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                 "avg_launch_ms": round(avg[dom], 4),
                 "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(NK)}}
-        if names[dom] in ("ddc_noise", "ddc_channel"):
+        direct = (names[dom] == "ddc_channel" and int(des.channelizer) == 1) or \
+                 (names[dom] == "ddc_noise" and int(des.squelch) == 1)
+        if direct:                                  # direct-form banks are ALU-bound: report the fp32 rate too
             fl = (fma_noise if names[dom] == "ddc_noise" else fma_ch) * 2.0 * S * slot
             roof["fp32_tflops"] = round(fl / (avg[dom] * 1e-3) / 1e12, 3)
             roof["fp32_frac"] = round(roof["fp32_tflops"] / FP32_PEAK_TFLOPS, 4)
+        # HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
+        # gfx950 + WRITE_SIZE), valid for the configuration they were collected on
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_fast_c79_pmc_hbm.json")))
+            key = {"ddc_channel": "pfb100_kernel<7, 1, 26, true, true", "ddc_noise": "pfb100_kernel<15, 5, 10, false, fa",
+                   "window": "window_kernel", "finish": "finish_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
+            if args.workload == "c79" and S == pmc["slots"] and key in pmc["kernels"] and not direct:
+                roof["traffic"] = pmc["kernels"][key]["hbm_bytes"]
+                roof["traffic_source"] = "profiles/r01_c_fast_c79_pmc_hbm.json"
+        except Exception:
+            pass
 
         # ---- cpu_baseline: the oracle (a port, NOT the upstream binary) on a bounded sample ----
         cpu = None
