@@ -348,8 +348,12 @@ class multi_sniffer(_MultiBlock):
     MODE = MODE_SNIFFER
     NAME = "bluetooth multi sniffer block"
 
-    def __init__(self, sample_rate, center_freq, squelch_threshold, tun=False, **kw):
+    def __init__(self, sample_rate, center_freq, squelch_threshold, tun=False, le=False, **kw):
+        """le=True adds the le_packet::sniff_aa pass the reference's work() always runs after the
+        classic one (lib/multi_sniffer_impl.cc:129-149); the C++ block mirror enables it."""
         self.tun = bool(tun)
+        if le:
+            kw["flags"] = kw.get("flags", 0) | FLAG_LE
         super().__init__(sample_rate, center_freq, squelch_threshold, **kw)
 
     def format_hit(self, h):

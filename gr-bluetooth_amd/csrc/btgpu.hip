@@ -94,7 +94,7 @@ struct btgpu_handle {
     // device memory
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
-    DevBuf d_eon, d_eoff, d_snr;
+    DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w;
     long long zstride = 0;
@@ -138,7 +138,7 @@ struct btgpu_handle {
     {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
-                         &d_eon, &d_eoff, &d_snr,
+                         &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -277,12 +277,14 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.omega0 = des.omega0; p.gain_omega = des.gain_omega; p.omega_mid = des.omega_mid;
         p.mode = des.cfg.mode; p.max_hits = max_hits;
         p.a0_lo = des.ac.a0_lo; p.a0_hi = des.ac.a0_hi;
+        p.le = (des.cfg.flags & BTGPU_FLAG_LE) ? 1 : 0; p.low_channel = d.low_channel;
         hipLaunchKernelGGL(window_kernel, dim3(S), dim3(kWinThreads), 0, st, p, (const float *)d_d.p, G,
                            (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
                            (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
                            (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
                            (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
-                           (unsigned int *)d_hitcount.p + 1);
+                           (unsigned int *)d_hitcount.p + 1, (const uint8_t *)d_le_hdr.p,
+                           (const uint16_t *)d_le_whiten.p, (const int8_t *)d_le_index.p);
         HIPCHK(this, hipEventRecord(ev[5], st));
         // ---- tail: finish + nsym on the tail stream, overlapping the next batch's banks ----
         HIPCHK(this, hipEventRecord(t.detect_done, st));
@@ -579,6 +581,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->upload(h->d_atan, des.atan_tab, sizeof des.atan_tab));
     TRY(h->upload(h->d_aclo, des.ac.byte_lo, sizeof des.ac.byte_lo));
     TRY(h->upload(h->d_achi, des.ac.byte_hi, sizeof des.ac.byte_hi));
+    TRY(h->upload(h->d_le_hdr, des.le.hdr, sizeof des.le.hdr));
+    TRY(h->upload(h->d_le_whiten, des.le.whiten16, sizeof des.le.whiten16));
+    TRY(h->upload(h->d_le_index, des.le.index_of_channel, sizeof des.le.index_of_channel));
     TRY(h->alloc(h->d_eon, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_eoff, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_snr, (size_t)S * nch * sizeof(double)));

@@ -314,6 +314,55 @@ int make_design(const btgpu_config &cfg, Design &o)
             o.ac.byte_hi[byte][v] = h;
         }
 
+    // ---- LE tables, regenerated from their rules ----
+    {
+        auto mind = [](unsigned v, const std::vector<unsigned> &set) {
+            int best = 99;
+            for (unsigned s : set) { int dd = __builtin_popcount(v ^ s); if (dd < best) best = dd; }
+            return (uint8_t)best;
+        };
+        std::vector<unsigned> acc_lsb, acc_msb, dat_lsb, dat_msb;
+        for (unsigned t = 0; t <= 6; t++) { acc_lsb.push_back(t); acc_lsb.push_back(0xc0 | t); }
+        for (unsigned t = 0x06; t <= 0x24; t++) acc_msb.push_back(t);
+        for (unsigned t = 0; t < 0x20; t++) { if (t & 3) dat_lsb.push_back(t); dat_msb.push_back(t); }
+        for (unsigned v = 0; v < 256; v++) {
+            o.le.hdr[0][v] = mind(v, acc_lsb); o.le.hdr[1][v] = mind(v, acc_msb);
+            o.le.hdr[2][v] = mind(v, dat_lsb); o.le.hdr[3][v] = mind(v, dat_msb);
+        }
+        uint8_t wseq[127] = {1, 1, 1, 0, 0, 0, 1};           // x^7 + x^4 + 1 whitening sequence
+        for (int i = 7; i < 127; i++) wseq[i] = wseq[i - 7] ^ wseq[i - 3];
+        for (int idx = 0; idx < 40; idx++) {
+            // LE whitening LFSR: position 0 = 1, positions 1..6 = channel index MSB first
+            uint8_t p[7], s7[7];
+            p[0] = 1;
+            for (int i = 0; i < 6; i++) p[1 + i] = (idx >> (5 - i)) & 1;
+            for (int k = 0; k < 7; k++) {
+                uint8_t ob = p[6];
+                s7[k] = ob;
+                uint8_t q[7] = {ob, p[0], p[1], p[2], (uint8_t)(p[3] ^ ob), p[4], p[5]};
+                std::memcpy(p, q, 7);
+            }
+            int start = 0;
+            for (int i = 0; i < 127; i++) {
+                bool ok = true;
+                for (int k = 0; k < 7 && ok; k++) ok = wseq[(i + k) % 127] == s7[k];
+                if (ok) { start = i; break; }
+            }
+            uint16_t m = 0;
+            for (int i = 0; i < 16; i++) m |= (uint16_t)(wseq[(start + i) % 127] << i);
+            o.le.whiten16[idx] = m;
+        }
+        for (int ch = 0; ch < 79; ch++) {
+            // le_packet::freq2index (lib/packet_impl.cc:1285-1314): even MHz only
+            int idx = -1;
+            if (ch % 2 == 0) {
+                int chan = ch / 2;
+                idx = chan == 0 ? 37 : chan == 12 ? 38 : chan == 39 ? 39 : (chan < 12 ? chan - 1 : chan - 2);
+            }
+            o.le.index_of_channel[ch] = (int8_t)idx;
+        }
+    }
+
     d.channelizer = cfg.channelizer == BTGPU_CHANNELIZER_AUTO ? BTGPU_CHANNELIZER_DIRECT
                                                               : cfg.channelizer;
     return BTGPU_OK;

@@ -34,6 +34,13 @@ struct AcTables {
     uint32_t byte_hi[3][256];
 };
 
+struct LeTables {                       // le_packet::sniff_aa (lib/packet_impl.cc:1452-1527)
+    uint8_t hdr[4][256];                 // min Hamming distance to the valid header-byte sets:
+                                         // 0 access LSB, 1 access MSB, 2 data LSB, 3 data MSB
+    uint16_t whiten16[40];               // first 16 whitening bits per LE channel index (bit i = i-th)
+    int8_t index_of_channel[79];         // classic channel number -> LE channel index, -1 = none
+};
+
 struct Design {
     btgpu_config cfg{};
     btgpu_design d{};
@@ -45,6 +52,7 @@ struct Design {
     float mmse[(kMmseSteps + 1) * kMmseTaps];
     float atan_tab[257];
     AcTables ac;
+    LeTables le;
     int blocks_per_window = 0;           // ddc_out / (slot/decim)
     int tail = 0;                        // ddc_out % (slot/decim)
     int outs_per_slot = 0;               // slot / decim

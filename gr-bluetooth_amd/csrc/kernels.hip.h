@@ -26,8 +26,8 @@ struct DeviceHit {            // 40 bytes, written by the window kernel
     int32_t  ac_errors;
     int32_t  kind;
     double   snr;
-    int32_t  nsym;            // len - offset, filled by nsym_patch_kernel once len is known
-    int32_t  pad_;
+    int32_t  nsym;            // len - sub - offset, filled by nsym_patch_kernel once len is known
+    int32_t  sub;             // symbols the classic pass consumed before the LE pass (Q6), else 0
 };
 
 struct FinishRec {            // M&M state of a window that reported hits, handed to finish_kernel
@@ -251,6 +251,8 @@ struct WindowParams {
     int mode;                   // BTGPU_MODE_*
     int max_hits;
     uint64_t a0_lo; uint32_t a0_hi;
+    int le;                     // run the le_packet::sniff_aa pass (multi_sniffer, BTGPU_FLAG_LE)
+    int low_channel;
 };
 
 __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
@@ -292,8 +294,11 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const uint32_t *__restrict__ ac_hi_g,
     double *__restrict__ e_on_out, double *__restrict__ e_off_out, double *__restrict__ snr_out,
     int *__restrict__ win_len, DeviceHit *__restrict__ hits, unsigned int *__restrict__ hit_count,
-    FinishRec *__restrict__ fin, unsigned int *__restrict__ fin_count)
+    FinishRec *__restrict__ fin, unsigned int *__restrict__ fin_count,
+    const uint8_t *__restrict__ le_hdr_g, const uint16_t *__restrict__ le_whiten_g,
+    const int8_t *__restrict__ le_index_g)
 {
+    __shared__ uint8_t le_hdr[4 * 256];
     __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
     __shared__ uint64_t ac_lo[3 * 256];
     __shared__ uint32_t ac_hi[3 * 256];
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) { ac_lo[i] = ac_lo_g[i]; ac_hi[i] = ac_hi_g[i]; }
     for (int i = threadIdx.x; i < kBitWords * kWinThreads; i += blockDim.x) bits[i] = 0u;
+    if (p.le) for (int i = threadIdx.x; i < 1024; i += blockDim.x) le_hdr[i] = le_hdr_g[i];
 
     const int k = blockIdx.x;
     const int c = threadIdx.x;
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                 if (slot_h < (unsigned int)p.max_hits) {
                     DeviceHit h;
                     h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
-                    h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.pad_ = 0;
+                    h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0;
                     hits[slot_h] = h;
                 }
                 nhits++;
@@ -473,6 +479,76 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             }
         }
         r0 = r1; r1 = r2; r2 = r3;
+    }
+    // ---- LE pass: le_packet::sniff_aa (lib/packet_impl.cc:1452-1527) with the loop of
+    // lib/multi_sniffer_impl.cc:129-149.  `len` keeps what the classic pass left (Q6): the search
+    // limit is min(len' - 68, 625) with len' = len - (last classic hit + 68); records carry
+    // sub = len - len' so that nsym = len' - offset.
+    const int le_index = (p.le && p.mode != 0) ? (int)le_index_g[p.low_channel + c] : -1;
+    if (le_index >= 0) {
+        const int sub = nhits > 0 ? resume : 0;                  // resume = last classic hit + 68
+        // phase 1 produced min(len, 693) symbols; len' - 68 >= 625 whenever the window was
+        // truncated at 693 (len >= 1875 in sniffer geometry), otherwise len is known exactly
+        int le_limit = (ii >= ni || oo >= demod_n) ? (len1 - sub - 68) : 625;
+        if (le_limit > 625) le_limit = 625;
+        const bool access = le_index >= 37;
+        const uint8_t *phl = le_hdr + (access ? 0 : 512), *phm = phl + 256;
+        const uint32_t wmask = le_whiten_g[le_index];
+        int le_resume = 0;
+        uint32_t q0 = mybits[0], q1 = mybits[kWinThreads], q2;
+        for (int b = 0; b * 32 < le_limit; b++) {
+            q2 = mybits[(b + 2) * kWinThreads];
+            // preamble + first AA bit (9 symbols): distance to 0x0aa or its complement 0x155
+            uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;         // bit-sliced mismatch count vs 0x0aa
+            for (int i = 0; i < 9; i++) {
+                uint32_t wv = i ? __funnelshift_r(q0, q1, i) : q0;
+                if (i & 1) wv = ~wv;                                 // 0x0aa: symbols 0,1,0,1,0,1,0,1,0
+                const uint32_t c0 = cnt0 & wv; cnt0 ^= wv;
+                const uint32_t c1 = cnt1 & c0; cnt1 ^= c0;
+                const uint32_t c2 = cnt2 & c1; cnt2 ^= c1;
+                cnt3 ^= c2;
+            }
+            // d = mismatches (0..9); min(d, 9 - d) <= maxd  (maxd = 2 on access channels, else 0)
+            uint32_t cand;
+            {
+                const uint32_t is0 = ~(cnt0 | cnt1 | cnt2 | cnt3);
+                const uint32_t is9 = cnt3 & ~cnt2 & ~cnt1 & cnt0;
+                cand = is0 | is9;
+                if (access) {
+                    const uint32_t le2 = ~cnt3 & ~cnt2 & ~(cnt1 & cnt0);                 // d <= 2
+                    const uint32_t ge7 = (cnt3) | (~cnt3 & cnt2 & cnt1 & cnt0);           // d >= 7
+                    cand |= le2 | ge7;
+                }
+            }
+            while (cand) {
+                const int j = __ffs(cand) - 1;
+                cand &= cand - 1;
+                const int cpos = 32 * b + j;
+                if (cpos < le_resume || cpos >= le_limit) continue;
+                const uint32_t x0 = j ? ((q0 >> j) | (q1 << (32 - j))) : q0;      // symbols cpos .. +31
+                const uint32_t x1 = j ? ((q1 >> j) | (q2 << (32 - j))) : q1;      // symbols cpos+32 .. +63
+                const uint32_t pre = x0 & 0x1ff;
+                int dist = __popc(pre ^ 0x0aa);
+                dist = dist < 9 - dist ? dist : 9 - dist;
+                const uint32_t aa = (x0 >> 8) | (x1 << 24);                        // symbols cpos+8 .. +39
+                const uint32_t hdr = ((x1 >> 8) & 0xffff) ^ wmask;                 // symbols cpos+40 .. +55, de-whitened
+                dist += phl[hdr & 0xff] + phm[hdr >> 8];
+                int maxd = 0;
+                if (access) { dist += __popc(aa ^ 0x8e89bed6u); maxd = 2; }
+                if (dist <= maxd) {
+                    const unsigned int slot_h = atomicAdd(hit_count, 1u);
+                    if (slot_h < (unsigned int)p.max_hits) {
+                        DeviceHit h;
+                        h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
+                        h.lap = aa; h.ac_errors = 0; h.kind = 1; h.snr = snr; h.nsym = -1; h.sub = sub;
+                        hits[slot_h] = h;
+                    }
+                    nhits++;
+                    le_resume = cpos + 40;
+                }
+            }
+            q0 = q1; q1 = q2;
+        }
     }
     if (nhits > 0) {
         if (ii >= ni || oo >= demod_n) win_len[w] = oo;                // the window ended inside phase 1
@@ -575,7 +651,7 @@ __global__ void nsym_patch_kernel(DeviceHit *__restrict__ hits, const unsigned i
     unsigned int n = *hit_count;
     if (n > (unsigned int)max_hits) n = (unsigned int)max_hits;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        hits[i].nsym = win_len[(size_t)hits[i].slot * nch + hits[i].channel_idx] - hits[i].offset;
+        hits[i].nsym = win_len[(size_t)hits[i].slot * nch + hits[i].channel_idx] - hits[i].sub - hits[i].offset;
 }
 
 }  // namespace btgpu

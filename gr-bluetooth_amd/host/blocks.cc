@@ -17,6 +17,9 @@ namespace bluetooth {
 
 multi_block::multi_block(double sample_rate, double center_freq, double squelch_threshold, int mode)
 {
+    // multi_sniffer always runs the LE access-address pass after the classic one
+    // (lib/multi_sniffer_impl.cc:94,129-149: leok = brok)
+    const int flags = mode == BTGPU_MODE_SNIFFER ? BTGPU_FLAG_LE : 0;
     d_sample_rate = sample_rate;
     d_center_freq = center_freq;
     d_target_snr = squelch_threshold;
@@ -26,6 +29,7 @@ multi_block::multi_block(double sample_rate, double center_freq, double squelch_
     cfg.squelch_db = squelch_threshold;
     cfg.mode = mode;
     cfg.device = -1;
+    cfg.flags = flags;
     int rc = btgpu_create(&cfg, &d_gpu);
     if (rc != BTGPU_OK)      // no CPU fallback: fail loudly
         throw std::runtime_error(std::string("gr::bluetooth: btgpu_create failed: ") + btgpu_strerror(rc));
@@ -110,6 +114,14 @@ protected:
     {
         // lib/multi_sniffer_impl.cc:177-178: the prefix ac() prints before the packet handlers
         // (header/payload decode = SURVEY section 8(f) "next"), terminated here.
+        if (h.kind == BTGPU_KIND_AA) {
+            // aa(): "time %6d, snr=%.1f, " + le_packet::print()'s first line up to the access address
+            // (lib/multi_sniffer_impl.cc:213, lib/packet_impl.cc:1586); PDU fields = "next" rows
+            const int chan = h.channel / 2;
+            const int index = chan == 0 ? 37 : chan == 12 ? 38 : chan == 39 ? 39 : (chan < 12 ? chan - 1 : chan - 2);
+            printf("time %6d, snr=%.1f, BTLE index=%02d, AA=%08x\n", (int)(h.slot & 0x7ffffff), h.snr_db, index, h.lap);
+            return;
+        }
         printf("time %6d, snr=%.1f, channel %2d, LAP %06x \n", (int)(h.slot & 0x7ffffff), h.snr_db,
                h.channel, h.lap);
     }

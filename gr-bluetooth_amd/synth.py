@@ -80,6 +80,40 @@ def packet_bits(lap, rng, payload_bits):
     return np.concatenate([access_code_bits(lap), hdr, pay])
 
 
+def le_whitening_bits(le_index, n):
+    """First n bits of the LE whitening sequence for channel index le_index (position 0 = 1,
+    positions 1..6 = index MSB first; x^7 + x^4 + 1)."""
+    p = [1] + [(le_index >> (5 - i)) & 1 for i in range(6)]
+    out = []
+    for _ in range(n):
+        o = p[6]
+        out.append(o)
+        p = [o, p[0], p[1], p[2], p[3] ^ o, p[4], p[5]]
+    return np.array(out, dtype=np.uint8)
+
+
+def le_advert_bits(le_index, rng, payload_bytes=12, pdu_type=0, aa=0x8E89BED6):
+    """Air-order bits of an LE advertising-channel packet: preamble, access address, whitened
+    (PDU header, payload); CRC bits are random (nothing on the hot path checks them)."""
+    aab = [(aa >> i) & 1 for i in range(32)]
+    pre = [0, 1, 0, 1, 0, 1, 0, 1] if aab[0] == 0 else [1, 0, 1, 0, 1, 0, 1, 0]
+    hdr = [(pdu_type >> i) & 1 for i in range(8)] + [(payload_bytes >> i) & 1 for i in range(8)]
+    body = np.array(hdr + list(rng.integers(0, 2, 8 * payload_bytes + 24)), dtype=np.uint8)
+    body ^= le_whitening_bits(le_index, len(body))
+    return np.concatenate([np.array(pre + aab, dtype=np.uint8), body])
+
+
+def add_burst(iq, bits, start, sample_rate, center_freq, channel, rng, cfo_hz=10e3, amplitude=1.0):
+    sps = int(round(sample_rate / SYMBOL_RATE))
+    bb = gfsk_baseband(bits, sps) * amplitude
+    f = (BASE_FREQUENCY + channel * 1e6 - center_freq) + float(rng.uniform(-cfo_hz, cfo_hz))
+    m = np.arange(len(bb))
+    bb = bb * np.exp(1j * (2 * np.pi * f / sample_rate * m + rng.uniform(0, 2 * np.pi)))
+    end = min(start + len(bb), len(iq))
+    if end > start:
+        iq[start:end] += bb[:end - start].astype(np.complex64)
+
+
 def make_capture(sample_rate, center_freq, n_slots, laps=(0x24D952,), seed=1, snr_db=25.0,
                  occupancy=0.3, cfo_hz=10e3, max_payload_bits=240, extra_slots=0.0,
                  channels=None, noise=True, amplitude=1.0):

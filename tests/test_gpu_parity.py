@@ -219,6 +219,47 @@ def test_ragged_pushes_and_small_batches_equal_one_shot(pkg, po, synth):
     blk.close()
 
 
+def test_le_pass_matches_oracle(pkg, po, synth):
+    """BTGPU_FLAG_LE: the le_packet::sniff_aa pass of multi_sniffer (lib/multi_sniffer_impl.cc:129-149)
+    on classic bursts + LE advertising packets on 2480 MHz (index 39) + noise false positives."""
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 26, laps=(0x24D952, 0x4831DD), seed=41, snr_db=24, occupancy=0.4)
+    rng = np.random.default_rng(5)
+    for k in (1, 3, 4, 8, 11, 15):
+        synth.add_burst(iq, synth.le_advert_bits(39, rng, payload_bytes=int(rng.integers(6, 30))),
+                        k * 5000 + int(rng.integers(100, 2000)), fs, fc, 78, rng)
+    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER, le=True).run_stream(iq, threads=8)
+    blk, got = _run_gpu(pkg, pkg.multi_sniffer, fs, fc, iq, flags=pkg.FLAG_LE)
+    kinds = [h.kind for h in want]
+    assert kinds.count(1) >= 5 and kinds.count(0) >= 5
+    assert sum(1 for h in want if h.kind == 1 and h.lap == 0x8E89BED6) >= 3      # the adverts
+    assert _keys(got) == _keys(want)
+    blk.close()
+    # default (flag off): classic records only, identical to the oracle without the LE pass
+    want0, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER, le=False).run_stream(iq, threads=8)
+    blk, got0 = _run_gpu(pkg, pkg.multi_sniffer, fs, fc, iq)
+    assert _keys(got0) == _keys(want0) and all(h.kind == 0 for h in got0)
+    blk.close()
+
+
+def test_le_pass_fast_path_c79(pkg, po, synth):
+    fs, fc = 100e6, 2441e6
+    laps = tuple(0x24D952 + 0x10101 * i for i in range(4))
+    iq, _ = synth.make_capture(fs, fc, 9, laps=laps, seed=42, snr_db=25, occupancy=0.5)
+    rng = np.random.default_rng(6)
+    for k, ch in ((0, 0), (1, 24), (2, 78), (2, 0)):
+        synth.add_burst(iq, synth.le_advert_bits({0: 37, 24: 38, 78: 39}[ch], rng, payload_bytes=20),
+                        k * 62500 + 3000, fs, fc, ch, rng)
+    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER, le=True).run_stream(iq, threads=16)
+    b = pkg.multi_sniffer(fs, fc, 10.0, False, flags=pkg.FLAG_LE)
+    b.push(iq)
+    got = b.poll()
+    b.close()
+    assert sum(1 for h in want if h.kind == 1 and h.lap == 0x8E89BED6) >= 3
+    assert [k[:6] for k in _keys(got)] == [k[:6] for k in _keys(want)]
+    assert max(abs(a[6] - c[6]) for a, c in zip(_keys(got), _keys(want))) <= 8
+
+
 def test_async_pipeline_equals_sync(pkg, po, synth):
     """BTGPU_FLAG_ASYNC: batches are enqueued without waiting; records arrive later, in stream
     order, and are the same records."""

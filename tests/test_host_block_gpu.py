@@ -23,12 +23,16 @@ def test_btrx_amd_prints_reference_lines(po, synth, tmp_path, sniff):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = [l for l in out.stdout.splitlines() if l]
-    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER if sniff else po.MODE_LAP)
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER if sniff else po.MODE_LAP, le=sniff)   # multi_sniffer runs the LE pass
     hits, _ = o.run_stream(iq)
     assert len(hits) > 3
     assert lines[0] == "history set to %d samples: channel=%d, noise=%d" % (o.history, o.ntaps_ch + o.decim * 8, o.ntaps_noise)
     if sniff:
-        want = ["time %6d, snr=%.1f, channel %2d, LAP %06x " % (h.slot, h.snr, h.channel, h.lap) for h in hits]
+        def le_index(ch):
+            chan = ch // 2
+            return 37 if chan == 0 else 38 if chan == 12 else 39 if chan == 39 else (chan - 1 if chan < 12 else chan - 2)
+        want = [("time %6d, snr=%.1f, channel %2d, LAP %06x " % (h.slot, h.snr, h.channel, h.lap)) if h.kind == 0 else
+                ("time %6d, snr=%.1f, BTLE index=%02d, AA=%08x" % (h.slot, h.snr, le_index(h.channel), h.lap)) for h in hits]
     else:
         want = ["GOT PACKET: ch=%d, LAP=%06x, err=%u at time slot %d" % (h.channel, h.lap, h.ac_errors, h.slot) for h in hits]
     assert lines[1:] == want
