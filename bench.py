@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
     ap.add_argument("--sync", action="store_true", help="harvest every batch before the next one is enqueued (no tail overlap)")
     ap.add_argument("--channelizer", type=int, default=0)
     ap.add_argument("--squelch-mode", type=int, default=0, help="0 auto, 1 direct, 2 staged")
@@ -61,10 +63,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if args.all_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = device if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     pkg = load_pkg()
     import importlib
@@ -100,7 +108,7 @@ def main():
             blk.flush()
         ints, snr = bdist.struct_to_arrays(blk.poll_arrays())
         if world > 1:                               # RCCL gather of whatever records are ready
-            ints, snr = bdist.gather_hits(ints, snr, device=device)
+            ints, snr = bdist.gather_hits(ints, snr, device=coll_device)
         return ints, snr
 
     def tdiff(a, b):
@@ -128,7 +136,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, kernel_launches = tdiff(tm0, blk.timing())
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # every step processes the same resident batch: keep one copy of the (identical) record set

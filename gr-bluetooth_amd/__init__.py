@@ -210,6 +210,20 @@ def debug_tables(sample_rate, center_freq, lap=0):
     return mmse, atab, lo.value, hi.value
 
 
+def staged_design(sample_rate, center_freq):
+    """Host-side parameters of the staged squelch filter (composite fit error, sizes)."""
+    cfg = make_config(sample_rate, center_freq)
+    err, ws = ctypes.c_double(), ctypes.c_double()
+    R, L1, L3, nw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    f = lib().btgpu_debug_staged_design
+    f.restype = ctypes.c_int
+    rc = f(ctypes.byref(cfg), ctypes.byref(err), ctypes.byref(R), ctypes.byref(L1), ctypes.byref(L3),
+           ctypes.byref(nw), ctypes.byref(ws))
+    if rc != OK:
+        raise BtgpuError(rc)
+    return dict(fit_l1_error=err.value, R=R.value, L1=L1.value, L3=L3.value, nw=nw.value, weight_sum=ws.value)
+
+
 def _as_f32(iq):
     a = np.ascontiguousarray(iq)
     if a.dtype == np.complex64:

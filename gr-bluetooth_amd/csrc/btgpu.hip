@@ -96,7 +96,9 @@ struct btgpu_handle {
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
-    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w;
+    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1;
+    LaunchShape shape_s1;
+    bool noise_pfb = false;
     long long zstride = 0;
     int ntiles_max = 0;
     LaunchShape shape_ch, shape_n;
@@ -140,7 +142,7 @@ struct btgpu_handle {
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
-                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w};
+                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d2.p = nullptr; }
         for (TailCtx &t : tc) {
@@ -231,21 +233,30 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     // ---- noise bank -> Qn[c][k] = noise_out * E_off ----
     if (use_staged) {
         const NoiseStage &ns = fp.noise;
-        const PfbBank &b = ns.pfb;
-        constexpr int NT = 10;
         const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
-        PfbParams p{};
-        p.x = d_x; p.x_len = (long long)x_len;
-        p.x0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
-        p.D = b.D; p.T = Tn;
-        p.taps = (const float2 *)d_pfb_taps_n.p; p.twiddle = (const float2 *)d_pfb_tw.p;
-        p.nsel = nch; p.binpos = (const int *)d_binpos_n.p; p.krot = (const float2 *)d_krot_n.p;
-        p.rot_period = b.rot_period;
-        p.ntiles = (int)((Tn + NT - 1) / NT);
-        p.Z = (float2 *)d_Z.p; p.zstride = zstride;
-        const int span = b.D * (NT - 1) + b.Q * 100;
-        const size_t lds = (size_t)(((span + 1) & ~1) + NT * 100) * sizeof(float2);
-        hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
+        const long long xs0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
+        if (noise_pfb) {
+            const PfbBank &b = ns.pfb;
+            constexpr int NT = 10;
+            PfbParams p{};
+            p.x = d_x; p.x_len = (long long)x_len; p.x0 = xs0;
+            p.D = b.D; p.T = Tn;
+            p.taps = (const float2 *)d_pfb_taps_n.p; p.twiddle = (const float2 *)d_pfb_tw.p;
+            p.nsel = nch; p.binpos = (const int *)d_binpos_n.p; p.krot = (const float2 *)d_krot_n.p;
+            p.rot_period = b.rot_period;
+            p.ntiles = (int)((Tn + NT - 1) / NT);
+            p.Z = (float2 *)d_Z.p; p.zstride = zstride;
+            const int span = b.D * (NT - 1) + b.Q * 100;
+            const size_t lds = (size_t)(((span + 1) & ~1) + NT * 100) * sizeof(float2);
+            hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
+        } else {
+            // stage 1 as a direct-form bank: B-spline prototype (a few hundred taps at most), hop R
+            const LaunchShape &s = shape_s1;
+            dim3 grid((unsigned)((Tn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
+            hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len, xs0, ns.R,
+                               ns.direct.ntp, s.JC, (const float2 *)d_taps_s1.p, (const float2 *)d_rot_s1.p,
+                               ns.direct.rot_period, (const double *)d_rotstep_s1.p, (float2 *)d_Z.p, Tn, zstride, nch);
+        }
         HIPCHK(this, hipEventRecord(ev[3], st));
         const int run = ns.outs * (kS2Slots - 1) + ns.nw;
         const size_t lds2 = (size_t)((run + ns.L3 + 4) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
@@ -452,6 +463,31 @@ int btgpu_debug_tables(const btgpu_config *cfg, float *mmse /*129*8*/, float *at
     return rc;
 }
 
+/* host-side view of the staged squelch design (CPU tests): composite-filter fit error etc. */
+int btgpu_debug_staged_design(const btgpu_config *cfg, double *fit_l1_error, int *R, int *L1, int *L3, int *nw,
+                              double *weight_sum)
+{
+    if (!cfg) return BTGPU_EINVAL;
+    Design *d = new (std::nothrow) Design();
+    FastPath *fp = new (std::nothrow) FastPath();
+    if (!d || !fp) { delete d; delete fp; return BTGPU_ENOMEM; }
+    int rc = make_design(*cfg, *d);
+    if (rc == BTGPU_OK) {
+        (void)make_fast_path(*d, *fp);
+        if (!fp->noise.available) rc = BTGPU_EUNSUPPORTED;
+        else {
+            if (fit_l1_error) *fit_l1_error = fp->noise.fit_l1_error;
+            if (R) *R = fp->noise.R;
+            if (L1) *L1 = fp->noise.L1;
+            if (L3) *L3 = fp->noise.L3;
+            if (nw) *nw = fp->noise.nw;
+            if (weight_sum) { double s = 0; for (double w : fp->noise.weights) s += w; *weight_sum = s; }
+        }
+    }
+    delete d; delete fp;
+    return rc;
+}
+
 int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
 {
     if (!cfg || !out) return BTGPU_EINVAL;
@@ -463,9 +499,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     {
         FastPath *fp = &h->fp;
         int frc = make_fast_path(h->des, *fp);
-        const bool pfb_ok = frc == BTGPU_OK && fp->channel.available && fp->channel.Q == 7 && fp->channel.S == 1 &&
+        const bool pfb_ok = (frc == BTGPU_OK || frc == BTGPU_EUNSUPPORTED) && fp->channel.available && fp->channel.Q == 7 && fp->channel.S == 1 &&
                             h->des.outs_per_slot % 25 == 0;
-        const bool staged_ok = pfb_ok && fp->noise.available && fp->noise.pfb.Q == 15 && fp->noise.pfb.S == 5;
+        const bool noise_pfb_ok = fp->noise.available && fp->noise.pfb.available && fp->noise.pfb.Q == 15 && fp->noise.pfb.S == 5;
+        const bool staged_ok = fp->noise.available &&
+                               (noise_pfb_ok || pick_shape(fp->noise.R, fp->noise.direct.ntp, h->shape_s1));
+        h->noise_pfb = noise_pfb_ok;
         int ch = cfg->channelizer, sq = cfg->squelch;
         if (ch == BTGPU_CHANNELIZER_AUTO) ch = pfb_ok ? BTGPU_CHANNELIZER_POLYPHASE : BTGPU_CHANNELIZER_DIRECT;
         if (sq == BTGPU_SQUELCH_AUTO) sq = staged_ok ? BTGPU_SQUELCH_STAGED : BTGPU_SQUELCH_DIRECT;
@@ -564,10 +603,18 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         const NoiseStage &ns = h->fp.noise;
         const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
         h->zstride = (Tn + 10 + 63) / 64 * 64;
-        TRY(h->upload(h->d_pfb_taps_n, ns.pfb.taps.data(), ns.pfb.taps.size() * sizeof(float)));
-        if (!h->d_pfb_tw.p) TRY(h->upload(h->d_pfb_tw, ns.pfb.twiddle.data(), ns.pfb.twiddle.size() * sizeof(float)));
-        TRY(h->upload(h->d_binpos_n, ns.pfb.binpos.data(), ns.pfb.binpos.size() * sizeof(int)));
-        TRY(h->upload(h->d_krot_n, ns.pfb.krot.data(), ns.pfb.krot.size() * sizeof(float)));
+        if (h->noise_pfb) {
+            TRY(h->upload(h->d_pfb_taps_n, ns.pfb.taps.data(), ns.pfb.taps.size() * sizeof(float)));
+            if (!h->d_pfb_tw.p) TRY(h->upload(h->d_pfb_tw, ns.pfb.twiddle.data(), ns.pfb.twiddle.size() * sizeof(float)));
+            TRY(h->upload(h->d_binpos_n, ns.pfb.binpos.data(), ns.pfb.binpos.size() * sizeof(int)));
+            TRY(h->upload(h->d_krot_n, ns.pfb.krot.data(), ns.pfb.krot.size() * sizeof(float)));
+        } else {
+            TRY(h->upload(h->d_taps_s1, ns.direct.taps.data(), ns.direct.taps.size() * sizeof(float)));
+            TRY(h->upload(h->d_rot_s1, ns.direct.rot.data(), ns.direct.rot.size() * sizeof(float)));
+            std::vector<double> st(nch);
+            for (int c = 0; c < nch; c++) st[c] = -ns.direct.foff[c] * ns.R / cfg->sample_rate;
+            TRY(h->upload(h->d_rotstep_s1, st.data(), st.size() * sizeof(double)));
+        }
         TRY(h->alloc(h->d_Z, (size_t)nch * h->zstride * sizeof(float2)));
         TRY(h->upload(h->d_h3, ns.h3.data(), ns.h3.size() * sizeof(float)));
         TRY(h->upload(h->d_w, ns.weights.data(), ns.weights.size() * sizeof(double)));

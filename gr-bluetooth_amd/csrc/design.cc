@@ -70,8 +70,8 @@ long long gcdll(long long a, long long b)
     return a;
 }
 
-void build_bank(FilterBank &b, const std::vector<float> &h, int low_ch, int nch, double extra_hz,
-                double center_freq, double fs, int decim)
+void build_bank_impl(FilterBank &b, const std::vector<float> &h, int low_ch, int nch, double extra_hz,
+                     double center_freq, double fs, int decim)
 {
     b.ntaps = (int)h.size();
     b.ntp = (b.ntaps + kFirLanes - 1) / kFirLanes * kFirLanes;
@@ -154,6 +154,12 @@ void build_mmse(float *tab)
 }
 
 }  // namespace
+
+void build_direct_bank(FilterBank &b, const std::vector<float> &h, int low_ch, int nch, double extra_hz,
+                       double center_freq, double fs, int decim)
+{
+    build_bank_impl(b, h, low_ch, nch, extra_hz, center_freq, fs, decim);
+}
 
 int firdes_ntaps(double fs, double tw)
 {
@@ -258,8 +264,8 @@ int make_design(const btgpu_config &cfg, Design &o)
     const int nch = hi >= lo ? hi - lo + 1 : 0;
     if (nch <= 0) return BTGPU_EINVAL;
 
-    build_bank(o.channel, o.h_channel, lo, nch, 0.0, cfg.center_freq, fs, d.decimation);
-    build_bank(o.noise, o.h_noise, lo, nch, 790000.0, cfg.center_freq, fs, d.decimation);
+    build_bank_impl(o.channel, o.h_channel, lo, nch, 0.0, cfg.center_freq, fs, d.decimation);
+    build_bank_impl(o.noise, o.h_noise, lo, nch, 790000.0, cfg.center_freq, fs, d.decimation);
 
     o.demod_gain = (float)(channel_sps / (kPi / 2));
     o.gain_mu = 0.175f;

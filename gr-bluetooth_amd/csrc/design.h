@@ -103,7 +103,8 @@ struct NoiseStage {
     std::vector<float> h3;              // [L3]
     std::vector<double> weights;        // [nw]
     double fit_l1_error = 0;            // ||composite - h_noise||_1 / ||h_noise||_1
-    PfbBank pfb;                        // stage 1
+    PfbBank pfb;                        // stage 1 as a polyphase bank (100 Msps)
+    FilterBank direct;                  // stage 1 as a direct-form bank (any rate): B-spline prototype, hop R
 };
 
 struct FastPath {
@@ -112,5 +113,9 @@ struct FastPath {
 };
 
 int make_fast_path(const Design &des, FastPath &fp);
+
+// direct-form bank builder shared by the reference-filter banks and the staged squelch
+void build_direct_bank(FilterBank &b, const std::vector<float> &h, int low_ch, int nch, double extra_hz,
+                       double center_freq, double fs, int decim);
 
 }  // namespace btgpu

@@ -167,7 +167,7 @@ int make_fast_path(const Design &des, FastPath &fp)
         std::vector<double> proto(des.h_channel.begin(), des.h_channel.end());
         build_pfb(fp.channel, proto, d.decimation, des.channel.foff, fs);
     }
-    if (!fp.channel.available) return BTGPU_EUNSUPPORTED;
+    // (the channel bank may be unavailable at other rates; the staged squelch below is generic)
 
     // ---- noise bank ----
     NoiseStage &ns = fp.noise;
@@ -246,8 +246,13 @@ int make_fast_path(const Design &des, FastPath &fp)
         }
         ns.weights[a] = s;
     }
-    // stage-1 polyphase bank on the noise offsets (+790 kHz)
-    if (!build_pfb(ns.pfb, p, ns.R, des.noise.foff, fs)) return BTGPU_OK;
+    // stage 1: polyphase bank on the noise offsets (+790 kHz) where the 100-bin kernel applies,
+    // otherwise a direct-form bank with the (much shorter) B-spline prototype at hop R
+    build_pfb(ns.pfb, p, ns.R, des.noise.foff, fs);
+    {
+        std::vector<float> pf(p.begin(), p.end());
+        build_direct_bank(ns.direct, pf, d.low_channel, nch, 790000.0, des.cfg.center_freq, fs, ns.R);
+    }
     ns.available = true;
     (void)nch;
     return BTGPU_OK;

@@ -123,9 +123,12 @@ def test_fast_path_is_default_at_100msps_and_margin_is_reported(pkg):
     assert b.design.channelizer == pkg.CHANNELIZER_POLYPHASE and b.design.squelch == pkg.SQUELCH_STAGED
     assert b.design.left_margin >= 2200
     b.close()
-    b = pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False)             # no 100-bin bank at 8 Msps: direct
-    assert b.design.channelizer == pkg.CHANNELIZER_DIRECT and b.design.squelch == pkg.SQUELCH_DIRECT
-    assert b.design.left_margin == 0
+    b = pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False)             # no 100-bin bank at 8 Msps: direct DDC,
+    assert b.design.channelizer == pkg.CHANNELIZER_DIRECT          # staged squelch (direct-form stage 1)
+    assert b.design.squelch == pkg.SQUELCH_STAGED and b.design.left_margin >= 200
+    b.close()
+    b = pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False, squelch=pkg.SQUELCH_DIRECT)
+    assert b.design.squelch == pkg.SQUELCH_DIRECT and b.design.left_margin == 0
     b.close()
     with pytest.raises(pkg.BtgpuError):
         pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False, channelizer=pkg.CHANNELIZER_POLYPHASE)
@@ -217,6 +220,27 @@ def test_ragged_pushes_and_small_batches_equal_one_shot(pkg, po, synth):
     got = blk.poll()
     assert _keys(got) == _keys(want)
     blk.close()
+
+
+@pytest.mark.parametrize("fs,fc,nslots", [(2e6, 2476e6, 30), (8e6, 2476.5e6, 20), (20e6, 2441e6, 14)])
+def test_staged_squelch_other_rates(pkg, po, synth, fs, fc, nslots):
+    """Staged squelch with the direct-form stage 1 (rates without the 100-bin bank): E_off within
+    1e-5 of the exact direct form, records identical to the oracle."""
+    iq, _ = synth.make_capture(fs, fc, nslots, laps=(0x24D952, 0x4831DD), seed=51, snr_db=24, occupancy=0.5)
+    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq, threads=8)
+    res = {}
+    for name, sq in (("direct", pkg.SQUELCH_DIRECT), ("staged", pkg.SQUELCH_STAGED)):
+        b = pkg.multi_sniffer(fs, fc, 10.0, False, channelizer=pkg.CHANNELIZER_DIRECT, squelch=sq)
+        b.push(iq)
+        nch = b.design.high_channel - b.design.low_channel + 1
+        res[name] = (b.poll(), b.debug_fetch(3, 0, 0, nslots * nch), b.debug_fetch(4, 0, 0, nslots * nch))
+        b.close()
+    assert len(want) >= 2
+    assert _keys(res["direct"][0]) == _keys(want)
+    assert _keys(res["staged"][0]) == _keys(want)
+    m = np.isfinite(res["direct"][2]) & (res["direct"][1] > 0)
+    assert m.sum() >= nslots // 2
+    assert np.max(np.abs(res["staged"][1][m] - res["direct"][1][m]) / res["direct"][1][m]) <= 1e-5
 
 
 def test_le_pass_matches_oracle(pkg, po, synth):
