@@ -73,6 +73,7 @@ struct btgpu_handle {
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
         DeviceHit *h_hits = nullptr;          // pinned: first kEagerHits records, copied by the tail stream
         hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t evn[3] = {nullptr, nullptr, nullptr};      // noise branch: start, after stage 1, after stage 2
         hipEvent_t detect_done = nullptr, tail_done = nullptr;
         int S = 0;
         uint64_t abs_first_slot = 0;
@@ -81,6 +82,8 @@ struct btgpu_handle {
     int cur = 0;
     bool async = false;
     hipStream_t copy_stream = nullptr;
+    hipStream_t noise_stream = nullptr;          // the squelch banks run beside the channel bank
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     static constexpr unsigned kEagerHits = 65536;
     std::string err;
     int sticky = BTGPU_OK;
@@ -99,6 +102,7 @@ struct btgpu_handle {
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1;
     LaunchShape shape_s1;
     bool noise_pfb = false;
+    bool overlap_noise = false;     // measured: running the two banks concurrently is slower (both saturate the CUs)
     long long zstride = 0;
     int ntiles_max = 0;
     LaunchShape shape_ch, shape_n;
@@ -149,6 +153,7 @@ struct btgpu_handle {
             DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_d2};
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
             for (auto &e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            for (auto &e : t.evn) if (e) { (void)hipEventDestroy(e); e = nullptr; }
             if (t.detect_done) { (void)hipEventDestroy(t.detect_done); t.detect_done = nullptr; }
             if (t.tail_done) { (void)hipEventDestroy(t.tail_done); t.tail_done = nullptr; }
             if (t.h_count) { (void)hipHostFree(t.h_count); t.h_count = nullptr; }
@@ -157,6 +162,9 @@ struct btgpu_handle {
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         if (tail_stream) { (void)hipStreamDestroy(tail_stream); tail_stream = nullptr; }
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+        if (noise_stream) { (void)hipStreamDestroy(noise_stream); noise_stream = nullptr; }
+        if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
+        if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
     }
 
     int process_batch(const float2 *d_x, size_t x_len, long long w0, uint64_t abs_first_slot, int S, hipStream_t st);
@@ -186,6 +194,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
 
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
     HIPCHK(this, hipEventRecord(ev[0], st));
+    // fork: the noise bank only needs the input, it runs on its own stream beside the channel bank
+    hipStream_t ns_st = overlap_noise ? noise_stream : st;
+    if (overlap_noise) {
+        HIPCHK(this, hipEventRecord(ev_fork, st));
+        HIPCHK(this, hipStreamWaitEvent(noise_stream, ev_fork, 0));
+    }
 
     // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 block sums P, Pt ----
     if (use_pfb) {
@@ -231,6 +245,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     HIPCHK(this, hipEventRecord(ev[2], st));
 
     // ---- noise bank -> Qn[c][k] = noise_out * E_off ----
+    HIPCHK(this, hipEventRecord(t.evn[0], ns_st));
     if (use_staged) {
         const NoiseStage &ns = fp.noise;
         const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
@@ -248,34 +263,36 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             p.Z = (float2 *)d_Z.p; p.zstride = zstride;
             const int span = b.D * (NT - 1) + b.Q * 100;
             const size_t lds = (size_t)(((span + 1) & ~1) + NT * 100) * sizeof(float2);
-            hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
+            hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false, 256>), dim3(p.ntiles), dim3(256), lds, ns_st, p);
         } else {
             // stage 1 as a direct-form bank: B-spline prototype (a few hundred taps at most), hop R
             const LaunchShape &s = shape_s1;
             dim3 grid((unsigned)((Tn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
-            hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len, xs0, ns.R,
+            hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, ns_st, d_x, (long long)x_len, xs0, ns.R,
                                ns.direct.ntp, s.JC, (const float2 *)d_taps_s1.p, (const float2 *)d_rot_s1.p,
                                ns.direct.rot_period, (const double *)d_rotstep_s1.p, (float2 *)d_Z.p, Tn, zstride, nch);
         }
-        HIPCHK(this, hipEventRecord(ev[3], st));
+        HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
         const int run = ns.outs * (kS2Slots - 1) + ns.nw;
         const size_t lds2 = (size_t)((run + ns.L3 + 4) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
-        hipLaunchKernelGGL(noise_stage2_kernel, dim3((S + kS2Slots - 1) / kS2Slots, nch), dim3(256), lds2, st,
+        hipLaunchKernelGGL(noise_stage2_kernel, dim3((S + kS2Slots - 1) / kS2Slots, nch), dim3(256), lds2, ns_st,
                            (const float2 *)d_Z.p, zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p,
                            (const double *)d_w.p, (double *)d_Q.p, S);
     } else {
         const LaunchShape &s = shape_n;
         dim3 grid((unsigned)((Gn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
-        hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len,
+        hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, ns_st, d_x, (long long)x_len,
                            w0 + (long long)d.first_noise_sample, d.decimation, des.noise.ntp, s.JC,
                            (const float2 *)d_taps_n.p, (const float2 *)d_rot_n.p, des.noise.rot_period,
                            (const double *)d_rotstep_n.p, (float2 *)d_Yn.p, Gn, ystride_n, nch);
-        HIPCHK(this, hipEventRecord(ev[3], st));
+        HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
         dim3 g2((unsigned)S, (unsigned)nch);
-        hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, st, (const float2 *)d_Yn.p, Gn,
+        hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, ns_st, (const float2 *)d_Yn.p, Gn,
                            ystride_n, ops, 0, (const float *)nullptr, 0.f, (float *)nullptr,
                            (double *)d_Q.p, (double *)nullptr, S, nch, (float *)nullptr, 0LL);
     }
+    HIPCHK(this, hipEventRecord(t.evn[2], ns_st));
+    if (overlap_noise) HIPCHK(this, hipStreamWaitEvent(st, t.evn[2], 0));      // join before the window kernel
     HIPCHK(this, hipEventRecord(ev[4], st));
 
     // ---- K3: squelch + M&M + slicer + access-code search ----
@@ -333,8 +350,10 @@ int btgpu_handle::harvest(TailCtx &t)
     HIPCHK(this, hipEventSynchronize(t.tail_done));
     t.pending = false;
     float ms = 0;
+    hipEvent_t a[6] = {t.ev[0], t.ev[1], t.evn[0], t.evn[1], t.ev[4], t.ev[5]};
+    hipEvent_t e[6] = {t.ev[1], t.ev[2], t.evn[1], t.evn[2], t.ev[5], t.ev[6]};
     for (int i = 0; i < 6; i++) {
-        HIPCHK(this, hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+        HIPCHK(this, hipEventElapsedTime(&ms, a[i], e[i]));
         timing.kernel_ms[i] += ms;
         timing.kernel_launches[i] += 1;
     }
@@ -564,8 +583,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
+    if (hipStreamCreateWithFlags(&h->noise_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
+    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
+    if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
     for (auto &t : h->tc) {
         for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
+        for (auto &e : t.evn) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
         if (hipEventCreateWithFlags(&t.detect_done, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
         if (hipEventCreateWithFlags(&t.tail_done, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
