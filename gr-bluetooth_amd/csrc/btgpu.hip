@@ -217,7 +217,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.tiles_per_block = ops / TT; p.tail = des.tail; p.nb = nb;
         p.atan_tab = (const float *)d_atan.p; p.gain = des.demod_gain;
         p.Z = keep_Y ? (float2 *)d_Y.p : nullptr; p.zstride = ystride;
-        const int span = b.D * (NT - 1) + b.Q * 100, wsz = nch * NT;
+        const int span = 2 * ((b.D * (NT - 1) + b.Q * 100 + 3) / 2), wsz = nch * NT;
         const int asz = ((span > wsz ? span : wsz) + 1) & ~1;
         const size_t lds = (size_t)(asz + NT * 100) * sizeof(float2) + (size_t)257 * sizeof(float);
         static_assert(NT * 79 + 2 + 3 * 80 * 2 * 2 <= 2 * (50 * 25 + 700), "epilogue scratch must fit the dead input tile");
@@ -261,8 +261,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             p.rot_period = b.rot_period;
             p.ntiles = (int)((Tn + NT - 1) / NT);
             p.Z = (float2 *)d_Z.p; p.zstride = zstride;
-            const int span = b.D * (NT - 1) + b.Q * 100;
-            const size_t lds = (size_t)(((span + 1) & ~1) + NT * 100) * sizeof(float2);
+            const int span = 2 * ((b.D * (NT - 1) + b.Q * 100 + 3) / 2);
+            const size_t lds = (size_t)(span + NT * 100) * sizeof(float2);
             hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false, 256>), dim3(p.ntiles), dim3(256), lds, ns_st, p);
         } else {
             // stage 1 as a direct-form bank: B-spline prototype (a few hundred taps at most), hop R

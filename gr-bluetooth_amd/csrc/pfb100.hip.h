@@ -134,6 +134,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH>
 __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
 {
+    constexpr int DH = S * 50;                               // hop: 2 D = S * 100
     // NTH lanes: NT*10 DFT tasks per pass must fit in one sweep (260 tasks -> 320 lanes), otherwise
     // one wave runs the whole DFT body twice for a handful of tasks and the workgroup waits for it
     constexpr int M = 100;
@@ -142,7 +143,9 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     static_assert(NT % 2 == 0, "NT must be even");
     extern __shared__ float4 lds4[];
     float2 *lds = (float2 *)lds4;
-    const int span = p.D * (NT - 1) + Q * M;                 // input samples staged per tile
+    constexpr int SPAN = DH * (NT - 1) + Q * M;              // input samples a tile needs
+    constexpr int N4 = (SPAN + 3) / 2;                       // 16-byte pieces staged (aligned start: +1 sample)
+    constexpr int span = 2 * N4;                             // samples resident in LDS
     const int wsz = CHAN ? p.nsel * NT : 0;
     const int asz = span > wsz ? span : wsz;                 // xs is dead after phase A -> reuse for W
     float2 *xs = lds;                                        // [span]  (aliased by Wb[nsel][NT])
@@ -157,32 +160,33 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
     const int l = threadIdx.x;
 
-    // ---- stage the input span: x[x0 + D*t0 + s], s < span; 16-byte loads where aligned ----
+    // ---- stage the input span.  The tile starts at the even sample a0 <= gs so that every piece is
+    // a 16-byte aligned load; all loads of a lane are issued before its first LDS store (one
+    // memory latency per tile instead of one per loop trip).
+    int shift;
     {
-        const long long gs = p.x0 + (long long)p.D * t0;
-        const int lead = (int)((2 - (gs & 1)) & 1);          // make (gs + lead) even -> 16 B aligned
-        for (int s = l; s < lead; s += NTH) {
-            long long a = gs + s;
-            xs[s] = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
-        }
-        const int npair = (span - lead) >> 1;
-        for (int i = l; i < npair; i += NTH) {
-            const int s = lead + 2 * i;
-            const long long a = gs + s;
-            float4 v;
-            if (a >= 0 && a + 1 < p.x_len) v = *(const float4 *)(p.x + a);
-            else {
-                float2 v0 = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
-                float2 v1 = (a + 1 >= 0 && a + 1 < p.x_len) ? p.x[a + 1] : make_float2(0.f, 0.f);
-                v = make_float4(v0.x, v0.y, v1.x, v1.y);
+        const long long gs = p.x0 + (long long)DH * t0;
+        const long long a0 = gs & ~1LL;
+        shift = (int)(gs - a0);
+        constexpr int PER = (N4 + NTH - 1) / NTH;
+        float4 v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int i = l + j * NTH;
+            const long long a = a0 + 2 * (long long)i;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < N4) {
+                if (a >= 0 && a + 1 < p.x_len) v[j] = *(const float4 *)(p.x + a);
+                else {
+                    if (a >= 0 && a < p.x_len) { const float2 q = p.x[a]; v[j].x = q.x; v[j].y = q.y; }
+                    if (a + 1 >= 0 && a + 1 < p.x_len) { const float2 q = p.x[a + 1]; v[j].z = q.x; v[j].w = q.y; }
+                }
             }
-            xs[s] = make_float2(v.x, v.y);
-            xs[s + 1] = make_float2(v.z, v.w);
         }
-        if (((span - lead) & 1) && l == 0) {
-            const int s = span - 1;
-            long long a = gs + s;
-            xs[s] = (a >= 0 && a < p.x_len) ? p.x[a] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int i = l + j * NTH;
+            if (i < N4) ((float4 *)xs)[i] = v[j];
         }
         if (CHAN) for (int i = l; i < 257; i += NTH) atab[i] = p.atan_tab[i];
         if (l < 100) s_tw[l] = p.twiddle[l];
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
             float2 a[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) a[q] = p.taps[q * M + pp];
-            const float2 *z = xs + p.D * r + pp;
+            const float2 *z = xs + shift + DH * r + pp;
             float2 zw[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) zw[q] = z[q * M];
