@@ -245,7 +245,6 @@ struct WindowParams {
     int blocks_per_window, tail;
     int nb;                     // number of energy blocks per channel
     long long ystride;
-    int dstride;                // row stride of d in floats (nch padded to a multiple of 4)
     double target_snr;
     float gain_mu, mu0, omega_relative_limit, omega0, gain_omega, omega_mid;
     int mode;                   // BTGPU_MODE_*

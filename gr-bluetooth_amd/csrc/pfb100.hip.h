@@ -8,15 +8,19 @@
 // from lib/multi_block.cc:204,275) for all channels at once: ~27 FMA + ~70 flop per input
 // sample instead of ~2100 FMA.
 //
-// Work decomposition (one workgroup = NT consecutive output instants, 256 lanes):
+// Work decomposition (one workgroup = NT consecutive output instants, NTH = 256 lanes):
+//   0  the input span of the tile is staged through LDS with aligned 16-byte loads, all loads of
+//      a lane in flight before its first LDS store; XCD-aware tile order keeps the filter-length
+//      overlap of neighbouring tiles in one L2.
 //   A  lanes (p, r): branch p, instants of parity r.  Because 2 D is a multiple of 100 the
 //      samples a branch needs for instant t+2 are the ones of instant t shifted by S = 2D/100
 //      taps: each lane keeps a Q-deep register window and reads every input sample from LDS
-//      exactly once.  Input tile staged with coalesced 16-byte global loads.
+//      exactly once.
 //   B  two passes of 10-point DFTs over the LDS matrix U[t][100], twiddle in between.
-//   C  epilogue.  CHANNEL bank: quadrature demod against the previous instant
-//      (multi_block::demod), |y|^2 tile sums in double, d written time-major [g][nch] so the
-//      window kernel's lanes (= channels) read it coalesced.  NOISE bank: stage-1 output Z.
+//   C  epilogue.  CHANNEL bank: lane (run, channel) walks <= 9 consecutive instants: de-rotate,
+//      quadrature demod against the previous instant (multi_block::demod), |y|^2 sums; d is
+//      written time-major [g][80] (the window kernel's lanes = channels read it coalesced) and
+//      channel-major [c][g] (finish_kernel streams single windows).  NOISE bank: stage-1 output Z.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
