@@ -306,7 +306,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.mode = des.cfg.mode; p.max_hits = max_hits;
         p.a0_lo = des.ac.a0_lo; p.a0_hi = des.ac.a0_hi;
         p.le = (des.cfg.flags & BTGPU_FLAG_LE) ? 1 : 0; p.low_channel = d.low_channel;
-        hipLaunchKernelGGL(window_kernel, dim3(S), dim3(kWinThreads), 0, st, p, (const float *)d_d.p, G,
+        hipLaunchKernelGGL(window_kernel, dim3((S + kWinSlots - 1) / kWinSlots), dim3(kWinThreads), 0, st, p, (const float *)d_d.p, G,
                            (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
                            (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
                            (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,

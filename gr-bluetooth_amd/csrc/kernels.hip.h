@@ -260,24 +260,25 @@ __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
     return da < db ? da : db;
 }
 
-constexpr int kWinThreads = 128;     // >= 79 visible channels; lane = channel
-constexpr int kWinRows = 64;         // demod rows staged per chunk
+constexpr int kWinSlots = 2;         // slots per workgroup: 2 x 79 lanes fill 3 waves to 82 % (1 x 79: 62 %)
+constexpr int kWinThreads = 192;     // >= kWinSlots * 79; lane = (slot, channel)
+constexpr int kWinRows = 64;         // demod rows staged per chunk and slot
 constexpr int kDetectSyms = 693;     // 625 search offsets + 68-symbol access code
 constexpr int kBitWords = 24;        // 32-bit words of sliced symbols kept per lane (>= 693 + 99 bits)
 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
 __device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | (c & (a | b)); }
 
-// One workgroup per slot k, one lane per channel c (nch <= 79 < 128).
+// One workgroup per kWinSlots consecutive slots, one lane per (slot, channel) window (nch <= 79).
 //
 // Phase 1 -- clock recovery.  The demodulated stream is time-major [g][80], so the rows a slot's
 // windows need are shared by all its lanes: they are staged through LDS in chunks of kWinRows
 // rows with contiguous 16-byte copies and the strictly sequential M&M recursion of each lane
 // (multi_block::mm_cr, lib/multi_block.cc:128-155; windowed reset) runs out of LDS.  Lanes drift
-// apart by a few samples only (omega is clipped to 2 +- 0.005), so a chunk starts at the minimum
-// input index over the live lanes.  Only the first 693 symbols can hold a reportable access code
-// (lib/multi_sniffer_impl.cc:108-126), so the recursion stops there; sliced symbols are packed
-// one bit each into a per-lane LDS bit buffer.
+// apart by a few samples only (omega is clipped to 2 +- 0.005), so a slot's chunk starts at the
+// minimum input index over its live lanes.  Only the first 693 symbols can hold a reportable
+// access code (lib/multi_sniffer_impl.cc:108-126), so the recursion stops there; sliced symbols
+// are packed one bit each into a per-lane LDS bit buffer.
 //
 // Phase 2 -- access-code search (classic_packet::sniff_ac, lib/packet_impl.cc:247-268) on the
 // packed bits, 32 offsets at a time: the 5-bit preamble and 7-bit Barker distance LUTs are
@@ -301,23 +302,25 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
     __shared__ uint64_t ac_lo[3 * 256];
     __shared__ uint32_t ac_hi[3 * 256];
-    __shared__ __attribute__((aligned(16))) float tile[kWinRows * 80];
+    __shared__ __attribute__((aligned(16))) float tile[kWinSlots][kWinRows * 80];
     __shared__ uint32_t bits[kBitWords * kWinThreads];
-    __shared__ int s_min;
+    __shared__ int s_min[kWinSlots];
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) { ac_lo[i] = ac_lo_g[i]; ac_hi[i] = ac_hi_g[i]; }
     for (int i = threadIdx.x; i < kBitWords * kWinThreads; i += blockDim.x) bits[i] = 0u;
     if (p.le) for (int i = threadIdx.x; i < 1024; i += blockDim.x) le_hdr[i] = le_hdr_g[i];
 
-    const int k = blockIdx.x;
-    const int c = threadIdx.x;
     const int nch = p.nch;
+    const int sl = (int)threadIdx.x / nch;                       // slot of this lane inside the workgroup
+    const int c = (int)threadIdx.x - sl * nch;
+    const int k = blockIdx.x * kWinSlots + sl;
+    const bool lane_ok = sl < kWinSlots && k < p.S;
     const long long w = (long long)k * nch + c;
     int nmax = 0;                                    // symbols this lane will produce in phase 1
     double snr = 0.0;
 
     // ---- squelch: multi_block::channel_samples energy + check_snr (multi_block.cc:206-293) ----
-    if (c < nch) {
+    if (lane_ok) {
         double e_on = 0.0;
         for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)c * p.nb + k + j];
         if (p.tail > 0) e_on += Pt[(size_t)c * p.nb + k + p.blocks_per_window];
@@ -333,53 +336,62 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
     if (nmax > demod_n) nmax = demod_n;
-    const long long row0 = (long long)k * p.outs_per_slot;       // global row of window index 0
     float mu = p.mu0, omega = p.omega0, last = 0.f;
     unsigned int ii = 0;
     int oo = 0;
     uint32_t cur = 0;
     uint32_t *mybits = bits + threadIdx.x;
+    const float *mytile = tile[sl < kWinSlots ? sl : 0];
 
     for (;;) {
-        if (threadIdx.x == 0) s_min = 0x7fffffff;
+        if (threadIdx.x < kWinSlots) s_min[threadIdx.x] = 0x7fffffff;
         __syncthreads();
-        if (oo < nmax && ii < ni) atomicMin(&s_min, (int)ii);
+        if (oo < nmax && ii < ni) atomicMin(&s_min[sl], (int)ii);
         __syncthreads();
-        const int base = s_min;
-        if (base == 0x7fffffff) break;                           // no live lane left (uniform)
+        int bases[kWinSlots];
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < kWinSlots; s++) { bases[s] = s_min[s]; any |= bases[s] != 0x7fffffff; }
+        if (!any) break;                                         // no live lane left (uniform)
         {
-            constexpr int kVec = kWinRows * 80 / 4;              // float4 per chunk
-            constexpr int kPer = (kVec + kWinThreads - 1) / kWinThreads;
-            const long long r_first = row0 + base;
-            const float4 *src = (const float4 *)(d + (size_t)r_first * 80);
-            long long rows_ok = d_rows - r_first;
-            const long long win_ok = (long long)p.ddc_out - base;
-            if (win_ok < rows_ok) rows_ok = win_ok;
-            const int vec_ok = rows_ok <= 0 ? 0 : (rows_ok >= kWinRows ? kVec : (int)rows_ok * 20);
+            constexpr int kVec = kWinRows * 80 / 4;              // float4 per chunk and slot
+            constexpr int kTot = kVec * kWinSlots;
+            constexpr int kPer = (kTot + kWinThreads - 1) / kWinThreads;
             float4 v[kPer];
 #pragma unroll
             for (int j = 0; j < kPer; j++) {
                 const int i = threadIdx.x + j * kWinThreads;
-                v[j] = (i < vec_ok) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int s = i / kVec, iv = i - s * kVec;
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < kTot && bases[s < kWinSlots ? s : 0] != 0x7fffffff) {
+                    const int base = bases[s];
+                    const long long r_first = ((long long)blockIdx.x * kWinSlots + s) * p.outs_per_slot + base;
+                    long long rows_ok = d_rows - r_first;
+                    const long long win_ok = (long long)p.ddc_out - base;
+                    if (win_ok < rows_ok) rows_ok = win_ok;
+                    const int vec_ok = rows_ok <= 0 ? 0 : (rows_ok >= kWinRows ? kVec : (int)rows_ok * 20);
+                    // policy Q1: demod_out[0] = 0 -- row 0 of the window is float4 index 0..19 of chunk 0
+                    if (iv < vec_ok && !(base == 0 && iv < 20))
+                        v[j] = ((const float4 *)(d + (size_t)r_first * 80))[iv];
+                }
             }
 #pragma unroll
             for (int j = 0; j < kPer; j++) {
                 const int i = threadIdx.x + j * kWinThreads;
-                // policy Q1: demod_out[0] = 0 -- row 0 of the window is float4 index 0..19 of chunk 0
-                if (base == 0 && i < 20) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < kVec) ((float4 *)tile)[i] = v[j];
+                if (i < kTot) ((float4 *)&tile[0][0])[i] = v[j];
             }
         }
         __syncthreads();
+        const int base = bases[sl < kWinSlots ? sl : 0];
         unsigned int lim = (unsigned int)(base + kWinRows - 8);
         if (lim > ni - 1) lim = ni - 1;                          // while (ii < ni) of the reference
-        const float *col = tile + c - base * 80;
+        const float *col = mytile + c - base * 80;
         while (ii <= lim && oo < nmax) {
             // interpolate: sum_q T[imu][7-q] * in[ii+q], q ascending
             int imu = (int)rintf(mu * 128.0f);
             imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
-            const float4 ta = *(const float4 *)&mmse[imu * 8 + 4];   // T[7], T[6], T[5], T[4] reversed below
-            const float4 tb = *(const float4 *)&mmse[imu * 8];
+            const float4 ta = *(const float4 *)&mmse[imu * 8 + 4];   // T[4..7]
+            const float4 tb = *(const float4 *)&mmse[imu * 8];       // T[0..3]
             const float *in = col + ii * 80;
             float acc = 0.f;
             acc = fmaf(ta.w, in[0 * 80], acc);
