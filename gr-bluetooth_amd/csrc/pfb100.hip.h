@@ -98,32 +98,29 @@ __device__ __forceinline__ void dft10(float2 *v)
     v[4] = caddf(E[4], o4); v[9] = csubf(E[4], o4);
 }
 
-// fast_atan2f with v_rcp_f32 instead of the IEEE divide (1 ulp on the ratio; tolerance path only)
+// fast_atan2f with v_rcp_f32 instead of the IEEE divide (1 ulp on the ratio; tolerance path only),
+// written branch-free: both the small-angle value and the table interpolation are formed and
+// one is selected, the quadrant fix-ups are selects.
 __device__ __forceinline__ float demod_fast(const float *__restrict__ tab, float gain, float2 a, float2 b)
 {
     const float pr = a.x * b.x + a.y * b.y;
     const float pi = a.y * b.x - a.x * b.y;
     const float ya = fabsf(pi), xa = fabsf(pr);
     const float mx = fmaxf(xa, ya), mn = fminf(xa, ya);
-    if (!(mx > 0.0f)) return 0.0f;
-    const float z = mn * __builtin_amdgcn_rcpf(mx);
-    float base;
-    if (z < 0.003921569f) base = z;
-    else {
-        float alpha = z * 255.0f;
-        const int index = ((int)alpha) & 0xff;
-        alpha -= (float)index;
-        const float t0 = tab[index];
-        base = t0 + (tab[index + 1] - t0) * alpha;
-    }
-    float ang;
-    if (xa > ya) {
-        ang = pr >= 0.0f ? base : 3.14159265358979323846f - base;
-        ang = pi >= 0.0f ? ang : -ang;
-    } else {
-        ang = pr >= 0.0f ? 1.57079632679489661923f - base : 1.57079632679489661923f + base;
-        ang = pi >= 0.0f ? ang : -ang;
-    }
+    const float z = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-37f));
+    const float alpha0 = z * 255.0f;
+    const int index = ((int)alpha0) & 0xff;
+    const float alpha = alpha0 - (float)index;
+    const float t0 = tab[index];
+    const float interp = t0 + (tab[index + 1] - t0) * alpha;
+    const float base = z < 0.003921569f ? z : interp;
+    const bool xbig = xa > ya;
+    // x-dominant: pr >= 0 ? base : pi - base ; y-dominant: pr >= 0 ? pi/2 - base : pi/2 + base
+    const float k = xbig ? (pr >= 0.0f ? 0.0f : 3.14159265358979323846f) : 1.57079632679489661923f;
+    const float sgn = (xbig == (pr >= 0.0f)) ? 1.0f : -1.0f;     // +base for (x-dom, pr>=0) and (y-dom, pr<0)
+    float ang = k + sgn * base;
+    ang = pi >= 0.0f ? ang : -ang;
+    ang = mx > 0.0f ? ang : 0.0f;
     return gain * ang;
 }
 
