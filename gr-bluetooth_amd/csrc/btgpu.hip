@@ -102,6 +102,7 @@ struct btgpu_handle {
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1;
     LaunchShape shape_s1;
     bool noise_pfb = false;
+    bool fuse_noise = false;         // noise stage 1 rides on the channel bank's staged input
     bool overlap_noise = false;     // measured: running the two banks concurrently is slower (both saturate the CUs)
     long long zstride = 0;
     int ntiles_max = 0;
@@ -221,7 +222,26 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         const int asz = ((span > wsz ? span : wsz) + 1) & ~1;
         const size_t lds = (size_t)(asz + NT * 100) * sizeof(float2) + (size_t)257 * sizeof(float);
         static_assert(NT * 79 + 2 + 3 * 80 * 2 * 2 <= 2 * (50 * 25 + 700), "epilogue scratch must fit the dead input tile");
-        if (b.real_taps)
+        if (fuse_noise) {
+            const NoiseStage &ns = fp.noise;
+            const long long xn0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
+            const long long delta0 = (p.x0 - b.D) - xn0;                       // tile-0 start minus noise origin
+            const long long c0 = (delta0 + ns.R - 1) / ns.R;                   // delta0 >= 0
+            p.n_taps = (const float2 *)d_pfb_taps_n.p; p.n_binpos = (const int *)d_binpos_n.p;
+            p.n_krot = (const float2 *)d_krot_n.p; p.n_period = ns.pfb.rot_period;
+            p.n_off = (int)(c0 * ns.R - delta0); p.n_u0 = (int)c0; p.pre_tiles = (int)((c0 + 4) / 5);
+            p.n_T = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+            p.n_Z = (float2 *)d_Z.p; p.n_zstride = zstride;
+            const int spanf = 2 * (((250 - 1) + 250 * 4 + 15 * 100 + 3) / 2);
+            const int aszf = ((spanf > wsz ? spanf : wsz) + 1) & ~1;
+            const size_t ldsf = (size_t)(aszf + NT * 100) * sizeof(float2) + (size_t)258 * sizeof(float) +
+                                (size_t)5 * 100 * sizeof(float2);
+            const dim3 gridf(p.ntiles + p.pre_tiles);
+            if (b.real_taps)
+                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, 256, true>), gridf, dim3(256), ldsf, st, p);
+            else
+                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, 256, true>), gridf, dim3(256), ldsf, st, p);
+        } else if (b.real_taps)
             hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
         else
             hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
@@ -250,7 +270,9 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         const NoiseStage &ns = fp.noise;
         const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
         const long long xs0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
-        if (noise_pfb) {
+        if (fuse_noise) {
+            // stage 1 already ran inside the channel-bank kernel
+        } else if (noise_pfb) {
             const PfbBank &b = ns.pfb;
             constexpr int NT = 10;
             PfbParams p{};
@@ -524,6 +546,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         const bool staged_ok = fp->noise.available &&
                                (noise_pfb_ok || pick_shape(fp->noise.R, fp->noise.direct.ntp, h->shape_s1));
         h->noise_pfb = noise_pfb_ok;
+        h->fuse_noise = false;
         int ch = cfg->channelizer, sq = cfg->squelch;
         if (ch == BTGPU_CHANNELIZER_AUTO) ch = pfb_ok ? BTGPU_CHANNELIZER_POLYPHASE : BTGPU_CHANNELIZER_DIRECT;
         if (sq == BTGPU_SQUELCH_AUTO) sq = staged_ok ? BTGPU_SQUELCH_STAGED : BTGPU_SQUELCH_DIRECT;
@@ -534,6 +557,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         h->use_staged = sq == BTGPU_SQUELCH_STAGED;
         h->keep_Y = !h->use_pfb || (cfg->flags & BTGPU_FLAG_DEBUG_Y);
         h->margin = h->use_staged ? kNoiseMargin : 0;
+        h->fuse_noise = h->use_pfb && h->use_staged && noise_pfb_ok && fp->channel.D == 50 && fp->noise.R == 250 &&
+                        !getenv("BTGPU_NO_FUSE");
         h->des.d.channelizer = ch;
         h->des.d.squelch = sq;
         h->des.d.left_margin = h->margin;
@@ -679,6 +704,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]

@@ -52,6 +52,17 @@ struct PfbParams {
     const float *atan_tab; float gain;
     // noise epilogue
     float2 *Z; long long zstride;   // [nsel][zstride]
+    // fused noise stage 1 (FUSEN): the channel tile's staged input also feeds the NU = 5 noise-bank
+    // instants whose first tap lies in the tile's 1250 new samples
+    const float2 *n_taps;        // [15*100]
+    const int *n_binpos;         // [nsel]
+    const float2 *n_krot;        // [nsel][n_period]
+    int n_period;
+    int n_off;                   // first owned noise instant starts n_off samples after the tile start
+    int n_u0;                    // noise instant index owned first by tile 0 (tile b: n_u0 + 5 b)
+    int pre_tiles;               // extra tiles in front (noise grid starts earlier than the channel grid)
+    long long n_T;               // noise instants in total
+    float2 *n_Z; long long n_zstride;
 };
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
@@ -132,10 +143,12 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH>
+template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false>
 __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
 {
     constexpr int DH = S * 50;                               // hop: 2 D = S * 100
+    constexpr int NQ = 15, NR = 250, NU = 5;                 // fused noise bank: taps/branch, hop, instants per tile
+    static_assert(!FUSEN || (CHAN && DH == 50 && NT == 26), "fused noise stage needs the C79 channel geometry");
     // NTH lanes: NT*10 DFT tasks per pass must fit in one sweep (260 tasks -> 320 lanes), otherwise
     // one wave runs the whole DFT body twice for a handful of tasks and the workgroup waits for it
     constexpr int M = 100;
@@ -144,7 +157,9 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     static_assert(NT % 2 == 0, "NT must be even");
     extern __shared__ float4 lds4[];
     float2 *lds = (float2 *)lds4;
-    constexpr int SPAN = DH * (NT - 1) + Q * M;              // input samples a tile needs
+    constexpr int SPAN_C = DH * (NT - 1) + Q * M;            // input samples the channel instants need
+    constexpr int SPAN_N = (NR - 1) + NR * (NU - 1) + NQ * M;   // ... and the owned noise instants
+    constexpr int SPAN = (FUSEN && SPAN_N > SPAN_C) ? SPAN_N : SPAN_C;
     constexpr int N4 = (SPAN + 3) / 2;                       // 16-byte pieces staged (aligned start: +1 sample)
     constexpr int span = 2 * N4;                             // samples resident in LDS
     const int wsz = CHAN ? p.nsel * NT : 0;
@@ -152,12 +167,14 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     float2 *xs = lds;                                        // [span]  (aliased by Wb[nsel][NT])
     float2 *U = lds + ((asz + 1) & ~1);                      // [NT][UST]
     float *atab = (float *)(U + NT * UST);                   // [257]               (CHAN)
+    float2 *Un = (float2 *)(atab + 258);                     // [NU][UST] noise branch outputs (FUSEN)
     __shared__ float2 s_tw[100];
     __shared__ float2 s_krot[80 * 4];
     __shared__ int s_binpos[80];
     const bool krot_lds = p.rot_period <= 4 && p.nsel <= 80;
 
-    const int tile = xcd_remap(blockIdx.x, p.ntiles);
+    const int tile = FUSEN ? xcd_remap(blockIdx.x, p.ntiles + p.pre_tiles) - p.pre_tiles
+                           : xcd_remap(blockIdx.x, p.ntiles);
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
     const int l = threadIdx.x;
 
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     // ---- phase A: polyphase branch filters ----
     {
         const int pp = l & 127, r = l >> 7;
-        if (pp < M && r < 2) {
+        if (pp < M && r < 2 && tile >= 0) {
             float2 a[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) a[q] = p.taps[q * M + pp];
@@ -232,13 +249,37 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
             }
         }
     }
+    if (FUSEN) {
+        // noise bank branches: lanes (p, r); r = 0 takes owned instants 0..2, r = 1 takes 3..4
+        const int pp = l & 127, r = l >> 7;
+        if (pp < M && r < 2) {
+            float2 an[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) an[q] = p.n_taps[q * M + pp];
+            const int i0 = r ? 3 : 0, i1 = r ? NU : 3;
+            for (int i = i0; i < i1; i++) {
+                const float2 *zz = xs + shift + p.n_off + NR * i + pp;
+                float ur = 0.f, ui = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const float2 v = zz[q * M];
+                    ur = fmaf(an[q].x, v.x, ur);
+                    ur = fmaf(-an[q].y, v.y, ur);
+                    ui = fmaf(an[q].x, v.y, ui);
+                    ui = fmaf(an[q].y, v.x, ui);
+                }
+                Un[i * UST + pp] = make_float2(ur, ui);
+            }
+        }
+    }
     __syncthreads();
 
     // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100} ----
-    for (int i = l; i < NT * 10; i += NTH) {
+    constexpr int NTASK = NT * 10 + (FUSEN ? NU * 10 : 0);
+    for (int i = l; i < NTASK; i += NTH) {
         const int tl = i / 10, p2 = i % 10;
         float2 v[10];
-        float2 *row = U + tl * UST + p2;
+        float2 *row = (FUSEN && tl >= NT) ? Un + (tl - NT) * UST + p2 : U + tl * UST + p2;
 #pragma unroll
         for (int k = 0; k < 10; k++) v[k] = row[10 * k];
         dft10(v);
@@ -247,10 +288,10 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     }
     __syncthreads();
     // ---- phase B2: DFT over p2; bin m = m1 + 10 m2 ends up at position 10 m1 + m2 ----
-    for (int i = l; i < NT * 10; i += NTH) {
+    for (int i = l; i < NTASK; i += NTH) {
         const int tl = i / 10, m1 = i % 10;
         float2 v[10];
-        float2 *row = U + tl * UST + 10 * m1;
+        float2 *row = (FUSEN && tl >= NT) ? Un + (tl - NT) * UST + 10 * m1 : U + tl * UST + 10 * m1;
 #pragma unroll
         for (int k = 0; k < 10; k++) v[k] = row[k];
         dft10(v);
@@ -260,6 +301,22 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     __syncthreads();
 
     // ---- phase C ----
+    if (FUSEN) {
+        // owned noise instants -> stage-1 output Z (de-rotated; consumed by noise_stage2_kernel)
+        const long long u0 = (long long)p.n_u0 + (long long)NU * tile;
+        const uint32_t np = (uint32_t)p.n_period;
+        const uint32_t ph0 = (uint32_t)(((u0 % (long long)np) + np) % np);     // block-uniform
+        for (int i = l; i < p.nsel * NU; i += NTH) {
+            const int c = i / NU, ui = i % NU;
+            const long long u = u0 + ui;
+            if (u < 0 || u >= p.n_T) continue;
+            uint32_t ph = ph0 + (uint32_t)ui;
+            ph = ph >= np ? ph - np : ph;
+            const float2 y = cmulf(Un[ui * UST + p.n_binpos[c]], p.n_krot[(size_t)c * np + ph]);
+            p.n_Z[(size_t)c * p.n_zstride + u] = y;
+        }
+        if (tile < 0) return;                                     // pre-tile: no channel instants
+    }
     const uint32_t period = (uint32_t)p.rot_period;
     // phase index of local instant 0: (t0 mod period) in 32-bit arithmetic (t0 >= -1)
     const uint32_t ph_t0 = (uint32_t)(((uint32_t)tile * (uint32_t)TT % period + period - (CHAN ? 1u : 0u)) % period);
