@@ -347,28 +347,33 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
             const int tl1 = tl0 + RUN < NT ? tl0 + RUN : NT;
             const int hr = p.tail % TT;                          // head length inside a tile
             float sum = 0.f, head = 0.f;                         // <= 9 terms per run; combined in double below
-            uint32_t ph = ph_t0 + (uint32_t)(tl0 - 1);
-            ph = ph >= period ? ph % period : ph;
-            const float2 *krc = krot_lds ? &s_krot[c * p.rot_period] : &p.krot[(size_t)c * p.rot_period];
-            float2 prev = cmulf(U[(tl0 - 1) * UST + pos], krc[ph]);
-            const bool full = t0 + NT <= p.T;                    // every instant of the tile exists
-            float *drow = p.d + (size_t)(t0 + tl0) * 80 + c;
-            for (int tl = tl0; tl < tl1; tl++) {
-                ph = ph + 1 == period ? 0 : ph + 1;
-                const float2 y = cmulf(U[tl * UST + pos], krc[ph]);
-                float dv = 0.f;
-                if (full || t0 + tl < p.T) {
-                    const float m = y.x * y.x + y.y * y.y;
-                    sum += m;
-                    if (tl - 1 < hr) head += m;
-                    dv = demod_fast(atab, p.gain, y, prev);
-                    *drow = dv;
-                    if (p.Z) p.Z[(size_t)c * p.zstride + (t0 + tl)] = y;          // BTGPU_FLAG_DEBUG_Y
+            // the run, instantiated once per address space of the de-rotation table so that the
+            // LDS copy is read with ds_read (a generic pointer would force flat loads + full waits)
+            auto run = [&](const float2 *krc) {
+                uint32_t ph = ph_t0 + (uint32_t)(tl0 - 1);
+                ph = ph >= period ? ph % period : ph;
+                float2 prev = cmulf(U[(tl0 - 1) * UST + pos], krc[ph]);
+                const bool full = t0 + NT <= p.T;                // every instant of the tile exists
+                float *drow = p.d + (size_t)(t0 + tl0) * 80 + c;
+                for (int tl = tl0; tl < tl1; tl++) {
+                    ph = ph + 1 == period ? 0 : ph + 1;
+                    const float2 y = cmulf(U[tl * UST + pos], krc[ph]);
+                    float dv = 0.f;
+                    if (full || t0 + tl < p.T) {
+                        const float m = y.x * y.x + y.y * y.y;
+                        sum += m;
+                        if (tl - 1 < hr) head += m;
+                        dv = demod_fast(atab, p.gain, y, prev);
+                        *drow = dv;
+                        if (p.Z) p.Z[(size_t)c * p.zstride + (t0 + tl)] = y;      // BTGPU_FLAG_DEBUG_Y
+                    }
+                    drow += 80;
+                    Db[c * NT + tl] = dv;
+                    prev = y;
                 }
-                drow += 80;
-                Db[c * NT + tl] = dv;
-                prev = y;
-            }
+            };
+            if (krot_lds) run(&s_krot[c * p.rot_period]);
+            else run(&p.krot[(size_t)c * p.rot_period]);
             part[(chunk * 80 + c) * 2 + 0] = (double)sum;
             part[(chunk * 80 + c) * 2 + 1] = (double)head;
         }
