@@ -36,8 +36,8 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c79", choices=sorted(WORKLOADS))
     ap.add_argument("--slots", type=int, default=0, help="slots per rank per step (0 = workload default)")
     ap.add_argument("--squelch", type=float, default=10.0, help="SNR squelch threshold in dB (btrx -t default 10.0)")
@@ -168,7 +168,10 @@ def main():
         names = pkg.KERNEL_NAMES
         NK = len(names)
         avg = [kernel_ms[i] / kernel_launches[i] if kernel_launches[i] else 0.0 for i in range(NK)]
-        dom = int(np.argmax(avg))
+        # the dominant kernel is looked for on the critical path: in pipelined mode the tail
+        # (finish_kernel) of batch n runs on its own stream underneath batch n+1
+        crit = [i for i in range(NK) if not (names[i] == "finish" and not args.sync)]
+        dom = max(crit, key=lambda i: avg[i])
         bytes_per_launch = 8.0 * S * slot                      # 8 B per complex input sample, read once
         ach = bytes_per_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         # algorithmic FMA per input sample of the direct-form banks
@@ -187,12 +190,12 @@ def main():
         # HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
         # gfx950 + WRITE_SIZE), valid for the configuration they were collected on
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_fast_c79_pmc_hbm.json")))
-            key = {"ddc_channel": "pfb100_kernel<7, 1, 26, true, true", "ddc_noise": "pfb100_kernel<15, 5, 10, false, fa",
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_fused_c79_pmc_hbm.json")))
+            key = {"ddc_channel": "pfb100_kernel<7, 1, 26, true, true", "ddc_noise": "pfb100_kernel<15, 5, 10, false, fa",   # absent when the noise stage is fused into the channel kernel
                    "window": "window_kernel", "finish": "finish_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
             if args.workload == "c79" and S == pmc["slots"] and key in pmc["kernels"] and not direct:
                 roof["traffic"] = pmc["kernels"][key]["hbm_bytes"]
-                roof["traffic_source"] = "profiles/r01_c_fast_c79_pmc_hbm.json"
+                roof["traffic_source"] = "profiles/r01_d_fused_c79_pmc_hbm.json"
         except Exception:
             pass
 
