@@ -180,7 +180,8 @@ def main():
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(ach, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                 "avg_launch_ms": round(avg[dom], 4),
-                "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(NK)}}
+                "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(NK)},
+                "note": "ddc_channel = channel bank (+ noise stage 1 when fused); ddc_noise = 0 then"}
         direct = (names[dom] == "ddc_channel" and int(des.channelizer) == 1) or \
                  (names[dom] == "ddc_noise" and int(des.squelch) == 1)
         if direct:                                  # direct-form banks are ALU-bound: report the fp32 rate too
