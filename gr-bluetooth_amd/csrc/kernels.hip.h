@@ -584,10 +584,16 @@ __global__ __launch_bounds__(64) void finish_kernel(
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
     const unsigned int *__restrict__ fin_count, int *__restrict__ win_len)
 {
-    __shared__ float mmse[129 * 8];
-    __shared__ float slab[64 * (2 * kFinRows + 1)];
+    constexpr unsigned int RING = 2 * kFinRows, MASK = RING - 1;
+    constexpr int SLAB = 2 * RING + 1;           // every row is stored twice (r and r + RING): the 8-tap
+                                                 // window [pos, pos + 8) never wraps, one address per step
+    __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
+    __shared__ float slab[64 * SLAB];
     const unsigned int n = *fin_count;
     if (blockIdx.x * blockDim.x >= n) return;                    // uniform: nothing for this workgroup
+    // a few dozen strictly sequential waves next to the throughput kernels of the following batch:
+    // give them the highest wave issue priority, they use a fraction of a percent of the issue slots
+    __builtin_amdgcn_s_setprio(3);
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
     __syncthreads();
     const unsigned int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -602,16 +608,14 @@ __global__ __launch_bounds__(64) void finish_kernel(
     float mu = r.mu, omega = r.omega, last = r.last;
     unsigned int ii = r.ii;
     int oo = r.oo;
-    // private ring of 2*kFinRows samples: rows [lo, lo + 2*kFinRows) live at my[row & (2*kFinRows-1)]
-    float *my = slab + threadIdx.x * (2 * kFinRows + 1);
-    constexpr unsigned int RING = 2 * kFinRows, MASK = RING - 1;
+    float *my = slab + threadIdx.x * SLAB;
     unsigned int hi = ii;                                        // rows [.., hi) are resident
     {
         float v[RING];
 #pragma unroll
         for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = idx < nvalid ? col[idx] : 0.f; }
 #pragma unroll
-        for (unsigned int j = 0; j < RING; j++) my[(hi + j) & MASK] = v[j];
+        for (unsigned int j = 0; j < RING; j++) { const unsigned int s = (hi + j) & MASK; my[s] = v[j]; my[s + RING] = v[j]; }
         hi += RING;
     }
     while (ii < ni && oo < demod_n) {
@@ -621,24 +625,29 @@ __global__ __launch_bounds__(64) void finish_kernel(
         for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = idx < nvalid ? col[idx] : 0.f; }
         // consume every step whose 8-tap window lies inside the resident rows [.., hi)
         while (ii + 8 <= hi && ii < ni && oo < demod_n) {
-            int imu = (int)rintf(mu * 128.0f);
-            imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
-            const float *t = &mmse[imu * 8];
+            const int imu = (int)rintf(mu * 128.0f);             // mu in [0, 1) -> 0..128
+            const float4 ta = *(const float4 *)&mmse[imu * 8 + 4];
+            const float4 tb = *(const float4 *)&mmse[imu * 8];
+            const float *in = my + (ii & MASK);
             float acc = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; q++) acc = fmaf(t[7 - q], my[(ii + q) & MASK], acc);
+            acc = fmaf(ta.w, in[0], acc);
+            acc = fmaf(ta.z, in[1], acc);
+            acc = fmaf(ta.y, in[2], acc);
+            acc = fmaf(ta.x, in[3], acc);
+            acc = fmaf(tb.w, in[4], acc);
+            acc = fmaf(tb.z, in[5], acc);
+            acc = fmaf(tb.y, in[6], acc);
+            acc = fmaf(tb.x, in[7], acc);
             const float out = acc;
-            const float s_last = (last < 0) ? -1.0f : 1.0f;
-            const float s_out = (out < 0) ? -1.0f : 1.0f;
-            const float mm_val = s_last * out - s_out * last;
+            const float s_last = __builtin_copysignf(1.0f, last);
+            const float s_out = __builtin_copysignf(1.0f, out);
+            const float mm_val = fmaf(s_last, out, -(s_out * last));     // both products exact
             last = out;
             omega = omega + (p.gain_omega * mm_val);
             {
                 const float xx = omega - p.omega_mid;
-                float x1 = fabsf(xx + p.omega_relative_limit);
-                const float x2 = fabsf(xx - p.omega_relative_limit);
-                x1 -= x2;
-                omega = p.omega_mid + 0.5f * x1;
+                const float x1 = fabsf(xx + p.omega_relative_limit) - fabsf(xx - p.omega_relative_limit);
+                omega = fmaf(0.5f, x1, p.omega_mid);                     // 0.5 * x1 is exact
             }
             mu = mu + (omega + (p.gain_mu * mm_val));
             const float fl = floorf(mu);
@@ -649,7 +658,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
         // here ii + 8 > hi (or the window is done): the ring slots of rows [hi-RING, hi-RING+kFinRows)
         // are all below ii and can take rows [hi, hi + kFinRows)
 #pragma unroll
-        for (int j = 0; j < kFinRows; j++) my[(hi + j) & MASK] = v[j];
+        for (int j = 0; j < kFinRows; j++) { const unsigned int s = (hi + j) & MASK; my[s] = v[j]; my[s + RING] = v[j]; }
         hi += kFinRows;
     }
     win_len[r.w] = oo;
