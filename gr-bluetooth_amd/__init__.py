@@ -29,7 +29,7 @@ OK, EINVAL, ENOMEM, EDEVICE, ENODEVICE, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3,
 MODE_LAP, MODE_SNIFFER = 0, 1
 CHANNELIZER_AUTO, CHANNELIZER_DIRECT, CHANNELIZER_POLYPHASE = 0, 1, 2
 SQUELCH_AUTO, SQUELCH_DIRECT, SQUELCH_STAGED = 0, 1, 2
-FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC = 1, 2, 4
+FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS = 1, 2, 4, 8
 KIND_AC, KIND_AA = 0, 1
 
 
@@ -75,7 +75,7 @@ class Timing(ctypes.Structure):
 EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_strerror",
            "btgpu_version", "btgpu_create", "btgpu_destroy", "btgpu_get_design", "btgpu_history",
            "btgpu_last_error", "btgpu_work", "btgpu_push", "btgpu_process_device", "btgpu_poll",
-           "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch"]
+           "btgpu_poll_symbols", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch"]
 
 
 class BtgpuError(RuntimeError):
@@ -150,6 +150,9 @@ def lib():
     L.btgpu_poll.argtypes = [vp, ctypes.POINTER(Hit), ctypes.c_int]
     L.btgpu_pending.restype = ctypes.c_int
     L.btgpu_pending.argtypes = [vp]
+    L.btgpu_poll_symbols.restype = ctypes.c_int
+    L.btgpu_poll_symbols.argtypes = [vp, ctypes.POINTER(Hit), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     L.btgpu_flush.restype = ctypes.c_int
     L.btgpu_flush.argtypes = [vp]
     L.btgpu_last_timing.restype = ctypes.c_int
@@ -321,6 +324,22 @@ class _MultiBlock:
                 raise BtgpuError(got, "btgpu_poll")
             buf = buf[:got]
         return buf
+
+    def poll_symbols(self, sym_cap=3125, max_hits=1 << 16):
+        """Hits plus the symbols the reference hands to ac()/aa() with each of them (needs
+        flags=FLAG_SYMBOLS): returns (structured hit array, uint8 [n, sym_cap], int32 [n])."""
+        n = min(max(self._L.btgpu_pending(self._h), 0), max_hits)
+        hits = np.zeros(n, self.HIT_DTYPE)
+        syms = np.zeros((n, sym_cap), np.uint8)
+        lens = np.zeros(n, np.int32)
+        if n:
+            got = self._L.btgpu_poll_symbols(self._h, hits.ctypes.data_as(ctypes.POINTER(Hit)),
+                                             syms.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), sym_cap,
+                                             lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n)
+            if got < 0:
+                raise BtgpuError(got, "btgpu_poll_symbols")
+            hits, syms, lens = hits[:got], syms[:got], lens[:got]
+        return hits, syms, lens
 
     def timing(self):
         t = Timing()

@@ -69,7 +69,8 @@ struct btgpu_handle {
     hipStream_t stream = nullptr;
     hipStream_t tail_stream = nullptr;
     struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
-        DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_d2;
+        DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_d2, d_winfin, d_symbits;
+        uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
         DeviceHit *h_hits = nullptr;          // pinned: first kEagerHits records, copied by the tail stream
         hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -85,6 +86,9 @@ struct btgpu_handle {
     hipStream_t noise_stream = nullptr;          // the squelch banks run beside the channel bank
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     static constexpr unsigned kEagerHits = 65536;
+    static constexpr unsigned kEagerFin = 8192;
+    bool want_syms = false;
+    std::vector<std::vector<uint32_t>> qbits;    // packed symbols per queued hit (BTGPU_FLAG_SYMBOLS)
     std::string err;
     int sticky = BTGPU_OK;
 
@@ -149,9 +153,11 @@ struct btgpu_handle {
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
-        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d2.p = nullptr; }
+        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d2.p = nullptr;
+                      tc[1].d_winfin.p = tc[1].d_symbits.p = nullptr; }
         for (TailCtx &t : tc) {
-            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_d2};
+            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_d2, &t.d_winfin, &t.d_symbits};
+            if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
             for (auto &e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
             for (auto &e : t.evn) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -191,6 +197,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     if (t.pending) { int hrc = harvest(t); if (hrc != BTGPU_OK && hrc != BTGPU_EOVERFLOW) return hrc; }
     hipEvent_t *ev = t.ev;
     DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin, &d_d2 = t.d_d2;
+    DevBuf &d_winfin = t.d_winfin, &d_symbits = t.d_symbits;
     t.S = S; t.abs_first_slot = abs_first_slot;
 
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
@@ -328,13 +335,15 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.mode = des.cfg.mode; p.max_hits = max_hits;
         p.a0_lo = des.ac.a0_lo; p.a0_hi = des.ac.a0_hi;
         p.le = (des.cfg.flags & BTGPU_FLAG_LE) ? 1 : 0; p.low_channel = d.low_channel;
+        p.syms = want_syms ? 1 : 0;
         hipLaunchKernelGGL(window_kernel, dim3((S + kWinSlots - 1) / kWinSlots), dim3(kWinThreads), 0, st, p, (const float *)d_d.p, G,
                            (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
                            (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
                            (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
                            (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
                            (unsigned int *)d_hitcount.p + 1, (const uint8_t *)d_le_hdr.p,
-                           (const uint16_t *)d_le_whiten.p, (const int8_t *)d_le_index.p);
+                           (const uint16_t *)d_le_whiten.p, (const int8_t *)d_le_index.p, (int *)d_winfin.p,
+                           (uint32_t *)d_symbits.p);
         HIPCHK(this, hipEventRecord(ev[5], st));
         // ---- tail: finish + nsym on the tail stream, overlapping the next batch's banks ----
         HIPCHK(this, hipEventRecord(t.detect_done, st));
@@ -343,11 +352,20 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             // windows with hits: at most one FinishRec per window; lanes beyond fin_count exit
             const long long cap = std::min<long long>((long long)S * nch, (long long)max_hits);
             const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
-            hipLaunchKernelGGL(finish_kernel, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d2.p,
-                               ystride, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
-                               (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p);
+            if (want_syms)
+                hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d2.p,
+                                   ystride, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
+                                   (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)d_symbits.p);
+            else
+                hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d2.p,
+                                   ystride, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
+                                   (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)nullptr);
             hipLaunchKernelGGL(nsym_patch_kernel, dim3(32), dim3(256), 0, tail_stream, (DeviceHit *)d_hits.p,
-                               (const unsigned int *)d_hitcount.p, max_hits, (const int *)d_winlen.p, nch);
+                               (const unsigned int *)d_hitcount.p, max_hits, (const int *)d_winlen.p, nch,
+                               want_syms ? (const int *)d_winfin.p : (const int *)nullptr);
+            if (want_syms)
+                HIPCHK(this, hipMemcpyAsync(t.h_sym, d_symbits.p, (size_t)kEagerFin * kSymWords * sizeof(uint32_t),
+                                         hipMemcpyDeviceToHost, tail_stream));
             // records travel to pinned host memory on the tail stream too: harvesting a batch is
             // then pure host work and never waits on the other stream
             HIPCHK(this, hipMemcpyAsync(t.h_count, d_hitcount.p, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
@@ -407,13 +425,37 @@ int btgpu_handle::harvest(TailCtx &t)
             o.nsym = x.nsym;
             o.snr_db = x.snr;
             queue.push_back(o);
+            if (want_syms) {
+                std::vector<uint32_t> bits;
+                if (x.sym >= 0) {
+                    bits.resize(kSymWords);
+                    if ((unsigned)x.sym < kEagerFin) std::memcpy(bits.data(), t.h_sym + (size_t)x.sym * kSymWords, kSymWords * sizeof(uint32_t));
+                    else {
+                        HIPCHK(this, hipMemcpyAsync(bits.data(), (const uint32_t *)t.d_symbits.p + (size_t)x.sym * kSymWords,
+                                                 kSymWords * sizeof(uint32_t), hipMemcpyDeviceToHost, copy_stream));
+                        HIPCHK(this, hipStreamSynchronize(copy_stream));
+                    }
+                }
+                qbits.push_back(std::move(bits));
+            }
         }
-        std::sort(queue.begin() + q0, queue.end(), [](const btgpu_hit &a, const btgpu_hit &b) {
+        auto less = [](const btgpu_hit &a, const btgpu_hit &b) {
             if (a.slot != b.slot) return a.slot < b.slot;
             if (a.channel != b.channel) return a.channel < b.channel;
             if (a.kind != b.kind) return a.kind < b.kind;
             return a.offset < b.offset;
-        });
+        };
+        if (!want_syms) std::sort(queue.begin() + q0, queue.end(), less);
+        else {
+            const size_t n = queue.size() - q0;
+            std::vector<size_t> idx(n);
+            for (size_t i = 0; i < n; i++) idx[i] = i;
+            std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return less(queue[q0 + a], queue[q0 + b]); });
+            std::vector<btgpu_hit> qs(n);
+            std::vector<std::vector<uint32_t>> bs(n);
+            for (size_t i = 0; i < n; i++) { qs[i] = queue[q0 + idx[i]]; bs[i] = std::move(qbits[q0 + idx[i]]); }
+            for (size_t i = 0; i < n; i++) { queue[q0 + i] = qs[i]; qbits[q0 + i] = std::move(bs[i]); }
+        }
     }
     return rc;
 }
@@ -618,6 +660,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (hipEventCreateWithFlags(&t.tail_done, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     h->async = (cfg->flags & BTGPU_FLAG_ASYNC) != 0;
+    h->want_syms = (cfg->flags & BTGPU_FLAG_SYMBOLS) != 0;
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != BTGPU_OK) { int c__ = rc__; std::string m__ = h->err; \
         if (getenv("BTGPU_VERBOSE")) fprintf(stderr, "btgpu_create: %s\n", m__.c_str()); return fail(c__); } } while (0)
@@ -689,14 +732,21 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
         TRY(h->alloc(t.d_fin, (size_t)S * nch * sizeof(FinishRec)));
         TRY(h->alloc(t.d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
+        if (h->want_syms) {
+            const size_t maxfin = std::min<size_t>((size_t)S * nch, (size_t)h->max_hits);
+            TRY(h->alloc(t.d_winfin, (size_t)S * nch * sizeof(int)));
+            TRY(h->alloc(t.d_symbits, std::max<size_t>(maxfin, btgpu_handle::kEagerFin) * kSymWords * sizeof(uint32_t)));
+        }
     }
     for (auto &t : h->tc) {
+        if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)btgpu_handle::kEagerFin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_count, 2 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_hits, (size_t)btgpu_handle::kEagerHits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
     }
     if (!h->async) {                      // synchronous mode: one context, used for every batch
         h->tc[1].d_winlen = h->tc[0].d_winlen; h->tc[1].d_hits = h->tc[0].d_hits;
         h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d2 = h->tc[0].d_d2;
+        h->tc[1].d_winfin = h->tc[0].d_winfin; h->tc[1].d_symbits = h->tc[0].d_symbits;
     }
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
@@ -828,6 +878,33 @@ int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits)
     if (n > 0) {
         std::memcpy(out, h->queue.data(), sizeof(btgpu_hit) * n);
         h->queue.erase(h->queue.begin(), h->queue.begin() + n);
+        if (h->want_syms) h->qbits.erase(h->qbits.begin(), h->qbits.begin() + n);
+    }
+    return n;
+}
+
+int btgpu_poll_symbols(btgpu_handle *h, btgpu_hit *out, uint8_t *symbols, int sym_cap, int *sym_len, int max_hits)
+{
+    if (!h || (!out && max_hits > 0) || max_hits < 0 || sym_cap < 0 || (!symbols && sym_cap > 0)) return BTGPU_EINVAL;
+    if (!h->want_syms) return BTGPU_EUNSUPPORTED;
+    (void)h->harvest_all(false);
+    int n = (int)std::min<size_t>((size_t)max_hits, h->queue.size());
+    for (int i = 0; i < n; i++) {
+        out[i] = h->queue[i];
+        const std::vector<uint32_t> &bits = h->qbits[i];
+        // what the reference hands to ac()/aa(): &symp[i], len - i  (one symbol per byte, air order)
+        int avail = bits.empty() ? 0 : out[i].nsym;
+        if (avail > sym_cap) avail = sym_cap;
+        const int first = out[i].offset;
+        const int limit = (int)bits.size() * 32 - first;
+        if (avail > limit) avail = limit < 0 ? 0 : limit;
+        uint8_t *dst = symbols + (size_t)i * sym_cap;
+        for (int s = 0; s < avail; s++) { const int b = first + s; dst[s] = (uint8_t)((bits[b >> 5] >> (b & 31)) & 1u); }
+        if (sym_len) sym_len[i] = avail;
+    }
+    if (n > 0) {
+        h->queue.erase(h->queue.begin(), h->queue.begin() + n);
+        h->qbits.erase(h->qbits.begin(), h->qbits.begin() + n);
     }
     return n;
 }

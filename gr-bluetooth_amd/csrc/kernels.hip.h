@@ -28,6 +28,8 @@ struct DeviceHit {            // 40 bytes, written by the window kernel
     double   snr;
     int32_t  nsym;            // len - sub - offset, filled by nsym_patch_kernel once len is known
     int32_t  sub;             // symbols the classic pass consumed before the LE pass (Q6), else 0
+    int32_t  sym;             // index of the window's packed symbols (BTGPU_FLAG_SYMBOLS), else -1
+    int32_t  pad_;
 };
 
 struct FinishRec {            // M&M state of a window that reported hits, handed to finish_kernel
@@ -35,7 +37,11 @@ struct FinishRec {            // M&M state of a window that reported hits, hande
     uint32_t ii;
     int32_t  oo;
     float    mu, omega, last;
+    int32_t  done;            // the window already ended inside the window kernel (len known)
+    int32_t  pad_;
 };
+
+constexpr int kSymWords = 120;    // packed symbols kept per hit window (3840 >= ~3760 symbols)
 
 // ------------------------------------------------------------------------------------
 // K1: direct-form decimating complex band-pass FIR bank (channel bank and noise bank).
@@ -251,6 +257,7 @@ struct WindowParams {
     int max_hits;
     uint64_t a0_lo; uint32_t a0_hi;
     int le;                     // run the le_packet::sniff_aa pass (multi_sniffer, BTGPU_FLAG_LE)
+    int syms;                   // export the packed symbols of hit windows (BTGPU_FLAG_SYMBOLS)
     int low_channel;
 };
 
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     int *__restrict__ win_len, DeviceHit *__restrict__ hits, unsigned int *__restrict__ hit_count,
     FinishRec *__restrict__ fin, unsigned int *__restrict__ fin_count,
     const uint8_t *__restrict__ le_hdr_g, const uint16_t *__restrict__ le_whiten_g,
-    const int8_t *__restrict__ le_index_g)
+    const int8_t *__restrict__ le_index_g, int *__restrict__ win_fin, uint32_t *__restrict__ symbits)
 {
     __shared__ uint8_t le_hdr[4 * 256];
     __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                 if (slot_h < (unsigned int)p.max_hits) {
                     DeviceHit h;
                     h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
-                    h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0;
+                    h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0; h.sym = -1; h.pad_ = 0;
                     hits[slot_h] = h;
                 }
                 nhits++;
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                     if (slot_h < (unsigned int)p.max_hits) {
                         DeviceHit h;
                         h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
-                        h.lap = aa; h.ac_errors = 0; h.kind = 1; h.snr = snr; h.nsym = -1; h.sub = sub;
+                        h.lap = aa; h.ac_errors = 0; h.kind = 1; h.snr = snr; h.nsym = -1; h.sub = sub; h.sym = -1; h.pad_ = 0;
                         hits[slot_h] = h;
                     }
                     nhits++;
@@ -562,14 +569,22 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         }
     }
     if (nhits > 0) {
-        if (ii >= ni || oo >= demod_n) win_len[w] = oo;                // the window ended inside phase 1
-        else {
-            // the handlers need len = symbols in the whole window: hand the M&M state to
-            // finish_kernel (dense waves of hit windows)
+        const bool ended = ii >= ni || oo >= demod_n;                  // the window ended inside phase 1
+        if (ended) win_len[w] = oo;
+        if (!ended || p.syms) {
+            // the handlers need len = symbols in the whole window (and, with BTGPU_FLAG_SYMBOLS, the
+            // symbols): hand the M&M state to finish_kernel (dense waves of hit windows)
             const unsigned int f = atomicAdd(fin_count, 1u);
             FinishRec r;
             r.w = (int32_t)w; r.ii = ii; r.oo = oo; r.mu = mu; r.omega = omega; r.last = last;
+            r.done = ended ? 1 : 0; r.pad_ = 0;
             fin[f] = r;
+            if (p.syms) {
+                win_fin[w] = (int)f;
+                uint32_t *dst = symbits + (size_t)f * kSymWords;
+                const int nw = (oo + 31) >> 5;
+                for (int j = 0; j < kSymWords; j++) dst[j] = j < nw ? mybits[j * kWinThreads] : 0u;
+            }
         }
     }
 }
@@ -579,10 +594,11 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 // (row stride 80 floats) into a private LDS slab, kFinRows rows at a time, all loads of a chunk
 // in flight together.  No cross-lane data => no barriers.
 constexpr int kFinRows = 32;
+template <bool SYMS>
 __global__ __launch_bounds__(64) void finish_kernel(
     WindowParams p, const float *__restrict__ d2, long long d2stride, long long d_rows,
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
-    const unsigned int *__restrict__ fin_count, int *__restrict__ win_len)
+    const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits)
 {
     constexpr unsigned int RING = 2 * kFinRows, MASK = RING - 1;
     constexpr int SLAB = 2 * RING + 1;           // every row is stored twice (r and r + RING): the 8-tap
@@ -599,6 +615,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     const unsigned int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     const FinishRec r = fin[f];
+    if (r.done) return;
     const int k = r.w / p.nch, c = r.w - k * p.nch;
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
@@ -609,6 +626,8 @@ __global__ __launch_bounds__(64) void finish_kernel(
     unsigned int ii = r.ii;
     int oo = r.oo;
     float *my = slab + threadIdx.x * SLAB;
+    uint32_t *sb = SYMS ? symbits + (size_t)f * kSymWords : nullptr;
+    uint32_t cur = (SYMS && (oo & 31)) ? sb[oo >> 5] : 0u;       // partially filled word left by the window kernel
     unsigned int hi = ii;                                        // rows [.., hi) are resident
     {
         float v[RING];
@@ -653,6 +672,10 @@ __global__ __launch_bounds__(64) void finish_kernel(
             const float fl = floorf(mu);
             ii += (unsigned int)(int)fl;
             mu = mu - fl;
+            if (SYMS) {
+                cur |= (out < 0.f ? 0u : 1u) << (oo & 31);
+                if ((oo & 31) == 31) { if ((oo >> 5) < kSymWords) sb[oo >> 5] = cur; cur = 0u; }
+            }
             oo++;
         }
         // here ii + 8 > hi (or the window is done): the ring slots of rows [hi-RING, hi-RING+kFinRows)
@@ -661,17 +684,23 @@ __global__ __launch_bounds__(64) void finish_kernel(
         for (int j = 0; j < kFinRows; j++) { const unsigned int s = (hi + j) & MASK; my[s] = v[j]; my[s + RING] = v[j]; }
         hi += kFinRows;
     }
+    if (SYMS && (oo & 31) && (oo >> 5) < kSymWords) sb[oo >> 5] = cur;
     win_len[r.w] = oo;
 }
 
 // nsym = len - offset for every hit record, once finish_kernel has produced the window lengths
 __global__ void nsym_patch_kernel(DeviceHit *__restrict__ hits, const unsigned int *__restrict__ hit_count,
-                                  int max_hits, const int *__restrict__ win_len, int nch)
+                                  int max_hits, const int *__restrict__ win_len, int nch,
+                                  const int *__restrict__ win_fin)
 {
     unsigned int n = *hit_count;
     if (n > (unsigned int)max_hits) n = (unsigned int)max_hits;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        hits[i].nsym = win_len[(size_t)hits[i].slot * nch + hits[i].channel_idx] - hits[i].sub - hits[i].offset;
+    {
+        const size_t w = (size_t)hits[i].slot * nch + hits[i].channel_idx;
+        hits[i].nsym = win_len[w] - hits[i].sub - hits[i].offset;
+        if (win_fin) hits[i].sym = win_fin[w];
+    }
 }
 
 }  // namespace btgpu

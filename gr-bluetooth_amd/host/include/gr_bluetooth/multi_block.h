@@ -30,11 +30,13 @@ protected:
     btgpu_design d_design{};
     uint64_t d_cumulative_count = 0;      // total samples consumed (reference: multi_block.h:62)
     double d_sample_rate = 0, d_center_freq = 0, d_target_snr = 0;
+    int d_mode = 0;
 
     // forwards one scheduler call to btgpu_work(); returns the number of items consumed
     int run_work(int noutput_items, gr_vector_const_void_star &input_items);
     // per-record output, in (slot, channel, offset) order
-    virtual void handle_hit(const btgpu_hit &h) = 0;
+    // `syms` = the window's sliced symbols from the hit on (multi_sniffer only), `nsyms` of them
+    virtual void handle_hit(const btgpu_hit &h, const uint8_t *syms, int nsyms) = 0;
 
 public:
     double samples_per_slot() const { return d_design.samples_per_slot; }

@@ -52,6 +52,8 @@ extern "C" {
 
 #define BTGPU_FLAG_LE        0x1        /* also run the le_packet::sniff_aa pass (sniffer mode)  */
 #define BTGPU_FLAG_DEBUG_Y   0x2        /* keep the channel-bank output Y for btgpu_debug_fetch  */
+#define BTGPU_FLAG_SYMBOLS   0x8        /* keep the sliced symbols of every window that reported a
+                                           hit; fetch them with btgpu_poll_symbols                */
 #define BTGPU_FLAG_ASYNC     0x4        /* work/process_device return once a batch is enqueued;
                                            its records appear in a later btgpu_poll (always in
                                            stream order) or after btgpu_flush.  The tail of batch
@@ -163,6 +165,12 @@ int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, si
 
 /* Drain queued hits, ordered by (slot, channel, kind, offset). Returns count (>=0) or <0. */
 int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits);
+/* Like btgpu_poll, plus what the reference hands to its packet handlers with every hit
+ * (lib/multi_sniffer_impl.cc:116: ac(&symp[i], len - i, ...)): the window's sliced symbols from the
+ * hit offset on, one symbol per byte (air order), up to sym_cap per hit, written to
+ * symbols[i*sym_cap ...]; sym_len[i] = number written (min(nsym, sym_cap)).  Needs
+ * BTGPU_FLAG_SYMBOLS; note the LE quirk Q6: for kind AA nsym counts from the reduced length. */
+int btgpu_poll_symbols(btgpu_handle *h, btgpu_hit *out, uint8_t *symbols, int sym_cap, int *sym_len, int max_hits);
 int btgpu_pending(const btgpu_handle *h);
 /* Wait for every enqueued batch and move its records to the poll queue (BTGPU_FLAG_ASYNC). */
 int btgpu_flush(btgpu_handle *h);

@@ -233,7 +233,6 @@ float bto_mmse_interpolate(const bto_ctx *c, const float *in, float mu)
 /* ------------------------------------------------------------------------- */
 
 static double channel_abs_freq(int ch) { return BASE_FREQUENCY + ch * CHANNEL_WIDTH; }
-static int abs_freq_channel(double f) { return (int)((f - BASE_FREQUENCY) / CHANNEL_WIDTH); }
 
 static void build_bank(fir_bank *b, const float *h, int ntaps, int nch, int low_ch,
                        double center, double fs, double extra)
@@ -731,6 +730,27 @@ int bto_sniff_aa(const char *stream, int stream_length, double freq)
         if (distance <= max_distance) return count;
     }
     return -1;
+}
+
+/* classic_packet_impl::header_present (lib/packet_impl.cc:1205-1242): `symbols` starts at the
+ * access code, `length` = symbols the packet object holds (min(len, 3125), packet_impl.cc:53) */
+int bto_header_present(const char *symbols, int length)
+{
+    if (length > 3125) length = 3125;
+    if (length < 126) return 0;
+    const char *stream = symbols + 67;
+    int be = 0;
+    char msb = stream[0] & 1;
+    be += (stream[1] & 1) ^ !msb;
+    be += (stream[2] & 1) ^ msb;
+    be += (stream[3] & 1) ^ !msb;
+    be += (stream[4] & 1) ^ msb;
+    stream += 5;
+    for (int a = 0; a < 54; a += 3) {
+        int b = a + 1, cc = a + 2;
+        be += ((stream[a] ^ stream[b]) | (stream[b] ^ stream[cc]) | (stream[cc] ^ stream[a])) & 1;
+    }
+    return be < 5;                                   /* ID_THRESHOLD, packet.h:185 */
 }
 
 /* ------------------------------------------------------------------------- */

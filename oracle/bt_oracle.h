@@ -117,6 +117,7 @@ int  bto_check_ac(const char *stream, uint32_t lap);
 int  bto_sniff_ac(const char *stream, int stream_length);
 int  bto_sniff_aa(const char *stream, int stream_length, double freq);
 int  bto_le_freq2index(double freq);
+int  bto_header_present(const char *symbols, int length);   /* lib/packet_impl.cc:1205-1242 */
 uint32_t bto_air_to_host32(const char *air, int bits);
 
 /* ---- block work() restatements; return number of hits appended ---- */

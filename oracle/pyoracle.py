@@ -92,6 +92,8 @@ def lib():
     L.bto_sniff_ac.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.bto_sniff_aa.restype = ctypes.c_int
     L.bto_sniff_aa.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_double]
+    L.bto_header_present.restype = ctypes.c_int
+    L.bto_header_present.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.bto_le_freq2index.restype = ctypes.c_int
     L.bto_le_freq2index.argtypes = [ctypes.c_double]
     L.bto_work.restype = ctypes.c_int
@@ -145,6 +147,13 @@ def sniff_aa(symbols, limit, freq):
     s = np.ascontiguousarray(symbols, dtype=np.uint8)
     pad = np.concatenate([s, np.zeros(80, np.uint8)])
     return lib().bto_sniff_aa(pad.tobytes(), int(limit), float(freq))
+
+
+def header_present(symbols, length=None):
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    n = len(s) if length is None else int(length)
+    pad = np.concatenate([s, np.zeros(140, np.uint8)])
+    return bool(lib().bto_header_present(pad.tobytes(), n))
 
 
 def scan_symbols(symbols, max_hits=4096):

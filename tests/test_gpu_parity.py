@@ -284,6 +284,55 @@ def test_le_pass_fast_path_c79(pkg, po, synth):
     assert max(abs(a[6] - c[6]) for a, c in zip(_keys(got), _keys(want))) <= 8
 
 
+@pytest.mark.parametrize("mode", ["sniffer", "lap"])
+def test_hit_symbols_equal_oracle(pkg, po, synth, mode):
+    """BTGPU_FLAG_SYMBOLS: every hit comes with the sliced symbols the reference passes to its
+    packet handlers (&symp[i], len - i); bit-exact against the oracle's channel_symbols on the
+    DIRECT path, and the access code is found at symbol 0."""
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 18, laps=(0x24D952, 0x4831DD), seed=71, snr_db=24, occupancy=0.5)
+    omode = po.MODE_SNIFFER if mode == "sniffer" else po.MODE_LAP
+    o = po.Oracle(fs, fc, 10.0, omode)
+    want, _ = o.run_stream(iq, threads=8)
+    cls = pkg.multi_sniffer if mode == "sniffer" else pkg.multi_LAP
+    kw = dict(channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT, flags=pkg.FLAG_SYMBOLS)
+    blk = cls(fs, fc, 10.0, False, **kw) if mode == "sniffer" else cls(fs, fc, 10.0, **kw)
+    blk.push(iq)
+    hits, syms, lens = blk.poll_symbols(sym_cap=3125)
+    blk.close()
+    assert len(hits) == len(want) > 3
+    for h, s, n, w in zip(hits, syms, lens, want):
+        assert (int(h["slot"]), int(h["channel"]), int(h["offset"]), int(h["lap"]), int(h["nsym"])) == \
+            (w.slot, w.channel, w.offset, w.lap, w.nsym)
+        assert n == min(w.nsym, 3125)
+        ch_iq, _ = o.channel_samples(o.window(iq, w.slot), w.channel)
+        osym, _ = o.channel_symbols(ch_iq)
+        assert len(osym) - w.offset == w.nsym
+        assert np.array_equal(s[:n], osym[w.offset:w.offset + n])
+        assert po.sniff_ac(s[:200], 1) == 0                       # the hit's access code starts at symbol 0
+        assert po.lib().bto_air_to_host32(s[38:62].tobytes(), 24) == w.lap
+
+
+def test_hit_symbols_fast_path(pkg, po, synth):
+    """Fast path: the packet part of the exported symbols (access code + header) equals the oracle's."""
+    fs, fc = 100e6, 2441e6
+    laps = tuple(0x24D952 + 0x10101 * i for i in range(6))
+    iq, _ = synth.make_capture(fs, fc, 9, laps=laps, seed=72, snr_db=25, occupancy=0.6)
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    want, _ = o.run_stream(iq, threads=16)
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, flags=pkg.FLAG_SYMBOLS)
+    blk.push(iq)
+    hits, syms, lens = blk.poll_symbols(sym_cap=400)
+    blk.close()
+    assert len(hits) == len(want) > 5
+    for h, s, n, w in zip(hits, syms, lens, want):
+        assert (int(h["slot"]), int(h["channel"]), int(h["offset"]), int(h["lap"])) == (w.slot, w.channel, w.offset, w.lap)
+        ch_iq, _ = o.channel_samples(o.window(iq, w.slot), w.channel)
+        osym, _ = o.channel_symbols(ch_iq)
+        assert n == 400
+        assert np.array_equal(s[:126], osym[w.offset:w.offset + 126])      # access code + FEC 1/3 header
+
+
 def test_async_pipeline_equals_sync(pkg, po, synth):
     """BTGPU_FLAG_ASYNC: batches are enqueued without waiting; records arrive later, in stream
     order, and are the same records."""
