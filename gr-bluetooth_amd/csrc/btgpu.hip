@@ -29,6 +29,8 @@ using namespace btgpu;
 
 namespace {
 
+constexpr int kFuseThreads = 320;   // fused bank kernel: 310 DFT tasks per pass in one sweep
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -103,7 +105,7 @@ struct btgpu_handle {
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
-    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1;
+    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof;
     LaunchShape shape_s1;
     bool noise_pfb = false;
     bool fuse_noise = false;         // noise stage 1 rides on the channel bank's staged input
@@ -151,7 +153,7 @@ struct btgpu_handle {
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
-                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1};
+                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d2.p = nullptr;
                       tc[1].d_winfin.p = tc[1].d_symbits.p = nullptr; }
@@ -225,10 +227,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.tiles_per_block = ops / TT; p.tail = des.tail; p.nb = nb;
         p.atan_tab = (const float *)d_atan.p; p.gain = des.demod_gain;
         p.Z = keep_Y ? (float2 *)d_Y.p : nullptr; p.zstride = ystride;
+        p.prof = (unsigned long long *)d_prof.p;
         const int span = 2 * ((b.D * (NT - 1) + b.Q * 100 + 3) / 2), wsz = nch * NT;
         const int asz = ((span > wsz ? span : wsz) + 1) & ~1;
-        const size_t lds = (size_t)(asz + NT * 100) * sizeof(float2) + (size_t)257 * sizeof(float);
-        static_assert(NT * 79 + 2 + 3 * 80 * 2 * 2 <= 2 * (50 * 25 + 700), "epilogue scratch must fit the dead input tile");
+        const size_t lds = (size_t)(asz + NT * kPfbUst + 1) * sizeof(float2) + (size_t)257 * sizeof(float);
+        static_assert(NT * 79 + 2 + 4 * 80 * 2 * 2 <= 2 * (50 * 25 + 700), "epilogue scratch must fit the dead input tile");
         if (fuse_noise) {
             const NoiseStage &ns = fp.noise;
             const long long xn0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
@@ -241,13 +244,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             p.n_Z = (float2 *)d_Z.p; p.n_zstride = zstride;
             const int spanf = 2 * (((250 - 1) + 250 * 4 + 15 * 100 + 3) / 2);
             const int aszf = ((spanf > wsz ? spanf : wsz) + 1) & ~1;
-            const size_t ldsf = (size_t)(aszf + NT * 100) * sizeof(float2) + (size_t)258 * sizeof(float) +
-                                (size_t)5 * 100 * sizeof(float2);
+            const size_t ldsf = (size_t)(aszf + NT * kPfbUst + 1) * sizeof(float2) + (size_t)258 * sizeof(float) +
+                                (size_t)5 * kPfbUst * sizeof(float2);
             const dim3 gridf(p.ntiles + p.pre_tiles);
             if (b.real_taps)
-                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, 256, true>), gridf, dim3(256), ldsf, st, p);
+                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, kFuseThreads, true>), gridf, dim3(kFuseThreads), ldsf, st, p);
             else
-                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, 256, true>), gridf, dim3(256), ldsf, st, p);
+                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, kFuseThreads, true>), gridf, dim3(kFuseThreads), ldsf, st, p);
         } else if (b.real_taps)
             hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
         else
@@ -291,7 +294,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             p.ntiles = (int)((Tn + NT - 1) / NT);
             p.Z = (float2 *)d_Z.p; p.zstride = zstride;
             const int span = 2 * ((b.D * (NT - 1) + b.Q * 100 + 3) / 2);
-            const size_t lds = (size_t)(span + NT * 100) * sizeof(float2);
+            const size_t lds = (size_t)(span + NT * kPfbUst + 1) * sizeof(float2);
             hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false, 256>), dim3(p.ntiles), dim3(256), lds, ns_st, p);
         } else {
             // stage 1 as a direct-form bank: B-spline prototype (a few hundred taps at most), hop R
@@ -717,6 +720,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_Q, (size_t)nch * S * sizeof(double)));
     TRY(h->upload(h->d_mmse, des.mmse, sizeof des.mmse));
     TRY(h->upload(h->d_atan, des.atan_tab, sizeof des.atan_tab));
+    if (getenv("BTGPU_PFB_PROF")) {                       // per-phase cycle sums of the bank kernel (diagnostics)
+        TRY(h->alloc(h->d_prof, (size_t)(h->ntiles_max + 64) * 8 * sizeof(unsigned long long)));
+        if (hipMemset(h->d_prof.p, 0, (size_t)(h->ntiles_max + 64) * 8 * sizeof(unsigned long long)) != hipSuccess) return fail(BTGPU_EDEVICE);
+    }
     TRY(h->upload(h->d_aclo, des.ac.byte_lo, sizeof des.ac.byte_lo));
     TRY(h->upload(h->d_achi, des.ac.byte_hi, sizeof des.ac.byte_hi));
     TRY(h->upload(h->d_le_hdr, des.le.hdr, sizeof des.le.hdr));
@@ -754,8 +761,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, kFuseThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, kFuseThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]
@@ -944,6 +951,7 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
             src = (const float *)h->tc[h->cur ^ 1].d_d2.p + (size_t)c * h->ystride; elem = sizeof(float); avail = (size_t)h->last_G; break;
         case 7: src = h->tc[h->cur ^ 1].d_winlen.p; elem = sizeof(int); avail = (size_t)h->last_S * nch; break;
         case 8: src = h->tc[h->cur ^ 1].d_fin.p; elem = sizeof(FinishRec); avail = (size_t)h->last_S * nch; break;
+        case 9: if (!h->d_prof.p) return BTGPU_EINVAL; src = h->d_prof.p; elem = sizeof(unsigned long long); avail = (size_t)(h->ntiles_max + 64) * 8; break;
         case 2: src = h->d_eon.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 3: src = h->d_eoff.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 4: src = h->d_snr.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;

@@ -32,6 +32,8 @@
 
 namespace btgpu {
 
+constexpr int kPfbUst = 107;
+
 struct PfbParams {
     const float2 *x; long long x_len; long long x0;   // x index of tap 0 for output instant 0
     int D;
@@ -63,6 +65,7 @@ struct PfbParams {
     int pre_tiles;               // extra tiles in front (noise grid starts earlier than the channel grid)
     long long n_T;               // noise instants in total
     float2 *n_Z; long long n_zstride;
+    unsigned long long *prof;    // optional [grid][8] per-phase cycle sums of wave 0 (BTGPU_PFB_PROF diagnostics)
 };
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
@@ -152,7 +155,8 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     // NTH lanes: NT*10 DFT tasks per pass must fit in one sweep (260 tasks -> 320 lanes), otherwise
     // one wave runs the whole DFT body twice for a handful of tasks and the workgroup waits for it
     constexpr int M = 100;
-    constexpr int UST = 100;
+    constexpr int UST = kPfbUst;                             // LDS row stride of U (complex): 107 spreads the
+                                                             // DFT passes' strided rows over the banks
     constexpr int TT = CHAN ? NT - 1 : NT;      // new output instants per tile
     static_assert(NT % 2 == 0, "NT must be even");
     extern __shared__ float4 lds4[];
@@ -177,10 +181,21 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
                            : xcd_remap(blockIdx.x, p.ntiles);
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
     const int l = threadIdx.x;
+    unsigned long long tprev = p.prof ? clock64() : 0ULL;
+    auto mark = [&](int k) {
+        if (p.prof) {
+            const unsigned long long now = clock64();
+            if (l == 0) p.prof[(size_t)blockIdx.x * 8 + k] += now - tprev;   // wave 0 of each tile
+            tprev = now;
+        }
+    };
 
     // ---- stage the input span.  The tile starts at the even sample a0 <= gs so that every piece is
     // a 16-byte aligned load; all loads of a lane are issued before its first LDS store (one
     // memory latency per tile instead of one per loop trip).
+    constexpr int NZT = FUSEN ? (80 * NU + NTH - 1) / NTH : 1;   // noise outputs per lane (phase C')
+    const int nz_u0 = FUSEN ? p.n_u0 + NU * tile : 0;            // first noise instant owned by this tile
+    int nz_pos[NZT]; float2 nz_rot[NZT];
     int shift;
     {
         const long long gs = p.x0 + (long long)DH * t0;
@@ -201,6 +216,24 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
                 }
             }
         }
+        if (FUSEN) {
+            // bin position and de-rotation factor of this lane's noise outputs (phase C'): fetched
+            // here so that their latency overlaps the input staging
+            const int np = p.n_period;
+            const int ph0 = ((nz_u0 % np) + np) % np;             // block-uniform
+#pragma unroll
+            for (int j = 0; j < NZT; j++) {
+                const int i = l + j * NTH;
+                nz_pos[j] = 0; nz_rot[j] = make_float2(0.f, 0.f);
+                if (i < p.nsel * NU) {
+                    const int c = i / NU;
+                    int ph = ph0 + i % NU;
+                    ph = ph >= np ? ph - np : ph;
+                    nz_pos[j] = p.n_binpos[c];
+                    nz_rot[j] = p.n_krot[(size_t)c * np + ph];
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const int i = l + j * NTH;
@@ -212,6 +245,7 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
         if (krot_lds) for (int i = l; i < p.nsel * p.rot_period; i += NTH) s_krot[i] = p.krot[i];
     }
     __syncthreads();
+    mark(0);
 
     // ---- phase A: polyphase branch filters ----
     {
@@ -250,29 +284,32 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
         }
     }
     if (FUSEN) {
-        // noise bank branches: lanes (p, r); r = 0 takes owned instants 0..2, r = 1 takes 3..4
-        const int pp = l & 127, r = l >> 7;
-        if (pp < M && r < 2) {
+        // noise bank branches: 500 tasks (instant i, branch pp) of 15 complex taps.  The channel
+        // branches above occupy waves 0..3; a fifth wave (NTH = 320) takes four tasks per lane and
+        // the others one each, so that every wave carries about the same number of FMAs.
+        int k, kend, kstep;
+        if (NTH > 256 && l >= 256) { k = l - 256; kend = 256; kstep = 64; }
+        else { k = (NTH > 256 ? 256 : 0) + l; kend = NU * M; kstep = 256; }
+        for (; k < kend; k += kstep) {
+            const int i = k / M, pp = k % M;
             float2 an[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++) an[q] = p.n_taps[q * M + pp];
-            const int i0 = r ? 3 : 0, i1 = r ? NU : 3;
-            for (int i = i0; i < i1; i++) {
-                const float2 *zz = xs + shift + p.n_off + NR * i + pp;
-                float ur = 0.f, ui = 0.f;
+            const float2 *zz = xs + shift + p.n_off + NR * i + pp;
+            float ur = 0.f, ui = 0.f;
 #pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    const float2 v = zz[q * M];
-                    ur = fmaf(an[q].x, v.x, ur);
-                    ur = fmaf(-an[q].y, v.y, ur);
-                    ui = fmaf(an[q].x, v.y, ui);
-                    ui = fmaf(an[q].y, v.x, ui);
-                }
-                Un[i * UST + pp] = make_float2(ur, ui);
+            for (int q = 0; q < NQ; q++) {
+                const float2 v = zz[q * M];
+                ur = fmaf(an[q].x, v.x, ur);
+                ur = fmaf(-an[q].y, v.y, ur);
+                ui = fmaf(an[q].x, v.y, ui);
+                ui = fmaf(an[q].y, v.x, ui);
             }
+            Un[i * UST + pp] = make_float2(ur, ui);
         }
     }
     __syncthreads();
+    mark(1);
 
     // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100} ----
     constexpr int NTASK = NT * 10 + (FUSEN ? NU * 10 : 0);
@@ -287,6 +324,7 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
         for (int k = 0; k < 10; k++) row[10 * k] = cmulf(v[k], s_tw[k * 10 + p2]);
     }
     __syncthreads();
+    mark(2);
     // ---- phase B2: DFT over p2; bin m = m1 + 10 m2 ends up at position 10 m1 + m2 ----
     for (int i = l; i < NTASK; i += NTH) {
         const int tl = i / 10, m1 = i % 10;
@@ -299,24 +337,23 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
         for (int k = 0; k < 10; k++) row[k] = v[k];
     }
     __syncthreads();
+    mark(3);
 
     // ---- phase C ----
     if (FUSEN) {
         // owned noise instants -> stage-1 output Z (de-rotated; consumed by noise_stage2_kernel)
-        const long long u0 = (long long)p.n_u0 + (long long)NU * tile;
-        const uint32_t np = (uint32_t)p.n_period;
-        const uint32_t ph0 = (uint32_t)(((u0 % (long long)np) + np) % np);     // block-uniform
-        for (int i = l; i < p.nsel * NU; i += NTH) {
+#pragma unroll
+        for (int j = 0; j < NZT; j++) {
+            const int i = l + j * NTH;
+            if (i >= p.nsel * NU) break;
             const int c = i / NU, ui = i % NU;
-            const long long u = u0 + ui;
+            const int u = nz_u0 + ui;
             if (u < 0 || u >= p.n_T) continue;
-            uint32_t ph = ph0 + (uint32_t)ui;
-            ph = ph >= np ? ph - np : ph;
-            const float2 y = cmulf(Un[ui * UST + p.n_binpos[c]], p.n_krot[(size_t)c * np + ph]);
-            p.n_Z[(size_t)c * p.n_zstride + u] = y;
+            p.n_Z[(size_t)c * p.n_zstride + u] = cmulf(Un[ui * UST + nz_pos[j]], nz_rot[j]);
         }
         if (tile < 0) return;                                     // pre-tile: no channel instants
     }
+    mark(4);
     const uint32_t period = (uint32_t)p.rot_period;
     // phase index of local instant 0: (t0 mod period) in 32-bit arithmetic (t0 >= -1)
     const uint32_t ph_t0 = (uint32_t)(((uint32_t)tile * (uint32_t)TT % period + period - (CHAN ? 1u : 0u)) % period);
@@ -337,7 +374,7 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     // forward in time with the previous instant's Y in registers: de-rotate, demodulate against
     // the previous instant (multi_block::demod), |Y|^2 partial sums in double (fixed order).
     {
-        constexpr int CH = 3, RUN = (TT + CH - 1) / CH;          // 3 runs of 9, 9, 7 instants
+        constexpr int CH = NTH / 80, RUN = (TT + CH - 1) / CH;   // 256 lanes: 3 runs of 9, 9, 7 instants
         float *Db = (float *)xs;                                 // [nsel][NT] demod values for the d2 copy
         double *part = (double *)(Db + ((p.nsel * NT + 1) & ~1)); // [CH][80][2] (sum, head)
         const int chunk = l / 80, c = l % 80;
@@ -378,6 +415,7 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
             part[(chunk * 80 + c) * 2 + 1] = (double)head;
         }
         __syncthreads();
+        mark(5);
         if (l < p.nsel) {
             double sum = 0.0, head = 0.0;
             for (int k = 0; k < CH; k++) { sum += part[(k * 80 + l) * 2]; head += part[(k * 80 + l) * 2 + 1]; }
@@ -391,6 +429,7 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
                 if (t < p.T) p.d2[(size_t)cc * p.d2stride + t] = Db[cc * NT + tl];
             }
         }
+        mark(6);
     }
 }
 

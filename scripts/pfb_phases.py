@@ -1,0 +1,39 @@
+"""Per-phase cycle split of the fused bank kernel (BTGPU_PFB_PROF diagnostics).
+
+Runs the C79 bench workload synchronously for a few batches with the in-kernel cycle marks
+enabled and prints the share of wave-cycles per phase.  GPU only.
+    python scripts/pfb_phases.py [slots] [batches]
+"""
+import os, sys
+os.environ["BTGPU_PFB_PROF"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib
+import numpy as np
+import torch
+from tests.conftest import load_pkg
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+pkg = load_pkg()
+synth = importlib.import_module("gr_bluetooth_amd.synth")
+fs, fc = 100e6, 2441e6
+blk = pkg.multi_sniffer(fs, fc, 10.0, False, device=0, max_batch_slots=S)
+des = blk.design
+dev = torch.device("cuda", 0)
+laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(8))
+seg, _ = synth.make_segment_torch(fs, fc, 0, S, dev, laps=laps, seed=1, snr_db=25.0,
+                                  left_pad=des.history - 1 + des.left_margin)
+seg = seg.contiguous()
+torch.cuda.synchronize()
+for _ in range(nb):
+    blk.process_device(seg.data_ptr(), seg.shape[0], 0, S, left_margin=des.left_margin)
+    blk.flush()
+    blk.poll_arrays()
+c = blk.debug_fetch(9, 0, 0, 1 << 24).astype(np.float64).reshape(-1, 8).sum(axis=0)
+names = ["stage input", "A branch FIR (+noise)", "B1 DFT pass + twiddle", "B2 DFT pass", "C noise store",
+         "epilogue runs", "tile sums + d2 copy", "-"]
+tot = c.sum()
+for n, v in zip(names, c):
+    print("%-24s %6.2f %%" % (n, 100.0 * v / tot))
+tm = blk.timing()
+print("ddc_channel avg ms %.4f (with marks enabled)" % (tm.kernel_ms[0] / max(tm.kernel_launches[0], 1)))
