@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
     ap.add_argument("--sync", action="store_true", help="harvest every batch before the next one is enqueued (no tail overlap)")
     ap.add_argument("--channelizer", type=int, default=0)
     ap.add_argument("--squelch-mode", type=int, default=0, help="0 auto, 1 direct, 2 staged")
@@ -121,6 +122,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Bring the device to its steady power state first: an idle MI355X sits at 500 MHz and needs
+    # some tens of milliseconds of load before the clocks settle (measured: the first ~5 batches
+    # after idle run ~1.5x slower).  Untimed, like the W warm-up steps that follow.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:
+        step(last=False)
+    step(last=True)
+    fence()
     for i in range(args.warmup):
         step(last=(i == args.warmup - 1))
     fence()

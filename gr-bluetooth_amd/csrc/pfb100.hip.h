@@ -146,14 +146,15 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false>
-__global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
+template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false, int KT = 1>
+__global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams p)
 {
     constexpr int DH = S * 50;                               // hop: 2 D = S * 100
     constexpr int NQ = 15, NR = 250, NU = 5;                 // fused noise bank: taps/branch, hop, instants per tile
     static_assert(!FUSEN || (CHAN && DH == 50 && NT == 26), "fused noise stage needs the C79 channel geometry");
-    // NTH lanes: NT*10 DFT tasks per pass must fit in one sweep (260 tasks -> 320 lanes), otherwise
-    // one wave runs the whole DFT body twice for a handful of tasks and the workgroup waits for it
+    static_assert(KT == 1 || FUSEN, "tile groups are implemented for the fused kernel");
+    // NTH lanes: the DFT tasks of a pass (10 per row) should fit in one sweep (310 tasks -> 320
+    // lanes), otherwise one wave runs the whole DFT body twice for a handful of tasks
     constexpr int M = 100;
     constexpr int UST = kPfbUst;                             // LDS row stride of U (complex): 107 spreads the
                                                              // DFT passes' strided rows over the banks
@@ -166,9 +167,12 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     constexpr int SPAN = (FUSEN && SPAN_N > SPAN_C) ? SPAN_N : SPAN_C;
     constexpr int N4 = (SPAN + 3) / 2;                       // 16-byte pieces staged (aligned start: +1 sample)
     constexpr int span = 2 * N4;                             // samples resident in LDS
+    constexpr int NEW4 = TT * DH / 2;                        // pieces that are new from one tile to the next
+    constexpr int NC4 = N4 - NEW4;                           // pieces carried over inside a tile group
+    static_assert(KT == 1 || (TT * DH) % 2 == 0, "tile hop must keep the 16-byte alignment");
     const int wsz = CHAN ? p.nsel * NT : 0;
-    const int asz = span > wsz ? span : wsz;                 // xs is dead after phase A -> reuse for W
-    float2 *xs = lds;                                        // [span]  (aliased by Wb[nsel][NT])
+    const int asz = span > wsz ? span : wsz;                 // the head of xs is dead after phase A -> reused as Db
+    float2 *xs = lds;                                        // [span]
     float2 *U = lds + ((asz + 1) & ~1);                      // [NT][UST]
     float *atab = (float *)(U + NT * UST);                   // [257]               (CHAN)
     float2 *Un = (float2 *)(atab + 258);                     // [NU][UST] noise branch outputs (FUSEN)
@@ -176,19 +180,61 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     __shared__ float2 s_krot[80 * 4];
     __shared__ int s_binpos[80];
     const bool krot_lds = p.rot_period <= 4 && p.nsel <= 80;
+    const int l0 = threadIdx.x;
 
-    const int tile = FUSEN ? xcd_remap(blockIdx.x, p.ntiles + p.pre_tiles) - p.pre_tiles
-                           : xcd_remap(blockIdx.x, p.ntiles);
-    const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
-    const int l = threadIdx.x;
+    // A workgroup runs KT consecutive tiles (a "group"): from the second tile on only the 1250 new
+    // samples are fetched -- prefetched into registers while the previous tile computes -- and the
+    // rest of the span is moved down inside LDS.  XCD-aware order over the groups.
+    const int ntl = p.ntiles + (FUSEN ? p.pre_tiles : 0);
+    const int ngroups = (ntl + KT - 1) / KT;
+    const int grp = xcd_remap(blockIdx.x, ngroups);
+    const int gi0 = grp * KT, gi1 = KT == 1 ? gi0 + 1 : (gi0 + KT < ntl ? gi0 + KT : ntl);
+
     unsigned long long tprev = p.prof ? clock64() : 0ULL;
     auto mark = [&](int k) {
         if (p.prof) {
             const unsigned long long now = clock64();
-            if (l == 0) p.prof[(size_t)blockIdx.x * 8 + k] += now - tprev;   // wave 0 of each tile
+            if (l0 == 0) p.prof[(size_t)blockIdx.x * 8 + k] += now - tprev;   // wave 0 of each group
             tprev = now;
         }
     };
+
+    if (CHAN) for (int i = l0; i < 257; i += NTH) atab[i] = p.atan_tab[i];
+    if (l0 < 100) s_tw[l0] = p.twiddle[l0];
+    if (l0 < p.nsel && l0 < 80) s_binpos[l0] = p.binpos[l0];
+    if (krot_lds) for (int i = l0; i < p.nsel * p.rot_period; i += NTH) s_krot[i] = p.krot[i];
+
+    // one 16-byte piece (two samples) of the input with the stream bounds applied
+    auto load_piece = [&](long long a) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a >= 0 && a + 1 < p.x_len) v = *(const float4 *)(p.x + a);
+        else {
+            if (a >= 0 && a < p.x_len) { const float2 q = p.x[a]; v.x = q.x; v.y = q.y; }
+            if (a + 1 >= 0 && a + 1 < p.x_len) { const float2 q = p.x[a + 1]; v.z = q.x; v.w = q.y; }
+        }
+        return v;
+    };
+
+    // phase-A lane roles and branch taps (fixed for the whole group)
+    float2 a[Q];
+    {
+        const int pp = l0 & 127;
+#pragma unroll
+        for (int q = 0; q < Q; q++) a[q] = (pp < M && l0 < 256) ? p.taps[q * M + pp] : make_float2(0.f, 0.f);
+    }
+
+    constexpr int PERN = (NEW4 + NTH - 1) / NTH;
+    float4 nv[PERN];                                             // next tile's new pieces (KT > 1)
+
+    for (int gi = gi0; gi < gi1; gi++) {
+    // With several trips the lane id is made opaque per trip: otherwise every lane-dependent
+    // address of the body is hoisted out of the loop and held in registers (2x the VGPRs).
+    int l = l0;
+    if (KT > 1) asm volatile("" : "+v"(l));
+    const int a_pp = l & 127, a_r = l >> 7;
+    const bool a_on = a_pp < M && a_r < 2;
+    const int tile = gi - (FUSEN ? p.pre_tiles : 0);
+    const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
 
     // ---- stage the input span.  The tile starts at the even sample a0 <= gs so that every piece is
     // a 16-byte aligned load; all loads of a lane are issued before its first LDS store (one
@@ -196,24 +242,18 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
     constexpr int NZT = FUSEN ? (80 * NU + NTH - 1) / NTH : 1;   // noise outputs per lane (phase C')
     const int nz_u0 = FUSEN ? p.n_u0 + NU * tile : 0;            // first noise instant owned by this tile
     int nz_pos[NZT]; float2 nz_rot[NZT];
-    int shift;
+    const long long gs = p.x0 + (long long)DH * t0;
+    const long long a0 = gs & ~1LL;
+    const int shift = (int)(gs - a0);
     {
-        const long long gs = p.x0 + (long long)DH * t0;
-        const long long a0 = gs & ~1LL;
-        shift = (int)(gs - a0);
         constexpr int PER = (N4 + NTH - 1) / NTH;
         float4 v[PER];
+        if (gi == gi0) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const int i = l + j * NTH;
-            const long long a = a0 + 2 * (long long)i;
-            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < N4) {
-                if (a >= 0 && a + 1 < p.x_len) v[j] = *(const float4 *)(p.x + a);
-                else {
-                    if (a >= 0 && a < p.x_len) { const float2 q = p.x[a]; v[j].x = q.x; v[j].y = q.y; }
-                    if (a + 1 >= 0 && a + 1 < p.x_len) { const float2 q = p.x[a + 1]; v[j].z = q.x; v[j].w = q.y; }
-                }
+            for (int j = 0; j < PER; j++) {
+                const int i = l + j * NTH;
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < N4) v[j] = load_piece(a0 + 2 * (long long)i);
             }
         }
         if (FUSEN) {
@@ -234,26 +274,28 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
                 }
             }
         }
+        if (gi == gi0) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const int i = l + j * NTH;
-            if (i < N4) ((float4 *)xs)[i] = v[j];
+            for (int j = 0; j < PER; j++) {
+                const int i = l + j * NTH;
+                if (i < N4) ((float4 *)xs)[i] = v[j];
+            }
+        } else {
+            // carried pieces were moved down at the end of the previous tile; append the new ones
+#pragma unroll
+            for (int j = 0; j < PERN; j++) {
+                const int i = l + j * NTH;
+                if (i < NEW4) ((float4 *)xs)[NC4 + i] = nv[j];
+            }
         }
-        if (CHAN) for (int i = l; i < 257; i += NTH) atab[i] = p.atan_tab[i];
-        if (l < 100) s_tw[l] = p.twiddle[l];
-        if (l < p.nsel && l < 80) s_binpos[l] = p.binpos[l];
-        if (krot_lds) for (int i = l; i < p.nsel * p.rot_period; i += NTH) s_krot[i] = p.krot[i];
     }
     __syncthreads();
     mark(0);
 
     // ---- phase A: polyphase branch filters ----
     {
-        const int pp = l & 127, r = l >> 7;
-        if (pp < M && r < 2 && tile >= 0) {
-            float2 a[Q];
-#pragma unroll
-            for (int q = 0; q < Q; q++) a[q] = p.taps[q * M + pp];
+        const int pp = a_pp, r = a_r;
+        if (a_on && tile >= 0) {
             const float2 *z = xs + shift + DH * r + pp;
             float2 zw[Q];
 #pragma unroll
@@ -308,6 +350,18 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
             Un[i * UST + pp] = make_float2(ur, ui);
         }
     }
+    if (KT > 1 && gi + 1 < gi1) {
+        // prefetch the next tile's new samples (consumed at the top of the next trip).  Issued after
+        // the last global load the tile waits for: memory returns in order, so anything issued
+        // behind the prefetch would wait for it
+        const long long an = a0 + 2LL * NEW4 + 2LL * NC4;
+#pragma unroll
+        for (int j = 0; j < PERN; j++) {
+            const int i = l + j * NTH;
+            nv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < NEW4) nv[j] = load_piece(an + 2 * (long long)i);
+        }
+    }
     __syncthreads();
     mark(1);
 
@@ -351,7 +405,7 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
             if (u < 0 || u >= p.n_T) continue;
             p.n_Z[(size_t)c * p.n_zstride + u] = cmulf(Un[ui * UST + nz_pos[j]], nz_rot[j]);
         }
-        if (tile < 0) return;                                     // pre-tile: no channel instants
+        __syncthreads();                                          // Un is reused for the run partial sums
     }
     mark(4);
     const uint32_t period = (uint32_t)p.rot_period;
@@ -368,22 +422,21 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
             const float2 y = cmulf(U[tl * UST + s_binpos[c]], kr);
             p.Z[(size_t)c * p.zstride + t] = y;
         }
-        return;
     }
     // Channel epilogue.  Lane (chunk, c): channel c, a run of <= 9 consecutive instants, walking
     // forward in time with the previous instant's Y in registers: de-rotate, demodulate against
-    // the previous instant (multi_block::demod), |Y|^2 partial sums in double (fixed order).
-    {
+    // the previous instant (multi_block::demod), |Y|^2 partial sums (combined in double, fixed order).
+    if (CHAN && tile >= 0) {                                     // pre-tiles hold no channel instants
         constexpr int CH = NTH / 80, RUN = (TT + CH - 1) / CH;   // 256 lanes: 3 runs of 9, 9, 7 instants
         float *Db = (float *)xs;                                 // [nsel][NT] demod values for the d2 copy
-        double *part = (double *)(Db + ((p.nsel * NT + 1) & ~1)); // [CH][80][2] (sum, head)
+        float *part = FUSEN ? (float *)Un : Db + p.nsel * NT;    // [CH][80][2] (sum, head)
         const int chunk = l / 80, c = l % 80;
         if (chunk < CH && c < p.nsel) {
             const int pos = s_binpos[c];
             const int tl0 = 1 + chunk * RUN;
             const int tl1 = tl0 + RUN < NT ? tl0 + RUN : NT;
             const int hr = p.tail % TT;                          // head length inside a tile
-            float sum = 0.f, head = 0.f;                         // <= 9 terms per run; combined in double below
+            float sum = 0.f, head = 0.f;                         // <= 9 terms per run
             // the run, instantiated once per address space of the de-rotation table so that the
             // LDS copy is read with ds_read (a generic pointer would force flat loads + full waits)
             auto run = [&](const float2 *krc) {
@@ -411,14 +464,17 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
             };
             if (krot_lds) run(&s_krot[c * p.rot_period]);
             else run(&p.krot[(size_t)c * p.rot_period]);
-            part[(chunk * 80 + c) * 2 + 0] = (double)sum;
-            part[(chunk * 80 + c) * 2 + 1] = (double)head;
+            part[(chunk * 80 + c) * 2 + 0] = sum;
+            part[(chunk * 80 + c) * 2 + 1] = head;
         }
         __syncthreads();
         mark(5);
         if (l < p.nsel) {
             double sum = 0.0, head = 0.0;
-            for (int k = 0; k < CH; k++) { sum += part[(k * 80 + l) * 2]; head += part[(k * 80 + l) * 2 + 1]; }
+            for (int k = 0; k < CH; k++) {
+                sum += (double)part[(k * 80 + l) * 2];
+                head += (double)part[(k * 80 + l) * 2 + 1];
+            }
             p.ptile[(size_t)l * p.ntiles + tile] = sum;
             p.phead[(size_t)l * p.ntiles + tile] = head;         // first (tail % TT) instants of this tile
         }
@@ -431,6 +487,23 @@ __global__ __launch_bounds__(NTH) void pfb100_kernel(PfbParams p)
         }
         mark(6);
     }
+    if (KT > 1 && gi + 1 < gi1) {
+        // move the part of the span the next tile shares down to the front of xs
+        static_assert(NC4 <= 3 * NTH, "three carried pieces per lane");
+        const float4 *src = (const float4 *)xs + NEW4;
+        float4 *dst = (float4 *)xs;
+        __syncthreads();                                         // Db / part readers are done
+        const int i0 = l, i1 = l + NTH, i2 = l + 2 * NTH;
+        const float4 c0 = src[i0 < NC4 ? i0 : 0];
+        const float4 c1 = src[i1 < NC4 ? i1 : 0];
+        const float4 c2 = src[i2 < NC4 ? i2 : 0];
+        __syncthreads();
+        if (i0 < NC4) dst[i0] = c0;
+        if (i1 < NC4) dst[i1] = c1;
+        if (i2 < NC4) dst[i2] = c2;
+        mark(7);
+    }
+    }   // tiles of the group
 }
 
 // tile sums -> per-slot-block sums P[c][b] and block-head sums Pt[c][b] (first `tail` instants of
