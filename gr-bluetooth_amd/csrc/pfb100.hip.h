@@ -147,7 +147,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 }
 
 template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false, int KT = 1>
-__global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams p)
+__global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams p)
 {
     constexpr int DH = S * 50;                               // hop: 2 D = S * 100
     constexpr int NQ = 15, NR = 250, NU = 5;                 // fused noise bank: taps/branch, hop, instants per tile
@@ -199,28 +199,44 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams 
         }
     };
 
-    if (CHAN) for (int i = l0; i < 257; i += NTH) atab[i] = p.atan_tab[i];
-    if (l0 < 100) s_tw[l0] = p.twiddle[l0];
-    if (l0 < p.nsel && l0 < 80) s_binpos[l0] = p.binpos[l0];
-    if (krot_lds) for (int i = l0; i < p.nsel * p.rot_period; i += NTH) s_krot[i] = p.krot[i];
-
-    // one 16-byte piece (two samples) of the input with the stream bounds applied
-    auto load_piece = [&](long long a) -> float4 {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a >= 0 && a + 1 < p.x_len) v = *(const float4 *)(p.x + a);
-        else {
-            if (a >= 0 && a < p.x_len) { const float2 q = p.x[a]; v.x = q.x; v.y = q.y; }
-            if (a + 1 >= 0 && a + 1 < p.x_len) { const float2 q = p.x[a + 1]; v.z = q.x; v.w = q.y; }
-        }
+    // Every global load of the prologue is unconditional (indices clamped, values selected
+    // afterwards): a load under a lane-dependent branch is waited for at the end of that branch,
+    // which would serialise the ~30 loads of a lane into as many memory round trips.
+    auto load_piece = [&](long long a0, int i, bool interior) -> float4 {
+        // 16-byte piece i (two samples) of the span starting at the even sample a0
+        if (interior) return *(const float4 *)(p.x + a0 + 2 * (long long)i);       // block-uniform branch
+        const long long a = a0 + 2 * (long long)i;
+        const long long ac = a < 0 ? 0 : (a + 1 < p.x_len ? a : (p.x_len >= 2 ? p.x_len - 2 : 0));
+        const long long bc = ac + 1 < p.x_len ? ac + 1 : ac;
+        const float2 q0 = p.x[ac], q1 = p.x[bc];
+        float4 v;
+        // sample a is q0 when a was in range, sample a + 1 is q1 (or q0 when a was clamped up by one)
+        const bool in0 = a >= 0 && a < p.x_len, in1 = a + 1 >= 0 && a + 1 < p.x_len;
+        const float2 s0 = (a == ac) ? q0 : q1;                     // a == x_len - 1: clamped to x_len - 2
+        const float2 s1 = (a + 1 == ac) ? q0 : q1;                 // a == -1: clamped to 0
+        v.x = in0 ? s0.x : 0.f; v.y = in0 ? s0.y : 0.f;
+        v.z = in1 ? s1.x : 0.f; v.w = in1 ? s1.y : 0.f;
         return v;
     };
 
     // phase-A lane roles and branch taps (fixed for the whole group)
     float2 a[Q];
-    {
-        const int pp = l0 & 127;
-#pragma unroll
-        for (int q = 0; q < Q; q++) a[q] = (pp < M && l0 < 256) ? p.taps[q * M + pp] : make_float2(0.f, 0.f);
+
+    // Noise-bank roles: 500 tasks (instant i, branch pp) of 15 complex taps.  The channel branches
+    // occupy waves 0..3; the fifth wave (NTH = 320) takes instants 0..3 of branches 0..63 and the
+    // other lanes one task each, so that every wave carries about the same number of FMAs and a
+    // lane needs the taps of one branch only (fetched once, behind the input staging).
+    int nz_pp = 0, nz_i0 = 0, nz_cnt = 0;
+    float2 an[FUSEN ? NQ : 1];
+    if (FUSEN) {
+        if (NTH > 256) {
+            if (l0 >= 256) { nz_pp = l0 - 256; nz_i0 = 0; nz_cnt = 4; }
+            else if (l0 < 64) { nz_pp = l0; nz_i0 = 4; nz_cnt = 1; }
+            else if (l0 < 64 + 36 * NU) { nz_pp = 64 + (l0 - 64) % 36; nz_i0 = (l0 - 64) / 36; nz_cnt = 1; }
+        } else {
+            // 256 lanes: branch pp = l % 100 for l < 200, instants split 3 / 2
+            if (l0 < 200) { nz_pp = l0 % 100; nz_i0 = l0 < 100 ? 0 : 3; nz_cnt = l0 < 100 ? 3 : 2; }
+        }
     }
 
     constexpr int PERN = (NEW4 + NTH - 1) / NTH;
@@ -249,11 +265,41 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams 
         constexpr int PER = (N4 + NTH - 1) / NTH;
         float4 v[PER];
         if (gi == gi0) {
+            const bool interior = a0 >= 0 && a0 + 2LL * N4 <= p.x_len;
+            if (interior) {                                      // block-uniform: one straight run of loads
 #pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const int i = l + j * NTH;
-                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < N4) v[j] = load_piece(a0 + 2 * (long long)i);
+                for (int j = 0; j < PER; j++) v[j] = load_piece(a0, l + j * NTH < N4 ? l + j * NTH : N4 - 1, true);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PER; j++) v[j] = load_piece(a0, l + j * NTH < N4 ? l + j * NTH : N4 - 1, false);
+            }
+            // tables -> LDS and the branch taps of this lane's roles (fixed for the group), issued
+            // behind the input loads: memory returns in order, so the staging wait excludes them
+            constexpr int NA = (257 + NTH - 1) / NTH, NK = (80 * 4 + NTH - 1) / NTH;
+            float at[NA]; float2 kr[NK];
+#pragma unroll
+            for (int k = 0; k < NA; k++) at[k] = CHAN ? p.atan_tab[l0 + k * NTH < 257 ? l0 + k * NTH : 256] : 0.f;
+            const float2 tw = p.twiddle[l0 < 100 ? l0 : 99];
+            const int bp = p.binpos[l0 < p.nsel ? l0 : p.nsel - 1];
+            const int nkr = p.nsel * p.rot_period;
+#pragma unroll
+            for (int k = 0; k < NK; k++) kr[k] = p.krot[l0 + k * NTH < nkr ? l0 + k * NTH : nkr - 1];
+            const int pp = l0 & 127;
+#pragma unroll
+            for (int q = 0; q < Q; q++) a[q] = p.taps[q * M + (pp < M ? pp : 0)];
+            if (FUSEN) {
+#pragma unroll
+                for (int q = 0; q < NQ; q++) an[q] = p.n_taps[q * M + nz_pp];
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++) asm volatile("" : "+v"(at[k]));   // keep the load out of the branch below
+#pragma unroll
+            for (int k = 0; k < NA; k++) if (CHAN && l0 + k * NTH < 257) atab[l0 + k * NTH] = at[k];
+            if (l0 < 100) s_tw[l0] = tw;
+            if (l0 < p.nsel && l0 < 80) s_binpos[l0] = bp;
+            if (krot_lds) {
+#pragma unroll
+                for (int k = 0; k < NK; k++) if (l0 + k * NTH < nkr) s_krot[l0 + k * NTH] = kr[k];
             }
         }
         if (FUSEN) {
@@ -263,15 +309,12 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams 
             const int ph0 = ((nz_u0 % np) + np) % np;             // block-uniform
 #pragma unroll
             for (int j = 0; j < NZT; j++) {
-                const int i = l + j * NTH;
-                nz_pos[j] = 0; nz_rot[j] = make_float2(0.f, 0.f);
-                if (i < p.nsel * NU) {
-                    const int c = i / NU;
-                    int ph = ph0 + i % NU;
-                    ph = ph >= np ? ph - np : ph;
-                    nz_pos[j] = p.n_binpos[c];
-                    nz_rot[j] = p.n_krot[(size_t)c * np + ph];
-                }
+                const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
+                const int c = i / NU;
+                int ph = ph0 + i % NU;
+                ph = ph >= np ? ph - np : ph;
+                nz_pos[j] = p.n_binpos[c];
+                nz_rot[j] = p.n_krot[(size_t)c * np + ph];
             }
         }
         if (gi == gi0) {
@@ -326,18 +369,9 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams 
         }
     }
     if (FUSEN) {
-        // noise bank branches: 500 tasks (instant i, branch pp) of 15 complex taps.  The channel
-        // branches above occupy waves 0..3; a fifth wave (NTH = 320) takes four tasks per lane and
-        // the others one each, so that every wave carries about the same number of FMAs.
-        int k, kend, kstep;
-        if (NTH > 256 && l >= 256) { k = l - 256; kend = 256; kstep = 64; }
-        else { k = (NTH > 256 ? 256 : 0) + l; kend = NU * M; kstep = 256; }
-        for (; k < kend; k += kstep) {
-            const int i = k / M, pp = k % M;
-            float2 an[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; q++) an[q] = p.n_taps[q * M + pp];
-            const float2 *zz = xs + shift + p.n_off + NR * i + pp;
+        // noise bank branches (taps preloaded above): nz_cnt instants of branch nz_pp
+        for (int i = nz_i0; i < nz_i0 + nz_cnt; i++) {
+            const float2 *zz = xs + shift + p.n_off + NR * i + nz_pp;
             float ur = 0.f, ui = 0.f;
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
@@ -347,7 +381,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams 
                 ui = fmaf(an[q].x, v.y, ui);
                 ui = fmaf(an[q].y, v.x, ui);
             }
-            Un[i * UST + pp] = make_float2(ur, ui);
+            Un[i * UST + nz_pp] = make_float2(ur, ui);
         }
     }
     if (KT > 1 && gi + 1 < gi1) {
@@ -355,11 +389,12 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams 
         // the last global load the tile waits for: memory returns in order, so anything issued
         // behind the prefetch would wait for it
         const long long an = a0 + 2LL * NEW4 + 2LL * NC4;
+        if (an >= 0 && an + 2LL * NEW4 <= p.x_len) {
 #pragma unroll
-        for (int j = 0; j < PERN; j++) {
-            const int i = l + j * NTH;
-            nv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < NEW4) nv[j] = load_piece(an + 2 * (long long)i);
+            for (int j = 0; j < PERN; j++) nv[j] = load_piece(an, l + j * NTH < NEW4 ? l + j * NTH : NEW4 - 1, true);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PERN; j++) nv[j] = load_piece(an, l + j * NTH < NEW4 ? l + j * NTH : NEW4 - 1, false);
         }
     }
     __syncthreads();
@@ -427,45 +462,54 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams 
     // forward in time with the previous instant's Y in registers: de-rotate, demodulate against
     // the previous instant (multi_block::demod), |Y|^2 partial sums (combined in double, fixed order).
     if (CHAN && tile >= 0) {                                     // pre-tiles hold no channel instants
-        constexpr int CH = NTH / 80, RUN = (TT + CH - 1) / CH;   // 256 lanes: 3 runs of 9, 9, 7 instants
+        constexpr int CH = NTH / 80, RUN = (TT + CH - 1) / CH;   // 320 lanes: runs of 7, 7, 7, 4 instants
         float *Db = (float *)xs;                                 // [nsel][NT] demod values for the d2 copy
         float *part = FUSEN ? (float *)Un : Db + p.nsel * NT;    // [CH][80][2] (sum, head)
         const int chunk = l / 80, c = l % 80;
         if (chunk < CH && c < p.nsel) {
             const int pos = s_binpos[c];
             const int tl0 = 1 + chunk * RUN;
-            const int tl1 = tl0 + RUN < NT ? tl0 + RUN : NT;
             const int hr = p.tail % TT;                          // head length inside a tile
+            // instants of this run that exist: inside the tile and inside the stream
+            const long long left = p.T - (t0 + tl0);
+            int nval = NT - tl0 < RUN ? NT - tl0 : RUN;
+            nval = left < nval ? (int)(left < 0 ? 0 : left) : nval;
             float sum = 0.f, head = 0.f;                         // <= 9 terms per run
+            float dv[RUN];
             // the run, instantiated once per address space of the de-rotation table so that the
-            // LDS copy is read with ds_read (a generic pointer would force flat loads + full waits)
+            // LDS copy is read with ds_read (a generic pointer would force flat loads + full waits).
+            // Fully unrolled: all bins of the run are fetched and de-rotated first, the demods
+            // are independent chains.
             auto run = [&](const float2 *krc) {
                 uint32_t ph = ph_t0 + (uint32_t)(tl0 - 1);
                 ph = ph >= period ? ph % period : ph;
-                float2 prev = cmulf(U[(tl0 - 1) * UST + pos], krc[ph]);
-                const bool full = t0 + NT <= p.T;                // every instant of the tile exists
-                float *drow = p.d + (size_t)(t0 + tl0) * 80 + c;
-                for (int tl = tl0; tl < tl1; tl++) {
+                float2 y[RUN + 1];
+#pragma unroll
+                for (int k = 0; k <= RUN; k++) {
+                    const int tl = tl0 - 1 + k < NT ? tl0 - 1 + k : NT - 1;
+                    y[k] = cmulf(U[tl * UST + pos], krc[ph]);
                     ph = ph + 1 == period ? 0 : ph + 1;
-                    const float2 y = cmulf(U[tl * UST + pos], krc[ph]);
-                    float dv = 0.f;
-                    if (full || t0 + tl < p.T) {
-                        const float m = y.x * y.x + y.y * y.y;
+                }
+                float *drow = p.d + (size_t)(t0 + tl0) * 80 + c;
+#pragma unroll
+                for (int k = 0; k < RUN; k++) {
+                    dv[k] = 0.f;
+                    if (k < nval) {
+                        const float m = y[k + 1].x * y[k + 1].x + y[k + 1].y * y[k + 1].y;
                         sum += m;
-                        if (tl - 1 < hr) head += m;
-                        dv = demod_fast(atab, p.gain, y, prev);
-                        *drow = dv;
-                        if (p.Z) p.Z[(size_t)c * p.zstride + (t0 + tl)] = y;      // BTGPU_FLAG_DEBUG_Y
+                        if (tl0 + k - 1 < hr) head += m;
+                        dv[k] = demod_fast(atab, p.gain, y[k + 1], y[k]);
+                        drow[k * 80] = dv[k];
+                        if (p.Z) p.Z[(size_t)c * p.zstride + (t0 + tl0 + k)] = y[k + 1];   // BTGPU_FLAG_DEBUG_Y
                     }
-                    drow += 80;
-                    Db[c * NT + tl] = dv;
-                    prev = y;
                 }
             };
             if (krot_lds) run(&s_krot[c * p.rot_period]);
             else run(&p.krot[(size_t)c * p.rot_period]);
             part[(chunk * 80 + c) * 2 + 0] = sum;
             part[(chunk * 80 + c) * 2 + 1] = head;
+#pragma unroll
+            for (int k = 0; k < RUN; k++) if (tl0 + k < NT) Db[c * NT + tl0 + k] = dv[k];
         }
         __syncthreads();
         mark(5);
@@ -478,7 +522,10 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 4 : 1)) void pfb100_kernel(PfbParams 
             p.ptile[(size_t)l * p.ntiles + tile] = sum;
             p.phead[(size_t)l * p.ntiles + tile] = head;         // first (tail % TT) instants of this tile
         }
-        if (p.d2) {                                              // channel-major copy, time fastest
+        if (p.d2) {
+            // channel-major copy for finish_kernel, time fastest.  (Storing each run straight from
+            // its lane -- 64 different rows per store instruction -- clogs the CU's memory pipeline:
+            // measured 1.3x slower overall.)
             for (int i = l; i < p.nsel * TT; i += NTH) {
                 const int cc = i / TT, tl = 1 + i % TT;
                 const long long t = t0 + tl;
