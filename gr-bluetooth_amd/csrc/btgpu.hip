@@ -307,7 +307,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         }
         HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
         const int run = ns.outs * (kS2Slots - 1) + ns.nw;
-        const size_t lds2 = (size_t)((run + ns.L3 + 4) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
+        const size_t lds2 = (size_t)((run + ns.L3 + 6) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
         hipLaunchKernelGGL(noise_stage2_kernel, dim3((S + kS2Slots - 1) / kS2Slots, nch), dim3(256), lds2, ns_st,
                            (const float2 *)d_Z.p, zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p,
                            (const double *)d_w.p, (double *)d_Q.p, S);
@@ -631,10 +631,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         !pick_shape(d.decimation, des.noise.ntp, h->shape_n))
         return fail(BTGPU_EUNSUPPORTED);
 
-    // batch size: bounded by ~3 GiB of intermediates
+    // batch size: bounded by ~24 GiB of intermediates (288 GB HBM; larger batches amortise the latency-bound window kernel)
     size_t per_slot = (size_t)nch * ops * ((h->keep_Y ? sizeof(float2) : 0) + (h->use_staged ? 2 : sizeof(float2)) + sizeof(float)) + (size_t)d.samples_per_slot * 8;
     int S = cfg->max_batch_slots > 0 ? cfg->max_batch_slots : 512;
-    size_t cap = (size_t)3 << 30;
+    size_t cap = (size_t)24 << 30;
     if ((size_t)S * per_slot > cap) S = (int)std::max<size_t>(8, cap / per_slot);
     h->max_slots = S;
     h->max_hits = cfg->max_hits > 0 ? cfg->max_hits : std::max(4096, S * nch * 2);

@@ -594,26 +594,48 @@ __global__ __launch_bounds__(256) void noise_stage2_kernel(
     const int ks = (S - k0) < kS2Slots ? (S - k0) : kS2Slots;        // slots in this run
     const int nout = outs * (ks - 1) + nw;                            // y^ needed
     const int need = nout + L3 - 1;                                   // stage-1 samples needed
-    float2 *zs = (float2 *)lds4;                                      // [need + 3]
-    float *m2 = (float *)(zs + ((outs * (kS2Slots - 1) + nw + L3 + 4) & ~1));   // [nout]
+    float2 *zs = (float2 *)lds4;                                      // [need + 5]
+    float *m2 = (float *)(zs + ((outs * (kS2Slots - 1) + nw + L3 + 6) & ~1));   // [nout]
     const float2 *z = Z + (size_t)c * zstride + (long long)k0 * outs;
-    for (int i = threadIdx.x; i < need + 3; i += blockDim.x) zs[i] = i < need ? z[i] : make_float2(0.f, 0.f);
-    __syncthreads();
-    const float4 *zq = (const float4 *)zs;                           // zq[n] = (z[2n], z[2n+1])
-    for (int j = 2 * threadIdx.x; j < nout; j += 2 * blockDim.x) {
-        float y0r = 0.f, y0i = 0.f, y1r = 0.f, y1i = 0.f;
-        float4 q = zq[j >> 1];
-        for (int m = 0; m < L3 / 2; m++) {                           // taps 2m, 2m+1 (L3 is even)
-            const float4 qn = zq[(j >> 1) + m + 1];
-            const float ha = h3[2 * m], hb = h3[2 * m + 1];
-            y0r = fmaf(ha, q.x, y0r);  y0i = fmaf(ha, q.y, y0i);
-            y0r = fmaf(hb, q.z, y0r);  y0i = fmaf(hb, q.w, y0i);
-            y1r = fmaf(ha, q.z, y1r);  y1i = fmaf(ha, q.w, y1i);
-            y1r = fmaf(hb, qn.x, y1r); y1i = fmaf(hb, qn.y, y1i);
-            q = qn;
+    __shared__ float h3s[128];                                        // taps (L3 <= 128), read as LDS broadcasts
+    for (int i = threadIdx.x; i < L3; i += blockDim.x) h3s[i] = h3[i];
+    // unconditional (clamped) loads in batches of five, so that a lane's loads are in flight
+    // together instead of one memory round trip per element
+    for (int base = 0; base < need + 5; base += 5 * (int)blockDim.x) {
+        float2 v[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = base + k * (int)blockDim.x + (int)threadIdx.x;
+            v[k] = z[i < need ? i : need - 1];
         }
-        m2[j] = (y0r * y0r) + (y0i * y0i);
-        if (j + 1 < nout) m2[j + 1] = (y1r * y1r) + (y1i * y1i);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = base + k * (int)blockDim.x + (int)threadIdx.x;
+            if (i < need + 5) zs[i] = i < need ? v[k] : make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    // four adjacent outputs per lane: one 16-byte LDS read feeds 16 FMAs (taps ascending per
+    // output, same order as the two-output form)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f *zv = (const v4f *)zs;
+    for (int j = 4 * threadIdx.x; j < nout; j += 4 * blockDim.x) {
+        v2f y0 = {0.f, 0.f}, y1 = y0, y2 = y0, y3 = y0;              // (re, im) pairs -> v_pk_fma_f32
+        v4f q0 = zv[j >> 1], q1 = zv[(j >> 1) + 1];
+        for (int m = 0; m < L3 / 2; m++) {                           // taps 2m, 2m+1 (L3 is even)
+            const v4f q2 = zv[(j >> 1) + m + 2];
+            const float ha = h3s[2 * m], hb = h3s[2 * m + 1];
+            const v2f a = {ha, ha}, b = {hb, hb};
+            y0 = __builtin_elementwise_fma(a, q0.xy, y0); y0 = __builtin_elementwise_fma(b, q0.zw, y0);
+            y1 = __builtin_elementwise_fma(a, q0.zw, y1); y1 = __builtin_elementwise_fma(b, q1.xy, y1);
+            y2 = __builtin_elementwise_fma(a, q1.xy, y2); y2 = __builtin_elementwise_fma(b, q1.zw, y2);
+            y3 = __builtin_elementwise_fma(a, q1.zw, y3); y3 = __builtin_elementwise_fma(b, q2.xy, y3);
+            q0 = q1; q1 = q2;
+        }
+        const v2f yy[4] = {y0, y1, y2, y3};
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (j + k < nout) m2[j + k] = (yy[k].x * yy[k].x) + (yy[k].y * yy[k].y);
     }
     __syncthreads();
     // slot sums: 32 lanes per slot, fixed order (lane partial sums combined by shuffles)
