@@ -68,57 +68,59 @@ struct PfbParams {
     unsigned long long *prof;    // optional [grid][8] per-phase cycle sums of wave 0 (BTGPU_PFB_PROF diagnostics)
 };
 
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+// Complex values are two-float ext vectors: with contraction enabled a * b + c on them is one
+// v_pk_fma_f32 (two FMAs per lane per issue); swizzles and sign flips map onto the packed
+// instructions' op_sel / neg modifiers.
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf mk(float re, float im) { cf v = {re, im}; return v; }
+__device__ __forceinline__ cf cmulf(cf a, cf b)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return a.xx * b + mk(-a.y, a.y) * b.yx;
 }
-__device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf mulmj(cf u) { return mk(u.y, -u.x); }     // -j u
 
 // forward 5-point DFT (kernel e^{-j 2 pi k n / 5})
-__device__ __forceinline__ void dft5(const float2 x0, const float2 x1, const float2 x2, const float2 x3,
-                                     const float2 x4, float2 *X)
+__device__ __forceinline__ void dft5(const cf x0, const cf x1, const cf x2, const cf x3, const cf x4, cf *X)
 {
     const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
     const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
-    const float2 a1 = caddf(x1, x4), a2 = caddf(x2, x3), b1 = csubf(x1, x4), b2 = csubf(x2, x3);
-    X[0] = caddf(x0, caddf(a1, a2));
-    const float2 t1 = make_float2(x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y);
-    const float2 t2 = make_float2(x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y);
-    const float2 u1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
-    const float2 u2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
-    X[1] = make_float2(t1.x + u1.y, t1.y - u1.x);
-    X[4] = make_float2(t1.x - u1.y, t1.y + u1.x);
-    X[2] = make_float2(t2.x + u2.y, t2.y - u2.x);
-    X[3] = make_float2(t2.x - u2.y, t2.y + u2.x);
+    const cf a1 = x1 + x4, a2 = x2 + x3, b1 = x1 - x4, b2 = x2 - x3;
+    X[0] = x0 + (a1 + a2);
+    const cf t1 = x0 + c1 * a1 + c2 * a2;
+    const cf t2 = x0 + c2 * a1 + c1 * a2;
+    const cf u1 = mulmj(s1 * b1 + s2 * b2);
+    const cf u2 = mulmj(s2 * b1 - s1 * b2);
+    X[1] = t1 + u1;
+    X[4] = t1 - u1;
+    X[2] = t2 + u2;
+    X[3] = t2 - u2;
 }
 
 // forward 10-point DFT, in place on v[0..9]
-__device__ __forceinline__ void dft10(float2 *v)
+__device__ __forceinline__ void dft10(cf *v)
 {
-    float2 E[5], O[5];
+    cf E[5], O[5];
     dft5(v[0], v[2], v[4], v[6], v[8], E);
     dft5(v[1], v[3], v[5], v[7], v[9], O);
-    const float2 w1 = make_float2(0.80901699437494742f, -0.58778525229247313f);
-    const float2 w2 = make_float2(0.30901699437494742f, -0.95105651629515357f);
-    const float2 w3 = make_float2(-0.30901699437494742f, -0.95105651629515357f);
-    const float2 w4 = make_float2(-0.80901699437494742f, -0.58778525229247313f);
-    const float2 o0 = O[0], o1 = cmulf(O[1], w1), o2 = cmulf(O[2], w2), o3 = cmulf(O[3], w3),
-                 o4 = cmulf(O[4], w4);
-    v[0] = caddf(E[0], o0); v[5] = csubf(E[0], o0);
-    v[1] = caddf(E[1], o1); v[6] = csubf(E[1], o1);
-    v[2] = caddf(E[2], o2); v[7] = csubf(E[2], o2);
-    v[3] = caddf(E[3], o3); v[8] = csubf(E[3], o3);
-    v[4] = caddf(E[4], o4); v[9] = csubf(E[4], o4);
+    const cf w1 = mk(0.80901699437494742f, -0.58778525229247313f);
+    const cf w2 = mk(0.30901699437494742f, -0.95105651629515357f);
+    const cf w3 = mk(-0.30901699437494742f, -0.95105651629515357f);
+    const cf w4 = mk(-0.80901699437494742f, -0.58778525229247313f);
+    const cf o0 = O[0], o1 = cmulf(O[1], w1), o2 = cmulf(O[2], w2), o3 = cmulf(O[3], w3), o4 = cmulf(O[4], w4);
+    v[0] = E[0] + o0; v[5] = E[0] - o0;
+    v[1] = E[1] + o1; v[6] = E[1] - o1;
+    v[2] = E[2] + o2; v[7] = E[2] - o2;
+    v[3] = E[3] + o3; v[8] = E[3] - o3;
+    v[4] = E[4] + o4; v[9] = E[4] - o4;
 }
 
 // fast_atan2f with v_rcp_f32 instead of the IEEE divide (1 ulp on the ratio; tolerance path only),
 // written branch-free: both the small-angle value and the table interpolation are formed and
 // one is selected, the quadrant fix-ups are selects.
-__device__ __forceinline__ float demod_fast(const float *__restrict__ tab, float gain, float2 a, float2 b)
+__device__ __forceinline__ float demod_fast(const float *__restrict__ tab, float gain, cf a, cf b)
 {
-    const float pr = a.x * b.x + a.y * b.y;
-    const float pi = a.y * b.x - a.x * b.y;
+    const cf pp = b.xx * a + b.yy * mk(a.y, -a.x);              // a conj(b) = (pr, pi)
+    const float pr = pp.x, pi = pp.y;
     const float ya = fabsf(pi), xa = fabsf(pr);
     const float mx = fmaxf(xa, ya), mn = fminf(xa, ya);
     const float z = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-37f));
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     constexpr int TT = CHAN ? NT - 1 : NT;      // new output instants per tile
     static_assert(NT % 2 == 0, "NT must be even");
     extern __shared__ float4 lds4[];
-    float2 *lds = (float2 *)lds4;
+    cf *lds = (cf *)lds4;
     constexpr int SPAN_C = DH * (NT - 1) + Q * M;            // input samples the channel instants need
     constexpr int SPAN_N = (NR - 1) + NR * (NU - 1) + NQ * M;   // ... and the owned noise instants
     constexpr int SPAN = (FUSEN && SPAN_N > SPAN_C) ? SPAN_N : SPAN_C;
@@ -172,12 +174,12 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     static_assert(KT == 1 || (TT * DH) % 2 == 0, "tile hop must keep the 16-byte alignment");
     const int wsz = CHAN ? p.nsel * NT : 0;
     const int asz = span > wsz ? span : wsz;                 // the head of xs is dead after phase A -> reused as Db
-    float2 *xs = lds;                                        // [span]
-    float2 *U = lds + ((asz + 1) & ~1);                      // [NT][UST]
+    cf *xs = lds;                                        // [span]
+    cf *U = lds + ((asz + 1) & ~1);                      // [NT][UST]
     float *atab = (float *)(U + NT * UST);                   // [257]               (CHAN)
-    float2 *Un = (float2 *)(atab + 258);                     // [NU][UST] noise branch outputs (FUSEN)
-    __shared__ float2 s_tw[100];
-    __shared__ float2 s_krot[80 * 4];
+    cf *Un = (cf *)(atab + 258);                     // [NU][UST] noise branch outputs (FUSEN)
+    __shared__ cf s_tw[100];
+    __shared__ cf s_krot[80 * 4];
     __shared__ int s_binpos[80];
     const bool krot_lds = p.rot_period <= 4 && p.nsel <= 80;
     const int l0 = threadIdx.x;
@@ -220,14 +222,14 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     };
 
     // phase-A lane roles and branch taps (fixed for the whole group)
-    float2 a[Q];
+    cf a[Q];
 
     // Noise-bank roles: 500 tasks (instant i, branch pp) of 15 complex taps.  The channel branches
     // occupy waves 0..3; the fifth wave (NTH = 320) takes instants 0..3 of branches 0..63 and the
     // other lanes one task each, so that every wave carries about the same number of FMAs and a
     // lane needs the taps of one branch only (fetched once, behind the input staging).
     int nz_pp = 0, nz_i0 = 0, nz_cnt = 0;
-    float2 an[FUSEN ? NQ : 1];
+    cf an[FUSEN ? NQ : 1];
     if (FUSEN) {
         if (NTH > 256) {
             if (l0 >= 256) { nz_pp = l0 - 256; nz_i0 = 0; nz_cnt = 4; }
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     // memory latency per tile instead of one per loop trip).
     constexpr int NZT = FUSEN ? (80 * NU + NTH - 1) / NTH : 1;   // noise outputs per lane (phase C')
     const int nz_u0 = FUSEN ? p.n_u0 + NU * tile : 0;            // first noise instant owned by this tile
-    int nz_pos[NZT]; float2 nz_rot[NZT];
+    int nz_pos[NZT]; cf nz_rot[NZT];
     const long long gs = p.x0 + (long long)DH * t0;
     const long long a0 = gs & ~1LL;
     const int shift = (int)(gs - a0);
@@ -276,20 +278,20 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
             // tables -> LDS and the branch taps of this lane's roles (fixed for the group), issued
             // behind the input loads: memory returns in order, so the staging wait excludes them
             constexpr int NA = (257 + NTH - 1) / NTH, NK = (80 * 4 + NTH - 1) / NTH;
-            float at[NA]; float2 kr[NK];
+            float at[NA]; cf kr[NK];
 #pragma unroll
             for (int k = 0; k < NA; k++) at[k] = CHAN ? p.atan_tab[l0 + k * NTH < 257 ? l0 + k * NTH : 256] : 0.f;
-            const float2 tw = p.twiddle[l0 < 100 ? l0 : 99];
+            const cf tw = ((const cf *)p.twiddle)[l0 < 100 ? l0 : 99];
             const int bp = p.binpos[l0 < p.nsel ? l0 : p.nsel - 1];
             const int nkr = p.nsel * p.rot_period;
 #pragma unroll
-            for (int k = 0; k < NK; k++) kr[k] = p.krot[l0 + k * NTH < nkr ? l0 + k * NTH : nkr - 1];
+            for (int k = 0; k < NK; k++) kr[k] = ((const cf *)p.krot)[l0 + k * NTH < nkr ? l0 + k * NTH : nkr - 1];
             const int pp = l0 & 127;
 #pragma unroll
-            for (int q = 0; q < Q; q++) a[q] = p.taps[q * M + (pp < M ? pp : 0)];
+            for (int q = 0; q < Q; q++) a[q] = ((const cf *)p.taps)[q * M + (pp < M ? pp : 0)];
             if (FUSEN) {
 #pragma unroll
-                for (int q = 0; q < NQ; q++) an[q] = p.n_taps[q * M + nz_pp];
+                for (int q = 0; q < NQ; q++) an[q] = ((const cf *)p.n_taps)[q * M + nz_pp];
             }
 #pragma unroll
             for (int k = 0; k < NA; k++) asm volatile("" : "+v"(at[k]));   // keep the load out of the branch below
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
                 int ph = ph0 + i % NU;
                 ph = ph >= np ? ph - np : ph;
                 nz_pos[j] = p.n_binpos[c];
-                nz_rot[j] = p.n_krot[(size_t)c * np + ph];
+                nz_rot[j] = ((const cf *)p.n_krot)[(size_t)c * np + ph];
             }
         }
         if (gi == gi0) {
@@ -339,26 +341,19 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     {
         const int pp = a_pp, r = a_r;
         if (a_on && tile >= 0) {
-            const float2 *z = xs + shift + DH * r + pp;
-            float2 zw[Q];
+            const cf *z = xs + shift + DH * r + pp;
+            cf zw[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) zw[q] = z[q * M];
 #pragma unroll
             for (int tau = 0; tau < NT / 2; tau++) {
-                float ur = 0.f, ui = 0.f;
+                cf u = mk(0.f, 0.f);
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    if (REAL) {
-                        ur = fmaf(a[q].x, zw[q].x, ur);
-                        ui = fmaf(a[q].x, zw[q].y, ui);
-                    } else {
-                        ur = fmaf(a[q].x, zw[q].x, ur);
-                        ur = fmaf(-a[q].y, zw[q].y, ur);
-                        ui = fmaf(a[q].x, zw[q].y, ui);
-                        ui = fmaf(a[q].y, zw[q].x, ui);
-                    }
+                    if (REAL) u = a[q].xx * zw[q] + u;
+                    else { u = a[q].xx * zw[q] + u; u = mk(-a[q].y, a[q].y) * zw[q].yx + u; }
                 }
-                U[(2 * tau + r) * UST + pp] = make_float2(ur, ui);
+                U[(2 * tau + r) * UST + pp] = u;
                 if (tau + 1 < NT / 2) {
 #pragma unroll
                     for (int q = 0; q + S < Q; q++) zw[q] = zw[q + S];
@@ -371,17 +366,15 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     if (FUSEN) {
         // noise bank branches (taps preloaded above): nz_cnt instants of branch nz_pp
         for (int i = nz_i0; i < nz_i0 + nz_cnt; i++) {
-            const float2 *zz = xs + shift + p.n_off + NR * i + nz_pp;
-            float ur = 0.f, ui = 0.f;
+            const cf *zz = xs + shift + p.n_off + NR * i + nz_pp;
+            cf u = mk(0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
-                const float2 v = zz[q * M];
-                ur = fmaf(an[q].x, v.x, ur);
-                ur = fmaf(-an[q].y, v.y, ur);
-                ui = fmaf(an[q].x, v.y, ui);
-                ui = fmaf(an[q].y, v.x, ui);
+                const cf v = zz[q * M];
+                u = an[q].xx * v + u;
+                u = mk(-an[q].y, an[q].y) * v.yx + u;
             }
-            Un[i * UST + nz_pp] = make_float2(ur, ui);
+            Un[i * UST + nz_pp] = u;
         }
     }
     if (KT > 1 && gi + 1 < gi1) {
@@ -404,8 +397,8 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     constexpr int NTASK = NT * 10 + (FUSEN ? NU * 10 : 0);
     for (int i = l; i < NTASK; i += NTH) {
         const int tl = i / 10, p2 = i % 10;
-        float2 v[10];
-        float2 *row = (FUSEN && tl >= NT) ? Un + (tl - NT) * UST + p2 : U + tl * UST + p2;
+        cf v[10];
+        cf *row = (FUSEN && tl >= NT) ? Un + (tl - NT) * UST + p2 : U + tl * UST + p2;
 #pragma unroll
         for (int k = 0; k < 10; k++) v[k] = row[10 * k];
         dft10(v);
@@ -417,8 +410,8 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     // ---- phase B2: DFT over p2; bin m = m1 + 10 m2 ends up at position 10 m1 + m2 ----
     for (int i = l; i < NTASK; i += NTH) {
         const int tl = i / 10, m1 = i % 10;
-        float2 v[10];
-        float2 *row = (FUSEN && tl >= NT) ? Un + (tl - NT) * UST + 10 * m1 : U + tl * UST + 10 * m1;
+        cf v[10];
+        cf *row = (FUSEN && tl >= NT) ? Un + (tl - NT) * UST + 10 * m1 : U + tl * UST + 10 * m1;
 #pragma unroll
         for (int k = 0; k < 10; k++) v[k] = row[k];
         dft10(v);
@@ -438,7 +431,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
             const int c = i / NU, ui = i % NU;
             const int u = nz_u0 + ui;
             if (u < 0 || u >= p.n_T) continue;
-            p.n_Z[(size_t)c * p.n_zstride + u] = cmulf(Un[ui * UST + nz_pos[j]], nz_rot[j]);
+            ((cf *)p.n_Z)[(size_t)c * p.n_zstride + u] = cmulf(Un[ui * UST + nz_pos[j]], nz_rot[j]);
         }
         __syncthreads();                                          // Un is reused for the run partial sums
     }
@@ -453,9 +446,9 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
             if (t >= p.T) continue;
             uint32_t ph = ph_t0 + (uint32_t)tl;
             ph = ph >= period ? ph % period : ph;
-            const float2 kr = krot_lds ? s_krot[c * p.rot_period + ph] : p.krot[(size_t)c * p.rot_period + ph];
-            const float2 y = cmulf(U[tl * UST + s_binpos[c]], kr);
-            p.Z[(size_t)c * p.zstride + t] = y;
+            const cf kr = krot_lds ? s_krot[c * p.rot_period + ph] : ((const cf *)p.krot)[(size_t)c * p.rot_period + ph];
+            const cf y = cmulf(U[tl * UST + s_binpos[c]], kr);
+            ((cf *)p.Z)[(size_t)c * p.zstride + t] = y;
         }
     }
     // Channel epilogue.  Lane (chunk, c): channel c, a run of <= 9 consecutive instants, walking
@@ -480,10 +473,10 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
             // LDS copy is read with ds_read (a generic pointer would force flat loads + full waits).
             // Fully unrolled: all bins of the run are fetched and de-rotated first, the demods
             // are independent chains.
-            auto run = [&](const float2 *krc) {
+            auto run = [&](const cf *krc) {
                 uint32_t ph = ph_t0 + (uint32_t)(tl0 - 1);
                 ph = ph >= period ? ph % period : ph;
-                float2 y[RUN + 1];
+                cf y[RUN + 1];
 #pragma unroll
                 for (int k = 0; k <= RUN; k++) {
                     const int tl = tl0 - 1 + k < NT ? tl0 - 1 + k : NT - 1;
@@ -500,12 +493,12 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
                         if (tl0 + k - 1 < hr) head += m;
                         dv[k] = demod_fast(atab, p.gain, y[k + 1], y[k]);
                         drow[k * 80] = dv[k];
-                        if (p.Z) p.Z[(size_t)c * p.zstride + (t0 + tl0 + k)] = y[k + 1];   // BTGPU_FLAG_DEBUG_Y
+                        if (p.Z) ((cf *)p.Z)[(size_t)c * p.zstride + (t0 + tl0 + k)] = y[k + 1];   // BTGPU_FLAG_DEBUG_Y
                     }
                 }
             };
             if (krot_lds) run(&s_krot[c * p.rot_period]);
-            else run(&p.krot[(size_t)c * p.rot_period]);
+            else run((const cf *)p.krot + (size_t)c * p.rot_period);
             part[(chunk * 80 + c) * 2 + 0] = sum;
             part[(chunk * 80 + c) * 2 + 1] = head;
 #pragma unroll
