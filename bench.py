@@ -36,7 +36,7 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c79", choices=sorted(WORKLOADS))
     ap.add_argument("--slots", type=int, default=0, help="slots per rank per step (0 = workload default)")
@@ -82,7 +82,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     fs, fc = wl["sample_rate"], wl["center_freq"]
-    S = args.slots or (1600 if args.workload == "c79" else 1600)      # 1 s of signal per step at C79
+    S = args.slots or 2048      # 1.28 s of signal per step at C79: 1024 window-kernel workgroups = two full rounds of 512
     laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(args.piconets))
 
     blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,

@@ -257,7 +257,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         else
             hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
         HIPCHK(this, hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 255) / 256), dim3(256), 0, st,
+        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, st,
                            (const double *)d_ptile.p, (const double *)d_phead.p, p.ntiles, p.tiles_per_block,
                            des.tail / TT, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     } else {

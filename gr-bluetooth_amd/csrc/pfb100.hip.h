@@ -548,15 +548,17 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
 
 // tile sums -> per-slot-block sums P[c][b] and block-head sums Pt[c][b] (first `tail` instants of
 // block b), the layout the direct path produces.  tail may span several tiles (multi_LAP: 144).
-__global__ void block_sum_kernel(const double *__restrict__ ptile, const double *__restrict__ phead,
+__global__ __launch_bounds__(256) void block_sum_kernel(const double *__restrict__ ptile, const double *__restrict__ phead,
                                  int ntiles, int tiles_per_block, int tail_tiles,
                                  double *__restrict__ P, double *__restrict__ Pt, int nb, int nch)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per (channel, block): lanes read the block's tile sums contiguously, then a fixed
+    // shuffle tree (deterministic order)
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nb * nch) return;
     const int c = i / nb, b = i % nb;
     double s = 0.0, h = 0.0;
-    for (int k = 0; k < tiles_per_block; k++) {
+    for (int k = lane; k < tiles_per_block; k += 64) {
         const int t = b * tiles_per_block + k;
         if (t < ntiles) {
             const double v = ptile[(size_t)c * ntiles + t];
@@ -565,8 +567,11 @@ __global__ void block_sum_kernel(const double *__restrict__ ptile, const double 
             else if (k == tail_tiles) h += phead[(size_t)c * ntiles + t];
         }
     }
-    P[(size_t)c * nb + b] = s;
-    Pt[(size_t)c * nb + b] = h;
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); h += __shfl_down(h, off, 64); }
+    if (lane == 0) {
+        P[(size_t)c * nb + b] = s;
+        Pt[(size_t)c * nb + b] = h;
+    }
 }
 
 // ------------------------------------------------------------------------------------
