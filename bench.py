@@ -200,12 +200,15 @@ def main():
         # HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
         # gfx950 + WRITE_SIZE), valid for the configuration they were collected on
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_fused_c79_pmc_hbm.json")))
-            key = {"ddc_channel": "pfb100_kernel<7, 1, 26, true, true", "ddc_noise": "pfb100_kernel<15, 5, 10, false, fa",   # absent when the noise stage is fused into the channel kernel
-                   "window": "window_kernel", "finish": "finish_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
-            if args.workload == "c79" and S == pmc["slots"] and key in pmc["kernels"] and not direct:
-                roof["traffic"] = pmc["kernels"][key]["hbm_bytes"]
-                roof["traffic_source"] = "profiles/r01_d_fused_c79_pmc_hbm.json"
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")), reverse=True):
+                pmc = json.load(open(path))
+                key = {"ddc_channel": "pfb100_kernel<7, 1, 26, true, true", "window": "window_kernel",
+                       "finish": "finish_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
+                if args.workload == "c79" and S == pmc["slots"] and key in pmc["kernels"] and not direct:
+                    roof["traffic"] = pmc["kernels"][key]["hbm_bytes"]
+                    roof["traffic_source"] = "profiles/" + os.path.basename(path)
+                    break
         except Exception:
             pass
 
