@@ -29,6 +29,7 @@ OK, EINVAL, ENOMEM, EDEVICE, ENODEVICE, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3,
 MODE_LAP, MODE_SNIFFER = 0, 1
 CHANNELIZER_AUTO, CHANNELIZER_DIRECT, CHANNELIZER_POLYPHASE = 0, 1, 2
 SQUELCH_AUTO, SQUELCH_DIRECT, SQUELCH_STAGED = 0, 1, 2
+CORRELATOR_AUTO, CORRELATOR_INTREE, CORRELATOR_BTBB = 0, 1, 2   # multi_LAP default: BTBB (libbtbb, as the reference)
 FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS = 1, 2, 4, 8
 KIND_AC, KIND_AA = 0, 1
 
@@ -39,7 +40,7 @@ class Config(ctypes.Structure):
                 ("device", ctypes.c_int32), ("channelizer", ctypes.c_int32),
                 ("squelch", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("max_batch_slots", ctypes.c_int32), ("max_hits", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("correlator", ctypes.c_int32)]
 
 
 class Design(ctypes.Structure):
@@ -50,7 +51,7 @@ class Design(ctypes.Structure):
                 ("first_noise_sample", ctypes.c_int32), ("history", ctypes.c_int32),
                 ("ddc_out", ctypes.c_int32), ("noise_out", ctypes.c_int32),
                 ("channelizer", ctypes.c_int32), ("squelch", ctypes.c_int32),
-                ("left_margin", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
+                ("left_margin", ctypes.c_int32), ("correlator", ctypes.c_int32)]
 
 
 class Hit(ctypes.Structure):
@@ -169,9 +170,9 @@ def lib():
 
 def make_config(sample_rate, center_freq, squelch_db=10.0, mode=MODE_SNIFFER, device=-1,
                 channelizer=CHANNELIZER_AUTO, squelch=SQUELCH_AUTO, flags=0, max_batch_slots=0,
-                max_hits=0):
+                max_hits=0, correlator=CORRELATOR_AUTO):
     return Config(float(sample_rate), float(center_freq), float(squelch_db), mode, device,
-                  channelizer, squelch, flags, max_batch_slots, max_hits, 0)
+                  channelizer, squelch, flags, max_batch_slots, max_hits, correlator)
 
 
 def design_query(sample_rate, center_freq, squelch_db=10.0, mode=MODE_SNIFFER, **kw):

@@ -106,7 +106,7 @@ struct btgpu_handle {
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
-    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof;
+    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol;
     LaunchShape shape_s1;
     bool noise_pfb = false;
     bool fuse_noise = false;         // noise stage 1 rides on the channel bank's staged input
@@ -154,7 +154,7 @@ struct btgpu_handle {
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
-                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof};
+                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d2.p = nullptr;
                       tc[1].d_winfin.p = tc[1].d_symbits.p = nullptr; }
@@ -340,6 +340,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.a0_lo = des.ac.a0_lo; p.a0_hi = des.ac.a0_hi;
         p.le = (des.cfg.flags & BTGPU_FLAG_LE) ? 1 : 0; p.low_channel = d.low_channel;
         p.syms = want_syms ? 1 : 0;
+        p.btbb = d.correlator == BTGPU_CORRELATOR_BTBB ? 1 : 0;
+        p.btbb_pcol = (const uint64_t *)d_pcol.p;
         hipLaunchKernelGGL(window_kernel, dim3((S + kWinSlots - 1) / kWinSlots), dim3(kWinThreads), 0, st, p, (const float *)d_d.p, G,
                            (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
                            (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
@@ -727,6 +729,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     TRY(h->upload(h->d_aclo, des.ac.byte_lo, sizeof des.ac.byte_lo));
     TRY(h->upload(h->d_achi, des.ac.byte_hi, sizeof des.ac.byte_hi));
+    TRY(h->upload(h->d_pcol, des.ac.btbb_pcol, sizeof des.ac.btbb_pcol));
     TRY(h->upload(h->d_le_hdr, des.le.hdr, sizeof des.le.hdr));
     TRY(h->upload(h->d_le_whiten, des.le.whiten16, sizeof des.le.whiten16));
     TRY(h->upload(h->d_le_index, des.le.index_of_channel, sizeof des.le.index_of_channel));

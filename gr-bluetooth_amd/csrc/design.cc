@@ -234,9 +234,14 @@ int make_design(const btgpu_config &cfg, Design &o)
     if (!(cfg.sample_rate >= 2e6) || !(cfg.sample_rate < 4e9) || !std::isfinite(cfg.center_freq))
         return BTGPU_EINVAL;                             // apps/btrx:66-78 requires >= 2 samples/symbol
     if (cfg.mode != BTGPU_MODE_LAP && cfg.mode != BTGPU_MODE_SNIFFER) return BTGPU_EINVAL;
+    int corr = cfg.correlator;
+    if (corr == BTGPU_CORRELATOR_AUTO) corr = cfg.mode == BTGPU_MODE_LAP ? BTGPU_CORRELATOR_BTBB : BTGPU_CORRELATOR_INTREE;
+    if (corr != BTGPU_CORRELATOR_INTREE && corr != BTGPU_CORRELATOR_BTBB) return BTGPU_EINVAL;
+    if (corr == BTGPU_CORRELATOR_BTBB && cfg.mode != BTGPU_MODE_LAP) return BTGPU_EUNSUPPORTED;   // multi_sniffer uses sniff_ac
     o.cfg = cfg;
     btgpu_design &d = o.d;
     std::memset(&d, 0, sizeof d);
+    d.correlator = corr;
     const double fs = cfg.sample_rate;
     d.samples_per_symbol = fs / kSymbolRate;
     o.samples_per_slot_d = (int)kSymbolsPerSlot * d.samples_per_symbol;
@@ -319,6 +324,15 @@ int make_design(const btgpu_config &cfg, Design &o)
             o.ac.byte_lo[byte][v] = l;
             o.ac.byte_hi[byte][v] = h;
         }
+
+    // parity column of each LAP bit taken alone: D^34 (D^k) mod g(D)
+    for (int k = 0; k < 24; k++) {
+        const uint64_t GEN = 0260534236651ULL;
+        uint64_t rem = 1ULL << (34 + k);
+        for (int bit = 63; bit >= 34; bit--)
+            if ((rem >> bit) & 1) rem ^= GEN << (bit - 34);
+        o.ac.btbb_pcol[k] = rem & ((1ULL << 34) - 1);
+    }
 
     // ---- LE tables, regenerated from their rules ----
     {

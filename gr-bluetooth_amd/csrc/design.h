@@ -32,6 +32,8 @@ struct AcTables {
     uint32_t a0_hi;                      //            bits 64..67
     uint64_t byte_lo[3][256];            // XOR of the affine columns selected by LAP byte b
     uint32_t byte_hi[3][256];
+    uint64_t btbb_pcol[24];              // BCH(64,30) parity column of LAP bit k alone (libbtbb-style
+                                         // single-error correction of a LAP bit), sync-word bit order
 };
 
 struct LeTables {                       // le_packet::sniff_aa (lib/packet_impl.cc:1452-1527)

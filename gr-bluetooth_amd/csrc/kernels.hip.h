@@ -259,6 +259,8 @@ struct WindowParams {
     int le;                     // run the le_packet::sniff_aa pass (multi_sniffer, BTGPU_FLAG_LE)
     int syms;                   // export the packed symbols of hit windows (BTGPU_FLAG_SYMBOLS)
     int low_channel;
+    int btbb;                   // multi_LAP: libbtbb-style search (BTGPU_CORRELATOR_BTBB)
+    const uint64_t *btbb_pcol;  // [24] parity column of each LAP bit (device memory)
 };
 
 __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
@@ -440,6 +442,66 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int len1 = oo;                                         // 693, or the whole window if shorter
     int limit = len1 - 68 < 625 ? len1 - 68 : 625;
     int resume = 0, nhits = 0;
+    if (p.btbb) {
+        // [EXT libbtbb, unpinned] btbb_find_ac(symbols, latest_ac, LAP_ANY, 1, &pkt) as multi_LAP calls it
+        // (lib/multi_LAP_impl.cc:93): per offset the 64-symbol sync word; gate on the 7-bit Barker field
+        // (sync bits 57..63, distance <= 1, then replaced by the nearest valid pattern); zero BCH(64,30)
+        // syndrome or a single-bit error over sync bits 0..57 corrected; first hit wins.  The
+        // syndrome is formed against the access code regenerated from the received LAP (systematic
+        // code: syndrome = received parity ^ re-encoded parity): weight 1 = a parity bit in error,
+        // equal to the parity column of LAP bit k = that LAP bit in error.
+        uint32_t q0 = mybits[0], q1 = mybits[kWinThreads], q2 = mybits[2 * kWinThreads];
+        for (int b = 0; b * 32 < limit && nhits == 0; b++) {
+            const uint32_t v57 = __funnelshift_r(q1, q2, 25), v58 = __funnelshift_r(q1, q2, 26);
+            const uint32_t v59 = __funnelshift_r(q1, q2, 27), v60 = __funnelshift_r(q1, q2, 28);
+            const uint32_t v61 = __funnelshift_r(q1, q2, 29), v62 = __funnelshift_r(q1, q2, 30);
+            const uint32_t v63 = __funnelshift_r(q1, q2, 31);
+            // mismatches against 0x27 (field bit j = sync bit 57 + j): 1,1,1,0,0,1,0
+            const uint32_t n0 = ~v57, n1 = ~v58, n2 = ~v59, n3 = v60, n4 = v61, n5 = ~v62, n6 = v63;
+            const uint32_t t1 = xor3(n0, n1, n2), u1 = maj3(n0, n1, n2);
+            const uint32_t t2 = xor3(n3, n4, n5), u2 = maj3(n3, n4, n5);
+            const uint32_t u3 = maj3(t1, t2, n6);
+            const uint32_t d1 = xor3(u1, u2, u3), d2 = maj3(u1, u2, u3);   // d = d0 + 2 d1 + 4 d2
+            uint32_t ok = ~(d1 ^ d2);                                  // d in {0, 1, 6, 7}: min(d, 7 - d) <= 1
+            while (ok && nhits == 0) {
+                const int j = __ffs(ok) - 1;
+                ok &= ok - 1;
+                const int cpos = 32 * b + j;
+                if (cpos >= limit) break;
+                const uint32_t x0 = j ? ((q0 >> j) | (q1 << (32 - j))) : q0;
+                const uint32_t x1 = j ? ((q1 >> j) | (q2 << (32 - j))) : q1;
+                uint64_t sw = ((uint64_t)x1 << 32) | x0;
+                const uint32_t top7 = (uint32_t)(sw >> 57);
+                const uint64_t fixed = __popc(top7 ^ 0x27u) <= 1 ? 0x27ull : 0x58ull;
+                sw = (sw & 0x01ffffffffffffffull) | (fixed << 57);
+                uint32_t lap = (uint32_t)(sw >> 34) & 0xffffff;
+                const uint64_t elo = p.a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^ ac_lo[512 + (lap >> 16)];
+                const uint32_t ehi = p.a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^ ac_hi[512 + (lap >> 16)];
+                const uint64_t expect = (elo >> 4) | ((uint64_t)(ehi & 0xf) << 60);
+                const uint64_t synd = sw ^ expect;                         // parity bits only
+                int err = -1;
+                if (synd == 0) err = 0;
+                else if ((synd & (synd - 1)) == 0) err = 1;
+                else {
+                    for (int kb = 0; kb < 24; kb++)
+                        if (synd == p.btbb_pcol[kb]) { lap ^= 1u << kb; err = 1; break; }
+                }
+                if (err >= 0) {
+                    const unsigned int slot_h = atomicAdd(hit_count, 1u);
+                    if (slot_h < (unsigned int)p.max_hits) {
+                        DeviceHit h;
+                        h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
+                        h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0; h.sym = -1; h.pad_ = 0;
+                        hits[slot_h] = h;
+                    }
+                    nhits++;
+                    resume = cpos + 68;
+                }
+            }
+            q0 = q1; q1 = q2; q2 = mybits[(b + 3) * kWinThreads];
+        }
+        limit = 0;                                                 // skip the in-tree search below
+    }
     uint32_t r0 = mybits[0], r1 = mybits[kWinThreads], r2 = mybits[2 * kWinThreads], r3;
     for (int b = 0; b * 32 < limit; b++) {
         r3 = mybits[(b + 3) * kWinThreads];

@@ -50,6 +50,13 @@ extern "C" {
 #define BTGPU_SQUELCH_DIRECT    1       /* exact direct-form 20001-tap-class noise DDC           */
 #define BTGPU_SQUELCH_STAGED    2       /* two-stage equivalent filter + quadrature (tolerance)  */
 
+#define BTGPU_CORRELATOR_AUTO   0       /* multi_LAP: BTBB (what the reference links), multi_sniffer: INTREE */
+#define BTGPU_CORRELATOR_INTREE 1       /* classic_packet::sniff_ac / check_ac (lib/packet_impl.cc:247-268,471-510) */
+#define BTGPU_CORRELATOR_BTBB   2       /* libbtbb btbb_find_ac with btbb_init(1), max_ac_errors 1, LAP_ANY
+                                           (lib/multi_LAP_impl.cc:55,93) [EXT libbtbb, unpinned]; multi_LAP
+                                           only; hit.offset is then the sync-word start and hit.ac_errors the
+                                           number of corrected bits (0 or 1)                            */
+
 #define BTGPU_FLAG_LE        0x1        /* also run the le_packet::sniff_aa pass (sniffer mode)  */
 #define BTGPU_FLAG_DEBUG_Y   0x2        /* keep the channel-bank output Y for btgpu_debug_fetch  */
 #define BTGPU_FLAG_SYMBOLS   0x8        /* keep the sliced symbols of every window that reported a
@@ -75,7 +82,7 @@ typedef struct btgpu_config {
     int32_t flags;            /* BTGPU_FLAG_*                               */
     int32_t max_batch_slots;  /* slots per internal batch, 0 = default      */
     int32_t max_hits;         /* hit-buffer capacity per batch, 0 = default */
-    int32_t reserved;
+    int32_t correlator;       /* BTGPU_CORRELATOR_*                          */
 } btgpu_config;
 
 /* Everything the multi_block constructor derives (lib/multi_block.cc:56-119). */
@@ -93,7 +100,7 @@ typedef struct btgpu_design {
     int32_t squelch;                          /* resolved BTGPU_SQUELCH_*           */
     int32_t left_margin;                      /* samples before a device segment the staged
                                                  squelch may read (0 for DIRECT)     */
-    int32_t reserved[1];
+    int32_t correlator;                       /* resolved BTGPU_CORRELATOR_*        */
 } btgpu_design;
 
 typedef struct btgpu_hit {

@@ -36,7 +36,7 @@ typedef struct fir_bank {
 
 struct bto_ctx {
     double sample_rate, center_freq, target_snr;
-    int    mode, mm_policy, le_enable;
+    int    mode, mm_policy, le_enable, correlator;
     double sps;                 /* d_samples_per_symbol            */
     double samples_per_slot;    /* d_samples_per_slot (double)     */
     int    slot;                /* (int) d_samples_per_slot        */
@@ -267,6 +267,9 @@ bto_ctx *bto_create(double sample_rate, double center_freq, double squelch_db, i
     c->center_freq = center_freq;
     c->mode = mode;
     c->mm_policy = BTO_MM_WINDOWED_RESET;
+    /* multi_LAP searches with libbtbb's btbb_find_ac (lib/multi_LAP_impl.cc:55,93), multi_sniffer
+     * with the in-tree classic_packet::sniff_ac (lib/multi_sniffer_impl.cc:110) */
+    c->correlator = (mode == BTO_MODE_LAP) ? BTO_CORRELATOR_BTBB : BTO_CORRELATOR_INTREE;
     c->le_enable = 0;
 
     int slots = 1;
@@ -341,6 +344,8 @@ void bto_destroy(bto_ctx *c)
 
 void bto_set_mm_policy(bto_ctx *c, int p) { c->mm_policy = p; }
 void bto_set_le(bto_ctx *c, int e) { c->le_enable = e; }
+void bto_set_correlator(bto_ctx *c, int which) { c->correlator = which; }
+int  bto_correlator(const bto_ctx *c) { return c->correlator; }
 int bto_history(const bto_ctx *c) { return c->history; }
 int bto_samples_per_slot(const bto_ctx *c) { return c->slot; }
 int bto_decimation(const bto_ctx *c) { return c->decim; }
@@ -757,23 +762,93 @@ int bto_header_present(const char *symbols, int length)
 /* work loops: lib/multi_sniffer_impl.cc:82-166, lib/multi_LAP_impl.cc:65-114  */
 /* ------------------------------------------------------------------------- */
 
+/* ---------------------------------------------------------------------------------------
+ * [EXT libbtbb -- NOT in /root/reference, version unpinned by the reference (cmake/Modules/
+ * FindBTBB.cmake only looks for btbb.h / libbtbb)].  Restatement of the published algorithm of
+ * btbb_find_ac() + btbb_init() (libbtbb, lib/src/bluetooth_packet.c), as called by
+ * lib/multi_LAP_impl.cc:55 (btbb_init(1)) and :93 (btbb_find_ac(symbols, latest_ac, LAP_ANY, 1, &pkt)):
+ *   for every offset `count` < search_length, sync word = 64 symbols from `count` (LSB first):
+ *     - gate: BARKER_DISTANCE[sync bits 57..63] <= MAX_BARKER_ERRORS (1); the 7-bit field is then
+ *       replaced by the nearest valid pattern (barker_correct[]), not counted as an error;
+ *     - codeword = syncword ^ PN; zero BCH(64,30) syndrome -> 0 errors; otherwise the syndrome is
+ *       looked up in the map btbb_init(n) builds from all error patterns of <= n bits over sync
+ *       bits 0..57 (the Barker bits are excluded there); a match is XORed into the sync word and
+ *       ac_errors = number of corrected bits; no match -> not an access code;
+ *     - LAP = (syncword >> 34) & 0xffffff; the first offset that passes is returned (this offset is
+ *       the sync-word start, 4 symbols after the preamble start bto_sniff_ac returns).
+ * PARITY UNPINNED: libbtbb is absent; anchored on the reference's call site only.
+ * --------------------------------------------------------------------------------------- */
+static uint64_t bch_parity30(uint64_t x30)
+{
+    /* parity(D) = D^34 x(D) mod g(D), g = 0260534236651 (octal), bit i of the result = D^i */
+    const uint64_t GEN = 0260534236651ULL;
+    uint64_t rem = (x30 & ((1ULL << 30) - 1)) << 34;
+    for (int bit = 63; bit >= 34; bit--)
+        if ((rem >> bit) & 1) rem ^= GEN << (bit - 34);
+    return rem & ((1ULL << 34) - 1);
+}
+static uint64_t bch_syndrome(uint64_t codeword)
+{
+    return (codeword & ((1ULL << 34) - 1)) ^ bch_parity30(codeword >> 34);
+}
+
+int bto_btbb_find_ac(const char *stream, int search_length, int max_ac_errors, uint32_t *lap_out,
+                     int *ac_errors_out)
+{
+    build_luts();
+    const uint64_t PN = 0x83848D96BBCC54FCULL;
+    if (max_ac_errors < 0 || max_ac_errors > 1) return -2;      /* the reference uses 1 */
+    static uint64_t synd1[58];
+    static int ready = 0;
+    if (!ready) { for (int i = 0; i < 58; i++) synd1[i] = bch_syndrome(1ULL << i); ready = 1; }
+    for (int count = 0; count < search_length; count++) {
+        const char *sym = &stream[count];
+        unsigned barker = 0;
+        for (int j = 0; j < 7; j++) barker |= ((unsigned)(sym[57 + j] & 1)) << j;
+        if (BARKER_DISTANCE[barker] > 1) continue;
+        uint64_t sw = 0;
+        for (int i = 0; i < 64; i++) sw |= ((uint64_t)(sym[i] & 1)) << i;
+        const unsigned fixed = (popc(barker ^ 0x27) <= popc(barker ^ 0x58)) ? 0x27u : 0x58u;
+        sw = (sw & 0x01ffffffffffffffULL) | ((uint64_t)fixed << 57);
+        uint64_t synd = bch_syndrome(sw ^ PN);
+        int errs = 0;
+        if (synd) {
+            int k = -1;
+            if (max_ac_errors >= 1)
+                for (int i = 0; i < 58; i++) if (synd1[i] == synd) { k = i; break; }
+            if (k < 0) continue;
+            sw ^= 1ULL << k;
+            errs = 1;
+        }
+        if (lap_out) *lap_out = (uint32_t)(sw >> 34) & 0xffffff;
+        if (ac_errors_out) *ac_errors_out = errs;
+        return count;
+    }
+    return -1;
+}
+
 static int search_symbols(const bto_ctx *c, char *symbols, int len, int channel, uint32_t slot,
                           double snr, bto_hit *hits, int max_hits)
 {
     int nh = 0;
     double freq = channel_abs_freq(channel);
     if (c->mode == BTO_MODE_LAP) {
-        /* multi_LAP_impl.cc:89-101 with the in-tree correlator (libbtbb tail unpinned) */
+        /* multi_LAP_impl.cc:89-101; the search is libbtbb's (default, as in the reference) or the
+         * in-tree classic_packet::sniff_ac (BTO_CORRELATOR_INTREE) */
         if (len >= SYMBOLS_PER_SHORTENED_AC) {
             int latest = ((len - SYMBOLS_PER_SHORTENED_AC) < SYMBOLS_PER_SLOT)
                              ? (len - SYMBOLS_PER_SHORTENED_AC) : SYMBOLS_PER_SLOT;
-            int off = bto_sniff_ac(symbols, latest);
+            uint32_t lap = 0; int errs = 0, off;
+            if (c->correlator == BTO_CORRELATOR_BTBB) off = bto_btbb_find_ac(symbols, latest, 1, &lap, &errs);
+            else {
+                off = bto_sniff_ac(symbols, latest);
+                if (off >= 0) { lap = bto_air_to_host32(&symbols[off + 38], 24); errs = bto_ac_errors(&symbols[off], lap); }
+            }
             if (off >= 0 && nh < max_hits) {
                 bto_hit *h = &hits[nh++];
                 memset(h, 0, sizeof *h);
                 h->slot = slot; h->channel = channel; h->offset = off;
-                h->lap = bto_air_to_host32(&symbols[off + 38], 24);
-                h->ac_errors = bto_ac_errors(&symbols[off], h->lap);
+                h->lap = lap; h->ac_errors = errs;
                 h->kind = BTO_KIND_AC; h->nsym = len - off; h->snr = snr;
             }
         }

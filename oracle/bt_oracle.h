@@ -21,6 +21,8 @@
  *   lib/packet_impl.cc:278-364  lfsr / acgen
  *   lib/packet_impl.cc:471-510  check_ac
  *   lib/packet_impl.cc:1285-1314,1452-1527  le_packet::freq2index / sniff_aa
+ *   lib/multi_LAP_impl.cc:55,93-99  btbb_init / btbb_find_ac  [EXT libbtbb: restated from the
+ *                               published algorithm, version unpinned -> PARITY UNPINNED]
  *
  * PARITY PINNING (see DESIGN.md "Oracle"):
  *  - integer half (acgen / check_ac / sniff_ac): pinned to the known answers the
@@ -55,6 +57,9 @@ extern "C" {
 #define BTO_MM_WINDOWED_RESET 0
 #define BTO_MM_REF_FAITHFUL   1
 
+#define BTO_CORRELATOR_INTREE 1  /* classic_packet::sniff_ac / check_ac (lib/packet_impl.cc:247-268) */
+#define BTO_CORRELATOR_BTBB   2  /* libbtbb btbb_find_ac, max_ac_errors = 1 (lib/multi_LAP_impl.cc:55,93) [EXT, unpinned] */
+
 #define BTO_KIND_AC 0
 #define BTO_KIND_AA 1
 
@@ -79,6 +84,8 @@ bto_ctx *bto_create(double sample_rate, double center_freq, double squelch_db, i
 void     bto_destroy(bto_ctx *c);
 void     bto_set_mm_policy(bto_ctx *c, int policy);
 void     bto_set_le(bto_ctx *c, int enable);    /* run the sniff_aa pass in sniffer mode */
+void     bto_set_correlator(bto_ctx *c, int which);   /* BTO_CORRELATOR_*; default: BTBB in LAP mode */
+int      bto_correlator(const bto_ctx *c);
 
 int bto_history(const bto_ctx *c);
 int bto_samples_per_slot(const bto_ctx *c);
@@ -116,6 +123,9 @@ int  bto_ac_errors(const char *stream, uint32_t lap);      /* mismatches over 68
 int  bto_check_ac(const char *stream, uint32_t lap);
 int  bto_sniff_ac(const char *stream, int stream_length);
 int  bto_sniff_aa(const char *stream, int stream_length, double freq);
+/* [EXT libbtbb, unpinned] btbb_find_ac(stream, search_length, LAP_ANY, max_ac_errors, &pkt): returns the
+ * sync-word offset or -1; LAP and corrected-bit count through the pointers */
+int  bto_btbb_find_ac(const char *stream, int search_length, int max_ac_errors, uint32_t *lap, int *ac_errors);
 int  bto_le_freq2index(double freq);
 int  bto_header_present(const char *symbols, int length);   /* lib/packet_impl.cc:1205-1242 */
 uint32_t bto_air_to_host32(const char *air, int bits);

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libbt_oracle.so")
 
 MODE_LAP, MODE_SNIFFER = 0, 1
+CORRELATOR_INTREE, CORRELATOR_BTBB = 1, 2   # multi_LAP default: BTBB (libbtbb, as the reference)
 MM_WINDOWED_RESET, MM_REF_FAITHFUL = 0, 1
 KIND_AC, KIND_AA = 0, 1
 
@@ -96,6 +97,11 @@ def lib():
     L.bto_header_present.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.bto_le_freq2index.restype = ctypes.c_int
     L.bto_le_freq2index.argtypes = [ctypes.c_double]
+    L.bto_btbb_find_ac.restype = ctypes.c_int
+    L.bto_btbb_find_ac.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32),
+                                   ctypes.POINTER(ctypes.c_int)]
+    L.bto_set_correlator.restype = None
+    L.bto_set_correlator.argtypes = [vp, ctypes.c_int]
     L.bto_work.restype = ctypes.c_int
     L.bto_work.argtypes = [vp, c_fp, ctypes.c_uint32, ctypes.POINTER(Hit), ctypes.c_int]
     L.bto_run_stream.restype = ctypes.c_int
@@ -149,6 +155,17 @@ def sniff_aa(symbols, limit, freq):
     return lib().bto_sniff_aa(pad.tobytes(), int(limit), float(freq))
 
 
+def btbb_find_ac(symbols, search_length=None, max_ac_errors=1):
+    """[EXT libbtbb, unpinned] -> (offset of the sync word or -1, lap, ac_errors)."""
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    if search_length is None:
+        search_length = len(s) - 63
+    pad = np.concatenate([s, np.zeros(80, np.uint8)])
+    lap, errs = ctypes.c_uint32(0), ctypes.c_int(0)
+    off = lib().bto_btbb_find_ac(pad.tobytes(), int(search_length), int(max_ac_errors), ctypes.byref(lap), ctypes.byref(errs))
+    return off, int(lap.value), int(errs.value)
+
+
 def header_present(symbols, length=None):
     s = np.ascontiguousarray(symbols, dtype=np.uint8)
     n = len(s) if length is None else int(length)
@@ -167,13 +184,15 @@ class Oracle:
     """One reference block instance (multi_LAP or multi_sniffer)."""
 
     def __init__(self, sample_rate, center_freq, squelch_db=10.0, mode=MODE_SNIFFER,
-                 mm_policy=MM_WINDOWED_RESET, le=False):
+                 mm_policy=MM_WINDOWED_RESET, le=False, correlator=None):
         self.L = lib()
         self.h = self.L.bto_create(sample_rate, center_freq, squelch_db, mode)
         if not self.h:
             raise MemoryError("bto_create")
         self.L.bto_set_mm_policy(self.h, mm_policy)
         self.L.bto_set_le(self.h, 1 if le else 0)
+        if correlator is not None:              # default: libbtbb in LAP mode, in-tree in sniffer mode
+            self.L.bto_set_correlator(self.h, int(correlator))
         g = lambda n: getattr(self.L, "bto_" + n)(self.h)
         self.history = g("history")
         self.slot = g("samples_per_slot")

@@ -46,10 +46,13 @@ def main():
     import importlib
     synth = importlib.import_module("gr_bluetooth_amd.synth")
     out = {}
-    for mode, name in ((po.MODE_SNIFFER, "sniffer"), (po.MODE_LAP, "lap")):
+    # "lap" = multi_LAP with the in-tree correlator, "lap_btbb" = with the libbtbb-style one (the
+    # block's default, as in the reference; [EXT] unpinned)
+    for mode, name, corr in ((po.MODE_SNIFFER, "sniffer", None), (po.MODE_LAP, "lap", po.CORRELATOR_INTREE),
+                             (po.MODE_LAP, "lap_btbb", po.CORRELATOR_BTBB)):
         iq, truth = synth.make_capture(8e6, 2476.5e6, 20, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=7,
                                        snr_db=22.0, occupancy=0.4)
-        hits, done = po.Oracle(8e6, 2476.5e6, 10.0, mode).run_stream(iq)
+        hits, done = po.Oracle(8e6, 2476.5e6, 10.0, mode, correlator=corr).run_stream(iq)
         out[name] = [[h.slot, h.channel, h.kind, h.offset, "%06x" % h.lap, h.ac_errors, h.nsym,
                       round(h.snr, 6)] for h in hits]
     out["params"] = dict(sample_rate=8e6, center_freq=2476.5e6, n_slots=20, laps=["24d952", "4831dd", "9e8b33"],

@@ -36,14 +36,22 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("fs,fc,nslots,occ", CONFIGS)
-@pytest.mark.parametrize("mode", ["sniffer", "lap"])
+@pytest.mark.parametrize("mode", ["sniffer", "lap", "lap_intree"])
 def test_hit_list_bit_exact(pkg, po, synth, fs, fc, nslots, occ, mode):
+    """"lap" = multi_LAP as the reference builds it (libbtbb's btbb_find_ac, the default of both
+    the block and the oracle); "lap_intree" = multi_LAP with classic_packet::sniff_ac."""
     iq, truth = synth.make_capture(fs, fc, nslots, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=int(fs / 1e6),
                                    snr_db=24, occupancy=occ)
     omode = po.MODE_SNIFFER if mode == "sniffer" else po.MODE_LAP
-    want, done = po.Oracle(fs, fc, 10.0, omode).run_stream(iq, threads=8)
+    okw, gkw = {}, {}
+    if mode == "lap_intree":
+        okw["correlator"] = po.CORRELATOR_INTREE
+        gkw["correlator"] = pkg.CORRELATOR_INTREE
+    want, done = po.Oracle(fs, fc, 10.0, omode, **okw).run_stream(iq, threads=8)
     cls = pkg.multi_sniffer if mode == "sniffer" else pkg.multi_LAP
-    blk, got = _run_gpu(pkg, cls, fs, fc, iq)
+    blk, got = _run_gpu(pkg, cls, fs, fc, iq, **gkw)
+    if mode == "lap":
+        assert blk.design.correlator == pkg.CORRELATOR_BTBB and all(h.ac_errors in (0, 1) for h in got)
     assert len(want) > 0
     assert _keys(got) == _keys(want)
     assert np.allclose([h.snr_db for h in got], [h.snr for h in want], rtol=1e-10, atol=1e-10)
@@ -142,8 +150,9 @@ def test_golden_fixture(pkg):
     iq, _ = synth.make_capture(p["sample_rate"], p["center_freq"], p["n_slots"],
                                laps=tuple(int(x, 16) for x in p["laps"]), seed=p["seed"],
                                snr_db=p["snr_db"], occupancy=p["occupancy"])
-    for cls, name in ((pkg.multi_sniffer, "sniffer"), (pkg.multi_LAP, "lap")):
-        blk, got = _run_gpu(pkg, cls, p["sample_rate"], p["center_freq"], iq, p["squelch_db"])
+    for cls, name, kw in ((pkg.multi_sniffer, "sniffer", {}), (pkg.multi_LAP, "lap", {"correlator": pkg.CORRELATOR_INTREE}),
+                          (pkg.multi_LAP, "lap_btbb", {})):
+        blk, got = _run_gpu(pkg, cls, p["sample_rate"], p["center_freq"], iq, p["squelch_db"], **kw)
         rows = [[h.slot, h.channel, h.kind, h.offset, "%06x" % h.lap, h.ac_errors, h.nsym] for h in got]
         assert rows == [g[:7] for g in gold[name]]
         assert np.allclose([h.snr_db for h in got], [g[7] for g in gold[name]], atol=1e-5)
@@ -309,8 +318,11 @@ def test_hit_symbols_equal_oracle(pkg, po, synth, mode):
         osym, _ = o.channel_symbols(ch_iq)
         assert len(osym) - w.offset == w.nsym
         assert np.array_equal(s[:n], osym[w.offset:w.offset + n])
-        assert po.sniff_ac(s[:200], 1) == 0                       # the hit's access code starts at symbol 0
-        assert po.lib().bto_air_to_host32(s[38:62].tobytes(), 24) == w.lap
+        if mode == "sniffer":
+            assert po.sniff_ac(s[:200], 1) == 0                   # the hit's access code starts at symbol 0
+            assert po.lib().bto_air_to_host32(s[38:62].tobytes(), 24) == w.lap
+        else:                                                     # multi_LAP (libbtbb): the sync word starts at symbol 0
+            assert po.btbb_find_ac(s[:200], 1) == (0, w.lap, w.ac_errors)
 
 
 def test_hit_symbols_fast_path(pkg, po, synth):
@@ -455,3 +467,19 @@ def test_full_size_properties_c79(pkg, synth):
     found = sum(any((t["slot"] + 6 + d, t["channel"], t["lap"]) in got for d in (-1, 0, 1)) for t in exp)
     assert len(exp) > 20 and found >= 0.9 * len(exp)
     blk.close()
+
+
+def test_btbb_correlator_corrects_one_error_like_the_oracle(pkg, po, synth):
+    """multi_LAP with the libbtbb-style search on noisy bursts (low SNR: single symbol errors in the
+    access code appear): records equal the oracle's, corrected hits (err = 1) included; and
+    the sniffer block refuses the libbtbb correlator (the reference does not offer that)."""
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 60, laps=(0x24D952, 0x4831DD, 0x9E8B33, 0xABCDEF), seed=11, snr_db=11,
+                               occupancy=0.7)
+    want, _ = po.Oracle(fs, fc, 6.0, po.MODE_LAP).run_stream(iq, threads=8)
+    blk, got = _run_gpu(pkg, pkg.multi_LAP, fs, fc, iq, squelch=6.0)
+    assert _keys(got) == _keys(want) and len(want) > 10
+    assert any(h.ac_errors == 1 for h in want)
+    blk.close()
+    with pytest.raises(pkg.BtgpuError):
+        pkg.multi_sniffer(fs, fc, 10.0, False, correlator=pkg.CORRELATOR_BTBB)

@@ -151,8 +151,9 @@ def test_golden_c8_seed7(po, synth):
     iq, _ = synth.make_capture(p["sample_rate"], p["center_freq"], p["n_slots"],
                                laps=tuple(int(x, 16) for x in p["laps"]), seed=p["seed"],
                                snr_db=p["snr_db"], occupancy=p["occupancy"])
-    for mode, name in ((po.MODE_SNIFFER, "sniffer"), (po.MODE_LAP, "lap")):
-        hits, _ = po.Oracle(p["sample_rate"], p["center_freq"], p["squelch_db"], mode).run_stream(iq)
+    for mode, name, corr in ((po.MODE_SNIFFER, "sniffer", None), (po.MODE_LAP, "lap", po.CORRELATOR_INTREE),
+                             (po.MODE_LAP, "lap_btbb", po.CORRELATOR_BTBB)):
+        hits, _ = po.Oracle(p["sample_rate"], p["center_freq"], p["squelch_db"], mode, correlator=corr).run_stream(iq)
         got = [[h.slot, h.channel, h.kind, h.offset, "%06x" % h.lap, h.ac_errors, h.nsym] for h in hits]
         assert got == [g[:7] for g in gold[name]]
         assert np.allclose([h.snr for h in hits], [g[7] for g in gold[name]], atol=1e-5)

@@ -119,3 +119,38 @@ def test_sniff_aa_known_answer(po):
     assert po.sniff_aa(s2, 300, 2402e6) == 50
     s2[50 + 30] ^= 1
     assert po.sniff_aa(s2, 300, 2402e6) == -1
+
+
+def test_btbb_find_ac_restatement(po):
+    """[EXT libbtbb, unpinned] btbb_find_ac as multi_LAP calls it (lib/multi_LAP_impl.cc:55,93:
+    btbb_init(1), max_ac_errors 1, LAP_ANY).  Properties of the published algorithm: the offset is
+    the sync-word start (preamble start + 4); one error over sync bits 0..57 is corrected and
+    counted, a LAP bit included; two are rejected; one Barker-field error passes the gate and is
+    not counted; agreement with the in-tree correlator on clean codes."""
+    rng = np.random.default_rng(5)
+    for lap in (0x24D952, 0x9E8B33, 0x000000, 0xFFFFFF, 0x800000, 0x7FFFFF):
+        st = np.zeros(400, np.uint8)
+        st[100:172] = po.ac_bits(lap)
+        assert po.sniff_ac(st, 300) == 100
+        assert po.btbb_find_ac(st, 300) == (104, lap, 0)
+        for pos in list(range(104, 104 + 57)):                      # parity bits and LAP bits 0..22
+            s1 = st.copy(); s1[pos] ^= 1
+            assert po.btbb_find_ac(s1, 300) == (104, lap, 1), pos
+        for _ in range(40):                                          # any two errors in bits 0..56
+            a, b = rng.choice(57, 2, replace=False)
+            s2 = st.copy(); s2[104 + a] ^= 1; s2[104 + b] ^= 1
+            off, got, errs = po.btbb_find_ac(s2, 300)
+            assert off != 104 or got != lap                         # never the true code at its place
+        for pos in range(104 + 57, 104 + 64):                        # 7-bit Barker field (LAP msb + Barker): fixed, not counted
+            s3 = st.copy(); s3[pos] ^= 1
+            assert po.btbb_find_ac(s3, 300) == (104, lap, 0)
+        # the search range is exclusive, like the loop `count < search_length`
+        assert po.btbb_find_ac(st, 104)[0] == -1 and po.btbb_find_ac(st, 105)[0] == 104
+    # channel37.dem: every clean in-tree hit is a btbb hit 4 symbols later with the same LAP
+    bits = np.unpackbits(np.load(os.path.join(G, "channel37.bits.npy")))[: json.load(open(os.path.join(G, "channel37_hits.json")))["n_symbols"]]
+    n = 0
+    for off, lap, errs in po.scan_symbols(bits):
+        if errs == 0:
+            assert po.btbb_find_ac(bits[off + 4: off + 4 + 64 + 1], 1) == (0, lap, 0)
+            n += 1
+    assert n >= 20
