@@ -130,6 +130,29 @@ int  bto_le_freq2index(double freq);
 int  bto_header_present(const char *symbols, int length);   /* lib/packet_impl.cc:1205-1242 */
 uint32_t bto_air_to_host32(const char *air, int bits);
 
+/* ---- classic header path (bt_uap.c): lib/packet_impl.cc:367-383, 386-468,
+ * 513-548, 597-1063; lib/piconet_impl.cc:433-547.  `symbols` start at the access code. ---- */
+int      bto_unfec13(const char *in, char *out, int length);
+int      bto_unfec23(const char *in, int length, char *out);      /* 0 where the reference returns NULL */
+void     bto_unwhiten(const char *in, char *out, int clock, int length, int skip);
+unsigned bto_crcgen(const char *payload, int length, int uap);
+int      bto_uap_from_hec(unsigned data, unsigned hec);
+int      bto_try_clock(const char *symbols, int clock, int *type, int *uap);
+int      bto_crc_check(const char *symbols, int length, int clock, int type, int uap);
+
+typedef struct bto_piconet {               /* the UAP/CLK1-6 part of basic_rate_piconet_impl */
+    uint32_t lap;
+    int got_first_packet, packets_observed, total_packets_observed;
+    uint32_t first_pkt_time;
+    int clock6_candidates[64];
+    int clk_offset, uap, have_uap, have_clk6;
+} bto_piconet;
+void bto_piconet_init(bto_piconet *pn, uint32_t lap);
+/* one packet with a header; returns 1 when UAP and CLK1-6 are resolved; `log` receives the lines
+ * the reference prints (lib/piconet_impl.cc:452,487,504,511,528) */
+int  bto_uap_from_header(bto_piconet *pn, const char *symbols, int length, uint32_t clkn, int channel,
+                         char *log, size_t log_cap);
+
 /* ---- block work() restatements; return number of hits appended ---- */
 int bto_work(bto_ctx *c, const float *win, uint32_t slot, bto_hit *hits, int max_hits);
 

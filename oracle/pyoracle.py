@@ -102,6 +102,17 @@ def lib():
                                    ctypes.POINTER(ctypes.c_int)]
     L.bto_set_correlator.restype = None
     L.bto_set_correlator.argtypes = [vp, ctypes.c_int]
+    L.bto_try_clock.restype = ctypes.c_int
+    L.bto_try_clock.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.bto_crc_check.restype = ctypes.c_int
+    L.bto_crc_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.bto_piconet_init.restype = None
+    L.bto_piconet_init.argtypes = [ctypes.POINTER(PiconetState), ctypes.c_uint32]
+    L.bto_uap_from_header.restype = ctypes.c_int
+    L.bto_uap_from_header.argtypes = [ctypes.POINTER(PiconetState), ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32,
+                                      ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    L.bto_unfec23.restype = ctypes.c_int
+    L.bto_unfec23.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.bto_work.restype = ctypes.c_int
     L.bto_work.argtypes = [vp, c_fp, ctypes.c_uint32, ctypes.POINTER(Hit), ctypes.c_int]
     L.bto_run_stream.restype = ctypes.c_int
@@ -164,6 +175,42 @@ def btbb_find_ac(symbols, search_length=None, max_ac_errors=1):
     lap, errs = ctypes.c_uint32(0), ctypes.c_int(0)
     off = lib().bto_btbb_find_ac(pad.tobytes(), int(search_length), int(max_ac_errors), ctypes.byref(lap), ctypes.byref(errs))
     return off, int(lap.value), int(errs.value)
+
+
+class PiconetState(ctypes.Structure):
+    _fields_ = [("lap", ctypes.c_uint32), ("got_first_packet", ctypes.c_int), ("packets_observed", ctypes.c_int),
+                ("total_packets_observed", ctypes.c_int), ("first_pkt_time", ctypes.c_uint32),
+                ("clock6_candidates", ctypes.c_int * 64), ("clk_offset", ctypes.c_int), ("uap", ctypes.c_int),
+                ("have_uap", ctypes.c_int), ("have_clk6", ctypes.c_int)]
+
+
+class Piconet:
+    """UAP / CLK1-6 discovery state of one LAP (basic_rate_piconet_impl::UAP_from_header)."""
+
+    def __init__(self, lap):
+        self.st = PiconetState()
+        lib().bto_piconet_init(ctypes.byref(self.st), lap)
+
+    def uap_from_header(self, symbols, clkn, channel=0):
+        """-> (resolved, lines the reference prints)"""
+        s = np.ascontiguousarray(symbols, dtype=np.uint8)
+        log = ctypes.create_string_buffer(2048)
+        r = lib().bto_uap_from_header(ctypes.byref(self.st), s.tobytes() + bytes(64), len(s), int(clkn), int(channel), log, 2048)
+        return bool(r), log.value.decode()
+
+
+def try_clock(symbols, clock):
+    """classic_packet::try_clock on symbols that start at the access code -> (uap, type, fec13_ok)"""
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    t, u = ctypes.c_int(-1), ctypes.c_int(-1)
+    r = lib().bto_try_clock(s.tobytes() + bytes(64), int(clock), ctypes.byref(t), ctypes.byref(u))
+    return r, t.value, t.value >= 0
+
+
+def crc_check(symbols, clock, ptype, uap):
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    pad = np.concatenate([s[:3125], np.zeros(3200 - min(len(s), 3125), np.uint8)])
+    return lib().bto_crc_check(pad.tobytes(), min(len(s), 3125), int(clock), int(ptype), int(uap))
 
 
 def header_present(symbols, length=None):
