@@ -145,8 +145,23 @@ typedef struct bto_piconet {               /* the UAP/CLK1-6 part of basic_rate_
     int got_first_packet, packets_observed, total_packets_observed;
     uint32_t first_pkt_time;
     int clock6_candidates[64];
-    int clk_offset, uap, have_uap, have_clk6;
+    uint32_t clk_offset;
+    int uap, have_uap, have_clk6, have_clk27;
 } bto_piconet;
+typedef struct bto_packet bto_packet;      /* classic_packet_impl state */
+typedef struct bto_sniffer bto_sniffer;    /* multi_sniffer_impl's piconet map and packet queues */
+bto_packet *bto_packet_new(const char *symbols, int length, uint32_t clkn, int channel);
+void bto_packet_free(bto_packet *p);
+int  bto_packet_try_clock(bto_packet *p, int clock);
+int  bto_packet_crc_check(bto_packet *p, int clock);
+int  bto_packet_type(const bto_packet *p);
+int  bto_packet_uap(const bto_packet *p);
+bto_sniffer *bto_sniffer_new(void);
+void bto_sniffer_free(bto_sniffer *s);
+/* multi_sniffer_impl::ac for one classic hit (lib/multi_sniffer_impl.cc:169-205, tun off): appends the text
+ * the reference prints -- the "time ..." line, ID / discovery / decode output -- to `log` */
+void bto_sniffer_ac(bto_sniffer *s, const char *symbols, int len, uint32_t clkn, int channel, double snr,
+                    char *log, size_t log_cap);
 void bto_piconet_init(bto_piconet *pn, uint32_t lap);
 /* one packet with a header; returns 1 when UAP and CLK1-6 are resolved; `log` receives the lines
  * the reference prints (lib/piconet_impl.cc:452,487,504,511,528) */

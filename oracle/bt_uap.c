@@ -167,35 +167,57 @@ int bto_try_clock(const char *symbols, int clock, int *type, int *uap)
     return *uap;
 }
 
-/* ---- payload parsers; `s` = symbols from the access code on, `len` symbols in total ---- */
-typedef struct { char bits[3000]; int length; /* bytes */ } payload_t;
+/* ---- the packet object: what classic_packet_impl keeps between calls (lib/packet_impl.h) ---- */
+struct bto_packet {
+    char sym[3125 + 64];          /* d_symbols: zero-initialised, clipped copy (packet::packet :41-59) */
+    int length;                   /* d_length */
+    uint32_t clkn; int channel; uint32_t lap;
+    int type, uap;                /* d_packet_type (0 at construction), d_UAP */
+    uint32_t clock; int have_clk6, have_clk27;
+    int have_payload, payload_length, payload_header_length, llid, flow;
+    char header[18];              /* d_packet_header */
+    char payload[3000];           /* d_payload, one bit per byte */
+};
 
-static int payload_crc_ok(const payload_t *p, int uap)
+bto_packet *bto_packet_new(const char *symbols, int length, uint32_t clkn, int channel)
 {
-    unsigned crc = bto_crcgen(p->bits, (p->length - 2) * 8, uap);
-    unsigned chk = air_bits(&p->bits[(p->length - 2) * 8], 16);
+    bto_packet *p = (bto_packet *)calloc(1, sizeof *p);
+    if (length > 3125) length = 3125;
+    memcpy(p->sym, symbols, (size_t)(length > 0 ? length : 0));
+    p->length = length; p->clkn = clkn; p->channel = channel;
+    p->lap = air_bits(&p->sym[38], 24);
+    return p;
+}
+void bto_packet_free(bto_packet *p) { free(p); }
+int  bto_packet_type(const bto_packet *p) { return p->type; }
+int  bto_packet_uap(const bto_packet *p) { return p->uap; }
+
+static int payload_crc_ok(const bto_packet *p)                                  /* :675-686 */
+{
+    unsigned crc = bto_crcgen(p->payload, (p->payload_length - 2) * 8, p->uap);
+    unsigned chk = air_bits(&p->payload[(p->payload_length - 2) * 8], 16);
     return crc == chk;
 }
 
-static int pk_fhs(const char *s, int len, int clock, int uap)                  /* :688-722 */
+static int pk_fhs(bto_packet *p, int clock)                                     /* :688-722 */
 {
-    const char *stream = s + 126;
-    int size = len - 126;
-    payload_t p; p.length = 20;
-    if (size < p.length * 12) return 1;
+    const char *stream = p->sym + 126;
+    int size = p->length - 126;
+    p->payload_length = 20;
+    if (size < p->payload_length * 12) return 1;
     char corrected[160];
-    if (!bto_unfec23(stream, p.length * 8, corrected)) return 0;
-    bto_unwhiten(corrected, p.bits, clock, p.length * 8, 18);
-    if (payload_crc_ok(&p, uap)) return 1000;
+    if (!bto_unfec23(stream, p->payload_length * 8, corrected)) return 0;
+    bto_unwhiten(corrected, p->payload, clock, p->payload_length * 8, 18);
+    if (payload_crc_ok(p)) return 1000;
     for (int c = 32; c < 64; c++) {
-        bto_unwhiten(corrected, p.bits, c, p.length * 8, 18);
-        if (payload_crc_ok(&p, uap)) return 1000;
+        bto_unwhiten(corrected, p->payload, c, p->payload_length * 8, 18);
+        if (payload_crc_ok(p)) return 1000;
     }
     return 0;
 }
 
-/* :725-767; returns 0 on failure, else sets *plen (bytes incl. payload header and CRC) */
-static int payload_header(const char *stream, int clock, int header_bytes, int size, int fec, int *plen)
+/* :725-767 */
+static int payload_header(bto_packet *p, const char *stream, int clock, int header_bytes, int size, int fec)
 {
     char ph[16], corrected[20];
     if (header_bytes == 2) {
@@ -205,7 +227,7 @@ static int payload_header(const char *stream, int clock, int header_bytes, int s
             if (!bto_unfec23(stream, 16, corrected)) return 0;
             bto_unwhiten(corrected, ph, clock, 16, 18);
         } else bto_unwhiten(stream, ph, clock, 16, 18);
-        *plen = (int)air_bits(&ph[3], 10) + 4;
+        p->payload_length = (int)air_bits(&ph[3], 10) + 4;
     } else {
         if (size < 8) return 0;
         if (fec) {
@@ -213,117 +235,149 @@ static int payload_header(const char *stream, int clock, int header_bytes, int s
             if (!bto_unfec23(stream, 8, corrected)) return 0;
             bto_unwhiten(corrected, ph, clock, 8, 18);
         } else bto_unwhiten(stream, ph, clock, 8, 18);
-        *plen = (int)air_bits(&ph[3], 5) + 3;
+        p->payload_length = (int)air_bits(&ph[3], 5) + 3;
     }
+    p->llid = (int)air_bits(&ph[0], 2);
+    p->flow = (int)air_bits(&ph[2], 1);
+    p->payload_header_length = header_bytes;
     return 1;
 }
 
-static int pk_dm(const char *s, int len, int clock, int type, int uap)          /* :770-830 */
+static int pk_dm(bto_packet *p, int clock)                                      /* :770-830 */
 {
-    const char *stream = s + 126;
-    int size = len - 126, header_bytes = 2, max_length;
-    switch (type) {
+    const char *stream = p->sym + 126;
+    int size = p->length - 126, header_bytes = 2, max_length;
+    switch (p->type) {
         case 8: stream += 80; size -= 80; header_bytes = 1; max_length = 12; break;
         case 3: header_bytes = 1; max_length = 20; break;
         case 10: max_length = 125; break;
         case 14: max_length = 228; break;
         default: return 0;
     }
-    payload_t p;
-    if (!payload_header(stream, clock, header_bytes, size, 1, &p.length)) return 0;
-    if (p.length > max_length) return 1;
-    int bitlength = p.length * 8;
+    if (!payload_header(p, stream, clock, header_bytes, size, 1)) return 0;
+    if (p->payload_length > max_length) return 1;
+    int bitlength = p->payload_length * 8;
     if (bitlength > size) return 1;
     char *corrected = (char *)malloc((size_t)bitlength + 16);
     int ok = bto_unfec23(stream, bitlength, corrected);
     if (!ok) { free(corrected); return 0; }
-    bto_unwhiten(corrected, p.bits, clock, bitlength, 18);
+    bto_unwhiten(corrected, p->payload, clock, bitlength, 18);
     free(corrected);
-    return payload_crc_ok(&p, uap) ? 10 : 1;
+    return payload_crc_ok(p) ? 10 : 1;
 }
 
-static int pk_dh(const char *s, int len, int clock, int type, int uap)          /* :834-884 */
+static int pk_dh(bto_packet *p, int clock)                                      /* :834-884 */
 {
-    const char *stream = s + 126;
-    int size = len - 126, header_bytes = 2, max_length;
-    switch (type) {
+    const char *stream = p->sym + 126;
+    int size = p->length - 126, header_bytes = 2, max_length;
+    switch (p->type) {
         case 9: case 4: header_bytes = 1; max_length = 30; break;
         case 11: max_length = 187; break;
         case 15: max_length = 343; break;
         default: return 0;
     }
-    payload_t p;
-    if (!payload_header(stream, clock, header_bytes, size, 0, &p.length)) return 0;
-    if (p.length > max_length) return 1;
-    int bitlength = p.length * 8;
+    if (!payload_header(p, stream, clock, header_bytes, size, 0)) return 0;
+    if (p->payload_length > max_length) return 1;
+    int bitlength = p->payload_length * 8;
     if (bitlength > size) return 1;
-    bto_unwhiten(stream, p.bits, clock, bitlength, 18);
-    if (type == 9) return 1;
-    return payload_crc_ok(&p, uap) ? 10 : 1;
+    bto_unwhiten(stream, p->payload, clock, bitlength, 18);
+    if (p->type == 9) return 1;
+    return payload_crc_ok(p) ? 10 : 1;
 }
 
-static int pk_ev35(const char *s, int len, int clock, int uap, int maxlength)   /* :886-915, :971-1000 */
+static int pk_ev35(bto_packet *p, int clock, int maxlength)                     /* :886-915, :971-1000 */
 {
-    const char *stream = s + 126;
-    int size = len - 126;
-    payload_t p;
-    for (p.length = 0; p.length < maxlength; p.length++) {
-        int bits = p.length * 8;
+    const char *stream = p->sym + 126;
+    int size = p->length - 126;
+    for (p->payload_length = 0; p->payload_length < maxlength; p->payload_length++) {
+        int bits = p->payload_length * 8;
         if (bits + 8 > size) return 1;
         /* the reference unwhitens `stream` (not stream + bits) into d_payload + bits */
-        bto_unwhiten(stream, p.bits + bits, clock, 8, 18 + bits);
-        if (p.length > 2 && payload_crc_ok(&p, uap)) return 10;
+        bto_unwhiten(stream, p->payload + bits, clock, 8, 18 + bits);
+        if (p->payload_length > 2 && payload_crc_ok(p)) return 10;
     }
     return 1;
 }
 
-static int pk_ev4(const char *s, int len, int clock, int uap)                   /* :917-969 */
+static int pk_ev4(bto_packet *p, int clock)                                     /* :917-969 */
 {
-    const char *stream = s + 126;
-    int size = len - 126, syms = 0, bits = 0;
-    payload_t p; p.length = 1;
+    const char *stream = p->sym + 126;
+    int size = p->length - 126, syms = 0, bits = 0;
+    p->payload_length = 1;
     while (syms < 1470) {
         char corrected[10];
         if (syms + 15 > size) return 1;
         if (!bto_unfec23(stream + syms, 10, corrected)) return syms < 45 ? 0 : 1;
-        bto_unwhiten(corrected, p.bits + bits, clock, 10, 18 + bits);
-        while (p.length * 8 <= bits) {
-            if (payload_crc_ok(&p, uap)) return 10;
-            p.length++;
+        bto_unwhiten(corrected, p->payload + bits, clock, 10, 18 + bits);
+        while (p->payload_length * 8 <= bits) {
+            if (payload_crc_ok(p)) return 10;
+            p->payload_length++;
         }
         syms += 15; bits += 10;
     }
     return 1;
 }
 
-static int pk_hv(const char *s, int len, int type)                              /* :1003-1043 */
+static int pk_hv(bto_packet *p, int clock)                                      /* :1003-1043 */
 {
-    int size = len - 126;
-    if (size < 240) return 1;
-    if (type == 5) {                       /* crc_check only routes HV1 here */
-        char corrected[80];
-        if (!bto_unfec13(s + 126, corrected, 80)) return 0;
+    const char *stream = p->sym + 126;
+    int size = p->length - 126;
+    if (size < 240) { p->payload_length = 0; return 1; }
+    switch (p->type) {
+        case 5: {
+            char corrected[80];
+            if (!bto_unfec13(stream, corrected, 80)) return 0;
+            p->payload_length = 10;
+            bto_unwhiten(corrected, p->payload, clock, 80, 18);
+            break;
+        }
+        case 6: {
+            char corrected[160];
+            if (!bto_unfec23(stream, 160, corrected)) return 0;
+            p->payload_length = 20;
+            bto_unwhiten(corrected, p->payload, clock, 160, 18);
+            break;
+        }
+        case 7:
+            p->payload_length = 30;
+            bto_unwhiten(stream, p->payload, clock, 240, 18);
+            break;
+        default: break;
     }
     return 1;
 }
 
+/* :1046-1063 on the packet object */
+int bto_packet_try_clock(bto_packet *p, int clock)
+{
+    return bto_try_clock(p->sym, clock, &p->type, &p->uap);
+}
+
 /* :612-671 -- 1 inconclusive, > 1 positive, 0 negative */
-int bto_crc_check(const char *symbols, int length, int clock, int type, int uap)
+int bto_packet_crc_check(bto_packet *p, int clock)
 {
     int r = 1;
-    if (length > 3125) length = 3125;                      /* packet::packet clips to MAX_SYMBOLS (:52-54) */
-    switch (type) {
-        case 2: r = pk_fhs(symbols, length, clock, uap); break;
-        case 8: case 3: case 10: case 14: r = pk_dm(symbols, length, clock, type, uap); break;
-        case 4: case 11: case 15: r = pk_dh(symbols, length, clock, type, uap); break;
-        case 7: r = pk_ev35(symbols, length, clock, uap, 32); break;
-        case 12: r = pk_ev4(symbols, length, clock, uap); break;
-        case 13: r = pk_ev35(symbols, length, clock, uap, 182); break;
-        case 5: r = pk_hv(symbols, length, type); break;
+    switch (p->type) {
+        case 2: r = pk_fhs(p, clock); break;
+        case 8: case 3: case 10: case 14: r = pk_dm(p, clock); break;
+        case 4: case 11: case 15: r = pk_dh(p, clock); break;
+        case 7: r = pk_ev35(p, clock, 32); break;
+        case 12: r = pk_ev4(p, clock); break;
+        case 13: r = pk_ev35(p, clock, 182); break;
+        case 5: r = pk_hv(p, clock); break;
         default: break;
     }
-    if (r == 0 && type != 2 && type != 3 && type != 5) return 1;
-    if (r > 1 && (type == 7 || type == 13)) return 1;
+    if (r == 0 && p->type != 2 && p->type != 3 && p->type != 5) return 1;
+    if (r > 1 && (p->type == 7 || p->type == 13)) return 1;
+    return r;
+}
+
+int bto_crc_check(const char *symbols, int length, int clock, int type, int uap)
+{
+    bto_packet *p = bto_packet_new(symbols, length, 0, 0);
+    p->type = type; p->uap = uap;
+    int r = bto_packet_crc_check(p, clock);
+    bto_packet_free(p);
     return r;
 }
 
@@ -334,50 +388,43 @@ void bto_piconet_init(bto_piconet *pn, uint32_t lap)
     pn->lap = lap;
 }
 
+#define LOGF(...) do { if (log) { size_t n__ = strlen(log); if (n__ < cap) snprintf(log + n__, cap - n__, __VA_ARGS__); } } while (0)
+
 static void pn_reset(bto_piconet *pn, char *log, size_t cap)                     /* :526-547 */
 {
-    if (log) snprintf(log + strlen(log), cap - strlen(log), "no candidates remaining! starting over . . .\n");
+    LOGF("no candidates remaining! starting over . . .\n");
     pn->got_first_packet = 0;
     pn->packets_observed = 0;
     pn->have_uap = 0;
     pn->have_clk6 = 0;
+    pn->have_clk27 = 0;
 }
 
-int bto_uap_from_header(bto_piconet *pn, const char *symbols, int length, uint32_t clkn, int channel,
-                        char *log, size_t cap)
+static int uap_from_header(bto_piconet *pn, bto_packet *pkt, char *log, size_t cap)
 {
-    (void)channel;
     int starting = 0, remaining = 0, first_clock = 0;
-    if (log && cap) log[0] = 0;
-    /* packet::packet (:41-59): a zero-initialised 3125-symbol copy, clipped */
-    char pkt[3125 + 64];
-    memset(pkt, 0, sizeof pkt);
-    if (length > 3125) length = 3125;
-    memcpy(pkt, symbols, (size_t)length);
-    symbols = pkt;
+    uint32_t clkn = pkt->clkn;
     if (!pn->got_first_packet) pn->first_pkt_time = clkn;
     if (pn->packets_observed >= 1000) {                                          /* MAX_PATTERN_LENGTH */
-        if (log) snprintf(log + strlen(log), cap - strlen(log), "Oops. More hops than we can remember.\n");
+        LOGF("Oops. More hops than we can remember.\n");
         pn_reset(pn, log, cap);
         return 0;
     }
     pn->packets_observed++;
     pn->total_packets_observed++;
-    int type = 0, uap_state = 0;                          /* d_packet_type = 0 (:46); d_UAP as left by try_clock */
     for (int count = 0; count < 64; count++) {
         if (pn->clock6_candidates[count] > -1 || !pn->got_first_packet) {
             int clock = (int)((count + clkn - pn->first_pkt_time) % 64);
             starting++;
-            int uap = bto_try_clock(symbols, clock, &type, &uap_state);
+            int uap = bto_packet_try_clock(pkt, clock);
             int retval = -1;
             if (!pn->got_first_packet || uap == pn->clock6_candidates[count])
-                retval = bto_crc_check(symbols, length, clock, type, uap_state);
+                retval = bto_packet_crc_check(pkt, clock);
             if (retval == -1 || retval == 0) pn->clock6_candidates[count] = -1;
             else if (retval == 1) { pn->clock6_candidates[count] = uap; first_clock = count; remaining++; }
             else {
-                if (log) snprintf(log + strlen(log), cap - strlen(log),
-                                  "Correct CRC! UAP = 0x%x found after %d total packets.\n", uap, pn->total_packets_observed);
-                pn->clk_offset = (count - (int)(pn->first_pkt_time & 0x3f)) & 0x3f;
+                LOGF("Correct CRC! UAP = 0x%x found after %d total packets.\n", uap, pn->total_packets_observed);
+                pn->clk_offset = (uint32_t)((count - (int)(pn->first_pkt_time & 0x3f)) & 0x3f);
                 pn->uap = uap; pn->have_clk6 = 1; pn->have_uap = 1;
                 pn->total_packets_observed = 0;
                 return 1;
@@ -385,16 +432,185 @@ int bto_uap_from_header(bto_piconet *pn, const char *symbols, int length, uint32
         }
     }
     pn->got_first_packet = 1;
-    if (log) snprintf(log + strlen(log), cap - strlen(log), "reduced from %d to %d CLK1-6 candidates\n", starting, remaining);
+    LOGF("reduced from %d to %d CLK1-6 candidates\n", starting, remaining);
     if (remaining == 1) {
-        pn->clk_offset = (first_clock - (int)(pn->first_pkt_time & 0x3f)) & 0x3f;
+        pn->clk_offset = (uint32_t)((first_clock - (int)(pn->first_pkt_time & 0x3f)) & 0x3f);
         pn->uap = pn->clock6_candidates[first_clock];
         pn->have_clk6 = 1; pn->have_uap = 1;
-        if (log) snprintf(log + strlen(log), cap - strlen(log),
-                          "We have a winner! UAP = 0x%x found after %d total packets.\n", pn->uap, pn->total_packets_observed);
+        LOGF("We have a winner! UAP = 0x%x found after %d total packets.\n", pn->uap, pn->total_packets_observed);
         pn->total_packets_observed = 0;
         return 1;
     }
     if (remaining == 0) pn_reset(pn, log, cap);
     return 0;
+}
+
+int bto_uap_from_header(bto_piconet *pn, const char *symbols, int length, uint32_t clkn, int channel,
+                        char *log, size_t cap)
+{
+    if (log && cap) log[0] = 0;
+    bto_packet *pkt = bto_packet_new(symbols, length, clkn, channel);
+    int r = uap_from_header(pn, pkt, log, cap);
+    bto_packet_free(pkt);
+    return r;
+}
+
+/* ---- packet::decode (:169-175), decode_header (:1066-1090), decode_payload (:1092-1165),
+ *      print (:1168-1179) ---- */
+static int decode_header(bto_packet *p, char *log, size_t cap)
+{
+    char header[18];
+    if (p->have_clk6 && bto_unfec13(p->sym + 72, header, 18)) {
+        bto_unwhiten(header, p->header, (int)p->clock, 18, 0);
+        unsigned data = air_bits(p->header, 10), hec = air_bits(p->header + 10, 8);
+        int uap = bto_uap_from_hec(data, hec);
+        if (uap == p->uap) { p->type = (int)air_bits(&p->header[3], 4); return 1; }
+        LOGF("bad HEC! %02x %02x %i ", uap, p->uap, (int)air_bits(&p->header[3], 4));
+    }
+    LOGF("failed to decode header\n");
+    return 0;
+}
+
+static void decode_payload(bto_packet *p)
+{
+    int clk = (int)p->clock;
+    p->payload_header_length = 0;
+    switch (p->type) {
+        case 0: case 1: p->payload_length = 0; break;
+        case 2: pk_fhs(p, clk); break;
+        case 3: pk_dm(p, clk); break;
+        case 4: pk_dh(p, clk); break;
+        case 5: case 6: pk_hv(p, clk); break;
+        case 7: if (pk_ev35(p, clk, 32) <= 1) pk_hv(p, clk); break;
+        case 8: pk_dm(p, clk); break;
+        case 9: pk_dh(p, clk); break;
+        case 10: pk_dm(p, clk); break;
+        case 11: pk_dh(p, clk); break;
+        case 12: pk_ev4(p, clk); break;
+        case 13: pk_ev35(p, clk, 182); pk_dm(p, clk); break;      /* EV5 falls through into the DM5 case (Q11) */
+        case 14: pk_dm(p, clk); break;
+        case 15: pk_dh(p, clk); break;
+    }
+    p->have_payload = 1;
+}
+
+static const char *TYPE_NAME[16] = {"NULL", "POLL", "FHS", "DM1", "DH1/2-DH1", "HV1", "HV2/2-EV3", "HV3/EV3/3-EV3",
+                                    "DV/3-DH1", "AUX1", "DM3/2-DH3", "DH3/3-DH3", "EV4/2-EV5", "EV5/3-EV5",
+                                    "DM5/2-DH5", "DH5/3-DH5"};
+
+/* ---- multi_sniffer_impl::ac / id / decode / discover / recall / fhs (lib/multi_sniffer_impl.cc:169-365),
+ *      tun = false ---- */
+#define MAX_PN 64
+#define MAX_Q 1024
+typedef struct { int used; bto_piconet pn; bto_packet *queue[MAX_Q]; int qn; uint32_t nap; int have_nap; } pn_slot;
+struct bto_sniffer { pn_slot pn[MAX_PN]; };
+
+bto_sniffer *bto_sniffer_new(void) { return (bto_sniffer *)calloc(1, sizeof(bto_sniffer)); }
+void bto_sniffer_free(bto_sniffer *s)
+{
+    if (!s) return;
+    for (int i = 0; i < MAX_PN; i++) for (int k = 0; k < s->pn[i].qn; k++) bto_packet_free(s->pn[i].queue[k]);
+    free(s);
+}
+
+static pn_slot *pn_get(bto_sniffer *s, uint32_t lap, int create)
+{
+    for (int i = 0; i < MAX_PN; i++) if (s->pn[i].used && s->pn[i].pn.lap == lap) return &s->pn[i];
+    if (!create) return NULL;
+    for (int i = 0; i < MAX_PN; i++) if (!s->pn[i].used) {
+        memset(&s->pn[i], 0, sizeof s->pn[i]);
+        s->pn[i].used = 1; bto_piconet_init(&s->pn[i].pn, lap);
+        return &s->pn[i];
+    }
+    return NULL;
+}
+static void pn_erase(bto_sniffer *s, uint32_t lap)
+{
+    pn_slot *q = pn_get(s, lap, 0);
+    if (!q) return;
+    for (int k = 0; k < q->qn; k++) bto_packet_free(q->queue[k]);
+    q->used = 0; q->qn = 0;
+}
+
+static void sn_discover(bto_sniffer *s, pn_slot *q, bto_packet *pkt, char *log, size_t cap);
+
+static void sn_fhs(bto_sniffer *s, bto_packet *pkt, char *log, size_t cap)         /* :324-365 */
+{
+    uint32_t lap = air_bits(&pkt->payload[34], 24);
+    unsigned uap = air_bits(&pkt->payload[64], 8);
+    unsigned nap = air_bits(&pkt->payload[72], 16) & 0xff;    /* nap_from_fhs uses air_to_host8(..., 16) (Q11) */
+    uint32_t clk = air_bits(&pkt->payload[115], 26) << 1;
+    uint32_t offset = (clk - pkt->clkn) & 0x7ffffff;
+    LOGF("FHS contents: BD_ADDR %2.2x:%2.2x:%2.2x:%2.2x:%2.2x:%2.2x, CLK %07x\n", (nap >> 8) & 0xff, nap & 0xff, uap,
+         (lap >> 16) & 0xff, (lap >> 8) & 0xff, lap & 0xff, clk);
+    pn_slot *q = pn_get(s, lap, 1);
+    if (!q) return;
+    q->pn.uap = (int)uap; q->pn.have_uap = 1;
+    q->nap = nap; q->have_nap = 1;
+    q->pn.clk_offset = offset; q->pn.have_clk6 = 1; q->pn.have_clk27 = 1;
+}
+
+static void sn_decode(bto_sniffer *s, pn_slot *q, bto_packet *pkt, int first_run, char *log, size_t cap)   /* :235-280 */
+{
+    uint32_t clock = pkt->clkn + q->pn.clk_offset;
+    pkt->clock = q->pn.have_clk27 ? (clock & 0x7ffffff) : (clock & 0x3f);
+    pkt->have_clk6 = 1; pkt->have_clk27 = q->pn.have_clk27;
+    pkt->uap = q->pn.uap;
+    pkt->have_payload = 0;
+    if (decode_header(pkt, log, cap)) decode_payload(pkt);
+    if (pkt->have_payload) {
+        LOGF("%s\n", TYPE_NAME[pkt->type & 15]);
+        if (pkt->payload_header_length > 0)
+            LOGF("  LLID: %d\n  flow: %d\n  payload length: %d\n", pkt->llid, pkt->flow, pkt->payload_length);
+        if (pkt->type == 2) sn_fhs(s, pkt, log, cap);
+        bto_packet_free(pkt);
+    } else if (first_run) {
+        LOGF("lost clock!\n");
+        pn_reset(&q->pn, log, cap);
+        sn_discover(s, q, pkt, log, cap);
+    } else {
+        LOGF("Giving up on queued packet!\n");
+        bto_packet_free(pkt);
+    }
+}
+
+static void sn_recall(bto_sniffer *s, pn_slot *q, char *log, size_t cap)           /* :303-319 */
+{
+    LOGF("Decoding queued packets\n");
+    while (q->qn > 0) {
+        bto_packet *pkt = q->queue[0];
+        memmove(&q->queue[0], &q->queue[1], sizeof(q->queue[0]) * (size_t)(q->qn - 1));
+        q->qn--;
+        LOGF("time %6d, channel %2d, LAP %06x ", (int)pkt->clkn, pkt->channel, pkt->lap);
+        sn_decode(s, q, pkt, 0, log, cap);
+    }
+    LOGF("Finished decoding queued packets\n");
+}
+
+static void sn_discover(bto_sniffer *s, pn_slot *q, bto_packet *pkt, char *log, size_t cap)   /* :286-297 */
+{
+    LOGF("working on UAP/CLK1-6\n");
+    if (q->qn < MAX_Q) q->queue[q->qn++] = pkt;
+    if (uap_from_header(&q->pn, pkt, log, cap)) sn_recall(s, q, log, cap);
+}
+
+/* one classic hit: `symbols` from the access code on, `len` symbols (lib/multi_sniffer_impl.cc:169-205).
+ * Appends everything the reference prints for it to `log`. */
+void bto_sniffer_ac(bto_sniffer *s, const char *symbols, int len, uint32_t clkn, int channel, double snr,
+                    char *log, size_t cap)
+{
+    clkn &= 0x7ffffff;
+    bto_packet *pkt = bto_packet_new(symbols, len, clkn, channel);
+    uint32_t lap = pkt->lap;
+    LOGF("time %6d, snr=%.1f, channel %2d, LAP %06x ", (int)clkn, snr, channel, lap);
+    if (bto_header_present(pkt->sym, pkt->length)) {
+        pn_slot *q = pn_get(s, lap, 1);
+        if (!q) { bto_packet_free(pkt); return; }
+        if (q->pn.have_clk6 && q->pn.have_uap) sn_decode(s, q, pkt, 1, log, cap);
+        else sn_discover(s, q, pkt, log, cap);
+        if (lap == 0x9e8b33 || lap == 0x9e8b00) pn_erase(s, lap);
+    } else {
+        LOGF("ID\n");
+        bto_packet_free(pkt);
+    }
 }

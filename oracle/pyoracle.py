@@ -111,6 +111,13 @@ def lib():
     L.bto_uap_from_header.restype = ctypes.c_int
     L.bto_uap_from_header.argtypes = [ctypes.POINTER(PiconetState), ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32,
                                       ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    L.bto_sniffer_new.restype = vp
+    L.bto_sniffer_new.argtypes = []
+    L.bto_sniffer_free.restype = None
+    L.bto_sniffer_free.argtypes = [vp]
+    L.bto_sniffer_ac.restype = None
+    L.bto_sniffer_ac.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_double,
+                                 ctypes.c_char_p, ctypes.c_size_t]
     L.bto_unfec23.restype = ctypes.c_int
     L.bto_unfec23.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.bto_work.restype = ctypes.c_int
@@ -180,8 +187,8 @@ def btbb_find_ac(symbols, search_length=None, max_ac_errors=1):
 class PiconetState(ctypes.Structure):
     _fields_ = [("lap", ctypes.c_uint32), ("got_first_packet", ctypes.c_int), ("packets_observed", ctypes.c_int),
                 ("total_packets_observed", ctypes.c_int), ("first_pkt_time", ctypes.c_uint32),
-                ("clock6_candidates", ctypes.c_int * 64), ("clk_offset", ctypes.c_int), ("uap", ctypes.c_int),
-                ("have_uap", ctypes.c_int), ("have_clk6", ctypes.c_int)]
+                ("clock6_candidates", ctypes.c_int * 64), ("clk_offset", ctypes.c_uint32), ("uap", ctypes.c_int),
+                ("have_uap", ctypes.c_int), ("have_clk6", ctypes.c_int), ("have_clk27", ctypes.c_int)]
 
 
 class Piconet:
@@ -197,6 +204,29 @@ class Piconet:
         log = ctypes.create_string_buffer(2048)
         r = lib().bto_uap_from_header(ctypes.byref(self.st), s.tobytes() + bytes(64), len(s), int(clkn), int(channel), log, 2048)
         return bool(r), log.value.decode()
+
+
+class Sniffer:
+    """The handler half of multi_sniffer_impl (ac / id / discover / recall / decode / fhs,
+    lib/multi_sniffer_impl.cc:169-365): feed classic hits in the order work() reports them, get the
+    text the reference prints."""
+
+    def __init__(self):
+        self.h = lib().bto_sniffer_new()
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().bto_sniffer_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def ac(self, symbols, clkn, channel, snr):
+        s = np.ascontiguousarray(symbols, dtype=np.uint8)
+        log = ctypes.create_string_buffer(1 << 16)
+        lib().bto_sniffer_ac(self.h, s.tobytes() + bytes(64), len(s), int(clkn), int(channel), float(snr), log, 1 << 16)
+        return log.value.decode()
 
 
 def try_clock(symbols, clock):

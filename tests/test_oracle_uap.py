@@ -73,3 +73,21 @@ def test_unfec23_never_corrects_data_bits(po):
         assert L.bto_unfec23(e1.tobytes(), 10, out) == 1 and list(out.raw[:10]) == d
         e2 = cw.copy(); e2[rng.integers(0, 10)] ^= 1                         # one data bit wrong: >= 2 parity mismatches
         assert L.bto_unfec23(e2.tobytes(), 10, out) == 0
+
+
+def test_sniffer_handlers_on_channel37(po):
+    """multi_sniffer_impl::ac/discover/recall/decode over the capture's hits (clkn = symbol offset / 625):
+    the ID line for a header-less hit, the discovery dialogue, the queued packets decoded after the
+    winner, and the re-discovery after the capture's clock drift breaks the HEC."""
+    bits = _channel37()
+    sn = po.Sniffer()
+    text = "".join(sn.ac(bits[off:off + 3125], off // 625, 37, 20.0) for off, lap, errs in po.scan_symbols(bits)[:9])
+    lines = text.split("\n")
+    assert lines[0] == "time    105, snr=20.0, channel 37, LAP f2f57b ID"
+    assert lines[1] == "time    330, snr=20.0, channel 37, LAP 24d952 working on UAP/CLK1-6"
+    assert "We have a winner! UAP = 0xaf found after 3 total packets." in lines
+    i = lines.index("Decoding queued packets")
+    assert lines[i + 1] == "time    330, channel 37, LAP 24d952 HV3/EV3/3-EV3"
+    assert lines[i + 4] == "Finished decoding queued packets"
+    assert "time    998, snr=20.0, channel 37, LAP 24d952 POLL" in lines
+    assert any(l.endswith("bad HEC! fd af 11 failed to decode header") for l in lines) and "lost clock!" in lines
