@@ -30,7 +30,7 @@ MODE_LAP, MODE_SNIFFER = 0, 1
 CHANNELIZER_AUTO, CHANNELIZER_DIRECT, CHANNELIZER_POLYPHASE = 0, 1, 2
 SQUELCH_AUTO, SQUELCH_DIRECT, SQUELCH_STAGED = 0, 1, 2
 CORRELATOR_AUTO, CORRELATOR_INTREE, CORRELATOR_BTBB = 0, 1, 2   # multi_LAP default: BTBB (libbtbb, as the reference)
-FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS = 1, 2, 4, 8
+FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS, FLAG_HEADERS = 1, 2, 4, 8, 16
 KIND_AC, KIND_AA = 0, 1
 
 
@@ -76,7 +76,7 @@ class Timing(ctypes.Structure):
 EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_strerror",
            "btgpu_version", "btgpu_create", "btgpu_destroy", "btgpu_get_design", "btgpu_history",
            "btgpu_last_error", "btgpu_work", "btgpu_push", "btgpu_process_device", "btgpu_poll",
-           "btgpu_poll_symbols", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch"]
+           "btgpu_poll_symbols", "btgpu_poll_headers", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch"]
 
 
 class BtgpuError(RuntimeError):
@@ -151,6 +151,9 @@ def lib():
     L.btgpu_poll.argtypes = [vp, ctypes.POINTER(Hit), ctypes.c_int]
     L.btgpu_pending.restype = ctypes.c_int
     L.btgpu_pending.argtypes = [vp]
+    L.btgpu_poll_headers.restype = ctypes.c_int
+    L.btgpu_poll_headers.argtypes = [vp, ctypes.POINTER(Hit), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     L.btgpu_poll_symbols.restype = ctypes.c_int
     L.btgpu_poll_symbols.argtypes = [vp, ctypes.POINTER(Hit), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_int), ctypes.c_int]
@@ -341,6 +344,25 @@ class _MultiBlock:
                 raise BtgpuError(got, "btgpu_poll_symbols")
             hits, syms, lens = hits[:got], syms[:got], lens[:got]
         return hits, syms, lens
+
+    HEADER_DTYPE = np.dtype([("uap", np.uint8, 64), ("type", np.uint8, 64), ("fec13_ok", "<i4"), ("reserved", "<i4")])
+
+    def poll_headers(self, sym_cap=3125, max_hits=1 << 16):
+        """poll_symbols plus, per hit, what classic_packet::try_clock gives for the 64 CLK1-6
+        candidates (needs flags=FLAG_HEADERS): (hits, headers [n] of HEADER_DTYPE, symbols, lens)."""
+        n = min(max(self._L.btgpu_pending(self._h), 0), max_hits)
+        hits = np.zeros(n, self.HIT_DTYPE)
+        hdrs = np.zeros(n, self.HEADER_DTYPE)
+        syms = np.zeros((n, sym_cap), np.uint8)
+        lens = np.zeros(n, np.int32)
+        if n:
+            got = self._L.btgpu_poll_headers(self._h, hits.ctypes.data_as(ctypes.POINTER(Hit)), hdrs.ctypes.data_as(ctypes.c_void_p),
+                                             syms.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), sym_cap,
+                                             lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n)
+            if got < 0:
+                raise BtgpuError(got, "btgpu_poll_headers")
+            hits, hdrs, syms, lens = hits[:got], hdrs[:got], syms[:got], lens[:got]
+        return hits, hdrs, syms, lens
 
     def timing(self):
         t = Timing()

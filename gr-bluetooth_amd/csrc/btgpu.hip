@@ -72,7 +72,8 @@ struct btgpu_handle {
     hipStream_t stream = nullptr;
     hipStream_t tail_stream = nullptr;
     struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
-        DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_d2, d_winfin, d_symbits;
+        DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_d2, d_winfin, d_symbits, d_hdr;
+        HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
         DeviceHit *h_hits = nullptr;          // pinned: first kEagerHits records, copied by the tail stream
@@ -90,7 +91,8 @@ struct btgpu_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     static constexpr unsigned kEagerHits = 65536;
     static constexpr unsigned kEagerFin = 8192;
-    bool want_syms = false;
+    bool want_syms = false, want_hdrs = false;
+    std::vector<btgpu_header> qhdr;              // header sweep per queued hit (BTGPU_FLAG_HEADERS)
     std::vector<std::vector<uint32_t>> qbits;    // packed symbols per queued hit (BTGPU_FLAG_SYMBOLS)
     std::string err;
     int sticky = BTGPU_OK;
@@ -106,7 +108,7 @@ struct btgpu_handle {
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
-    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol;
+    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
     LaunchShape shape_s1;
     bool noise_pfb = false;
     bool fuse_noise = false;         // noise stage 1 rides on the channel bank's staged input
@@ -154,12 +156,13 @@ struct btgpu_handle {
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
-                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol};
+                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d2.p = nullptr;
-                      tc[1].d_winfin.p = tc[1].d_symbits.p = nullptr; }
+                      tc[1].d_winfin.p = tc[1].d_symbits.p = tc[1].d_hdr.p = nullptr; }
         for (TailCtx &t : tc) {
-            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_d2, &t.d_winfin, &t.d_symbits};
+            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_d2, &t.d_winfin, &t.d_symbits, &t.d_hdr};
+            if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
             for (auto &e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -369,6 +372,15 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             hipLaunchKernelGGL(nsym_patch_kernel, dim3(32), dim3(256), 0, tail_stream, (DeviceHit *)d_hits.p,
                                (const unsigned int *)d_hitcount.p, max_hits, (const int *)d_winlen.p, nch,
                                want_syms ? (const int *)d_winfin.p : (const int *)nullptr);
+            if (want_hdrs) {
+                const btgpu_design &dd = des.d;
+                hipLaunchKernelGGL(header_sweep_kernel, dim3(1024), dim3(64), 0, tail_stream, (const DeviceHit *)d_hits.p,
+                                   (const unsigned int *)d_hitcount.p, max_hits, (const uint32_t *)d_symbits.p,
+                                   (const uint32_t *)d_wh18.p, dd.correlator == BTGPU_CORRELATOR_BTBB ? 68 : 72,
+                                   (HeaderRec *)t.d_hdr.p);
+                HIPCHK(this, hipMemcpyAsync(t.h_hdr, t.d_hdr.p, std::min<size_t>((size_t)max_hits, (size_t)kEagerFin) * sizeof(HeaderRec),
+                                         hipMemcpyDeviceToHost, tail_stream));
+            }
             if (want_syms)
                 HIPCHK(this, hipMemcpyAsync(t.h_sym, d_symbits.p, (size_t)kEagerFin * kSymWords * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, tail_stream));
@@ -420,7 +432,9 @@ int btgpu_handle::harvest(TailCtx &t)
             HIPCHK(this, hipStreamSynchronize(copy_stream));
         }
         size_t q0 = queue.size();
+        size_t hi = 0;
         for (const DeviceHit &x : hh) {
+            const size_t hit_index = hi++;
             btgpu_hit o{};
             o.slot = t.abs_first_slot + x.slot;
             o.channel = d.low_channel + x.channel_idx;
@@ -444,6 +458,18 @@ int btgpu_handle::harvest(TailCtx &t)
                 }
                 qbits.push_back(std::move(bits));
             }
+            if (want_hdrs) {
+                btgpu_header hd;
+                std::memset(&hd, 0, sizeof hd);
+                HeaderRec r;
+                if (hit_index < kEagerFin) r = t.h_hdr[hit_index];
+                else {
+                    HIPCHK(this, hipMemcpyAsync(&r, (const HeaderRec *)t.d_hdr.p + hit_index, sizeof r, hipMemcpyDeviceToHost, copy_stream));
+                    HIPCHK(this, hipStreamSynchronize(copy_stream));
+                }
+                std::memcpy(hd.uap, r.uap, 64); std::memcpy(hd.type, r.type, 64); hd.fec13_ok = r.fec13_ok;
+                qhdr.push_back(hd);
+            }
         }
         auto less = [](const btgpu_hit &a, const btgpu_hit &b) {
             if (a.slot != b.slot) return a.slot < b.slot;
@@ -459,8 +485,15 @@ int btgpu_handle::harvest(TailCtx &t)
             std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return less(queue[q0 + a], queue[q0 + b]); });
             std::vector<btgpu_hit> qs(n);
             std::vector<std::vector<uint32_t>> bs(n);
-            for (size_t i = 0; i < n; i++) { qs[i] = queue[q0 + idx[i]]; bs[i] = std::move(qbits[q0 + idx[i]]); }
-            for (size_t i = 0; i < n; i++) { queue[q0 + i] = qs[i]; qbits[q0 + i] = std::move(bs[i]); }
+            std::vector<btgpu_header> hs(want_hdrs ? n : 0);
+            for (size_t i = 0; i < n; i++) {
+                qs[i] = queue[q0 + idx[i]]; bs[i] = std::move(qbits[q0 + idx[i]]);
+                if (want_hdrs) hs[i] = qhdr[q0 + idx[i]];
+            }
+            for (size_t i = 0; i < n; i++) {
+                queue[q0 + i] = qs[i]; qbits[q0 + i] = std::move(bs[i]);
+                if (want_hdrs) qhdr[q0 + i] = hs[i];
+            }
         }
     }
     return rc;
@@ -666,7 +699,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (hipEventCreateWithFlags(&t.tail_done, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     h->async = (cfg->flags & BTGPU_FLAG_ASYNC) != 0;
-    h->want_syms = (cfg->flags & BTGPU_FLAG_SYMBOLS) != 0;
+    h->want_hdrs = (cfg->flags & BTGPU_FLAG_HEADERS) != 0;
+    h->want_syms = (cfg->flags & BTGPU_FLAG_SYMBOLS) != 0 || h->want_hdrs;
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != BTGPU_OK) { int c__ = rc__; std::string m__ = h->err; \
         if (getenv("BTGPU_VERBOSE")) fprintf(stderr, "btgpu_create: %s\n", m__.c_str()); return fail(c__); } } while (0)
@@ -730,6 +764,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->upload(h->d_aclo, des.ac.byte_lo, sizeof des.ac.byte_lo));
     TRY(h->upload(h->d_achi, des.ac.byte_hi, sizeof des.ac.byte_hi));
     TRY(h->upload(h->d_pcol, des.ac.btbb_pcol, sizeof des.ac.btbb_pcol));
+    TRY(h->upload(h->d_wh18, des.wh.first18, sizeof des.wh.first18));
     TRY(h->upload(h->d_le_hdr, des.le.hdr, sizeof des.le.hdr));
     TRY(h->upload(h->d_le_whiten, des.le.whiten16, sizeof des.le.whiten16));
     TRY(h->upload(h->d_le_index, des.le.index_of_channel, sizeof des.le.index_of_channel));
@@ -743,6 +778,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
         TRY(h->alloc(t.d_fin, (size_t)S * nch * sizeof(FinishRec)));
         TRY(h->alloc(t.d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
+        if (h->want_hdrs) TRY(h->alloc(t.d_hdr, (size_t)h->max_hits * sizeof(HeaderRec)));
         if (h->want_syms) {
             const size_t maxfin = std::min<size_t>((size_t)S * nch, (size_t)h->max_hits);
             TRY(h->alloc(t.d_winfin, (size_t)S * nch * sizeof(int)));
@@ -750,6 +786,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         }
     }
     for (auto &t : h->tc) {
+        if (h->want_hdrs && hipHostMalloc((void **)&t.h_hdr, (size_t)btgpu_handle::kEagerFin * sizeof(HeaderRec), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)btgpu_handle::kEagerFin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_count, 2 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_hits, (size_t)btgpu_handle::kEagerHits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
@@ -757,7 +794,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     if (!h->async) {                      // synchronous mode: one context, used for every batch
         h->tc[1].d_winlen = h->tc[0].d_winlen; h->tc[1].d_hits = h->tc[0].d_hits;
         h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d2 = h->tc[0].d_d2;
-        h->tc[1].d_winfin = h->tc[0].d_winfin; h->tc[1].d_symbits = h->tc[0].d_symbits;
+        h->tc[1].d_winfin = h->tc[0].d_winfin; h->tc[1].d_symbits = h->tc[0].d_symbits; h->tc[1].d_hdr = h->tc[0].d_hdr;
     }
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
@@ -890,18 +927,21 @@ int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits)
         std::memcpy(out, h->queue.data(), sizeof(btgpu_hit) * n);
         h->queue.erase(h->queue.begin(), h->queue.begin() + n);
         if (h->want_syms) h->qbits.erase(h->qbits.begin(), h->qbits.begin() + n);
+        if (h->want_hdrs) h->qhdr.erase(h->qhdr.begin(), h->qhdr.begin() + n);
     }
     return n;
 }
 
-int btgpu_poll_symbols(btgpu_handle *h, btgpu_hit *out, uint8_t *symbols, int sym_cap, int *sym_len, int max_hits)
+static int poll_symbols_impl(btgpu_handle *h, btgpu_hit *out, btgpu_header *hdr, uint8_t *symbols, int sym_cap, int *sym_len,
+                             int max_hits)
 {
     if (!h || (!out && max_hits > 0) || max_hits < 0 || sym_cap < 0 || (!symbols && sym_cap > 0)) return BTGPU_EINVAL;
-    if (!h->want_syms) return BTGPU_EUNSUPPORTED;
+    if (!h->want_syms || (hdr && !h->want_hdrs)) return BTGPU_EUNSUPPORTED;
     (void)h->harvest_all(false);
     int n = (int)std::min<size_t>((size_t)max_hits, h->queue.size());
     for (int i = 0; i < n; i++) {
         out[i] = h->queue[i];
+        if (hdr) hdr[i] = h->qhdr[i];
         const std::vector<uint32_t> &bits = h->qbits[i];
         // what the reference hands to ac()/aa(): &symp[i], len - i  (one symbol per byte, air order)
         int avail = bits.empty() ? 0 : out[i].nsym;
@@ -916,8 +956,21 @@ int btgpu_poll_symbols(btgpu_handle *h, btgpu_hit *out, uint8_t *symbols, int sy
     if (n > 0) {
         h->queue.erase(h->queue.begin(), h->queue.begin() + n);
         h->qbits.erase(h->qbits.begin(), h->qbits.begin() + n);
+        if (h->want_hdrs) h->qhdr.erase(h->qhdr.begin(), h->qhdr.begin() + n);
     }
     return n;
+}
+
+int btgpu_poll_symbols(btgpu_handle *h, btgpu_hit *out, uint8_t *symbols, int sym_cap, int *sym_len, int max_hits)
+{
+    return poll_symbols_impl(h, out, nullptr, symbols, sym_cap, sym_len, max_hits);
+}
+
+int btgpu_poll_headers(btgpu_handle *h, btgpu_hit *out, btgpu_header *hdr, uint8_t *symbols, int sym_cap, int *sym_len,
+                       int max_hits)
+{
+    if (!hdr && max_hits > 0) return BTGPU_EINVAL;
+    return poll_symbols_impl(h, out, hdr, symbols, sym_cap, sym_len, max_hits);
 }
 
 int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out)

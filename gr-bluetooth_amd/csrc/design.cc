@@ -351,6 +351,21 @@ int make_design(const btgpu_config &cfg, Design &o)
         }
         uint8_t wseq[127] = {1, 1, 1, 0, 0, 0, 1};           // x^7 + x^4 + 1 whitening sequence
         for (int i = 7; i < 127; i++) wseq[i] = wseq[i - 7] ^ wseq[i - 3];
+        // classic whitening: the same register run from position 6 = 1, positions 0..5 = CLK1..CLK6
+        // (the output is the bit leaving position 6); the header uses the first 18 bits
+        for (int clk = 0; clk < 64; clk++) {
+            uint8_t p[7];
+            for (int i = 0; i < 6; i++) p[i] = (clk >> i) & 1;
+            p[6] = 1;
+            uint32_t m = 0;
+            for (int k = 0; k < 18; k++) {
+                const uint8_t ob = p[6];
+                m |= (uint32_t)ob << k;
+                uint8_t q[7] = {ob, p[0], p[1], p[2], (uint8_t)(p[3] ^ ob), p[4], p[5]};
+                std::memcpy(p, q, 7);
+            }
+            o.wh.first18[clk] = m;
+        }
         for (int idx = 0; idx < 40; idx++) {
             // LE whitening LFSR: position 0 = 1, positions 1..6 = channel index MSB first
             uint8_t p[7], s7[7];

@@ -36,6 +36,10 @@ struct AcTables {
                                          // single-error correction of a LAP bit), sync-word bit order
 };
 
+struct ClassicWhitening {                // classic_packet_impl::unwhiten (lib/packet_impl.cc:513-526)
+    uint32_t first18[64];                // first 18 whitening bits for CLK1-6 = c (bit i = i-th), for the header
+};
+
 struct LeTables {                       // le_packet::sniff_aa (lib/packet_impl.cc:1452-1527)
     uint8_t hdr[4][256];                 // min Hamming distance to the valid header-byte sets:
                                          // 0 access LSB, 1 access MSB, 2 data LSB, 3 data MSB
@@ -55,6 +59,7 @@ struct Design {
     float atan_tab[257];
     AcTables ac;
     LeTables le;
+    ClassicWhitening wh;
     int blocks_per_window = 0;           // ddc_out / (slot/decim)
     int tail = 0;                        // ddc_out % (slot/decim)
     int outs_per_slot = 0;               // slot / decim

@@ -765,4 +765,59 @@ __global__ void nsym_patch_kernel(DeviceHit *__restrict__ hits, const unsigned i
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Header sweep: what basic_rate_piconet::UAP_from_header asks of a packet for
+// each of the 64 candidate clocks -- classic_packet::try_clock (lib/packet_impl.cc:1046-1063): the
+// 18 header bits out of the 1/3-rate FEC (unfec13, :367-383), unwhitened with the clock's sequence
+// (:513-526), the UAP that makes the HEC come out right (UAP_from_hec, :597-609) and the packet
+// type.  One wave per classic hit, lane = clock.  `to_header` = symbols from hit.offset to the
+// header (72 for the in-tree correlator's offset, 68 for libbtbb's).
+// ------------------------------------------------------------------------------------
+struct HeaderRec { uint8_t uap[64]; uint8_t type[64]; int32_t fec13_ok; int32_t pad_; };
+
+__global__ __launch_bounds__(64) void header_sweep_kernel(
+    const DeviceHit *__restrict__ hits, const unsigned int *__restrict__ hit_count, int max_hits,
+    const uint32_t *__restrict__ symbits, const uint32_t *__restrict__ wh18, int to_header,
+    HeaderRec *__restrict__ out)
+{
+    unsigned int n = *hit_count;
+    if (n > (unsigned int)max_hits) n = (unsigned int)max_hits;
+    const int lane = threadIdx.x;
+    const uint32_t mask = wh18[lane];
+    for (unsigned int i = blockIdx.x; i < n; i += gridDim.x) {
+        const DeviceHit h = hits[i];
+        HeaderRec *o = &out[i];
+        if (h.kind != 0 || h.sym < 0) {
+            o->uap[lane] = 0; o->type[lane] = 0;
+            if (lane == 0) { o->fec13_ok = 0; o->pad_ = 0; }
+            continue;
+        }
+        const uint32_t *row = symbits + (size_t)h.sym * kSymWords;
+        // lanes 0..17: majority vote of header bit `lane`
+        uint32_t bit = 0, dis = 0;
+        if (lane < 18) {
+            const int b0 = h.offset + to_header + 3 * lane;
+            uint32_t v[3];
+            for (int j = 0; j < 3; j++) {
+                const int b = b0 + j;
+                v[j] = (b >> 5) < kSymWords ? (row[b >> 5] >> (b & 31)) & 1u : 0u;
+            }
+            bit = (v[0] & v[1]) | (v[1] & v[2]) | (v[2] & v[0]);
+            dis = (v[0] ^ v[1]) | (v[1] ^ v[2]) | (v[2] ^ v[0]);
+        }
+        const uint32_t hdr = (uint32_t)(__ballot(bit != 0) & 0x3ffffull);
+        const int be = __popcll(__ballot(dis != 0));
+        const uint32_t plain = hdr ^ mask;
+        const uint32_t data = plain & 0x3ffu;
+        uint32_t hec = (plain >> 10) & 0xffu;
+        for (int k = 9; k >= 0; k--) {
+            if (hec & 0x80u) hec ^= 0x65u;
+            hec = ((hec << 1) | (((hec >> 7) ^ (data >> k)) & 1u)) & 0xffu;
+        }
+        o->uap[lane] = (uint8_t)(__brev(hec) >> 24);
+        o->type[lane] = (uint8_t)((plain >> 3) & 0xfu);
+        if (lane == 0) { o->fec13_ok = be < 18 / 4 ? 1 : 0; o->pad_ = 0; }
+    }
+}
+
 }  // namespace btgpu

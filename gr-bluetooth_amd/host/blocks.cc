@@ -12,6 +12,8 @@
 #include <gr_bluetooth/multi_LAP.h>
 #include <gr_bluetooth/multi_sniffer.h>
 
+#include "classic.h"
+
 namespace gr {
 namespace bluetooth {
 
@@ -19,8 +21,9 @@ multi_block::multi_block(double sample_rate, double center_freq, double squelch_
 {
     // multi_sniffer always runs the LE access-address pass after the classic one
     // (lib/multi_sniffer_impl.cc:94,129-149: leok = brok)
-    // and hands the sliced symbols of every hit to its packet handlers
-    const int flags = mode == BTGPU_MODE_SNIFFER ? (BTGPU_FLAG_LE | BTGPU_FLAG_SYMBOLS) : 0;
+    // and hands the sliced symbols of every hit, with the GPU's sweep of its packet header over the
+    // 64 clock candidates, to its packet handlers
+    const int flags = mode == BTGPU_MODE_SNIFFER ? (BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS) : 0;
     d_sample_rate = sample_rate;
     d_center_freq = center_freq;
     d_target_snr = squelch_threshold;
@@ -58,21 +61,22 @@ int multi_block::run_work(int noutput_items, gr_vector_const_void_star &input_it
         fprintf(stderr, "Error: %s (%s)\n", btgpu_strerror(rc), btgpu_last_error(d_gpu));
         abort();
     }
-    std::vector<btgpu_hit> buf(1024);
+    std::vector<btgpu_hit> buf(256);
     if (d_mode == BTGPU_MODE_SNIFFER) {
-        const int cap = 128;                          // enough for header_present (126 symbols)
+        const int cap = 3125;                         // classic_packet keeps at most MAX_SYMBOLS
         std::vector<uint8_t> syms((size_t)buf.size() * cap);
         std::vector<int> lens(buf.size());
+        std::vector<btgpu_header> hdrs(buf.size());
         for (;;) {
-            int n = btgpu_poll_symbols(d_gpu, buf.data(), syms.data(), cap, lens.data(), (int)buf.size());
+            int n = btgpu_poll_headers(d_gpu, buf.data(), hdrs.data(), syms.data(), cap, lens.data(), (int)buf.size());
             if (n <= 0) break;
-            for (int i = 0; i < n; i++) handle_hit(buf[i], syms.data() + (size_t)i * cap, lens[i]);
+            for (int i = 0; i < n; i++) handle_hit(buf[i], &hdrs[i], syms.data() + (size_t)i * cap, lens[i]);
         }
     } else {
         for (;;) {
             int n = btgpu_poll(d_gpu, buf.data(), (int)buf.size());
             if (n <= 0) break;
-            for (int i = 0; i < n; i++) handle_hit(buf[i], nullptr, 0);
+            for (int i = 0; i < n; i++) handle_hit(buf[i], nullptr, nullptr, 0);
         }
     }
     d_cumulative_count += consumed;
@@ -92,7 +96,7 @@ public:
         return run_work(noutput_items, input_items);
     }
 protected:
-    void handle_hit(const btgpu_hit &h, const uint8_t *, int) override
+    void handle_hit(const btgpu_hit &h, const btgpu_header *, const uint8_t *, int) override
     {
         // lib/multi_LAP_impl.cc:97-100
         printf("GOT PACKET: ch=%d, LAP=%06x, err=%u at time slot %d\n", h.channel, h.lap,
@@ -123,23 +127,9 @@ public:
         return run_work(noutput_items, input_items);
     }
 protected:
-    // classic_packet_impl::header_present (lib/packet_impl.cc:1205-1242): trailer + FEC 1/3 agreement
-    static bool header_present(const uint8_t *s, int avail, int nsym)
+    host::sniffer_handlers d_handlers;
+    void handle_hit(const btgpu_hit &h, const btgpu_header *hdr, const uint8_t *syms, int nsyms) override
     {
-        const int length = nsym > 3125 ? 3125 : nsym;             // packet ctor keeps at most MAX_SYMBOLS
-        if (length < 126 || avail < 126) return false;
-        const uint8_t *st = s + 67;
-        int be = 0;
-        const uint8_t msb = st[0];
-        be += st[1] ^ !msb; be += st[2] ^ msb; be += st[3] ^ !msb; be += st[4] ^ msb;
-        st += 5;
-        for (int a = 0; a < 54; a += 3) be += (st[a] ^ st[a + 1]) | (st[a + 1] ^ st[a + 2]) | (st[a + 2] ^ st[a]);
-        return be < 5;                                            // ID_THRESHOLD
-    }
-    void handle_hit(const btgpu_hit &h, const uint8_t *syms, int nsyms) override
-    {
-        // lib/multi_sniffer_impl.cc:177-178: the prefix ac() prints before the packet handlers
-        // (header/payload decode = SURVEY section 8(f) "next"), terminated here.
         if (h.kind == BTGPU_KIND_AA) {
             // aa(): "time %6d, snr=%.1f, " + le_packet::print()'s first line up to the access address
             // (lib/multi_sniffer_impl.cc:213, lib/packet_impl.cc:1586); PDU fields = "next" rows
@@ -148,9 +138,10 @@ protected:
             printf("time %6d, snr=%.1f, BTLE index=%02d, AA=%08x\n", (int)(h.slot & 0x7ffffff), h.snr_db, index, h.lap);
             return;
         }
-        printf("time %6d, snr=%.1f, channel %2d, LAP %06x ", (int)(h.slot & 0x7ffffff), h.snr_db, h.channel, h.lap);
-        if (header_present(syms, nsyms, h.nsym)) printf("\n");    // discover()/decode() output: "next" rows
-        else printf("ID\n");                                      // id(): lib/multi_sniffer_impl.cc:229-235
+        // ac() and everything it calls (lib/multi_sniffer_impl.cc:169-365): the "time ..." prefix,
+        // then ID, the UAP/CLK1-6 discovery dialogue or the decoded packet
+        const std::string text = d_handlers.ac(h, *hdr, syms, nsyms);
+        fputs(text.c_str(), stdout);
     }
 };
 

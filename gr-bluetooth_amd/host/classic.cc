@@ -1,0 +1,530 @@
+// classic.cc -- see classic.h.  Reference behaviour is kept down to its quirks:
+//  * unfec23 never corrects a data bit: the byte that collects the five syndrome bits still holds the
+//    mismatch count and is shifted once too often, so its switch cannot match (lib/packet_impl.cc:433-464);
+//  * EV3/EV5 unwhiten the first payload byte again and again (:905, :990) and their positive CRC
+//    results are discarded by crc_check (:665-667);
+//  * decode_payload's EV5 case falls through into the DM5 case (:1147-1153);
+//  * nap_from_fhs reads 16 bits through an 8-bit accumulator (:1259-1263).
+#include "classic.h"
+
+#include <cstdarg>
+#include <cstring>
+
+namespace gr {
+namespace bluetooth {
+namespace host {
+
+namespace {
+
+void appendf(std::string &out, const char *fmt, ...)
+{
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    out += buf;
+}
+
+// whitening sequence of x^7 + x^4 + 1 and, per CLK1-6 value, where in it the register that starts
+// with position 6 = 1, positions 0..5 = CLK1..CLK6 begins (lib/packet_impl.cc:84-90, :182-186)
+struct whitening_tables {
+    uint8_t seq[127];
+    uint8_t start[64];
+    whitening_tables()
+    {
+        const uint8_t seed[7] = {1, 1, 1, 0, 0, 0, 1};
+        for (int i = 0; i < 7; i++) seq[i] = seed[i];
+        for (int i = 7; i < 127; i++) seq[i] = seq[i - 7] ^ seq[i - 3];
+        for (int clk = 0; clk < 64; clk++) {
+            uint8_t reg[7], first[7];
+            for (int i = 0; i < 6; i++) reg[i] = (clk >> i) & 1;
+            reg[6] = 1;
+            for (int k = 0; k < 7; k++) {
+                const uint8_t o = reg[6];
+                first[k] = o;
+                const uint8_t nxt[7] = {o, reg[0], reg[1], reg[2], (uint8_t)(reg[3] ^ o), reg[4], reg[5]};
+                std::memcpy(reg, nxt, 7);
+            }
+            start[clk] = 0;
+            for (int i = 0; i < 127; i++) {
+                bool same = true;
+                for (int k = 0; k < 7 && same; k++) same = seq[(i + k) % 127] == first[k];
+                if (same) { start[clk] = (uint8_t)i; break; }
+            }
+        }
+    }
+};
+const whitening_tables &wt()
+{
+    static const whitening_tables t;
+    return t;
+}
+
+uint8_t reverse8(uint8_t b)
+{
+    uint8_t r = 0;
+    for (int i = 0; i < 8; i++) r |= (uint8_t)(((b >> i) & 1) << (7 - i));
+    return r;
+}
+
+const char *const TYPE_NAMES[16] = {"NULL", "POLL", "FHS", "DM1", "DH1/2-DH1", "HV1", "HV2/2-EV3", "HV3/EV3/3-EV3",
+                                    "DV/3-DH1", "AUX1", "DM3/2-DH3", "DH3/3-DH3", "EV4/2-EV5", "EV5/3-EV5",
+                                    "DM5/2-DH5", "DH5/3-DH5"};
+constexpr uint32_t GIAC = 0x9e8b33, LIAC = 0x9e8b00;
+
+}  // namespace
+
+// ------------------------------------------------------------------ classic_packet
+uint32_t classic_packet::bits(const uint8_t *air, int n)
+{
+    uint32_t v = 0;
+    for (int i = 0; i < n; i++) v |= (uint32_t)(air[i] & 1) << i;
+    return v;
+}
+
+classic_packet::classic_packet(const uint8_t *symbols, int length, uint32_t clkn, int channel, const btgpu_header &sweep)
+    : d_symbols(MAX_SYMBOLS + 64, 0), d_clkn(clkn), d_channel(channel), d_sweep(sweep), d_payload(3000, 0)
+{
+    if (length > MAX_SYMBOLS) length = MAX_SYMBOLS;
+    if (length < 0) length = 0;
+    std::memcpy(d_symbols.data(), symbols, (size_t)length);
+    d_length = length;
+    d_lap = bits(&d_symbols[38], 24);
+}
+
+bool classic_packet::header_present() const
+{
+    // trailer (4 bits alternating out of the sync word's last bit) + the 54 header symbols must
+    // look like a 1/3-rate code: fewer than ID_THRESHOLD (5) disagreements
+    if (d_length < 126) return false;
+    const uint8_t *st = &d_symbols[67];
+    int be = 0;
+    const uint8_t msb = st[0];
+    be += st[1] ^ !msb; be += st[2] ^ msb; be += st[3] ^ !msb; be += st[4] ^ msb;
+    st += 5;
+    for (int a = 0; a < 54; a += 3) be += (st[a] ^ st[a + 1]) | (st[a + 1] ^ st[a + 2]) | (st[a + 2] ^ st[a]);
+    return be < 5;
+}
+
+bool classic_packet::unfec13(const uint8_t *in, uint8_t *out, int length)
+{
+    int be = 0;
+    for (int i = 0; i < length; i++) {
+        const uint8_t a = in[3 * i] & 1, b = in[3 * i + 1] & 1, c = in[3 * i + 2] & 1;
+        out[i] = (uint8_t)((a & b) | (b & c) | (c & a));
+        be += (a ^ b) | (b ^ c) | (c ^ a);
+    }
+    return be < length / 4;
+}
+
+bool classic_packet::unfec23(const uint8_t *in, int length, std::vector<uint8_t> &out)
+{
+    if (length % 10) length += 10 - length % 10;
+    out.assign((size_t)length, 0);
+    for (int blk = 0; blk < length / 10; blk++) {
+        const uint8_t *cw = in + 15 * blk;
+        for (int k = 0; k < 10; k++) out[(size_t)10 * blk + k] = cw[k];
+        // parity of the ten data bits: the register of lfsr(data, 15, 10, {1,1,0,1,0,1})
+        // (lib/packet_impl.cc:278-307), feedback taps at positions 0, 1 and 3
+        uint8_t par[5] = {0, 0, 0, 0, 0};
+        for (int i = 9; i >= 0; i--) {
+            const uint8_t fb = (uint8_t)((cw[i] & 1) ^ par[4]);
+            par[4] = par[3];
+            par[3] = (uint8_t)(par[2] ^ fb);
+            par[2] = par[1];
+            par[1] = (uint8_t)(par[0] ^ fb);
+            par[0] = fb;
+        }
+        int mismatches = 0;
+        for (int k = 0; k < 5; k++) mismatches += par[k] != (cw[10 + k] & 1);
+        if (mismatches >= 2) return false;        // the reference's correction table is unreachable (see top)
+    }
+    return true;
+}
+
+void classic_packet::unwhiten(const uint8_t *in, uint8_t *out, int clock, int length, int skip)
+{
+    const whitening_tables &t = wt();
+    int idx = (t.start[clock & 0x3f] + skip) % 127;
+    for (int i = 0; i < length; i++) {
+        out[i] = (uint8_t)((in[i] & 1) ^ t.seq[idx]);
+        idx = idx + 1 == 127 ? 0 : idx + 1;
+    }
+}
+
+uint16_t classic_packet::crcgen(const uint8_t *payload, int length, int uap)
+{
+    uint16_t reg = (uint16_t)(reverse8((uint8_t)uap) << 8);
+    for (int i = 0; i < length; i++) {
+        reg = (uint16_t)((reg >> 1) | (((reg & 1) ^ (payload[i] & 1)) << 15));
+        reg ^= (uint16_t)((reg & 0x8000) >> 5);
+        reg ^= (uint16_t)((reg & 0x8000) >> 12);
+    }
+    return reg;
+}
+
+int classic_packet::uap_from_hec(uint16_t data, uint8_t hec)
+{
+    for (int i = 9; i >= 0; i--) {
+        if (hec & 0x80) hec ^= 0x65;
+        hec = (uint8_t)((hec << 1) | (((hec >> 7) ^ (data >> i)) & 1));
+    }
+    return reverse8(hec);
+}
+
+uint8_t classic_packet::try_clock(int clock)
+{
+    if (!d_sweep.fec13_ok) return 0;               // type and UAP stay as they were
+    d_uap = d_sweep.uap[clock & 63];
+    d_type = d_sweep.type[clock & 63];
+    return d_uap;
+}
+
+void classic_packet::set_clock(uint32_t clock, bool have27)
+{
+    d_clock = have27 ? (clock & 0x7ffffff) : (clock & 0x3f);
+    d_have_clk6 = true;
+    d_have_clk27 = have27;
+}
+
+bool classic_packet::payload_crc() const
+{
+    const uint16_t crc = crcgen(d_payload.data(), (d_payload_length - 2) * 8, d_uap);
+    return crc == (uint16_t)bits(&d_payload[(size_t)(d_payload_length - 2) * 8], 16);
+}
+
+int classic_packet::fhs(int clock)
+{
+    const uint8_t *stream = &d_symbols[126];
+    const int size = d_length - 126;
+    d_payload_length = 20;
+    if (size < d_payload_length * 12) return 1;
+    std::vector<uint8_t> corrected;
+    if (!unfec23(stream, d_payload_length * 8, corrected)) return 0;
+    unwhiten(corrected.data(), d_payload.data(), clock, d_payload_length * 8, 18);
+    if (payload_crc()) return 1000;
+    for (int c = 32; c < 64; c++) {                // every X-input value
+        unwhiten(corrected.data(), d_payload.data(), c, d_payload_length * 8, 18);
+        if (payload_crc()) return 1000;
+    }
+    return 0;
+}
+
+bool classic_packet::decode_payload_header(const uint8_t *stream, int clock, int header_bytes, int size, bool fec)
+{
+    uint8_t ph[16];
+    const int nbits = header_bytes * 8;
+    if (size < nbits) return false;
+    if (fec) {
+        if (size < nbits * 15 / 8) return false;   // 30 resp. 15 symbols
+        std::vector<uint8_t> corrected;
+        if (!unfec23(stream, nbits, corrected)) return false;
+        unwhiten(corrected.data(), ph, clock, nbits, 18);
+    } else {
+        unwhiten(stream, ph, clock, nbits, 18);
+    }
+    // body length + payload header + 2 bytes CRC
+    d_payload_length = header_bytes == 2 ? (int)bits(&ph[3], 10) + 4 : (int)bits(&ph[3], 5) + 3;
+    d_llid = (int)bits(&ph[0], 2);
+    d_flow = (int)bits(&ph[2], 1);
+    d_payload_header_length = header_bytes;
+    return true;
+}
+
+int classic_packet::DM(int clock)
+{
+    const uint8_t *stream = &d_symbols[126];
+    int size = d_length - 126, header_bytes = 2, max_length;
+    switch (d_type) {
+        case 8: stream += 80; size -= 80; header_bytes = 1; max_length = 12; break;     // DV: skip the voice field
+        case 3: header_bytes = 1; max_length = 20; break;
+        case 10: max_length = 125; break;
+        case 14: max_length = 228; break;
+        default: return 0;
+    }
+    if (!decode_payload_header(stream, clock, header_bytes, size, true)) return 0;
+    if (d_payload_length > max_length) return 1;   // could be encrypted
+    const int bitlength = d_payload_length * 8;
+    if (bitlength > size) return 1;
+    std::vector<uint8_t> corrected;
+    if (!unfec23(stream, bitlength, corrected)) return 0;
+    unwhiten(corrected.data(), d_payload.data(), clock, bitlength, 18);
+    return payload_crc() ? 10 : 1;
+}
+
+int classic_packet::DH(int clock)
+{
+    const uint8_t *stream = &d_symbols[126];
+    const int size = d_length - 126;
+    int header_bytes = 2, max_length;
+    switch (d_type) {
+        case 9: case 4: header_bytes = 1; max_length = 30; break;
+        case 11: max_length = 187; break;
+        case 15: max_length = 343; break;
+        default: return 0;
+    }
+    if (!decode_payload_header(stream, clock, header_bytes, size, false)) return 0;
+    if (d_payload_length > max_length) return 1;
+    const int bitlength = d_payload_length * 8;
+    if (bitlength > size) return 1;
+    unwhiten(stream, d_payload.data(), clock, bitlength, 18);
+    if (d_type == 9) return 1;                     // AUX1 has no CRC
+    return payload_crc() ? 10 : 1;
+}
+
+int classic_packet::EV(int clock, int maxlength)
+{
+    const uint8_t *stream = &d_symbols[126];
+    const int size = d_length - 126;
+    for (d_payload_length = 0; d_payload_length < maxlength; d_payload_length++) {
+        const int nb = d_payload_length * 8;
+        if (nb + 8 > size) return 1;
+        unwhiten(stream, &d_payload[(size_t)nb], clock, 8, 18 + nb);     // always the first byte of the stream
+        if (d_payload_length > 2 && payload_crc()) return 10;
+    }
+    return 1;
+}
+
+int classic_packet::EV4(int clock)
+{
+    const uint8_t *stream = &d_symbols[126];
+    const int size = d_length - 126;
+    int syms = 0, nb = 0;
+    d_payload_length = 1;
+    while (syms < 1470) {
+        if (syms + 15 > size) return 1;
+        std::vector<uint8_t> corrected;
+        if (!unfec23(stream + syms, 10, corrected)) return syms < 45 ? 0 : 1;
+        unwhiten(corrected.data(), &d_payload[(size_t)nb], clock, 10, 18 + nb);
+        while (d_payload_length * 8 <= nb) {
+            if (payload_crc()) return 10;
+            d_payload_length++;
+        }
+        syms += 15;
+        nb += 10;
+    }
+    return 1;
+}
+
+int classic_packet::HV(int clock)
+{
+    const uint8_t *stream = &d_symbols[126];
+    const int size = d_length - 126;
+    if (size < 240) { d_payload_length = 0; return 1; }
+    if (d_type == 5) {
+        uint8_t corrected[80];
+        if (!unfec13(stream, corrected, 80)) return 0;
+        d_payload_length = 10;
+        unwhiten(corrected, d_payload.data(), clock, 80, 18);
+    } else if (d_type == 6) {
+        std::vector<uint8_t> corrected;
+        if (!unfec23(stream, 160, corrected)) return 0;
+        d_payload_length = 20;
+        unwhiten(corrected.data(), d_payload.data(), clock, 160, 18);
+    } else if (d_type == 7) {
+        d_payload_length = 30;
+        unwhiten(stream, d_payload.data(), clock, 240, 18);
+    }
+    return 1;
+}
+
+int classic_packet::crc_check(int clock)
+{
+    int r = 1;                                     // 1 inconclusive, > 1 positive, 0 negative
+    switch (d_type) {
+        case 2: r = fhs(clock); break;
+        case 8: case 3: case 10: case 14: r = DM(clock); break;
+        case 4: case 11: case 15: r = DH(clock); break;
+        case 7: r = EV(clock, 32); break;
+        case 12: r = EV4(clock); break;
+        case 13: r = EV(clock, 182); break;
+        case 5: r = HV(clock); break;
+        default: break;
+    }
+    if (r == 0 && d_type != 2 && d_type != 3 && d_type != 5) return 1;      // may be another logical transport
+    if (r > 1 && (d_type == 7 || d_type == 13)) return 1;                   // EV3 / EV5: too many false positives
+    return r;
+}
+
+bool classic_packet::decode_header(std::string &out)
+{
+    uint8_t header[18];
+    if (d_have_clk6 && unfec13(&d_symbols[72], header, 18)) {
+        unwhiten(header, d_header, (int)d_clock, 18, 0);
+        const int uap = uap_from_hec((uint16_t)bits(d_header, 10), (uint8_t)bits(d_header + 10, 8));
+        if (uap == d_uap) { d_type = (int)bits(&d_header[3], 4); return true; }
+        appendf(out, "bad HEC! %02x %02x %i ", uap, d_uap, (int)bits(&d_header[3], 4));
+    }
+    out += "failed to decode header\n";
+    return false;
+}
+
+void classic_packet::decode_payload()
+{
+    const int clk = (int)d_clock;
+    d_payload_header_length = 0;
+    switch (d_type) {
+        case 0: case 1: d_payload_length = 0; break;
+        case 2: fhs(clk); break;
+        case 3: case 8: case 10: case 14: DM(clk); break;
+        case 4: case 9: case 11: case 15: DH(clk); break;
+        case 5: case 6: HV(clk); break;
+        case 7: if (EV(clk, 32) <= 1) HV(clk); break;
+        case 12: EV4(clk); break;
+        case 13: EV(clk, 182); DM(clk); break;     // falls through into the DM5 case
+    }
+    d_have_payload = true;
+}
+
+void classic_packet::decode(std::string &out)
+{
+    d_have_payload = false;
+    if (decode_header(out)) decode_payload();
+}
+
+void classic_packet::print(std::string &out) const
+{
+    if (!d_have_payload) return;
+    out += TYPE_NAMES[d_type & 15];
+    out += "\n";
+    if (d_payload_header_length > 0)
+        appendf(out, "  LLID: %d\n  flow: %d\n  payload length: %d\n", d_llid, d_flow, d_payload_length);
+}
+
+// --------------------------------------------------------------- basic_rate_piconet
+void basic_rate_piconet::reset(std::string &out)
+{
+    out += "no candidates remaining! starting over . . .\n";
+    d_got_first_packet = false;
+    d_packets_observed = 0;
+    d_have_uap = false;
+    d_have_clk6 = false;
+    d_have_clk27 = false;
+}
+
+bool basic_rate_piconet::uap_from_header(classic_packet &pkt, std::string &out)
+{
+    const uint32_t clkn = pkt.clkn();
+    int starting = 0, remaining = 0, first_clock = 0;
+    if (!d_got_first_packet) d_first_pkt_time = clkn;
+    if (d_packets_observed >= 1000) {              // MAX_PATTERN_LENGTH
+        out += "Oops. More hops than we can remember.\n";
+        reset(out);
+        return false;
+    }
+    d_packets_observed++;
+    d_total_packets_observed++;
+    // every possible clock value of the first packet
+    for (int count = 0; count < 64; count++) {
+        if (!(d_clock6_candidates[count] > -1 || !d_got_first_packet)) continue;
+        const int clock = (int)(((uint32_t)count + clkn - d_first_pkt_time) % 64);
+        starting++;
+        const uint8_t uap = pkt.try_clock(clock);
+        int verdict = -1;
+        if (!d_got_first_packet || uap == d_clock6_candidates[count]) verdict = pkt.crc_check(clock);
+        if (verdict == -1 || verdict == 0) {
+            d_clock6_candidates[count] = -1;
+        } else if (verdict == 1) {
+            d_clock6_candidates[count] = uap;
+            first_clock = count;
+            remaining++;
+        } else {
+            appendf(out, "Correct CRC! UAP = 0x%x found after %d total packets.\n", uap, d_total_packets_observed);
+            d_clk_offset = (uint32_t)((count - (int)(d_first_pkt_time & 0x3f)) & 0x3f);
+            d_uap = uap;
+            d_have_clk6 = d_have_uap = true;
+            d_total_packets_observed = 0;
+            return true;
+        }
+    }
+    d_got_first_packet = true;
+    appendf(out, "reduced from %d to %d CLK1-6 candidates\n", starting, remaining);
+    if (remaining == 1) {
+        d_clk_offset = (uint32_t)((first_clock - (int)(d_first_pkt_time & 0x3f)) & 0x3f);
+        d_uap = (uint8_t)d_clock6_candidates[first_clock];
+        d_have_clk6 = d_have_uap = true;
+        appendf(out, "We have a winner! UAP = 0x%x found after %d total packets.\n", d_uap, d_total_packets_observed);
+        d_total_packets_observed = 0;
+        return true;
+    }
+    if (remaining == 0) reset(out);
+    return false;
+}
+
+// ----------------------------------------------------------------- sniffer_handlers
+std::string sniffer_handlers::ac(const btgpu_hit &hit, const btgpu_header &sweep, const uint8_t *symbols, int nsymbols)
+{
+    std::string out;
+    const uint32_t clkn = (uint32_t)(hit.slot & 0x7ffffff);
+    auto pkt = std::make_shared<classic_packet>(symbols, nsymbols, clkn, hit.channel, sweep);
+    const uint32_t lap = pkt->lap();
+    appendf(out, "time %6d, snr=%.1f, channel %2d, LAP %06x ", (int)clkn, hit.snr_db, hit.channel, lap);
+    if (!pkt->header_present()) { id(out); return out; }
+    auto &slot = d_piconets[lap];
+    if (!slot) slot = std::make_shared<basic_rate_piconet>(lap);
+    auto pn = slot;
+    if (pn->have_clk6() && pn->have_uap()) decode(pkt, pn, true, out);
+    else discover(pkt, pn, out);
+    if (lap == GIAC || lap == LIAC) d_piconets.erase(lap);      // inquiry responses: keep no state
+    return out;
+}
+
+void sniffer_handlers::id(std::string &out) { out += "ID\n"; }
+
+void sniffer_handlers::decode(std::shared_ptr<classic_packet> pkt, std::shared_ptr<basic_rate_piconet> pn, bool first_run,
+                              std::string &out)
+{
+    pkt->set_clock(pkt->clkn() + pn->offset(), pn->have_clk27());
+    pkt->set_uap(pn->uap());
+    pkt->decode(out);
+    if (pkt->got_payload()) {
+        pkt->print(out);
+        if (pkt->type() == 2) fhs(*pkt, out);
+    } else if (first_run) {
+        out += "lost clock!\n";
+        pn->reset(out);
+        discover(pkt, pn, out);                    // start rediscovery with this packet
+    } else {
+        out += "Giving up on queued packet!\n";
+    }
+}
+
+void sniffer_handlers::discover(std::shared_ptr<classic_packet> pkt, std::shared_ptr<basic_rate_piconet> pn, std::string &out)
+{
+    out += "working on UAP/CLK1-6\n";
+    pn->queue.push_back(pkt);                      // decoded once discovery completes
+    if (pn->uap_from_header(*pkt, out)) recall(pn, out);
+}
+
+void sniffer_handlers::recall(std::shared_ptr<basic_rate_piconet> pn, std::string &out)
+{
+    out += "Decoding queued packets\n";
+    while (!pn->queue.empty()) {
+        auto pkt = pn->queue.front();
+        pn->queue.pop_front();
+        appendf(out, "time %6d, channel %2d, LAP %06x ", (int)pkt->clkn(), pkt->channel(), pkt->lap());
+        decode(pkt, pn, false, out);
+    }
+    out += "Finished decoding queued packets\n";
+}
+
+void sniffer_handlers::fhs(classic_packet &pkt, std::string &out)
+{
+    const uint32_t lap = pkt.lap_from_fhs();
+    const uint8_t uap = pkt.uap_from_fhs();
+    const uint16_t nap = pkt.nap_from_fhs();
+    const uint32_t clk = pkt.clock_from_fhs() << 1;            // units of 625 us
+    const uint32_t offset = (clk - pkt.clkn()) & 0x7ffffff;
+    appendf(out, "FHS contents: BD_ADDR %2.2x:%2.2x:%2.2x:%2.2x:%2.2x:%2.2x, CLK %07x\n", (nap >> 8) & 0xff, nap & 0xff, uap,
+            (lap >> 16) & 0xff, (lap >> 8) & 0xff, lap & 0xff, clk);
+    auto &slot = d_piconets[lap];
+    if (!slot) slot = std::make_shared<basic_rate_piconet>(lap);
+    slot->set_uap(uap);
+    slot->set_nap(nap);
+    slot->set_offset(offset);
+}
+
+}  // namespace host
+}  // namespace bluetooth
+}  // namespace gr

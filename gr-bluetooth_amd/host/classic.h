@@ -1,0 +1,134 @@
+// classic.h -- host half of multi_sniffer's packet handlers:
+// the per-LAP piconet bookkeeping and the payload parsers that turn LAP hits into UAP / CLK1-6 and
+// printed packets.  The GPU supplies, per hit, the sliced symbols and the header sweep over the 64
+// clock candidates (btgpu_poll_headers); everything here is sequential protocol state and stays on
+// the host, as in the reference:
+//   classic_packet            lib/packet_impl.cc:226-246 (ctor), :367-468 (FEC), :513-548, :597-1202
+//   basic_rate_piconet        lib/piconet_impl.cc:433-547 (UAP_from_header, reset), :371-411
+//   sniffer_handlers          lib/multi_sniffer_impl.cc:169-365 (ac, id, decode, discover, recall, fhs)
+#ifndef GR_BLUETOOTH_AMD_CLASSIC_H
+#define GR_BLUETOOTH_AMD_CLASSIC_H
+
+#include <cstdint>
+#include <cstdio>
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <btgpu.h>
+
+namespace gr {
+namespace bluetooth {
+namespace host {
+
+class classic_packet
+{
+public:
+    static constexpr int MAX_SYMBOLS = 3125;
+    // symbols from the access code on, one per byte; `sweep` = the GPU's try_clock results
+    classic_packet(const uint8_t *symbols, int length, uint32_t clkn, int channel, const btgpu_header &sweep);
+
+    uint32_t lap() const { return d_lap; }
+    uint32_t clkn() const { return d_clkn; }
+    int channel() const { return d_channel; }
+    int type() const { return d_type; }
+    bool got_payload() const { return d_have_payload; }
+    bool header_present() const;                       // lib/packet_impl.cc:1205-1242
+
+    uint8_t try_clock(int clock);                      // :1046-1063, served from the sweep
+    int crc_check(int clock);                          // :612-671
+    void set_clock(uint32_t clock, bool have27);       // :582-594
+    void set_uap(uint8_t uap) { d_uap = uap; }
+    void decode(std::string &out);                     // :169-175, :1066-1165
+    void print(std::string &out) const;                // :1168-1179
+    // FHS payload fields (:1245-1281)
+    uint32_t lap_from_fhs() const { return bits(&d_payload[34], 24); }
+    uint8_t uap_from_fhs() const { return (uint8_t)bits(&d_payload[64], 8); }
+    uint16_t nap_from_fhs() const { return (uint8_t)bits(&d_payload[72], 16); }   // air_to_host8 on 16 bits (Q11)
+    uint32_t clock_from_fhs() const { return bits(&d_payload[115], 26); }
+
+    static bool unfec13(const uint8_t *in, uint8_t *out, int length);
+    static bool unfec23(const uint8_t *in, int length, std::vector<uint8_t> &out);
+    static void unwhiten(const uint8_t *in, uint8_t *out, int clock, int length, int skip);
+    static uint16_t crcgen(const uint8_t *payload, int length, int uap);
+    static int uap_from_hec(uint16_t data, uint8_t hec);
+    static uint32_t bits(const uint8_t *air, int n);
+
+private:
+    bool payload_crc() const;
+    bool decode_payload_header(const uint8_t *stream, int clock, int header_bytes, int size, bool fec);
+    int fhs(int clock);
+    int DM(int clock);
+    int DH(int clock);
+    int EV(int clock, int maxlength);
+    int EV4(int clock);
+    int HV(int clock);
+    bool decode_header(std::string &out);
+    void decode_payload();
+
+    std::vector<uint8_t> d_symbols;                    // MAX_SYMBOLS + slack, zero beyond d_length
+    int d_length;
+    uint32_t d_clkn;
+    int d_channel;
+    uint32_t d_lap;
+    btgpu_header d_sweep;
+    int d_type = 0;
+    uint8_t d_uap = 0;
+    uint32_t d_clock = 0;
+    bool d_have_clk6 = false, d_have_clk27 = false;
+    bool d_have_payload = false;
+    int d_payload_length = 0, d_payload_header_length = 0, d_llid = 0, d_flow = 0;
+    uint8_t d_header[18] = {0};
+    std::vector<uint8_t> d_payload;                    // one bit per byte
+};
+
+class basic_rate_piconet
+{
+public:
+    explicit basic_rate_piconet(uint32_t lap) : d_lap(lap) {}
+    bool have_uap() const { return d_have_uap; }
+    bool have_clk6() const { return d_have_clk6; }
+    bool have_clk27() const { return d_have_clk27; }
+    bool have_nap() const { return d_have_nap; }
+    uint8_t uap() const { return d_uap; }
+    uint32_t offset() const { return d_clk_offset; }
+    void set_uap(uint8_t u) { d_uap = u; d_have_uap = true; }
+    void set_nap(uint16_t n) { d_nap = n; d_have_nap = true; }
+    void set_offset(uint32_t o) { d_clk_offset = o; d_have_clk6 = true; d_have_clk27 = true; }
+    bool uap_from_header(classic_packet &pkt, std::string &out);   // lib/piconet_impl.cc:433-517
+    void reset(std::string &out);                                  // :526-547
+    std::deque<std::shared_ptr<classic_packet>> queue;
+
+private:
+    uint32_t d_lap;
+    bool d_got_first_packet = false;
+    int d_packets_observed = 0, d_total_packets_observed = 0;
+    uint32_t d_first_pkt_time = 0;
+    int d_clock6_candidates[64] = {0};
+    uint32_t d_clk_offset = 0;
+    uint8_t d_uap = 0;
+    uint16_t d_nap = 0;
+    bool d_have_uap = false, d_have_nap = false, d_have_clk6 = false, d_have_clk27 = false;
+};
+
+class sniffer_handlers
+{
+public:
+    // one classic hit, in the order work() reports them; returns the text the reference prints
+    std::string ac(const btgpu_hit &hit, const btgpu_header &sweep, const uint8_t *symbols, int nsymbols);
+
+private:
+    void id(std::string &out);
+    void decode(std::shared_ptr<classic_packet> pkt, std::shared_ptr<basic_rate_piconet> pn, bool first_run, std::string &out);
+    void discover(std::shared_ptr<classic_packet> pkt, std::shared_ptr<basic_rate_piconet> pn, std::string &out);
+    void recall(std::shared_ptr<basic_rate_piconet> pn, std::string &out);
+    void fhs(classic_packet &pkt, std::string &out);
+    std::map<uint32_t, std::shared_ptr<basic_rate_piconet>> d_piconets;
+};
+
+}  // namespace host
+}  // namespace bluetooth
+}  // namespace gr
+#endif

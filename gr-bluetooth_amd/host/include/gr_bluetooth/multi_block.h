@@ -36,7 +36,8 @@ protected:
     int run_work(int noutput_items, gr_vector_const_void_star &input_items);
     // per-record output, in (slot, channel, offset) order
     // `syms` = the window's sliced symbols from the hit on (multi_sniffer only), `nsyms` of them
-    virtual void handle_hit(const btgpu_hit &h, const uint8_t *syms, int nsyms) = 0;
+    // hdr: the GPU header sweep of a classic hit (multi_sniffer), else nullptr
+    virtual void handle_hit(const btgpu_hit &h, const btgpu_header *hdr, const uint8_t *syms, int nsyms) = 0;
 
 public:
     double samples_per_slot() const { return d_design.samples_per_slot; }

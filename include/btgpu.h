@@ -61,6 +61,8 @@ extern "C" {
 #define BTGPU_FLAG_DEBUG_Y   0x2        /* keep the channel-bank output Y for btgpu_debug_fetch  */
 #define BTGPU_FLAG_SYMBOLS   0x8        /* keep the sliced symbols of every window that reported a
                                            hit; fetch them with btgpu_poll_symbols                */
+#define BTGPU_FLAG_HEADERS   0x10       /* (implies SYMBOLS) sweep the packet header of every classic hit
+                                           over the 64 CLK1-6 candidates on the GPU; btgpu_poll_headers   */
 #define BTGPU_FLAG_ASYNC     0x4        /* work/process_device return once a batch is enqueued;
                                            its records appear in a later btgpu_poll (always in
                                            stream order) or after btgpu_flush.  The tail of batch
@@ -178,6 +180,18 @@ int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits);
  * symbols[i*sym_cap ...]; sym_len[i] = number written (min(nsym, sym_cap)).  Needs
  * BTGPU_FLAG_SYMBOLS; note the LE quirk Q6: for kind AA nsym counts from the reduced length. */
 int btgpu_poll_symbols(btgpu_handle *h, btgpu_hit *out, uint8_t *symbols, int sym_cap, int *sym_len, int max_hits);
+/* What classic_packet::try_clock(clock) yields for clock = 0..63 (lib/packet_impl.cc:1046-1063): the UAP
+ * that satisfies the HEC and the packet type, from the FEC-1/3-decoded, unwhitened header; fec13_ok = 0
+ * where unfec13 (:367-383) reports failure (try_clock then returns 0 and leaves type/UAP alone). */
+typedef struct btgpu_header {
+    uint8_t uap[64];
+    uint8_t type[64];
+    int32_t fec13_ok;
+    int32_t reserved;
+} btgpu_header;
+/* btgpu_poll_symbols plus the header sweep of each record (zeroed for kind AA); needs BTGPU_FLAG_HEADERS */
+int btgpu_poll_headers(btgpu_handle *h, btgpu_hit *out, btgpu_header *hdr, uint8_t *symbols, int sym_cap,
+                       int *sym_len, int max_hits);
 int btgpu_pending(const btgpu_handle *h);
 /* Wait for every enqueued batch and move its records to the poll queue (BTGPU_FLAG_ASYNC). */
 int btgpu_flush(btgpu_handle *h);

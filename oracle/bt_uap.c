@@ -83,7 +83,7 @@ int bto_unfec13(const char *in, char *out, int length)
     return be < (length / 4);
 }
 
-/* :386-468 -- (15,10) shortened Hamming, g(D) = D^5 + D^4 + D^2 + 1; `out` holds
+/* :386-468 -- (15,10) shortened Hamming, fecgen = {1,1,0,1,0,1}; `out` holds
  * ceil(length/10)*10 bits.  Returns 1, or 0 where the reference returns NULL. */
 int bto_unfec23(const char *in, int length, char *out)
 {

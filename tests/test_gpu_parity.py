@@ -483,3 +483,25 @@ def test_btbb_correlator_corrects_one_error_like_the_oracle(pkg, po, synth):
     blk.close()
     with pytest.raises(pkg.BtgpuError):
         pkg.multi_sniffer(fs, fc, 10.0, False, correlator=pkg.CORRELATOR_BTBB)
+
+
+def test_header_sweep_equals_try_clock(pkg, po, synth):
+    """BTGPU_FLAG_HEADERS: for every classic hit the GPU sweep over the 64 CLK1-6 candidates equals
+    classic_packet::try_clock of the oracle (UAP from the HEC, packet type, FEC-1/3 verdict) on
+    the symbols the hit hands over."""
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 18, laps=(0x24D952, 0x4831DD), seed=71, snr_db=24, occupancy=0.5)
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT,
+                            flags=pkg.FLAG_HEADERS)
+    blk.push(iq)
+    hits, hdrs, syms, lens = blk.poll_headers(sym_cap=3125)
+    blk.close()
+    assert len(hits) > 3
+    for h, hd, s, n in zip(hits, hdrs, syms, lens):
+        assert n >= 126
+        want = [po.try_clock(s[:n], c) for c in range(64)]
+        ok = want[0][2]
+        assert bool(hd["fec13_ok"]) == ok
+        if ok:
+            assert [int(x) for x in hd["uap"]] == [w[0] for w in want]
+            assert [int(x) for x in hd["type"]] == [w[1] for w in want]
