@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
+    ap.add_argument("--headers", action="store_true", help="also export hit symbols and run the GPU header sweep (BTGPU_FLAG_HEADERS), as the C++ multi_sniffer block does")
     ap.add_argument("--sync", action="store_true", help="harvest every batch before the next one is enqueued (no tail overlap)")
     ap.add_argument("--channelizer", type=int, default=0)
     ap.add_argument("--squelch-mode", type=int, default=0, help="0 auto, 1 direct, 2 staged")
@@ -87,7 +88,7 @@ def main():
 
     blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
                             channelizer=args.channelizer, squelch=args.squelch_mode,
-                            flags=0 if args.sync else pkg.FLAG_ASYNC)
+                            flags=(0 if args.sync else pkg.FLAG_ASYNC) | (pkg.FLAG_HEADERS if args.headers else 0))
     des = blk.design
     H, slot = des.history, des.samples_per_slot
     nch = des.high_channel - des.low_channel + 1
