@@ -30,7 +30,6 @@ using namespace btgpu;
 namespace {
 
 constexpr int kFuseThreads = 320;   // fused bank kernel: 310 DFT tasks per pass in one sweep
-constexpr int kFuseTiles = 1;       // consecutive tiles per workgroup (>1: input carried in LDS, next tile prefetched; slower on gfx950)
 
 struct DevBuf {
     void *p = nullptr;
@@ -250,11 +249,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             const int aszf = ((spanf > wsz ? spanf : wsz) + 1) & ~1;
             const size_t ldsf = (size_t)(aszf + NT * kPfbUst + 1) * sizeof(float2) + (size_t)258 * sizeof(float) +
                                 (size_t)5 * kPfbUst * sizeof(float2);
-            const dim3 gridf((p.ntiles + p.pre_tiles + kFuseTiles - 1) / kFuseTiles);
+            const dim3 gridf(p.ntiles + p.pre_tiles);
             if (b.real_taps)
-                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, kFuseThreads, true, kFuseTiles>), gridf, dim3(kFuseThreads), ldsf, st, p);
+                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, kFuseThreads, true>), gridf, dim3(kFuseThreads), ldsf, st, p);
             else
-                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, kFuseThreads, true, kFuseTiles>), gridf, dim3(kFuseThreads), ldsf, st, p);
+                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, kFuseThreads, true>), gridf, dim3(kFuseThreads), ldsf, st, p);
         } else if (b.real_taps)
             hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
         else
@@ -802,8 +801,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, kFuseThreads, true, kFuseTiles>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, kFuseThreads, true, kFuseTiles>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, kFuseThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, kFuseThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]

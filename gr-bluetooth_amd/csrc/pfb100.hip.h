@@ -148,13 +148,12 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false, int KT = 1>
-__global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams p)
+template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false>
+__global__ __launch_bounds__(NTH, (FUSEN ? 6 : 1)) void pfb100_kernel(PfbParams p)
 {
     constexpr int DH = S * 50;                               // hop: 2 D = S * 100
     constexpr int NQ = 15, NR = 250, NU = 5;                 // fused noise bank: taps/branch, hop, instants per tile
     static_assert(!FUSEN || (CHAN && DH == 50 && NT == 26), "fused noise stage needs the C79 channel geometry");
-    static_assert(KT == 1 || FUSEN, "tile groups are implemented for the fused kernel");
     // NTH lanes: the DFT tasks of a pass (10 per row) should fit in one sweep (310 tasks -> 320
     // lanes), otherwise one wave runs the whole DFT body twice for a handful of tasks
     constexpr int M = 100;
@@ -169,9 +168,6 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     constexpr int SPAN = (FUSEN && SPAN_N > SPAN_C) ? SPAN_N : SPAN_C;
     constexpr int N4 = (SPAN + 3) / 2;                       // 16-byte pieces staged (aligned start: +1 sample)
     constexpr int span = 2 * N4;                             // samples resident in LDS
-    constexpr int NEW4 = TT * DH / 2;                        // pieces that are new from one tile to the next
-    constexpr int NC4 = N4 - NEW4;                           // pieces carried over inside a tile group
-    static_assert(KT == 1 || (TT * DH) % 2 == 0, "tile hop must keep the 16-byte alignment");
     const int wsz = CHAN ? p.nsel * NT : 0;
     const int asz = span > wsz ? span : wsz;                 // the head of xs is dead after phase A -> reused as Db
     cf *xs = lds;                                        // [span]
@@ -184,19 +180,15 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     const bool krot_lds = p.rot_period <= 4 && p.nsel <= 80;
     const int l0 = threadIdx.x;
 
-    // A workgroup runs KT consecutive tiles (a "group"): from the second tile on only the 1250 new
-    // samples are fetched -- prefetched into registers while the previous tile computes -- and the
-    // rest of the span is moved down inside LDS.  XCD-aware order over the groups.
+    // one workgroup = one tile; XCD-aware order (pre-tiles of the fused noise bank come first)
     const int ntl = p.ntiles + (FUSEN ? p.pre_tiles : 0);
-    const int ngroups = (ntl + KT - 1) / KT;
-    const int grp = xcd_remap(blockIdx.x, ngroups);
-    const int gi0 = grp * KT, gi1 = KT == 1 ? gi0 + 1 : (gi0 + KT < ntl ? gi0 + KT : ntl);
+    const int tile = xcd_remap(blockIdx.x, ntl) - (FUSEN ? p.pre_tiles : 0);
 
     unsigned long long tprev = p.prof ? clock64() : 0ULL;
     auto mark = [&](int k) {
         if (p.prof) {
             const unsigned long long now = clock64();
-            if (l0 == 0) p.prof[(size_t)blockIdx.x * 8 + k] += now - tprev;   // wave 0 of each group
+            if (l0 == 0) p.prof[(size_t)blockIdx.x * 8 + k] += now - tprev;   // wave 0 of each tile
             tprev = now;
         }
     };
@@ -241,17 +233,9 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
         }
     }
 
-    constexpr int PERN = (NEW4 + NTH - 1) / NTH;
-    float4 nv[PERN];                                             // next tile's new pieces (KT > 1)
-
-    for (int gi = gi0; gi < gi1; gi++) {
-    // With several trips the lane id is made opaque per trip: otherwise every lane-dependent
-    // address of the body is hoisted out of the loop and held in registers (2x the VGPRs).
-    int l = l0;
-    if (KT > 1) asm volatile("" : "+v"(l));
+    const int l = l0;
     const int a_pp = l & 127, a_r = l >> 7;
     const bool a_on = a_pp < M && a_r < 2;
-    const int tile = gi - (FUSEN ? p.pre_tiles : 0);
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
 
     // ---- stage the input span.  The tile starts at the even sample a0 <= gs so that every piece is
@@ -266,7 +250,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
     {
         constexpr int PER = (N4 + NTH - 1) / NTH;
         float4 v[PER];
-        if (gi == gi0) {
+        {
             const bool interior = a0 >= 0 && a0 + 2LL * N4 <= p.x_len;
             if (interior) {                                      // block-uniform: one straight run of loads
 #pragma unroll
@@ -319,19 +303,10 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
                 nz_rot[j] = ((const cf *)p.n_krot)[(size_t)c * np + ph];
             }
         }
-        if (gi == gi0) {
 #pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const int i = l + j * NTH;
-                if (i < N4) ((float4 *)xs)[i] = v[j];
-            }
-        } else {
-            // carried pieces were moved down at the end of the previous tile; append the new ones
-#pragma unroll
-            for (int j = 0; j < PERN; j++) {
-                const int i = l + j * NTH;
-                if (i < NEW4) ((float4 *)xs)[NC4 + i] = nv[j];
-            }
+        for (int j = 0; j < PER; j++) {
+            const int i = l + j * NTH;
+            if (i < N4) ((float4 *)xs)[i] = v[j];
         }
     }
     __syncthreads();
@@ -375,19 +350,6 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
                 u = mk(-an[q].y, an[q].y) * v.yx + u;
             }
             Un[i * UST + nz_pp] = u;
-        }
-    }
-    if (KT > 1 && gi + 1 < gi1) {
-        // prefetch the next tile's new samples (consumed at the top of the next trip).  Issued after
-        // the last global load the tile waits for: memory returns in order, so anything issued
-        // behind the prefetch would wait for it
-        const long long an = a0 + 2LL * NEW4 + 2LL * NC4;
-        if (an >= 0 && an + 2LL * NEW4 <= p.x_len) {
-#pragma unroll
-            for (int j = 0; j < PERN; j++) nv[j] = load_piece(an, l + j * NTH < NEW4 ? l + j * NTH : NEW4 - 1, true);
-        } else {
-#pragma unroll
-            for (int j = 0; j < PERN; j++) nv[j] = load_piece(an, l + j * NTH < NEW4 ? l + j * NTH : NEW4 - 1, false);
         }
     }
     __syncthreads();
@@ -527,23 +489,6 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 5 : 1)) void pfb100_kernel(PfbParams 
         }
         mark(6);
     }
-    if (KT > 1 && gi + 1 < gi1) {
-        // move the part of the span the next tile shares down to the front of xs
-        static_assert(NC4 <= 3 * NTH, "three carried pieces per lane");
-        const float4 *src = (const float4 *)xs + NEW4;
-        float4 *dst = (float4 *)xs;
-        __syncthreads();                                         // Db / part readers are done
-        const int i0 = l, i1 = l + NTH, i2 = l + 2 * NTH;
-        const float4 c0 = src[i0 < NC4 ? i0 : 0];
-        const float4 c1 = src[i1 < NC4 ? i1 : 0];
-        const float4 c2 = src[i2 < NC4 ? i2 : 0];
-        __syncthreads();
-        if (i0 < NC4) dst[i0] = c0;
-        if (i1 < NC4) dst[i1] = c1;
-        if (i2 < NC4) dst[i2] = c2;
-        mark(7);
-    }
-    }   // tiles of the group
 }
 
 // tile sums -> per-slot-block sums P[c][b] and block-head sums Pt[c][b] (first `tail` instants of
