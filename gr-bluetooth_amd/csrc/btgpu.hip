@@ -234,7 +234,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         const int span = 2 * ((b.D * (NT - 1) + b.Q * 100 + 3) / 2), wsz = nch * NT;
         const int asz = ((span > wsz ? span : wsz) + 1) & ~1;
         const size_t lds = (size_t)(asz + NT * kPfbUst + 1) * sizeof(float2) + (size_t)257 * sizeof(float);
-        static_assert(NT * 79 + 2 + 4 * 80 * 2 * 2 <= 2 * (50 * 25 + 700), "epilogue scratch must fit the dead input tile");
+        static_assert(NT * 79 + (256 / 80) * 80 * 2 <= 2 * 2 * (50 * 25 + 700), "epilogue scratch (floats) of the 256-lane variant must fit the dead input tile");
         if (fuse_noise) {
             const NoiseStage &ns = fp.noise;
             const long long xn0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
