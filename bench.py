@@ -101,7 +101,7 @@ def main():
     n_complex = seg.shape[0]
     torch.cuda.synchronize()
 
-    def step(last=False):
+    def step(last=False, gather=True):
         """One pass of the hot path over the rank's batch.  In the (default) pipelined mode the
         records of a batch are harvested while the next batch runs; the last step of a timed
         region flushes, so every record of every step is on the host inside the timed region."""
@@ -109,7 +109,7 @@ def main():
         if last:
             blk.flush()
         ints, snr = bdist.struct_to_arrays(blk.poll_arrays())
-        if world > 1:                               # RCCL gather of whatever records are ready
+        if world > 1 and gather:                    # RCCL gather of whatever records are ready
             ints, snr = bdist.gather_hits(ints, snr, device=coll_device)
         return ints, snr
 
@@ -127,9 +127,9 @@ def main():
     # some tens of milliseconds of load before the clocks settle (measured: the first ~5 batches
     # after idle run ~1.5x slower).  Untimed, like the W warm-up steps that follow.
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:
-        step(last=False)
-    step(last=True)
+    while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:      # per-rank clock: no collectives in here
+        step(last=False, gather=False)
+    step(last=True, gather=False)
     fence()
     for i in range(args.warmup):
         step(last=(i == args.warmup - 1))
