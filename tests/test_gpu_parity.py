@@ -505,3 +505,20 @@ def test_header_sweep_equals_try_clock(pkg, po, synth):
         if ok:
             assert [int(x) for x in hd["uap"]] == [w[0] for w in want]
             assert [int(x) for x in hd["type"]] == [w[1] for w in want]
+
+
+def test_hit_buffer_overflow_is_reported_not_silent(pkg, po, synth):
+    """max_hits smaller than the number of records: BTGPU_EOVERFLOW comes back from the call that
+    produced them, exactly max_hits records are kept, every one of them a record of the full
+    list, and the handle keeps working."""
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 24, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=8, snr_db=24, occupancy=0.4)
+    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq, threads=8)
+    assert len(want) > 8
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT, max_hits=5)
+    with pytest.raises(pkg.BtgpuError) as e:
+        blk.push(iq)
+    assert e.value.code == pkg.EOVERFLOW
+    got = blk.poll()
+    assert len(got) == 5 and set(_keys(got)) <= set(_keys(want))
+    blk.close()
