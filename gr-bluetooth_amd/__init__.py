@@ -76,7 +76,9 @@ class Timing(ctypes.Structure):
 EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_strerror",
            "btgpu_version", "btgpu_create", "btgpu_destroy", "btgpu_get_design", "btgpu_history",
            "btgpu_last_error", "btgpu_work", "btgpu_push", "btgpu_process_device", "btgpu_poll",
-           "btgpu_poll_symbols", "btgpu_poll_headers", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch"]
+           "btgpu_poll_symbols", "btgpu_poll_headers", "btgpu_hopseq_create", "btgpu_hopseq_destroy",
+           "btgpu_hopseq_init_candidates", "btgpu_hopseq_winnow", "btgpu_hopseq_candidates", "btgpu_hopseq_lookup",
+           "btgpu_hopseq_fetch", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch"]
 
 
 class BtgpuError(RuntimeError):
@@ -154,6 +156,20 @@ def lib():
     L.btgpu_poll_headers.restype = ctypes.c_int
     L.btgpu_poll_headers.argtypes = [vp, ctypes.POINTER(Hit), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    L.btgpu_hopseq_create.restype = ctypes.c_int
+    L.btgpu_hopseq_create.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.btgpu_hopseq_destroy.restype = None
+    L.btgpu_hopseq_destroy.argtypes = [vp]
+    L.btgpu_hopseq_init_candidates.restype = ctypes.c_int
+    L.btgpu_hopseq_init_candidates.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.btgpu_hopseq_winnow.restype = ctypes.c_int
+    L.btgpu_hopseq_winnow.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.btgpu_hopseq_candidates.restype = ctypes.c_int
+    L.btgpu_hopseq_candidates.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+    L.btgpu_hopseq_lookup.restype = ctypes.c_int
+    L.btgpu_hopseq_lookup.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.POINTER(ctypes.c_uint8)]
+    L.btgpu_hopseq_fetch.restype = ctypes.c_long
+    L.btgpu_hopseq_fetch.argtypes = [vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint8)]
     L.btgpu_poll_symbols.restype = ctypes.c_int
     L.btgpu_poll_symbols.argtypes = [vp, ctypes.POINTER(Hit), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_int), ctypes.c_int]
@@ -415,3 +431,60 @@ class multi_sniffer(_MultiBlock):
     def format_hit(self, h):
         # lib/multi_sniffer_impl.cc:177-178 (prefix printed by ac() before the handlers)
         return "time %6d, snr=%.1f, channel %2d, LAP %06x " % (h.slot & 0x7ffffff, h.snr_db, h.channel, h.lap)
+
+
+class HopSequence:
+    """The complete hopping sequence of one piconet on the GPU and its CLK1-27 candidate list
+    (basic_rate_piconet hop reversal, lib/piconet_impl.cc:96-338)."""
+    LENGTH = 1 << 27
+
+    def __init__(self, address, afh=False, device=-1):
+        import torch  # noqa: F401  (one HIP runtime per process, see lib())
+        self._L = lib()
+        h = ctypes.c_void_p()
+        rc = self._L.btgpu_hopseq_create(int(address) & 0xFFFFFFF, 1 if afh else 0, device, ctypes.byref(h))
+        if rc != OK:
+            raise BtgpuError(rc, "btgpu_hopseq_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.btgpu_hopseq_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def init_candidates(self, channel, known_clock_bits, aliased=False):
+        n = self._L.btgpu_hopseq_init_candidates(self._h, int(channel), int(known_clock_bits), 1 if aliased else 0)
+        if n < 0:
+            raise BtgpuError(n, "btgpu_hopseq_init_candidates")
+        return n
+
+    def winnow(self, offset, channel, aliased=False):
+        n = self._L.btgpu_hopseq_winnow(self._h, int(offset), int(channel), 1 if aliased else 0)
+        if n < 0:
+            raise BtgpuError(n, "btgpu_hopseq_winnow")
+        return n
+
+    def candidates(self, cap=1 << 22):
+        buf = np.zeros(cap, np.uint32)
+        n = self._L.btgpu_hopseq_candidates(self._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), cap)
+        if n < 0:
+            raise BtgpuError(n, "btgpu_hopseq_candidates")
+        return buf[:min(n, cap)]
+
+    def lookup(self, index):
+        idx = np.ascontiguousarray(index, dtype=np.uint32)
+        out = np.zeros(len(idx), np.uint8)
+        rc = self._L.btgpu_hopseq_lookup(self._h, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(idx),
+                                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+        if rc != OK:
+            raise BtgpuError(rc, "btgpu_hopseq_lookup")
+        return out
+
+    def fetch(self, first, count):
+        out = np.zeros(count, np.uint8)
+        n = self._L.btgpu_hopseq_fetch(self._h, first, count, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+        if n < 0:
+            raise BtgpuError(int(n), "btgpu_hopseq_fetch")
+        return out[:n]

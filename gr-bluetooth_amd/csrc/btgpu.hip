@@ -15,6 +15,7 @@
 #include "design.h"
 #include "kernels.hip.h"
 #include "pfb100.hip.h"
+#include "hopseq.hip.h"
 
 using namespace btgpu;
 
@@ -1022,6 +1023,129 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
     if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
     if (hipMemcpy(out, (const char *)src + first * elem, count * elem, hipMemcpyDeviceToHost) != hipSuccess)
         return BTGPU_EDEVICE;
+    return (long)count;
+}
+
+// ---------------------------------------------------------------------------------------
+// hop reversal (basic_rate_piconet::init_hop_reversal / winnow, lib/piconet_impl.cc:96-338)
+// ---------------------------------------------------------------------------------------
+struct btgpu_hopseq {
+    int device = 0;
+    uint8_t *d_sequence = nullptr;
+    uint32_t *d_cand[2] = {nullptr, nullptr};
+    unsigned int *d_count = nullptr;
+    int cur = 0;
+    unsigned int ncand = 0;
+    size_t cand_cap = 0;
+};
+
+int btgpu_hopseq_create(uint32_t address, int afh, int device, btgpu_hopseq **out)
+{
+    if (!out) return BTGPU_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BTGPU_ENODEVICE;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev || hipSetDevice(device) != hipSuccess) return BTGPU_EINVAL;
+    btgpu_hopseq *h = new (std::nothrow) btgpu_hopseq();
+    if (!h) return BTGPU_ENOMEM;
+    h->device = device;
+    h->cand_cap = (size_t)kSequenceLength / 64 + 64;           // every probe could match
+    if (hipMalloc((void **)&h->d_sequence, kSequenceLength) != hipSuccess ||
+        hipMalloc((void **)&h->d_cand[0], h->cand_cap * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&h->d_cand[1], h->cand_cap * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&h->d_count, sizeof(unsigned int)) != hipSuccess) { btgpu_hopseq_destroy(h); return BTGPU_ENOMEM; }
+    address &= 0xfffffff;
+    HopAddress ad;                                             // address_precalc (lib/piconet_impl.cc:149-167)
+    ad.a1 = (address >> 23) & 0x1f;
+    ad.b = (address >> 19) & 0x0f;
+    ad.c1 = ((address >> 4) & 0x10) + ((address >> 3) & 0x08) + ((address >> 2) & 0x04) + ((address >> 1) & 0x02) + (address & 0x01);
+    ad.d1 = (address >> 10) & 0x1ff;
+    ad.e = ((address >> 7) & 0x40) + ((address >> 6) & 0x20) + ((address >> 5) & 0x10) + ((address >> 4) & 0x08) +
+           ((address >> 3) & 0x04) + ((address >> 2) & 0x02) + ((address >> 1) & 0x01);
+    ad.afh = afh ? 1 : 0;
+    hipLaunchKernelGGL(gen_hops_kernel, dim3(kSequenceLength / 2 / 256), dim3(256), 0, 0, ad, h->d_sequence);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { btgpu_hopseq_destroy(h); return BTGPU_EDEVICE; }
+    *out = h;
+    return BTGPU_OK;
+}
+
+void btgpu_hopseq_destroy(btgpu_hopseq *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->d_sequence) (void)hipFree(h->d_sequence);
+    if (h->d_cand[0]) (void)hipFree(h->d_cand[0]);
+    if (h->d_cand[1]) (void)hipFree(h->d_cand[1]);
+    if (h->d_count) (void)hipFree(h->d_count);
+    delete h;
+}
+
+int btgpu_hopseq_init_candidates(btgpu_hopseq *h, int channel, int known_clock_bits, int aliased)
+{
+    if (!h || known_clock_bits < 0 || known_clock_bits > 63) return BTGPU_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
+    if (hipMemset(h->d_count, 0, sizeof(unsigned int)) != hipSuccess) return BTGPU_EDEVICE;
+    h->cur = 0;
+    hipLaunchKernelGGL(init_candidates_kernel, dim3(kSequenceLength / 64 / 256), dim3(256), 0, 0, (const uint8_t *)h->d_sequence,
+                       channel, known_clock_bits, aliased ? 1 : 0, h->d_cand[0], h->d_count);
+    if (hipMemcpy(&h->ncand, h->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
+    return (int)h->ncand;
+}
+
+int btgpu_hopseq_winnow(btgpu_hopseq *h, int offset, int channel, int aliased)
+{
+    if (!h) return BTGPU_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
+    if (h->ncand == 0) return 0;
+    if (hipMemset(h->d_count, 0, sizeof(unsigned int)) != hipSuccess) return BTGPU_EDEVICE;
+    hipLaunchKernelGGL(winnow_kernel, dim3((h->ncand + 255) / 256), dim3(256), 0, 0, (const uint8_t *)h->d_sequence,
+                       (const uint32_t *)h->d_cand[h->cur], h->ncand, (uint32_t)offset, channel, aliased ? 1 : 0,
+                       h->d_cand[h->cur ^ 1], h->d_count);
+    if (hipMemcpy(&h->ncand, h->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
+    h->cur ^= 1;
+    return (int)h->ncand;
+}
+
+int btgpu_hopseq_candidates(btgpu_hopseq *h, uint32_t *out, int cap)
+{
+    if (!h || cap < 0 || (!out && cap > 0)) return BTGPU_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
+    std::vector<uint32_t> all(h->ncand);
+    if (h->ncand && hipMemcpy(all.data(), h->d_cand[h->cur], sizeof(uint32_t) * h->ncand, hipMemcpyDeviceToHost) != hipSuccess)
+        return BTGPU_EDEVICE;
+    std::sort(all.begin(), all.end());                         // the reference's list is ascending
+    const int n = std::min<int>(cap, (int)all.size());
+    if (n > 0) std::memcpy(out, all.data(), sizeof(uint32_t) * (size_t)n);
+    return (int)h->ncand;
+}
+
+int btgpu_hopseq_lookup(btgpu_hopseq *h, const uint32_t *index, int n, uint8_t *channel)
+{
+    if (!h || n < 0 || (n > 0 && (!index || !channel))) return BTGPU_EINVAL;
+    if (n == 0) return BTGPU_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
+    uint32_t *d_i = nullptr; uint8_t *d_o = nullptr;
+    if (hipMalloc((void **)&d_i, sizeof(uint32_t) * (size_t)n) != hipSuccess) return BTGPU_ENOMEM;
+    if (hipMalloc((void **)&d_o, (size_t)n) != hipSuccess) { (void)hipFree(d_i); return BTGPU_ENOMEM; }
+    int rc = BTGPU_OK;
+    if (hipMemcpy(d_i, index, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = BTGPU_EDEVICE;
+    if (rc == BTGPU_OK) {
+        hipLaunchKernelGGL(hop_lookup_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const uint8_t *)h->d_sequence,
+                           (const uint32_t *)d_i, n, d_o);
+        if (hipMemcpy(channel, d_o, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = BTGPU_EDEVICE;
+    }
+    (void)hipFree(d_i); (void)hipFree(d_o);
+    return rc;
+}
+
+long btgpu_hopseq_fetch(btgpu_hopseq *h, size_t first, size_t count, uint8_t *out)
+{
+    if (!h || !out) return BTGPU_EINVAL;
+    if (first >= kSequenceLength) return 0;
+    count = std::min<size_t>(count, (size_t)kSequenceLength - first);
+    if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
+    if (hipMemcpy(out, h->d_sequence + first, count, hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
     return (long)count;
 }
 

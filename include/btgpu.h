@@ -206,6 +206,24 @@ int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out);
  * channel is a classic channel number (ignored for 2..4); returns elements copied. */
 long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, size_t count, void *out);
 
+/* ---- hop reversal: the piconet's complete hopping sequence on the GPU ----
+ * Replaces basic_rate_piconet_impl::init_hop_reversal's precalc + address_precalc + gen_hops
+ * (lib/piconet_impl.cc:96-255: a 128 MiB table, one entry per 625 us slot, index = CLK27..1),
+ * init_candidates (:285-302), winnow(offset, channel) (:305-321) and hop(clock) (:279-282).
+ * address = (UAP << 24 | LAP) & 0xfffffff; afh = the piconet's d_afh flag. */
+typedef struct btgpu_hopseq btgpu_hopseq;
+int  btgpu_hopseq_create(uint32_t address, int afh, int device, btgpu_hopseq **out);
+void btgpu_hopseq_destroy(btgpu_hopseq *h);
+/* candidate CLK1-27 values whose hop matches `channel` among those with the known CLK1-6 bits;
+ * returns the number of candidates (or a negative error) */
+int  btgpu_hopseq_init_candidates(btgpu_hopseq *h, int channel, int known_clock_bits, int aliased);
+/* keep the candidates whose hop `offset` slots later is `channel`; returns how many remain */
+int  btgpu_hopseq_winnow(btgpu_hopseq *h, int offset, int channel, int aliased);
+/* the surviving candidates in ascending order (up to cap); returns their total number */
+int  btgpu_hopseq_candidates(btgpu_hopseq *h, uint32_t *out, int cap);
+int  btgpu_hopseq_lookup(btgpu_hopseq *h, const uint32_t *index, int n, uint8_t *channel);
+long btgpu_hopseq_fetch(btgpu_hopseq *h, size_t first, size_t count, uint8_t *out);   /* table slice */
+
 #ifdef __cplusplus
 }
 #endif

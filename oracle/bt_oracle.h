@@ -168,6 +168,19 @@ void bto_piconet_init(bto_piconet *pn, uint32_t lap);
 int  bto_uap_from_header(bto_piconet *pn, const char *symbols, int length, uint32_t clkn, int channel,
                          char *log, size_t log_cap);
 
+/* ---- hop reversal (bt_hop.c): lib/piconet_impl.cc:131-338, 520-523.  PARITY UNPINNED
+ * (no vectors in the reference).  Sequence index = CLK27..1 (one entry per slot). ---- */
+#define BTO_SEQUENCE_LENGTH 134217728u
+typedef struct bto_hopper bto_hopper;
+bto_hopper *bto_hopper_new(uint32_t address /* (UAP << 24 | LAP) & 0xfffffff */, int afh);
+void bto_hopper_free(bto_hopper *h);
+int  bto_single_hop(const bto_hopper *h, uint32_t clock /* CLK27..0 */);
+const uint8_t *bto_gen_hops(bto_hopper *h);                /* the whole 2^27-entry table (cached) */
+int  bto_aliased_channel(int channel);
+int  bto_hop_init_candidates(bto_hopper *h, int channel, int known_clock_bits, int aliased);
+int  bto_hop_winnow(bto_hopper *h, int offset, int channel, int aliased);
+int  bto_hop_candidates(const bto_hopper *h, uint32_t *out, int cap);
+
 /* ---- block work() restatements; return number of hits appended ---- */
 int bto_work(bto_ctx *c, const float *win, uint32_t slot, bto_hit *hits, int max_hits);
 

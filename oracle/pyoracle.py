@@ -111,6 +111,22 @@ def lib():
     L.bto_uap_from_header.restype = ctypes.c_int
     L.bto_uap_from_header.argtypes = [ctypes.POINTER(PiconetState), ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32,
                                       ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    L.bto_hopper_new.restype = vp
+    L.bto_hopper_new.argtypes = [ctypes.c_uint32, ctypes.c_int]
+    L.bto_hopper_free.restype = None
+    L.bto_hopper_free.argtypes = [vp]
+    L.bto_single_hop.restype = ctypes.c_int
+    L.bto_single_hop.argtypes = [vp, ctypes.c_uint32]
+    L.bto_gen_hops.restype = ctypes.POINTER(ctypes.c_uint8)
+    L.bto_gen_hops.argtypes = [vp]
+    L.bto_hop_init_candidates.restype = ctypes.c_int
+    L.bto_hop_init_candidates.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.bto_hop_winnow.restype = ctypes.c_int
+    L.bto_hop_winnow.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.bto_hop_candidates.restype = ctypes.c_int
+    L.bto_hop_candidates.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+    L.bto_aliased_channel.restype = ctypes.c_int
+    L.bto_aliased_channel.argtypes = [ctypes.c_int]
     L.bto_sniffer_new.restype = vp
     L.bto_sniffer_new.argtypes = []
     L.bto_sniffer_free.restype = None
@@ -204,6 +220,40 @@ class Piconet:
         log = ctypes.create_string_buffer(2048)
         r = lib().bto_uap_from_header(ctypes.byref(self.st), s.tobytes() + bytes(64), len(s), int(clkn), int(channel), log, 2048)
         return bool(r), log.value.decode()
+
+
+class Hopper:
+    """Hop reversal of one piconet (lib/piconet_impl.cc:96-338): selection kernel, full table,
+    candidate list.  [PARITY UNPINNED: the reference holds no hop vectors.]"""
+    LENGTH = 1 << 27
+
+    def __init__(self, address, afh=False):
+        self.h = lib().bto_hopper_new(int(address) & 0xFFFFFFF, 1 if afh else 0)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().bto_hopper_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def single_hop(self, clock):
+        return lib().bto_single_hop(self.h, int(clock))
+
+    def table(self):
+        return np.ctypeslib.as_array(lib().bto_gen_hops(self.h), (self.LENGTH,)).copy()   # outlives the handle
+
+    def init_candidates(self, channel, known_clock_bits, aliased=False):
+        return lib().bto_hop_init_candidates(self.h, int(channel), int(known_clock_bits), 1 if aliased else 0)
+
+    def winnow(self, offset, channel, aliased=False):
+        return lib().bto_hop_winnow(self.h, int(offset), int(channel), 1 if aliased else 0)
+
+    def candidates(self, cap=1 << 22):
+        buf = np.zeros(cap, np.uint32)
+        n = lib().bto_hop_candidates(self.h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), cap)
+        return buf[:min(n, cap)]
 
 
 class Sniffer:

@@ -522,3 +522,29 @@ def test_hit_buffer_overflow_is_reported_not_silent(pkg, po, synth):
     got = blk.poll()
     assert len(got) == 5 and set(_keys(got)) <= set(_keys(want))
     blk.close()
+
+
+def test_hop_sequence_table_and_winnowing_equal_oracle(pkg, po):
+    """gen_hops / init_candidates / winnow on the GPU (btgpu_hopseq_*) vs the oracle: the whole
+    2^27-entry table byte for byte, candidate lists identical at every step, AFH and aliased variants."""
+    for addr, afh in (((0xAF << 24) | 0x24D952, False), ((0x5C << 24) | 0x9E8B33, True)):
+        hp = po.Hopper(addr, afh)
+        want = hp.table()
+        seq = pkg.HopSequence(addr, afh)
+        step = 1 << 24
+        for first in range(0, 1 << 27, step):
+            assert np.array_equal(seq.fetch(first, step), want[first:first + step])
+        rng = np.random.default_rng(2)
+        idx = rng.integers(0, 1 << 27, 1000).astype(np.uint32)
+        assert np.array_equal(seq.lookup(idx), want[idx])
+        clk = 0x5A3C2F1
+        for aliased in (False, True):
+            obs = (lambda c: po.lib().bto_aliased_channel(int(c))) if aliased else (lambda c: int(c))
+            assert seq.init_candidates(obs(want[clk]), clk & 0x3F, aliased) == hp.init_candidates(obs(want[clk]), clk & 0x3F, aliased)
+            assert np.array_equal(seq.candidates(), hp.candidates())
+            for off in (5, 31, 77, 260, 1000, 4099):
+                ch = obs(want[(clk + off) % (1 << 27)])
+                assert seq.winnow(off, ch, aliased) == hp.winnow(off, ch, aliased)
+                assert np.array_equal(seq.candidates(), hp.candidates())
+            assert int(seq.candidates()[0]) == clk and len(seq.candidates()) == 1
+        seq.close()
