@@ -10,6 +10,7 @@
 #include <vector>
 
 #include <gr_bluetooth/multi_LAP.h>
+#include <gr_bluetooth/multi_hopper.h>
 #include <gr_bluetooth/multi_sniffer.h>
 
 #include "classic.h"
@@ -17,13 +18,15 @@
 namespace gr {
 namespace bluetooth {
 
-multi_block::multi_block(double sample_rate, double center_freq, double squelch_threshold, int mode)
+multi_block::multi_block(double sample_rate, double center_freq, double squelch_threshold, int mode, bool hopper)
 {
     // multi_sniffer always runs the LE access-address pass after the classic one
     // (lib/multi_sniffer_impl.cc:94,129-149: leok = brok)
     // and hands the sliced symbols of every hit, with the GPU's sweep of its packet header over the
     // 64 clock candidates, to its packet handlers
-    const int flags = mode == BTGPU_MODE_SNIFFER ? (BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS) : 0;
+    // multi_hopper (lib/multi_hopper_impl.cc:52-56) has the sniffer's symbol history but no LE pass
+    const int flags = mode == BTGPU_MODE_SNIFFER ? ((hopper ? 0 : BTGPU_FLAG_LE) | BTGPU_FLAG_HEADERS) : 0;
+    d_headers = (flags & BTGPU_FLAG_HEADERS) != 0;
     d_sample_rate = sample_rate;
     d_center_freq = center_freq;
     d_target_snr = squelch_threshold;
@@ -62,7 +65,7 @@ int multi_block::run_work(int noutput_items, gr_vector_const_void_star &input_it
         abort();
     }
     std::vector<btgpu_hit> buf(256);
-    if (d_mode == BTGPU_MODE_SNIFFER) {
+    if (d_headers) {
         const int cap = 3125;                         // classic_packet keeps at most MAX_SYMBOLS
         std::vector<uint8_t> syms((size_t)buf.size() * cap);
         std::vector<int> lens(buf.size());
@@ -144,6 +147,38 @@ protected:
         fputs(text.c_str(), stdout);
     }
 };
+
+// ------------------------------------------------------------- multi_hopper
+class multi_hopper_impl : public multi_hopper
+{
+    host::hopper_handlers d_handlers;
+public:
+    multi_hopper_impl(double sample_rate, double center_freq, double squelch_threshold, int LAP, bool aliased, bool tun)
+        : gr::sync_block("bluetooth multi hopper block", gr::io_signature::make(1, 1, sizeof(gr_complex)),
+                         gr::io_signature::make(0, 0, 0)),
+          multi_block(sample_rate, center_freq, squelch_threshold, BTGPU_MODE_SNIFFER, true),
+          d_handlers((uint32_t)LAP, aliased, d_design.low_channel, d_design.high_channel)
+    {
+        if (tun)      // the TAP sink is outside the hot path
+            fprintf(stderr, "warning: was not able to open TUN device, disabling Wireshark interface\n");
+    }
+    int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &) override
+    {
+        return run_work(noutput_items, input_items);
+    }
+protected:
+    void handle_hit(const btgpu_hit &h, const btgpu_header *hdr, const uint8_t *syms, int nsyms) override
+    {
+        const std::string text = d_handlers.hit(h, *hdr, syms, nsyms);
+        if (!text.empty()) fputs(text.c_str(), stdout);
+    }
+};
+
+multi_hopper::sptr multi_hopper::make(double sample_rate, double center_freq, double squelch_threshold, int LAP,
+                                      bool aliased, bool tun)
+{
+    return gnuradio::get_initial_sptr(new multi_hopper_impl(sample_rate, center_freq, squelch_threshold, LAP, aliased, tun));
+}
 
 multi_sniffer::sptr multi_sniffer::make(double sample_rate, double center_freq, double squelch_threshold,
                                         bool tun)

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <gr_bluetooth/multi_LAP.h>
+#include <gr_bluetooth/multi_hopper.h>
 #include <gr_bluetooth/multi_sniffer.h>
 
 static double eng(const char *s)
@@ -30,13 +31,14 @@ static double eng(const char *s)
 
 static void usage()
 {
-    fprintf(stderr, "usage: btrx_amd -r RATE [-f FREQ] [-i FILE|-] [-s] [-N NSAMPLES] [-S] [-t SNR] [-w] [-c CHUNK_SLOTS]\n");
+    fprintf(stderr, "usage: btrx_amd -r RATE [-f FREQ] [-i FILE|-] [-s] [-N NSAMPLES] [-S] [-l LAP -p [--aliased]] [-t SNR] [-w] [-c CHUNK_SLOTS]\n");
 }
 
 int main(int argc, char **argv)
 {
     double freq = 2.476e9, rate = 0, snr = 10.0, nsamples = -1;
-    bool sniff = false, shorts = false, tun = false;
+    bool sniff = false, shorts = false, tun = false, hop = false, aliased = false;
+    long lap = -1;
     std::string file;
     int chunk_slots = 64;
     for (int i = 1; i < argc; i++) {
@@ -49,6 +51,9 @@ int main(int argc, char **argv)
         else if (a == "-t" || a == "--snr") snr = eng(need("-t"));
         else if (a == "-c") chunk_slots = atoi(need("-c"));
         else if (a == "-S" || a == "--sniff") sniff = true;
+        else if (a == "-l" || a == "--lap") lap = strtol(need("-l"), nullptr, 16);     // apps/btrx:42-43
+        else if (a == "-p" || a == "--hop") hop = true;                                // apps/btrx:46-47
+        else if (a == "--aliased") aliased = true;
         else if (a == "-s" || a == "--input-shorts") shorts = true;
         else if (a == "-w" || a == "--wireshark") tun = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -63,6 +68,8 @@ int main(int argc, char **argv)
     std::shared_ptr<gr::bluetooth::multi_block> blk;
     try {
         if (sniff) blk = gr::bluetooth::multi_sniffer::make(rate, freq, snr, tun);
+        else if (lap >= 0 && hop) blk = gr::bluetooth::multi_hopper::make(rate, freq, snr, (int)lap, aliased, tun);   // apps/btrx:151-155
+        else if (lap >= 0) { fprintf(stderr, "multi_UAP (-l without -p) is not part of this build; use -S or -l LAP -p\n"); return 1; }
         else blk = gr::bluetooth::multi_LAP::make(rate, freq, snr);
     } catch (const std::exception &e) {
         fprintf(stderr, "%s\n", e.what());

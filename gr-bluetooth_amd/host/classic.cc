@@ -8,6 +8,7 @@
 #include "classic.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 namespace gr {
@@ -393,14 +394,84 @@ void classic_packet::print(std::string &out) const
 }
 
 // --------------------------------------------------------------- basic_rate_piconet
+basic_rate_piconet::~basic_rate_piconet()
+{
+    if (d_hops) btgpu_hopseq_destroy(d_hops);
+}
+
 void basic_rate_piconet::reset(std::string &out)
 {
     out += "no candidates remaining! starting over . . .\n";
+    if (d_hop_reversal_inited && d_hops) { btgpu_hopseq_destroy(d_hops); d_hops = nullptr; }
     d_got_first_packet = false;
     d_packets_observed = 0;
+    d_hop_reversal_inited = false;
     d_have_uap = false;
     d_have_clk6 = false;
     d_have_clk27 = false;
+    // two packets in a row on one channel were seen: assume AFH next time
+    d_afh = d_looks_like_afh;
+    d_looks_like_afh = false;
+}
+
+int basic_rate_piconet::init_hop_reversal(bool aliased, std::string &out)
+{
+    out += "\nCalculating complete hopping sequence.\n";
+    if (d_hops) { btgpu_hopseq_destroy(d_hops); d_hops = nullptr; }
+    const uint32_t address = (((uint32_t)d_uap << 24) | d_lap) & 0xfffffff;
+    if (btgpu_hopseq_create(address, d_afh ? 1 : 0, -1, &d_hops) != BTGPU_OK) {
+        fprintf(stderr, "Error: btgpu_hopseq_create failed\n");      // no CPU fallback
+        abort();
+    }
+    const int clock = (int)((d_clk_offset + d_first_pkt_time) & 0x3f);
+    d_num_candidates = btgpu_hopseq_init_candidates(d_hops, d_pattern_channels[0], clock, aliased ? 1 : 0);
+    d_winnowed = 0;
+    d_hop_reversal_inited = true;
+    d_have_clk27 = false;
+    d_aliased = aliased;
+    appendf(out, "%d initial CLK1-27 candidates\n", d_num_candidates);
+    return d_num_candidates;
+}
+
+int basic_rate_piconet::winnow(int offset, int channel, std::string &out)
+{
+    const int n = btgpu_hopseq_winnow(d_hops, offset, channel, d_aliased ? 1 : 0);
+    d_num_candidates = n;
+    if (n == 1) {
+        uint32_t survivor = 0;
+        btgpu_hopseq_candidates(d_hops, &survivor, 1);
+        d_clk_offset = (survivor - d_first_pkt_time) & 0x7ffffff;
+        d_have_clk27 = true;
+        appendf(out, "\nAcquired CLK1-27 offset = 0x%07x\n", d_clk_offset);
+    } else if (n == 0) {
+        reset(out);
+    } else {
+        appendf(out, "%d CLK1-27 candidates remaining\n", n);
+    }
+    return n;
+}
+
+int basic_rate_piconet::winnow(std::string &out)
+{
+    int n = d_num_candidates;
+    for (; d_winnowed < d_packets_observed; d_winnowed++) {
+        const int index = d_pattern_indices[d_winnowed], channel = d_pattern_channels[d_winnowed];
+        n = winnow(index, channel, out);
+        if (!d_hop_reversal_inited) break;         // reset() inside: the observed pattern is gone
+        if (d_winnowed > 0) {                      // (the reference also looks at entry -1 when d_winnowed == 0)
+            const int last_index = d_pattern_indices[d_winnowed - 1], last_channel = d_pattern_channels[d_winnowed - 1];
+            if (!d_looks_like_afh && index == last_index + 1 && channel == last_channel) d_looks_like_afh = true;
+        }
+    }
+    return n;
+}
+
+int basic_rate_piconet::hop(uint32_t clock)
+{
+    uint32_t idx = clock;
+    uint8_t ch = 0;
+    if (!d_hops || btgpu_hopseq_lookup(d_hops, &idx, 1, &ch) != BTGPU_OK) return -1;
+    return ch;
 }
 
 bool basic_rate_piconet::uap_from_header(classic_packet &pkt, std::string &out)
@@ -413,6 +484,8 @@ bool basic_rate_piconet::uap_from_header(classic_packet &pkt, std::string &out)
         reset(out);
         return false;
     }
+    d_pattern_indices[d_packets_observed] = (int)(clkn - d_first_pkt_time);
+    d_pattern_channels[d_packets_observed] = (uint8_t)pkt.channel();
     d_packets_observed++;
     d_total_packets_observed++;
     // every possible clock value of the first packet
@@ -450,6 +523,56 @@ bool basic_rate_piconet::uap_from_header(classic_packet &pkt, std::string &out)
     }
     if (remaining == 0) reset(out);
     return false;
+}
+
+// ------------------------------------------------------------------ hopper_handlers
+std::string hopper_handlers::hit(const btgpu_hit &hit, const btgpu_header &sweep, const uint8_t *symbols, int nsymbols)
+{
+    std::string out;
+    if (hit.slot != d_slot) {                      // a new work() call of the reference
+        d_slot = hit.slot;
+        d_last_channel = -1;
+        d_slot_done = false;
+        d_locked = d_piconet.have_clk27();
+    }
+    if (hit.kind != BTGPU_KIND_AC || hit.channel == d_last_channel) return out;      // sniff_ac: first hit of a channel
+    d_last_channel = hit.channel;
+    if (d_slot_done) return out;
+    const uint32_t clkn = (uint32_t)(hit.slot & 0x7ffffff);
+    if (d_locked) {
+        // hopalong: only the channel the sequence predicts for this slot
+        const uint32_t clock27 = (clkn + d_piconet.offset()) & 0x7ffffff;
+        const int hop = d_piconet.hop(clock27);
+        const int obs = d_aliased ? basic_rate_piconet::aliased_channel(hop) : hop;
+        if (obs < d_low || obs > d_high || hit.channel != hop) return out;
+        d_slot_done = true;
+        classic_packet pkt(symbols, nsymbols, 0, obs, sweep);
+        if (pkt.lap() != d_lap) return out;
+        appendf(out, "clock 0x%07x, channel %2d: ", clock27, obs);
+        if (pkt.header_present()) {
+            pkt.set_uap(d_piconet.uap());
+            pkt.set_clock(clock27, true);
+            pkt.decode(out);
+            if (pkt.got_payload()) pkt.print(out);
+        } else {
+            out += "ID\n";
+        }
+        return out;
+    }
+    classic_packet pkt(symbols, nsymbols, clkn, hit.channel, sweep);
+    if (pkt.lap() != d_lap || !pkt.header_present()) return out;
+    d_slot_done = true;                            // the reference breaks out of its channel loop here
+    if (!d_piconet.have_clk6()) {
+        d_piconet.uap_from_header(pkt, out);       // CLK1-6 / UAP discovery
+        if (d_piconet.have_clk6()) {
+            d_piconet.init_hop_reversal(d_aliased, out);
+            d_piconet.winnow(out);                 // with the packets seen so far
+        }
+    } else {
+        d_piconet.uap_from_header(pkt, out);       // timing of one more packet
+        if (d_piconet.have_clk6()) d_piconet.winnow(out);
+    }
+    return out;
 }
 
 // ----------------------------------------------------------------- sniffer_handlers

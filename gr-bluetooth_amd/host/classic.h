@@ -88,6 +88,9 @@ class basic_rate_piconet
 {
 public:
     explicit basic_rate_piconet(uint32_t lap) : d_lap(lap) {}
+    ~basic_rate_piconet();
+    basic_rate_piconet(const basic_rate_piconet &) = delete;
+    basic_rate_piconet &operator=(const basic_rate_piconet &) = delete;
     bool have_uap() const { return d_have_uap; }
     bool have_clk6() const { return d_have_clk6; }
     bool have_clk27() const { return d_have_clk27; }
@@ -99,6 +102,13 @@ public:
     void set_offset(uint32_t o) { d_clk_offset = o; d_have_clk6 = true; d_have_clk27 = true; }
     bool uap_from_header(classic_packet &pkt, std::string &out);   // lib/piconet_impl.cc:433-517
     void reset(std::string &out);                                  // :526-547
+    // hop reversal (lib/piconet_impl.cc:96-129, 279-368): the sequence table, the CLK1-27 candidate
+    // list and its winnowing live on the GPU (btgpu_hopseq_*)
+    int init_hop_reversal(bool aliased, std::string &out);
+    int winnow(std::string &out);
+    int winnow(int offset, int channel, std::string &out);
+    int hop(uint32_t clock);
+    static int aliased_channel(int channel) { return ((channel + 24) % 25) + 26; }
     std::deque<std::shared_ptr<classic_packet>> queue;
 
 private:
@@ -111,6 +121,31 @@ private:
     uint8_t d_uap = 0;
     uint16_t d_nap = 0;
     bool d_have_uap = false, d_have_nap = false, d_have_clk6 = false, d_have_clk27 = false;
+    int d_pattern_indices[1000] = {0};
+    uint8_t d_pattern_channels[1000] = {0};
+    int d_winnowed = 0, d_num_candidates = 0;
+    bool d_hop_reversal_inited = false, d_aliased = false, d_afh = false, d_looks_like_afh = false;
+    btgpu_hopseq *d_hops = nullptr;
+};
+
+// gr::bluetooth::multi_hopper's per-slot logic (lib/multi_hopper_impl.cc:76-209) on the hit records
+class hopper_handlers
+{
+public:
+    hopper_handlers(uint32_t lap, bool aliased, int low_channel, int high_channel)
+        : d_lap(lap & 0xffffff), d_aliased(aliased), d_low(low_channel), d_high(high_channel), d_piconet(lap & 0xffffff) {}
+    // records in (slot, channel, offset) order; returns the text the reference prints
+    std::string hit(const btgpu_hit &hit, const btgpu_header &sweep, const uint8_t *symbols, int nsymbols);
+    const basic_rate_piconet &piconet() const { return d_piconet; }
+
+private:
+    uint32_t d_lap;
+    bool d_aliased;
+    int d_low, d_high;
+    basic_rate_piconet d_piconet;
+    uint64_t d_slot = ~0ull;
+    int d_last_channel = -1;
+    bool d_slot_done = false, d_locked = false;
 };
 
 class sniffer_handlers

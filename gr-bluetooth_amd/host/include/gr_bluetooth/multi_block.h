@@ -23,7 +23,8 @@ class GR_BLUETOOTH_API multi_block : virtual public gr::sync_block
 {
 protected:
     multi_block() {}
-    multi_block(double sample_rate, double center_freq, double squelch_threshold, int mode);
+    // hopper: multi_hopper's geometry = the sniffer's history without the LE pass
+    multi_block(double sample_rate, double center_freq, double squelch_threshold, int mode, bool hopper = false);
     virtual ~multi_block();
 
     btgpu_handle *d_gpu = nullptr;
@@ -31,6 +32,7 @@ protected:
     uint64_t d_cumulative_count = 0;      // total samples consumed (reference: multi_block.h:62)
     double d_sample_rate = 0, d_center_freq = 0, d_target_snr = 0;
     int d_mode = 0;
+    bool d_headers = false;               // records come with symbols and the header sweep
 
     // forwards one scheduler call to btgpu_work(); returns the number of items consumed
     int run_work(int noutput_items, gr_vector_const_void_star &input_items);

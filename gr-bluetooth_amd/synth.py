@@ -103,6 +103,140 @@ def le_advert_bits(le_index, rng, payload_bytes=12, pdu_type=0, aa=0x8E89BED6):
     return np.concatenate([np.array(pre + aab, dtype=np.uint8), body])
 
 
+# ---------------------------------------------------------------------------------------------
+# A piconet that really hops: Bluetooth basic-rate hop selection (Core Vol 2 Part B 2.6), packet
+# header with HEC, data whitening, DH1 payload with CRC.  Written from the specification, independent
+# of the oracle and of the HIP path (which are tested against captures built with it).
+# ---------------------------------------------------------------------------------------------
+def _perm5(z, p_high, p_low):
+    i1 = (0, 2, 1, 3, 0, 1, 0, 3, 1, 0, 2, 1, 0, 1)
+    i2 = (1, 3, 2, 4, 4, 3, 2, 4, 4, 3, 4, 3, 3, 2)
+    p = [(p_low >> i) & 1 for i in range(9)] + [(p_high >> i) & 1 for i in range(5)]
+    zb = [(z >> i) & 1 for i in range(5)]
+    for i in range(13, -1, -1):
+        if p[i]:
+            zb[i1[i]], zb[i2[i]] = zb[i2[i]], zb[i1[i]]
+    return sum(b << i for i, b in enumerate(zb))
+
+
+def hop_channel(address, slot_clock):
+    """RF channel of the 79-hop system for master clock CLK27..1 = slot_clock (one value per
+    625 us slot); address = (UAP << 24 | LAP) & 0xfffffff."""
+    address &= 0xFFFFFFF
+    clk = (slot_clock << 1) & 0xFFFFFFF                      # CLK27..0
+    a1 = (address >> 23) & 0x1F
+    b = (address >> 19) & 0x0F
+    c1 = sum(((address >> (2 * i)) & 1) << i for i in range(5))
+    d1 = (address >> 10) & 0x1FF
+    e = sum(((address >> (2 * i + 1)) & 1) << i for i in range(7))
+    x = (clk >> 2) & 0x1F
+    y1 = (clk >> 1) & 1
+    a = (a1 ^ (clk >> 21)) & 0x1F
+    c = (c1 ^ (clk >> 16)) & 0x1F
+    d = (d1 ^ (clk >> 7)) & 0x1FF
+    f = (clk >> 3) & 0x1FFFFF0
+    k = (_perm5(((x + a) % 32) ^ b, (y1 * 0x1F) ^ c, d) + e + f + 32 * y1) % 79
+    return (2 * k) % 79                                      # register bank: even channels first
+
+
+def whitening_bits(clk6, n, skip=0):
+    """Data whitening sequence (x^7 + x^4 + 1) for CLK6..1 = clk6: register position 6 = 1,
+    positions 0..5 = CLK1..CLK6."""
+    p = [(clk6 >> i) & 1 for i in range(6)] + [1]
+    out = []
+    for _ in range(skip + n):
+        o = p[6]
+        out.append(o)
+        p = [o, p[0], p[1], p[2], p[3] ^ o, p[4], p[5]]
+    return np.array(out[skip:], dtype=np.uint8)
+
+
+def _rev8(b):
+    return int("{:08b}".format(b & 0xFF)[::-1], 2)
+
+
+def _uap_of_hec(data, hec):
+    for i in range(9, -1, -1):
+        if hec & 0x80:
+            hec ^= 0x65
+        hec = ((hec << 1) | (((hec >> 7) ^ (data >> i)) & 1)) & 0xFF
+    return _rev8(hec)
+
+
+def _crc16(bits, uap):
+    reg = (_rev8(uap) << 8) & 0xFF00
+    for b in bits:
+        reg = ((reg >> 1) | (((reg & 1) ^ int(b)) << 15)) & 0xFFFF
+        reg ^= (reg & 0x8000) >> 5
+        reg ^= (reg & 0x8000) >> 12
+    return reg
+
+
+def classic_poll_bits(lap, uap, slot_clock, lt_addr=1, flow=1, arqn=0, seqn=0, ptype=1):
+    """Air-order bits of a POLL (or NULL, ptype 0) packet: access code + whitened FEC-1/3 header."""
+    fields = (lt_addr & 7) | ((ptype & 15) << 3) | ((flow & 1) << 7) | ((arqn & 1) << 8) | ((seqn & 1) << 9)
+    hec = next(h for h in range(256) if _uap_of_hec(fields, h) == (uap & 0xFF))
+    header = np.array([(fields >> i) & 1 for i in range(10)] + [(hec >> i) & 1 for i in range(8)], np.uint8)
+    header ^= whitening_bits(slot_clock & 0x3F, 18)
+    return np.concatenate([access_code_bits(lap), np.repeat(header, 3)])
+
+
+def classic_dh1_bits(lap, uap, slot_clock, body, lt_addr=1, llid=2, flow=1, arqn=0, seqn=0):
+    """Air-order bits of a DH1 packet: 72-bit access code, FEC-1/3 header (LT_ADDR, TYPE 4, FLOW,
+    ARQN, SEQN, HEC(UAP)), payload header + body + CRC(UAP); header and payload whitened with CLK6..1."""
+    body = bytes(body)
+    assert len(body) <= 27
+    fields = (lt_addr & 7) | (4 << 3) | ((flow & 1) << 7) | ((arqn & 1) << 8) | ((seqn & 1) << 9)
+    hec = next(h for h in range(256) if _uap_of_hec(fields, h) == (uap & 0xFF))
+    header = [(fields >> i) & 1 for i in range(10)] + [(hec >> i) & 1 for i in range(8)]
+    ph = (llid & 3) | ((flow & 1) << 2) | (len(body) << 3)
+    pay = [(ph >> i) & 1 for i in range(8)]
+    for byte in body:
+        pay += [(byte >> i) & 1 for i in range(8)]
+    crc = _crc16(pay, uap)
+    pay += [(crc >> i) & 1 for i in range(16)]
+    clk6 = slot_clock & 0x3F
+    wh = whitening_bits(clk6, 18 + len(pay))
+    header = np.array(header, np.uint8) ^ wh[:18]
+    pay = np.array(pay, np.uint8) ^ wh[18:]
+    return np.concatenate([access_code_bits(lap), np.repeat(header, 3), pay])
+
+
+def make_hopping_capture(sample_rate, center_freq, n_slots, lap, uap, clk0, seed=1, snr_db=24.0, occupancy=0.9,
+                         cfo_hz=5e3, start_symbol=40, dh1_fraction=1.0):
+    """One master hopping over all 79 channels by the real selection kernel, a DH1 packet in each of
+    its transmit slots (even CLK1) with probability `occupancy` (a POLL packet instead with
+    probability 1 - dh1_fraction); only the channels inside the capture's band are rendered.  Slot k of the capture carries master clock clk0 + k.
+    Returns (iq, truth) with truth = [(slot, clock, channel)] of the rendered packets."""
+    rng = np.random.default_rng(seed)
+    sps = int(round(sample_rate / SYMBOL_RATE))
+    slot = 625 * sps
+    n = n_slots * slot
+    sigma2 = (sample_rate / 1e6) / (10.0 ** (snr_db / 10.0))
+    s = math.sqrt(sigma2 / 2)
+    iq = (rng.standard_normal(n) * s + 1j * rng.standard_normal(n) * s).astype(np.complex64)
+    lo, hi = visible_channels(sample_rate, center_freq)
+    address = ((uap & 0xFF) << 24) | (lap & 0xFFFFFF)
+    truth = []
+    for k in range(n_slots - 4):
+        clk = (clk0 + k) & 0x7FFFFFF
+        # master transmits in even slots, the addressed slave answers in the following odd slot
+        if rng.random() >= (occupancy if not clk & 1 else occupancy * 0.5):
+            continue
+        ch = hop_channel(address, clk)
+        body = bytes(rng.integers(0, 256, int(rng.integers(4, 27)), dtype=np.uint8))
+        poll = rng.random() >= dh1_fraction
+        lt, flow, arqn, seqn = int(rng.integers(1, 8)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        if lo <= ch <= hi:
+            if poll:
+                bits = classic_poll_bits(lap, uap, clk, lt_addr=lt, flow=flow, arqn=arqn, seqn=seqn, ptype=int(rng.integers(0, 2)))
+            else:
+                bits = classic_dh1_bits(lap, uap, clk, body, lt_addr=lt, flow=flow, arqn=arqn, seqn=seqn)
+            add_burst(iq, bits, k * slot + start_symbol * sps, sample_rate, center_freq, ch, rng, cfo_hz=cfo_hz)
+            truth.append((k, clk, ch))
+    return iq, truth
+
+
 def add_burst(iq, bits, start, sample_rate, center_freq, channel, rng, cfo_hz=10e3, amplitude=1.0):
     sps = int(round(sample_rate / SYMBOL_RATE))
     bb = gfsk_baseband(bits, sps) * amplitude

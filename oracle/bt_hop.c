@@ -146,3 +146,112 @@ int bto_hop_candidates(const bto_hopper *h, uint32_t *out, int cap)
     if (out && n > 0) memcpy(out, h->cand, sizeof(uint32_t) * (size_t)n);
     return h->ncand;
 }
+
+/* ---- basic_rate_piconet hop reversal on a bto_piconet ---- */
+#include <stdio.h>
+#define HLOG(...) do { if (log) { size_t n__ = strlen(log); if (n__ < cap) snprintf(log + n__, cap - n__, __VA_ARGS__); } } while (0)
+
+int bto_piconet_init_hop_reversal(bto_piconet *pn, int aliased, char *log, size_t cap)       /* :96-129 */
+{
+    HLOG("\nCalculating complete hopping sequence.\n");
+    if (pn->hops) bto_hopper_free(pn->hops);
+    pn->hops = bto_hopper_new((((uint32_t)pn->uap << 24) | pn->lap) & 0xfffffff, pn->afh);
+    int clock = (int)((pn->clk_offset + pn->first_pkt_time) & 0x3f);
+    pn->num_candidates = bto_hop_init_candidates(pn->hops, pn->pattern_channels[0], clock, aliased);
+    pn->winnowed = 0;
+    pn->hop_reversal_inited = 1;
+    pn->have_clk27 = 0;
+    pn->aliased = aliased;
+    HLOG("%d initial CLK1-27 candidates\n", pn->num_candidates);
+    return pn->num_candidates;
+}
+
+static int pn_winnow_one(bto_piconet *pn, int offset, int channel, char *log, size_t cap)    /* :305-338 */
+{
+    int n = bto_hop_winnow(pn->hops, offset, channel, pn->aliased);
+    pn->num_candidates = n;
+    if (n == 1) {
+        uint32_t c0 = 0;
+        bto_hop_candidates(pn->hops, &c0, 1);
+        pn->clk_offset = (c0 - pn->first_pkt_time) & 0x7ffffff;
+        pn->have_clk27 = 1;
+        HLOG("\nAcquired CLK1-27 offset = 0x%07x\n", pn->clk_offset);
+    } else if (n == 0) {
+        bto_piconet_reset(pn, log, cap);
+    } else {
+        HLOG("%d CLK1-27 candidates remaining\n", n);
+    }
+    return n;
+}
+
+int bto_piconet_winnow(bto_piconet *pn, char *log, size_t cap)                               /* :341-368 */
+{
+    int n = pn->num_candidates;
+    for (; pn->winnowed < pn->packets_observed; pn->winnowed++) {
+        int index = pn->pattern_indices[pn->winnowed], channel = pn->pattern_channels[pn->winnowed];
+        n = pn_winnow_one(pn, index, channel, log, cap);
+        if (!pn->hop_reversal_inited) break;                   /* reset() inside: the pattern is gone */
+        if (pn->packets_observed > 0 && pn->winnowed > 0) {    /* the reference also reads entry -1 (not reproduced) */
+            int last_index = pn->pattern_indices[pn->winnowed - 1], last_channel = pn->pattern_channels[pn->winnowed - 1];
+            if (!pn->looks_like_afh && index == last_index + 1 && channel == last_channel) pn->looks_like_afh = 1;
+        }
+    }
+    return n;
+}
+
+/* ---- gr::bluetooth::multi_hopper work() (lib/multi_hopper_impl.cc:76-209) ---- */
+struct bto_hopper_block { uint32_t lap; int aliased; bto_piconet pn; };
+
+bto_hopper_block *bto_hopper_block_new(uint32_t lap, int aliased)
+{
+    bto_hopper_block *b = (bto_hopper_block *)calloc(1, sizeof *b);
+    b->lap = lap & 0xffffff; b->aliased = aliased;
+    bto_piconet_init(&b->pn, b->lap);
+    return b;
+}
+void bto_hopper_block_free(bto_hopper_block *b) { if (b) { bto_piconet_release(&b->pn); free(b); } }
+const bto_piconet *bto_hopper_block_piconet(const bto_hopper_block *b) { return &b->pn; }
+
+void bto_hopper_block_slot(bto_hopper_block *b, uint32_t clkn, int nhits, const int *channels, const char *const *symbols,
+                           const int *lens, int low_channel, int high_channel, char *log, size_t cap)
+{
+    bto_piconet *pn = &b->pn;
+    clkn &= 0x7ffffff;
+    if (pn->have_clk27) {
+        /* hopalong (:152-209): only the predicted channel of this slot */
+        uint32_t clock27 = (clkn + pn->clk_offset) & 0x7ffffff;
+        int hop = bto_gen_hops(pn->hops)[clock27];
+        int obs = b->aliased ? bto_aliased_channel(hop) : hop;
+        if (obs < low_channel || obs > high_channel) return;
+        for (int i = 0; i < nhits; i++) {
+            if (channels[i] != hop) continue;                  /* the front end runs on the true hop frequency */
+            bto_packet *pkt = bto_packet_new(symbols[i], lens[i], 0, obs);
+            if (bto_packet_lap(pkt) == b->lap) {
+                HLOG("clock 0x%07x, channel %2d: ", clock27, obs);
+                if (bto_packet_header_present(pkt)) bto_packet_decode_print(pkt, pn->uap, clock27, 1, log, cap);
+                else HLOG("ID\n");
+            }
+            bto_packet_free(pkt);
+            break;
+        }
+        return;
+    }
+    for (int i = 0; i < nhits; i++) {                          /* channels ascending, first hit of each */
+        bto_packet *pkt = bto_packet_new(symbols[i], lens[i], clkn, channels[i]);
+        if (bto_packet_lap(pkt) == b->lap && bto_packet_header_present(pkt)) {
+            if (!pn->have_clk6) {
+                bto_piconet_uap_from_header_pkt(pn, pkt, log, cap);
+                if (pn->have_clk6) {
+                    bto_piconet_init_hop_reversal(pn, b->aliased, log, cap);
+                    bto_piconet_winnow(pn, log, cap);
+                }
+            } else {
+                bto_piconet_uap_from_header_pkt(pn, pkt, log, cap);
+                if (pn->have_clk6) bto_piconet_winnow(pn, log, cap);
+            }
+            bto_packet_free(pkt);
+            break;
+        }
+        bto_packet_free(pkt);
+    }
+}

@@ -130,6 +130,7 @@ int  bto_le_freq2index(double freq);
 int  bto_header_present(const char *symbols, int length);   /* lib/packet_impl.cc:1205-1242 */
 uint32_t bto_air_to_host32(const char *air, int bits);
 
+/* (bto_piconet below embeds a hop-reversal state; struct bto_hopper is declared further down) */
 /* ---- classic header path (bt_uap.c): lib/packet_impl.cc:367-383, 386-468,
  * 513-548, 597-1063; lib/piconet_impl.cc:433-547.  `symbols` start at the access code. ---- */
 int      bto_unfec13(const char *in, char *out, int length);
@@ -147,7 +148,13 @@ typedef struct bto_piconet {               /* the UAP/CLK1-6 part of basic_rate_
     int clock6_candidates[64];
     uint32_t clk_offset;
     int uap, have_uap, have_clk6, have_clk27;
+    /* hop reversal (lib/piconet_impl.h:99-117): observed pattern, AFH heuristics */
+    int pattern_indices[1000];
+    uint8_t pattern_channels[1000];
+    int winnowed, num_candidates, hop_reversal_inited, aliased, afh, looks_like_afh;
+    struct bto_hopper *hops;
 } bto_piconet;
+struct bto_hopper;
 typedef struct bto_packet bto_packet;      /* classic_packet_impl state */
 typedef struct bto_sniffer bto_sniffer;    /* multi_sniffer_impl's piconet map and packet queues */
 bto_packet *bto_packet_new(const char *symbols, int length, uint32_t clkn, int channel);
@@ -180,6 +187,26 @@ int  bto_aliased_channel(int channel);
 int  bto_hop_init_candidates(bto_hopper *h, int channel, int known_clock_bits, int aliased);
 int  bto_hop_winnow(bto_hopper *h, int offset, int channel, int aliased);
 int  bto_hop_candidates(const bto_hopper *h, uint32_t *out, int cap);
+
+/* basic_rate_piconet hop reversal on a bto_piconet (lib/piconet_impl.cc:96-129, 305-368, 526-547) */
+int  bto_piconet_uap_from_header_pkt(bto_piconet *pn, bto_packet *pkt, char *log, size_t cap);
+void bto_piconet_reset(bto_piconet *pn, char *log, size_t cap);
+int  bto_piconet_init_hop_reversal(bto_piconet *pn, int aliased, char *log, size_t cap);
+int  bto_piconet_winnow(bto_piconet *pn, char *log, size_t cap);
+void bto_piconet_release(bto_piconet *pn);
+uint32_t bto_packet_lap(const bto_packet *p);
+int  bto_packet_header_present(const bto_packet *p);
+int  bto_packet_decode_print(bto_packet *p, int uap, uint32_t clock, int have27, char *log, size_t cap);
+
+/* gr::bluetooth::multi_hopper's work() for one time slot (lib/multi_hopper_impl.cc:76-209, tun off): the
+ * first access-code hit of every channel that has one, ascending channel order, symbols from the hit on.
+ * Appends what the reference prints. */
+typedef struct bto_hopper_block bto_hopper_block;
+bto_hopper_block *bto_hopper_block_new(uint32_t lap, int aliased);
+void bto_hopper_block_free(bto_hopper_block *b);
+void bto_hopper_block_slot(bto_hopper_block *b, uint32_t clkn, int nhits, const int *channels, const char *const *symbols,
+                           const int *lens, int low_channel, int high_channel, char *log, size_t cap);
+const bto_piconet *bto_hopper_block_piconet(const bto_hopper_block *b);
 
 /* ---- block work() restatements; return number of hits appended ---- */
 int bto_work(bto_ctx *c, const float *win, uint32_t slot, bto_hit *hits, int max_hits);

@@ -393,12 +393,21 @@ void bto_piconet_init(bto_piconet *pn, uint32_t lap)
 static void pn_reset(bto_piconet *pn, char *log, size_t cap)                     /* :526-547 */
 {
     LOGF("no candidates remaining! starting over . . .\n");
+    if (pn->hop_reversal_inited) { bto_hopper_free(pn->hops); pn->hops = NULL; }
     pn->got_first_packet = 0;
     pn->packets_observed = 0;
+    pn->hop_reversal_inited = 0;
     pn->have_uap = 0;
     pn->have_clk6 = 0;
     pn->have_clk27 = 0;
+    /* two packets in a row on one channel were seen: try AFH next time (:541-546) */
+    pn->afh = pn->looks_like_afh;
+    pn->looks_like_afh = 0;
 }
+void bto_piconet_reset(bto_piconet *pn, char *log, size_t cap) { pn_reset(pn, log, cap); }
+void bto_piconet_release(bto_piconet *pn) { if (pn->hops) { bto_hopper_free(pn->hops); pn->hops = NULL; } }
+uint32_t bto_packet_lap(const bto_packet *p) { return p->lap; }
+int bto_packet_header_present(const bto_packet *p) { return bto_header_present(p->sym, p->length); }
 
 static int uap_from_header(bto_piconet *pn, bto_packet *pkt, char *log, size_t cap)
 {
@@ -410,6 +419,8 @@ static int uap_from_header(bto_piconet *pn, bto_packet *pkt, char *log, size_t c
         pn_reset(pn, log, cap);
         return 0;
     }
+    pn->pattern_indices[pn->packets_observed] = (int)(clkn - pn->first_pkt_time);
+    pn->pattern_channels[pn->packets_observed] = (uint8_t)pkt->channel;
     pn->packets_observed++;
     pn->total_packets_observed++;
     for (int count = 0; count < 64; count++) {
@@ -443,6 +454,11 @@ static int uap_from_header(bto_piconet *pn, bto_packet *pkt, char *log, size_t c
     }
     if (remaining == 0) pn_reset(pn, log, cap);
     return 0;
+}
+
+int bto_piconet_uap_from_header_pkt(bto_piconet *pn, bto_packet *pkt, char *log, size_t cap)
+{
+    return uap_from_header(pn, pkt, log, cap);
 }
 
 int bto_uap_from_header(bto_piconet *pn, const char *symbols, int length, uint32_t clkn, int channel,
@@ -614,3 +630,20 @@ void bto_sniffer_ac(bto_sniffer *s, const char *symbols, int len, uint32_t clkn,
         bto_packet_free(pkt);
     }
 }
+
+/* decode() + print() of a packet with known UAP / clock (hopalong, lib/multi_hopper_impl.cc:181-186) */
+int bto_packet_decode_print(bto_packet *p, int uap, uint32_t clock, int have27, char *log, size_t cap)
+{
+    p->uap = uap;
+    p->clock = have27 ? (clock & 0x7ffffff) : (clock & 0x3f);
+    p->have_clk6 = 1; p->have_clk27 = have27;
+    p->have_payload = 0;
+    if (decode_header(p, log, cap)) decode_payload(p);
+    if (p->have_payload) {
+        LOGF("%s\n", TYPE_NAME[p->type & 15]);
+        if (p->payload_header_length > 0)
+            LOGF("  LLID: %d\n  flow: %d\n  payload length: %d\n", p->llid, p->flow, p->payload_length);
+    }
+    return p->have_payload;
+}
+

@@ -111,6 +111,16 @@ def lib():
     L.bto_uap_from_header.restype = ctypes.c_int
     L.bto_uap_from_header.argtypes = [ctypes.POINTER(PiconetState), ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32,
                                       ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    L.bto_hopper_block_new.restype = vp
+    L.bto_hopper_block_new.argtypes = [ctypes.c_uint32, ctypes.c_int]
+    L.bto_hopper_block_free.restype = None
+    L.bto_hopper_block_free.argtypes = [vp]
+    L.bto_hopper_block_slot.restype = None
+    L.bto_hopper_block_slot.argtypes = [vp, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                        ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_char_p, ctypes.c_size_t]
+    L.bto_hopper_block_piconet.restype = ctypes.POINTER(PiconetState)
+    L.bto_hopper_block_piconet.argtypes = [vp]
     L.bto_hopper_new.restype = vp
     L.bto_hopper_new.argtypes = [ctypes.c_uint32, ctypes.c_int]
     L.bto_hopper_free.restype = None
@@ -204,7 +214,11 @@ class PiconetState(ctypes.Structure):
     _fields_ = [("lap", ctypes.c_uint32), ("got_first_packet", ctypes.c_int), ("packets_observed", ctypes.c_int),
                 ("total_packets_observed", ctypes.c_int), ("first_pkt_time", ctypes.c_uint32),
                 ("clock6_candidates", ctypes.c_int * 64), ("clk_offset", ctypes.c_uint32), ("uap", ctypes.c_int),
-                ("have_uap", ctypes.c_int), ("have_clk6", ctypes.c_int), ("have_clk27", ctypes.c_int)]
+                ("have_uap", ctypes.c_int), ("have_clk6", ctypes.c_int), ("have_clk27", ctypes.c_int),
+                ("pattern_indices", ctypes.c_int * 1000), ("pattern_channels", ctypes.c_uint8 * 1000),
+                ("winnowed", ctypes.c_int), ("num_candidates", ctypes.c_int), ("hop_reversal_inited", ctypes.c_int),
+                ("aliased", ctypes.c_int), ("afh", ctypes.c_int), ("looks_like_afh", ctypes.c_int),
+                ("hops", ctypes.c_void_p)]
 
 
 class Piconet:
@@ -254,6 +268,38 @@ class Hopper:
         buf = np.zeros(cap, np.uint32)
         n = lib().bto_hop_candidates(self.h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), cap)
         return buf[:min(n, cap)]
+
+
+class HopperBlock:
+    """gr::bluetooth::multi_hopper's work() on top of the front end's hit list
+    (lib/multi_hopper_impl.cc:76-209): one call per time slot with the first access-code hit of
+    every channel that has one."""
+
+    def __init__(self, lap, aliased=False):
+        self.h = lib().bto_hopper_block_new(int(lap), 1 if aliased else 0)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().bto_hopper_block_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def slot(self, clkn, hits, low_channel, high_channel):
+        """hits: list of (channel, symbols) in ascending channel order -> printed text"""
+        n = len(hits)
+        ch = (ctypes.c_int * max(n, 1))(*[int(c) for c, _ in hits])
+        bufs = [np.ascontiguousarray(s, dtype=np.uint8).tobytes() + bytes(64) for _, s in hits]
+        ptrs = (ctypes.c_char_p * max(n, 1))(*bufs)
+        lens = (ctypes.c_int * max(n, 1))(*[len(s) for _, s in hits])
+        log = ctypes.create_string_buffer(1 << 16)
+        lib().bto_hopper_block_slot(self.h, int(clkn), n, ch, ptrs, lens, int(low_channel), int(high_channel), log, 1 << 16)
+        return log.value.decode()
+
+    @property
+    def piconet(self):
+        return lib().bto_hopper_block_piconet(self.h).contents
 
 
 class Sniffer:

@@ -103,3 +103,26 @@ def test_btrx_amd_uap_discovery_on_captured_symbols(po, synth, tmp_path):
     got = out.stdout.split("\n", 1)[1]
     assert "We have a winner! UAP = 0xaf" in want and "Decoding queued packets" in want
     assert got == want
+
+
+def test_btrx_amd_hopper_follows_a_hopping_piconet(po, synth, tmp_path):
+    """btrx_amd -l LAP -p (multi_hopper): GPU front end + GPU header sweep + GPU hop reversal
+    (btgpu_hopseq_*) + host piconet logic print exactly what the oracle pipeline prints: UAP / CLK1-6
+    discovery, candidate winnowing down to the master clock, then one line per followed packet."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("toh", os.path.join(ROOT, "tests", "test_oracle_hop.py"))
+    toh = importlib.util.module_from_spec(spec); spec.loader.exec_module(toh)
+    fs, fc = 8e6, 2476.5e6
+    lap, uap, clk0, nsl = 0x24D952, 0xAF, 0x3A5C7E1, 700
+    iq, truth = synth.make_hopping_capture(fs, fc, nsl, lap, uap, clk0, seed=5, dh1_fraction=0.0)
+    path = str(tmp_path / "hop.cfile")
+    iq.tofile(path)
+    out = subprocess.run([BTRX, "-f", "2476.5M", "-r", "8M", "-i", path, "-l", "%06x" % lap, "-p"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    hits, _ = o.run_stream(iq, threads=16)
+    want, hb = toh._hopper_text(po, o, iq, hits, lap, nsl)
+    got = out.stdout.split("\n", 1)[1]
+    assert "Acquired CLK1-27 offset = 0x%07x" % ((clk0 - 6) & 0x7FFFFFF) in want
+    assert got == want

@@ -47,3 +47,61 @@ def test_winnowing_converges_on_the_true_clock(po):
     for off in (3, 17, 40, 122, 500, 1021, 2000, 3001):
         m = hp2.winnow(off, al(int(tab[(clk + off) % (1 << 27)])), aliased=True)
     assert m == 1 and int(hp2.candidates()[0]) == clk
+
+
+def _hopper_text(po, o, iq, hits, lap, n_slots):
+    """stdout of multi_hopper for the oracle front end's hit list (first classic hit of each channel
+    per slot, ascending channels) through the oracle's hopper block."""
+    hb = po.HopperBlock(lap)
+    by_slot = {}
+    for h in hits:
+        if h.kind == 0:
+            by_slot.setdefault(h.slot, {}).setdefault(h.channel, h)
+    text = ""
+    for k in range(n_slots):
+        lst = []
+        for ch in sorted(by_slot.get(k, {})):
+            h = by_slot[k][ch]
+            ch_iq, _ = o.channel_samples(o.window(iq, h.slot), h.channel)
+            sym, _ = o.channel_symbols(ch_iq)
+            lst.append((ch, sym[h.offset:h.offset + min(h.nsym, 3125)]))
+        if lst:
+            text += hb.slot(k, lst, o.low_ch, o.high_ch)
+    return text, hb
+
+
+def test_hopper_block_acquires_the_master_clock(po, synth):
+    """A master hopping by the real selection kernel (generator written from the specification,
+    independent of the oracle), 8 of 79 channels visible: UAP / CLK1-6 from header consistency,
+    CLK1-27 from the hop pattern, then hopalong decodes every visible packet with the true master
+    clock.  CLK offset = clk0 - 6: a packet sent in slot s is reported by work() call s + 6."""
+    fs, fc = 8e6, 2476.5e6
+    lap, uap, clk0, nsl = 0x24D952, 0xAF, 0x3A5C7E1, 700
+    iq, truth = synth.make_hopping_capture(fs, fc, nsl, lap, uap, clk0, seed=5, dh1_fraction=0.0)
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    hits, _ = o.run_stream(iq, threads=16)
+    text, hb = _hopper_text(po, o, iq, hits, lap, nsl)
+    pn = hb.piconet
+    assert pn.have_clk27 and pn.uap == uap and pn.clk_offset == (clk0 - 6) & 0x7FFFFFF
+    assert "We have a winner! UAP = 0xaf" in text and "\nCalculating complete hopping sequence.\n" in text
+    assert "\nAcquired CLK1-27 offset = 0x%07x\n" % ((clk0 - 6) & 0x7FFFFFF) in text
+    tail = text.split("Acquired CLK1-27 offset")[1].splitlines()[1:]
+    sent = {clk: ch for k, clk, ch in truth}
+    assert len(tail) > 20
+    for line in tail:                               # "clock 0x%07x, channel %2d: POLL"
+        clk, ch = int(line[6:15], 16), int(line[25:27])
+        assert sent[clk] == ch and line.split(": ")[1] in ("POLL", "NULL")
+
+
+def test_hopper_block_crc_success_quirk(po, synth):
+    """Reference behaviour kept: when the very first packet already passes its payload CRC,
+    UAP_from_header returns before d_got_first_packet is set (lib/piconet_impl.cc:482-493 vs :498), every
+    later packet gets pattern index 0 and the hop reversal starts over with each new channel."""
+    fs, fc = 8e6, 2476.5e6
+    lap, uap, clk0, nsl = 0x24D952, 0xAF, 0x3A5C7E1, 260
+    iq, _ = synth.make_hopping_capture(fs, fc, nsl, lap, uap, clk0, seed=5, dh1_fraction=1.0)
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    hits, _ = o.run_stream(iq, threads=16)
+    text, hb = _hopper_text(po, o, iq, hits, lap, nsl)
+    assert "Correct CRC! UAP = 0xaf found after 1 total packets." in text
+    assert "no candidates remaining! starting over . . ." in text and not hb.piconet.have_clk27
