@@ -134,11 +134,9 @@ protected:
     void handle_hit(const btgpu_hit &h, const btgpu_header *hdr, const uint8_t *syms, int nsyms) override
     {
         if (h.kind == BTGPU_KIND_AA) {
-            // aa(): "time %6d, snr=%.1f, " + le_packet::print()'s first line up to the access address
-            // (lib/multi_sniffer_impl.cc:213, lib/packet_impl.cc:1586); PDU fields = "next" rows
-            const int chan = h.channel / 2;
-            const int index = chan == 0 ? 37 : chan == 12 ? 38 : chan == 39 ? 39 : (chan < 12 ? chan - 1 : chan - 2);
-            printf("time %6d, snr=%.1f, BTLE index=%02d, AA=%08x\n", (int)(h.slot & 0x7ffffff), h.snr_db, index, h.lap);
+            // aa() (lib/multi_sniffer_impl.cc:207-226): "time %6d, snr=%.1f, " + le_packet::print()
+            printf("time %6d, snr=%.1f, ", (int)(h.slot & 0x7ffffff), h.snr_db);
+            fputs(host::le_packet_text(syms, nsyms, h.channel).c_str(), stdout);
             return;
         }
         // ac() and everything it calls (lib/multi_sniffer_impl.cc:169-365): the "time ..." prefix,

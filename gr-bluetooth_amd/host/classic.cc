@@ -393,6 +393,74 @@ void classic_packet::print(std::string &out) const
         appendf(out, "  LLID: %d\n  flow: %d\n  payload length: %d\n", d_llid, d_flow, d_payload_length);
 }
 
+// ------------------------------------------------------------------------ le_packet
+std::string le_packet_text(const uint8_t *symbols, int avail, int channel)
+{
+    std::string out;
+    // le_packet::freq2index (lib/packet_impl.cc:1285-1314): LE channels sit on the even classic channels
+    if (channel < 0 || channel > 78 || (channel & 1)) return out;
+    const int chan = channel / 2;
+    const int index = chan == 0 ? 37 : chan == 12 ? 38 : chan == 39 ? 39 : (chan < 12 ? chan - 1 : chan - 2);
+    // whitening: the x^7 + x^4 + 1 register started with position 0 = 1, positions 1..6 = the channel
+    // index MSB first (:1446-1450), from link symbol 40 (the PDU header) on
+    uint8_t reg[7];
+    reg[0] = 1;
+    for (int i = 0; i < 6; i++) reg[1 + i] = (uint8_t)((index >> (5 - i)) & 1);
+    constexpr int N = 376;                         // LE_MAX_SYMBOLS; symbols past `avail` count as 0
+    uint8_t link[N];
+    for (int i = 0; i < N; i++) link[i] = (uint8_t)(i < avail ? (symbols[i] & 1) : 0);
+    for (int i = 40; i < N; i++) {
+        const uint8_t o = reg[6];
+        link[i] ^= o;
+        const uint8_t nxt[7] = {o, reg[0], reg[1], reg[2], (uint8_t)(reg[3] ^ o), reg[4], reg[5]};
+        std::memcpy(reg, nxt, 7);
+    }
+    const uint32_t aa = classic_packet::bits(&link[8], 32);
+    const uint32_t header = classic_packet::bits(&link[40], 16);
+    uint8_t pdu[64] = {0};                         // d_pdu[39]; bytes beyond it (read out of bounds by the reference) = 0
+    for (int pi = 0, i = 56; i + 8 < N; pi++, i += 8) pdu[pi] = (uint8_t)classic_packet::bits(&link[i], 8);
+    auto six = [&](const char *name, int at) {
+        appendf(out, "  %s=%02x%02x%02x%02x%02x%02x\n", name, pdu[at], pdu[at + 1], pdu[at + 2], pdu[at + 3], pdu[at + 4], pdu[at + 5]);
+    };
+    if (index >= 37) {
+        const unsigned type = header & 0xf, length = (header >> 8) & 0x3f;
+        appendf(out, "BTLE index=%02d, AA=%08x, PDUType=%d, TxAdd=%d, RxAdd=%d, Length=%d\n", index, aa, type, (header >> 6) & 1,
+                (header >> 7) & 1, length);
+        switch (type) {
+            case 0: case 2: case 4: case 6: {
+                const char *what = type == 4 ? "ScanRspData" : "AdvData";
+                six("AdvA", 0);
+                appendf(out, "\n  (char) %s=", what);
+                for (unsigned i = 6; i < length; i++) {
+                    char c = (char)pdu[i];
+                    if (c < ' ' || c > '~') c = '.';
+                    appendf(out, " %c", c);
+                }
+                appendf(out, "\n  (byte) %s=", what);
+                for (unsigned i = 6; i < length; i++) appendf(out, "%02x", pdu[i]);
+                out += "\n";
+                break;
+            }
+            case 1: six("AdvA", 0); six("InitA", 6); break;
+            case 3: six("ScanA", 0); six("AdvA", 6); break;
+            case 5: {
+                six("InitA", 0); six("AdvA", 6);
+                auto le = [&](int at, int nbytes) { uint64_t v = 0; for (int k = 0; k < nbytes; k++) v |= (uint64_t)pdu[at + k] << (8 * k); return v; };
+                appendf(out, "  AA=%08x, CRCInit=%06x, WinSize=%d, WinOffset=%d\n", (unsigned)le(12, 4), (unsigned)le(16, 3), pdu[19],
+                        (int)le(20, 2));
+                appendf(out, "  Interval=%d, Latency=%d, Timeout=%d, ChM=%010lx, Hop=%d, SCA=%d\n", (int)le(22, 2), (int)le(24, 2),
+                        (int)le(26, 2), (unsigned long)le(28, 5), pdu[33] & 0x1f, (pdu[33] >> 5) & 7);
+                break;
+            }
+            default: break;
+        }
+    } else {
+        appendf(out, "BTLE index=%02d, AA=%08x, LLID=%d, NESN=%d, SN=%d, MD=%d, Length=%d\n", index, aa, header & 3, (header >> 2) & 1,
+                (header >> 3) & 1, (header >> 4) & 1, (header >> 8) & 0x1f);
+    }
+    return out;
+}
+
 // --------------------------------------------------------------- basic_rate_piconet
 basic_rate_piconet::~basic_rate_piconet()
 {

@@ -84,6 +84,10 @@ private:
     std::vector<uint8_t> d_payload;                    // one bit per byte
 };
 
+// le_packet_impl constructor + print (lib/packet_impl.cc:1529-1664): what aa() prints after its
+// "time .., snr=.., " prefix for symbols that start at the LE preamble on classic channel `channel`
+std::string le_packet_text(const uint8_t *symbols, int avail, int channel);
+
 class basic_rate_piconet
 {
 public:

@@ -706,6 +706,75 @@ int bto_le_freq2index(double freq)
 }
 
 /* lib/packet_impl.cc:1452-1527 (diagnostic printf omitted) */
+/* le_packet_impl::le_packet_impl + print (lib/packet_impl.cc:1529-1664): de-whitened link symbols,
+ * header fields, PDU bytes; `stream` = symbols from the preamble on, `avail` of them valid (the
+ * reference copies LE_MAX_SYMBOLS = 376 whatever the length is; symbols past `avail` count as 0 here,
+ * and PDU bytes past d_pdu[38] -- which the reference reads out of bounds for Length > 39 -- as 0). */
+int bto_le_print(const char *stream, int avail, double freq, char *out, size_t cap)
+{
+    build_luts();
+    int index = bto_le_freq2index(freq);
+    if (index < 0 || !out || cap == 0) return -1;
+    uint8_t link[376];
+    for (int i = 0; i < 376; i++) link[i] = (uint8_t)(i < avail ? (stream[i] & 1) : 0);
+    for (unsigned i = 40, wi = LE_INDICES[index]; i < 376; i++, wi = (wi + 1) % 127) link[i] ^= WHITENING[wi];
+    unsigned aa = 0, header = 0;
+    for (int i = 0; i < 32; i++) aa |= (unsigned)link[8 + i] << i;
+    for (int i = 0; i < 16; i++) header |= (unsigned)link[40 + i] << i;
+    uint8_t pdu[64];
+    memset(pdu, 0, sizeof pdu);
+    for (unsigned pi = 0, i = 56; i + 8 < 376; pi++, i += 8) {
+        unsigned v = 0;
+        for (int b = 0; b < 8; b++) v |= (unsigned)link[i + b] << b;
+        pdu[pi] = (uint8_t)v;
+    }
+    size_t n = 0;
+#define P(...) do { if (n < cap) n += (size_t)snprintf(out + n, cap - n, __VA_ARGS__); } while (0)
+    out[0] = 0;
+    if (index >= 37) {
+        unsigned type = header & 0xf, txadd = (header >> 6) & 1, rxadd = (header >> 7) & 1, len = (header >> 8) & 0x3f;
+        P("BTLE index=%02d, AA=%08x, PDUType=%d, TxAdd=%d, RxAdd=%d, Length=%d\n", index, aa, type, txadd, rxadd, len);
+        switch (type) {
+        case 0: case 2: case 4: case 6:
+            P("  AdvA=%02x%02x%02x%02x%02x%02x\n", pdu[0], pdu[1], pdu[2], pdu[3], pdu[4], pdu[5]);
+            P(type == 4 ? "\n  (char) ScanRspData=" : "\n  (char) AdvData=");
+            for (unsigned i = 6; i < len; i++) { char c = (char)pdu[i]; if (c < ' ' || c > '~') c = '.'; P(" %c", c); }
+            P(type == 4 ? "\n  (byte) ScanRspData=" : "\n  (byte) AdvData=");
+            for (unsigned i = 6; i < len; i++) P("%02x", pdu[i]);
+            P("\n");
+            break;
+        case 1:
+            P("  AdvA=%02x%02x%02x%02x%02x%02x\n  InitA=%02x%02x%02x%02x%02x%02x\n", pdu[0], pdu[1], pdu[2], pdu[3], pdu[4],
+              pdu[5], pdu[6], pdu[7], pdu[8], pdu[9], pdu[10], pdu[11]);
+            break;
+        case 3:
+            P("  ScanA=%02x%02x%02x%02x%02x%02x\n  AdvA=%02x%02x%02x%02x%02x%02x\n", pdu[0], pdu[1], pdu[2], pdu[3], pdu[4],
+              pdu[5], pdu[6], pdu[7], pdu[8], pdu[9], pdu[10], pdu[11]);
+            break;
+        case 5: {
+            P("  InitA=%02x%02x%02x%02x%02x%02x\n  AdvA=%02x%02x%02x%02x%02x%02x\n", pdu[0], pdu[1], pdu[2], pdu[3], pdu[4],
+              pdu[5], pdu[6], pdu[7], pdu[8], pdu[9], pdu[10], pdu[11]);
+            uint32_t caa = pdu[12] | ((uint32_t)pdu[13] << 8) | ((uint32_t)pdu[14] << 16) | ((uint32_t)pdu[15] << 24);
+            uint32_t crcinit = pdu[16] | ((uint32_t)pdu[17] << 8) | ((uint32_t)pdu[18] << 16);
+            unsigned winsize = pdu[19], winoffset = pdu[20] | (pdu[21] << 8), interval = pdu[22] | (pdu[23] << 8);
+            unsigned latency = pdu[24] | (pdu[25] << 8), timeout = pdu[26] | (pdu[27] << 8);
+            uint64_t chm = pdu[28] | ((uint64_t)pdu[29] << 8) | ((uint64_t)pdu[30] << 16) | ((uint64_t)pdu[31] << 24) |
+                           ((uint64_t)pdu[32] << 32);
+            P("  AA=%08x, CRCInit=%06x, WinSize=%d, WinOffset=%d\n", caa, crcinit, winsize, winoffset);
+            P("  Interval=%d, Latency=%d, Timeout=%d, ChM=%010lx, Hop=%d, SCA=%d\n", interval, latency, timeout,
+              (unsigned long)chm, pdu[33] & 0x1f, (pdu[33] >> 5) & 7);
+            break;
+        }
+        default: break;
+        }
+    } else {
+        P("BTLE index=%02d, AA=%08x, LLID=%d, NESN=%d, SN=%d, MD=%d, Length=%d\n", index, aa, header & 3, (header >> 2) & 1,
+          (header >> 3) & 1, (header >> 4) & 1, (header >> 8) & 0x1f);
+    }
+#undef P
+    return (int)n;
+}
+
 int bto_sniff_aa(const char *stream, int stream_length, double freq)
 {
     build_luts();

@@ -127,6 +127,8 @@ int  bto_sniff_aa(const char *stream, int stream_length, double freq);
  * sync-word offset or -1; LAP and corrected-bit count through the pointers */
 int  bto_btbb_find_ac(const char *stream, int search_length, int max_ac_errors, uint32_t *lap, int *ac_errors);
 int  bto_le_freq2index(double freq);
+/* le_packet_impl ctor + print (lib/packet_impl.cc:1529-1664): the text aa() prints after "time .., snr=.., " */
+int  bto_le_print(const char *stream, int avail, double freq, char *out, size_t cap);
 int  bto_header_present(const char *symbols, int length);   /* lib/packet_impl.cc:1205-1242 */
 uint32_t bto_air_to_host32(const char *air, int bits);
 

@@ -146,6 +146,8 @@ def lib():
                                  ctypes.c_char_p, ctypes.c_size_t]
     L.bto_unfec23.restype = ctypes.c_int
     L.bto_unfec23.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    L.bto_le_print.restype = ctypes.c_int
+    L.bto_le_print.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_double, ctypes.c_char_p, ctypes.c_size_t]
     L.bto_work.restype = ctypes.c_int
     L.bto_work.argtypes = [vp, c_fp, ctypes.c_uint32, ctypes.POINTER(Hit), ctypes.c_int]
     L.bto_run_stream.restype = ctypes.c_int
@@ -337,6 +339,14 @@ def crc_check(symbols, clock, ptype, uap):
     s = np.ascontiguousarray(symbols, dtype=np.uint8)
     pad = np.concatenate([s[:3125], np.zeros(3200 - min(len(s), 3125), np.uint8)])
     return lib().bto_crc_check(pad.tobytes(), min(len(s), 3125), int(clock), int(ptype), int(uap))
+
+
+def le_print(symbols, freq):
+    """le_packet::print() for symbols that start at the LE preamble (lib/packet_impl.cc:1529-1664)."""
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    buf = ctypes.create_string_buffer(4096)
+    lib().bto_le_print(s.tobytes() + bytes(8), len(s), float(freq), buf, 4096)
+    return buf.value.decode()
 
 
 def header_present(symbols, length=None):

@@ -14,17 +14,14 @@ BTRX = os.path.join(ROOT, "gr-bluetooth_amd", "host", "btrx_amd")
 def _sniffer_text(po, o, iq, hits):
     """stdout of multi_sniffer for the oracle's hit list: the oracle's packet handlers
     (multi_sniffer_impl::ac and below) fed with the symbols each hit hands over, LE lines as aa() prints."""
-    def le_index(ch):
-        chan = ch // 2
-        return 37 if chan == 0 else 38 if chan == 12 else 39 if chan == 39 else (chan - 1 if chan < 12 else chan - 2)
     sn = po.Sniffer()
     text = ""
     for h in hits:
-        if h.kind != 0:
-            text += "time %6d, snr=%.1f, BTLE index=%02d, AA=%08x\n" % (h.slot, h.snr, le_index(h.channel), h.lap)
-            continue
         ch_iq, _ = o.channel_samples(o.window(iq, h.slot), h.channel)
         sym, _ = o.channel_symbols(ch_iq)
+        if h.kind != 0:              # aa(): prefix + le_packet::print() on the symbols from the preamble on
+            text += "time %6d, snr=%.1f, " % (h.slot, h.snr) + po.le_print(sym[h.offset:h.offset + max(h.nsym, 0)], 2402e6 + 1e6 * h.channel)
+            continue
         text += sn.ac(sym[h.offset:h.offset + min(h.nsym, 3125)], h.slot, h.channel, h.snr)
     return text
 
@@ -38,6 +35,9 @@ def test_btrx_amd_prints_reference_lines(po, synth, tmp_path, sniff):
     rng = np.random.default_rng(3)
     for k in (1, 4, 6):                                          # ID packets: 68-symbol access code only
         synth.add_burst(iq, synth.access_code_bits(0x9E8B33)[:68], k * 5000 + 300, fs, fc, 73 + k % 3, rng)
+    for k, pdu in ((2, 0), (5, 4), (9, 5), (11, 3)):              # LE adverts on index 39 = classic channel 78
+        synth.add_burst(iq, synth.le_advert_bits(39, rng, payload_bytes=34 if pdu == 5 else 18, pdu_type=pdu),
+                        k * 5000 + 900, fs, fc, 78, rng)
     path = str(tmp_path / "cap.cfile")
     iq.astype(np.complex64).tofile(path)                      # .cfile = raw interleaved float32 I/Q
     cmd = [BTRX, "-f", "2476.5M", "-r", "8M", "-i", path, "-c", "3"] + (["-S"] if sniff else [])
@@ -46,12 +46,14 @@ def test_btrx_amd_prints_reference_lines(po, synth, tmp_path, sniff):
     lines = [l for l in out.stdout.splitlines() if l]
     if sniff:
         assert any(l.endswith("ID") for l in lines)
+        assert sum("BTLE index=39, AA=8e89bed6, PDUType=" in l for l in lines) >= 3 and any("CRCInit=" in l for l in lines)
     o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER if sniff else po.MODE_LAP, le=sniff)   # multi_sniffer runs the LE pass
     hits, _ = o.run_stream(iq)
     assert len(hits) > 3
     assert lines[0] == "history set to %d samples: channel=%d, noise=%d" % (o.history, o.ntaps_ch + o.decim * 8, o.ntaps_noise)
     if sniff:
-        want = _sniffer_text(po, o, iq, hits).splitlines()
+        want = [l for l in _sniffer_text(po, o, iq, hits).splitlines() if l]
+        assert out.stdout.split("\n", 1)[1] == _sniffer_text(po, o, iq, hits)      # blank lines of le_packet::print included
     else:
         want = ["GOT PACKET: ch=%d, LAP=%06x, err=%u at time slot %d" % (h.channel, h.lap, h.ac_errors, h.slot) for h in hits]
     assert lines[1:] == want
