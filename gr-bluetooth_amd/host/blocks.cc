@@ -122,8 +122,10 @@ public:
                          gr::io_signature::make(0, 0, 0)),
           multi_block(sample_rate, center_freq, squelch_threshold, BTGPU_MODE_SNIFFER), d_tun(tun)
     {
-        if (d_tun)    // the TAP sink is outside the hot path
-            fprintf(stderr, "warning: was not able to open TUN device, disabling Wireshark interface\n");
+        if (d_tun) {  // lib/multi_sniffer_impl.cc:63-70
+            if (d_tap.open("btbb")) d_handlers.set_tap(&d_tap);
+            else fprintf(stderr, "warning: was not able to open TUN device, disabling Wireshark interface\n");
+        }
     }
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &) override
     {
@@ -131,6 +133,7 @@ public:
     }
 protected:
     host::sniffer_handlers d_handlers;
+    host::tap_sink d_tap;
     void handle_hit(const btgpu_hit &h, const btgpu_header *hdr, const uint8_t *syms, int nsyms) override
     {
         if (h.kind == BTGPU_KIND_AA) {
@@ -157,14 +160,17 @@ public:
           multi_block(sample_rate, center_freq, squelch_threshold, BTGPU_MODE_SNIFFER, true),
           d_handlers((uint32_t)LAP, aliased, d_design.low_channel, d_design.high_channel)
     {
-        if (tun)      // the TAP sink is outside the hot path
-            fprintf(stderr, "warning: was not able to open TUN device, disabling Wireshark interface\n");
+        if (tun) {    // lib/multi_hopper_impl.cc:59-67
+            if (d_tap.open("btbb")) d_handlers.set_tap(&d_tap);
+            else fprintf(stderr, "warning: was not able to open TUN device, disabling Wireshark interface\n");
+        }
     }
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &) override
     {
         return run_work(noutput_items, input_items);
     }
 protected:
+    host::tap_sink d_tap;
     void handle_hit(const btgpu_hit &h, const btgpu_header *hdr, const uint8_t *syms, int nsyms) override
     {
         const std::string text = d_handlers.hit(h, *hdr, syms, nsyms);

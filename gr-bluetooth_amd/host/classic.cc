@@ -11,6 +11,12 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <fcntl.h>
+#include <linux/if.h>
+#include <linux/if_tun.h>
+#include <sys/ioctl.h>
+#include <unistd.h>
+
 namespace gr {
 namespace bluetooth {
 namespace host {
@@ -75,6 +81,57 @@ const char *const TYPE_NAMES[16] = {"NULL", "POLL", "FHS", "DM1", "DH1/2-DH1", "
 constexpr uint32_t GIAC = 0x9e8b33, LIAC = 0x9e8b00;
 
 }  // namespace
+
+// ------------------------------------------------------------------------ tap_sink
+tap_sink::~tap_sink()
+{
+    if (d_fd >= 0) ::close(d_fd);
+    if (d_file) fclose(d_file);
+}
+
+bool tap_sink::open(const char *name)
+{
+    int fd = ::open("/dev/net/tun", O_RDWR);
+    if (fd >= 0) {
+        struct ifreq ifr;
+        std::memset(&ifr, 0, sizeof ifr);
+        ifr.ifr_flags = IFF_TAP | IFF_NO_PI;
+        snprintf(ifr.ifr_name, IFNAMSIZ, "%s", name);
+        int one = 1;
+        if (ioctl(fd, TUNSETIFF, (void *)&ifr) == -1 || ioctl(fd, TUNSETPERSIST, (void *)&one) == -1) { ::close(fd); fd = -1; }
+    }
+    d_fd = fd;
+    if (d_fd < 0) {
+        const char *path = getenv("BTGPU_TAP_FILE");
+        if (path && *path) d_file = fopen(path, "wb");
+    }
+    return is_open();
+}
+
+std::vector<uint8_t> tap_sink::frame(const uint8_t *data, unsigned len, uint64_t src_addr, uint64_t dst_addr, uint16_t ether_type)
+{
+    std::vector<uint8_t> f(14 + len, 0);
+    for (int i = 0; i < 6; i++) {
+        f[i] = (uint8_t)(dst_addr >> (8 * (5 - i)));
+        f[6 + i] = (uint8_t)(src_addr >> (8 * (5 - i)));
+    }
+    f[12] = (uint8_t)(ether_type >> 8);
+    f[13] = (uint8_t)ether_type;
+    if (data && len) std::memcpy(&f[14], data, len);
+    return f;
+}
+
+void tap_sink::write(const uint8_t *data, unsigned len, uint64_t src_addr, uint64_t dst_addr, uint16_t ether_type)
+{
+    if (!is_open()) return;
+    const std::vector<uint8_t> f = frame(data, len, src_addr, dst_addr, ether_type);
+    if (d_fd >= 0) { if (::write(d_fd, f.data(), f.size()) == -1) perror("write"); return; }
+    const uint32_t n = (uint32_t)f.size();
+    const uint8_t hdr[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+    fwrite(hdr, 1, 4, d_file);
+    fwrite(f.data(), 1, f.size(), d_file);
+    fflush(d_file);
+}
 
 // ------------------------------------------------------------------ classic_packet
 uint32_t classic_packet::bits(const uint8_t *air, int n)
@@ -461,6 +518,19 @@ std::string le_packet_text(const uint8_t *symbols, int avail, int channel)
     return out;
 }
 
+std::vector<uint8_t> classic_packet::tun_format() const
+{
+    std::vector<uint8_t> t((size_t)9 + (size_t)d_payload_length, 0);
+    t[0] = (uint8_t)d_clock; t[1] = (uint8_t)(d_clock >> 8); t[2] = (uint8_t)(d_clock >> 16); t[3] = (uint8_t)(d_clock >> 24);
+    t[4] = (uint8_t)d_channel;
+    t[5] = (uint8_t)((d_have_clk27 ? 1 : 0) | ((d_have_nap ? 1 : 0) << 1));
+    t[6] = (uint8_t)bits(&d_header[0], 7);         // LT_ADDR and type
+    t[7] = (uint8_t)bits(&d_header[7], 3);         // flags
+    t[8] = (uint8_t)bits(&d_header[10], 8);        // HEC
+    for (int i = 0; i < d_payload_length; i++) t[(size_t)9 + i] = (uint8_t)bits(&d_payload[(size_t)i * 8], 8);
+    return t;
+}
+
 // --------------------------------------------------------------- basic_rate_piconet
 basic_rate_piconet::~basic_rate_piconet()
 {
@@ -621,9 +691,16 @@ std::string hopper_handlers::hit(const btgpu_hit &hit, const btgpu_header &sweep
             pkt.set_uap(d_piconet.uap());
             pkt.set_clock(clock27, true);
             pkt.decode(out);
-            if (pkt.got_payload()) pkt.print(out);
+            if (pkt.got_payload()) {
+                pkt.print(out);
+                if (d_tap) {
+                    const std::vector<uint8_t> data = pkt.tun_format();
+                    d_tap->write(data.data(), (unsigned)data.size(), 0, ((uint32_t)pkt.uap() << 24) | pkt.lap(), tap_sink::ETHER_TYPE);
+                }
+            }
         } else {
             out += "ID\n";
+            if (d_tap) d_tap->write(nullptr, 0, 0, ((uint32_t)d_piconet.uap() << 24) | pkt.lap(), tap_sink::ETHER_TYPE);
         }
         return out;
     }
@@ -651,7 +728,7 @@ std::string sniffer_handlers::ac(const btgpu_hit &hit, const btgpu_header &sweep
     auto pkt = std::make_shared<classic_packet>(symbols, nsymbols, clkn, hit.channel, sweep);
     const uint32_t lap = pkt->lap();
     appendf(out, "time %6d, snr=%.1f, channel %2d, LAP %06x ", (int)clkn, hit.snr_db, hit.channel, lap);
-    if (!pkt->header_present()) { id(out); return out; }
+    if (!pkt->header_present()) { id(lap, out); return out; }
     auto &slot = d_piconets[lap];
     if (!slot) slot = std::make_shared<basic_rate_piconet>(lap);
     auto pn = slot;
@@ -661,7 +738,11 @@ std::string sniffer_handlers::ac(const btgpu_hit &hit, const btgpu_header &sweep
     return out;
 }
 
-void sniffer_handlers::id(std::string &out) { out += "ID\n"; }
+void sniffer_handlers::id(uint32_t lap, std::string &out)
+{
+    out += "ID\n";
+    if (d_tap) d_tap->write(nullptr, 0, 0, lap, tap_sink::ETHER_TYPE);
+}
 
 void sniffer_handlers::decode(std::shared_ptr<classic_packet> pkt, std::shared_ptr<basic_rate_piconet> pn, bool first_run,
                               std::string &out)
@@ -671,6 +752,12 @@ void sniffer_handlers::decode(std::shared_ptr<classic_packet> pkt, std::shared_p
     pkt->decode(out);
     if (pkt->got_payload()) {
         pkt->print(out);
+        if (d_tap) {
+            uint64_t addr = ((uint64_t)pkt->uap() << 24) | pkt->lap();
+            if (pn->have_nap()) { addr |= (uint64_t)pn->nap() << 32; pkt->set_nap(); }
+            const std::vector<uint8_t> data = pkt->tun_format();      // 9 bytes of meta data and header + payload
+            d_tap->write(data.data(), (unsigned)data.size(), 0, addr, tap_sink::ETHER_TYPE);
+        }
         if (pkt->type() == 2) fhs(*pkt, out);
     } else if (first_run) {
         out += "lost clock!\n";

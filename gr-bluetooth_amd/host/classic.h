@@ -23,6 +23,26 @@ namespace gr {
 namespace bluetooth {
 namespace host {
 
+// The Wireshark side channel of the reference (lib/tun.cc): Ethernet-framed packets on a TAP device
+// "btbb".  open() tries /dev/net/tun like mktun() (:6-79); where that is not possible and the
+// environment names a file in BTGPU_TAP_FILE, frames go there instead, each preceded by its length
+// (uint32 little endian).  write() = write_interface (:92-123): 14-byte header (dst MAC, src MAC,
+// ethertype, big endian) + data.
+class tap_sink
+{
+public:
+    ~tap_sink();
+    bool open(const char *name);
+    bool is_open() const { return d_fd >= 0 || d_file; }
+    void write(const uint8_t *data, unsigned len, uint64_t src_addr, uint64_t dst_addr, uint16_t ether_type);
+    static std::vector<uint8_t> frame(const uint8_t *data, unsigned len, uint64_t src_addr, uint64_t dst_addr, uint16_t ether_type);
+    static constexpr uint16_t ETHER_TYPE = 0xFFF0;       // lib/multi_sniffer_impl.h:52
+
+private:
+    int d_fd = -1;
+    FILE *d_file = nullptr;
+};
+
 class classic_packet
 {
 public:
@@ -43,6 +63,10 @@ public:
     void set_uap(uint8_t uap) { d_uap = uap; }
     void decode(std::string &out);                     // :169-175, :1066-1165
     void print(std::string &out) const;                // :1168-1179
+    std::vector<uint8_t> tun_format() const;           // :1181-1210: 6 bytes meta data, 3 bytes header, payload
+    void set_nap() { d_have_nap = true; }
+    int payload_length() const { return d_payload_length; }
+    uint8_t uap() const { return d_uap; }
     // FHS payload fields (:1245-1281)
     uint32_t lap_from_fhs() const { return bits(&d_payload[34], 24); }
     uint8_t uap_from_fhs() const { return (uint8_t)bits(&d_payload[64], 8); }
@@ -77,7 +101,7 @@ private:
     int d_type = 0;
     uint8_t d_uap = 0;
     uint32_t d_clock = 0;
-    bool d_have_clk6 = false, d_have_clk27 = false;
+    bool d_have_clk6 = false, d_have_clk27 = false, d_have_nap = false;
     bool d_have_payload = false;
     int d_payload_length = 0, d_payload_header_length = 0, d_llid = 0, d_flow = 0;
     uint8_t d_header[18] = {0};
@@ -101,6 +125,7 @@ public:
     bool have_nap() const { return d_have_nap; }
     uint8_t uap() const { return d_uap; }
     uint32_t offset() const { return d_clk_offset; }
+    uint16_t nap() const { return d_nap; }
     void set_uap(uint8_t u) { d_uap = u; d_have_uap = true; }
     void set_nap(uint16_t n) { d_nap = n; d_have_nap = true; }
     void set_offset(uint32_t o) { d_clk_offset = o; d_have_clk6 = true; d_have_clk27 = true; }
@@ -141,6 +166,7 @@ public:
     // records in (slot, channel, offset) order; returns the text the reference prints
     std::string hit(const btgpu_hit &hit, const btgpu_header &sweep, const uint8_t *symbols, int nsymbols);
     const basic_rate_piconet &piconet() const { return d_piconet; }
+    void set_tap(tap_sink *t) { d_tap = t; }
 
 private:
     uint32_t d_lap;
@@ -150,6 +176,7 @@ private:
     uint64_t d_slot = ~0ull;
     int d_last_channel = -1;
     bool d_slot_done = false, d_locked = false;
+    tap_sink *d_tap = nullptr;
 };
 
 class sniffer_handlers
@@ -157,9 +184,11 @@ class sniffer_handlers
 public:
     // one classic hit, in the order work() reports them; returns the text the reference prints
     std::string ac(const btgpu_hit &hit, const btgpu_header &sweep, const uint8_t *symbols, int nsymbols);
+    void set_tap(tap_sink *t) { d_tap = t; }
 
 private:
-    void id(std::string &out);
+    void id(uint32_t lap, std::string &out);
+    tap_sink *d_tap = nullptr;
     void decode(std::shared_ptr<classic_packet> pkt, std::shared_ptr<basic_rate_piconet> pn, bool first_run, std::string &out);
     void discover(std::shared_ptr<classic_packet> pkt, std::shared_ptr<basic_rate_piconet> pn, std::string &out);
     void recall(std::shared_ptr<basic_rate_piconet> pn, std::string &out);

@@ -167,6 +167,8 @@ int  bto_packet_type(const bto_packet *p);
 int  bto_packet_uap(const bto_packet *p);
 bto_sniffer *bto_sniffer_new(void);
 void bto_sniffer_free(bto_sniffer *s);
+void bto_sniffer_set_tun(bto_sniffer *s, int on);      /* collect the TAP frames (lib/tun.cc:92-123) */
+size_t bto_sniffer_tap(const bto_sniffer *s, uint8_t *out, size_t cap);   /* frames, each after its uint32 LE length */
 /* multi_sniffer_impl::ac for one classic hit (lib/multi_sniffer_impl.cc:169-205, tun off): appends the text
  * the reference prints -- the "time ..." line, ID / discovery / decode output -- to `log` */
 void bto_sniffer_ac(bto_sniffer *s, const char *symbols, int len, uint32_t clkn, int channel, double snr,

@@ -173,7 +173,7 @@ struct bto_packet {
     int length;                   /* d_length */
     uint32_t clkn; int channel; uint32_t lap;
     int type, uap;                /* d_packet_type (0 at construction), d_UAP */
-    uint32_t clock; int have_clk6, have_clk27;
+    uint32_t clock; int have_clk6, have_clk27, have_nap;
     int have_payload, payload_length, payload_header_length, llid, flow;
     char header[18];              /* d_packet_header */
     char payload[3000];           /* d_payload, one bit per byte */
@@ -519,13 +519,49 @@ static const char *TYPE_NAME[16] = {"NULL", "POLL", "FHS", "DM1", "DH1/2-DH1", "
 #define MAX_PN 64
 #define MAX_Q 1024
 typedef struct { int used; bto_piconet pn; bto_packet *queue[MAX_Q]; int qn; uint32_t nap; int have_nap; } pn_slot;
-struct bto_sniffer { pn_slot pn[MAX_PN]; };
+struct bto_sniffer { pn_slot pn[MAX_PN]; int tun; uint8_t *tap; size_t tap_len, tap_cap; };
 
 bto_sniffer *bto_sniffer_new(void) { return (bto_sniffer *)calloc(1, sizeof(bto_sniffer)); }
+
+/* tun_format (lib/packet_impl.cc:1181-1210) and write_interface (lib/tun.cc:92-123): with `tun` on, every
+ * frame the reference writes to its TAP device is appended here, preceded by its length (uint32 LE) */
+void bto_sniffer_set_tun(bto_sniffer *s, int on) { s->tun = on; }
+size_t bto_sniffer_tap(const bto_sniffer *s, uint8_t *out, size_t cap)
+{
+    size_t n = s->tap_len < cap ? s->tap_len : cap;
+    if (out && n) memcpy(out, s->tap, n);
+    return s->tap_len;
+}
+static void tap_write(bto_sniffer *s, const uint8_t *data, unsigned len, uint64_t src, uint64_t dst, unsigned ether_type)
+{
+    if (!s->tun) return;
+    size_t need = s->tap_len + 4 + 14 + len;
+    if (need > s->tap_cap) { s->tap_cap = need * 2 + 4096; s->tap = (uint8_t *)realloc(s->tap, s->tap_cap); }
+    uint8_t *f = s->tap + s->tap_len;
+    uint32_t n = 14 + len;
+    f[0] = (uint8_t)n; f[1] = (uint8_t)(n >> 8); f[2] = (uint8_t)(n >> 16); f[3] = (uint8_t)(n >> 24);
+    f += 4;
+    for (int i = 0; i < 6; i++) { f[i] = (uint8_t)(dst >> (8 * (5 - i))); f[6 + i] = (uint8_t)(src >> (8 * (5 - i))); }
+    f[12] = (uint8_t)(ether_type >> 8); f[13] = (uint8_t)ether_type;
+    if (len) memcpy(f + 14, data, len);
+    s->tap_len = need;
+}
+static unsigned packet_tun_format(const bto_packet *p, uint8_t *t)
+{
+    t[0] = (uint8_t)p->clock; t[1] = (uint8_t)(p->clock >> 8); t[2] = (uint8_t)(p->clock >> 16); t[3] = (uint8_t)(p->clock >> 24);
+    t[4] = (uint8_t)p->channel;
+    t[5] = (uint8_t)((p->have_clk27 ? 1 : 0) | ((p->have_nap ? 1 : 0) << 1));
+    t[6] = (uint8_t)air_bits(&p->header[0], 7);
+    t[7] = (uint8_t)air_bits(&p->header[7], 3);
+    t[8] = (uint8_t)air_bits(&p->header[10], 8);
+    for (int i = 0; i < p->payload_length; i++) t[9 + i] = (uint8_t)air_bits(&p->payload[i * 8], 8);
+    return 9u + (unsigned)p->payload_length;
+}
 void bto_sniffer_free(bto_sniffer *s)
 {
     if (!s) return;
     for (int i = 0; i < MAX_PN; i++) for (int k = 0; k < s->pn[i].qn; k++) bto_packet_free(s->pn[i].queue[k]);
+    free(s->tap);
     free(s);
 }
 
@@ -578,6 +614,13 @@ static void sn_decode(bto_sniffer *s, pn_slot *q, bto_packet *pkt, int first_run
         LOGF("%s\n", TYPE_NAME[pkt->type & 15]);
         if (pkt->payload_header_length > 0)
             LOGF("  LLID: %d\n  flow: %d\n  payload length: %d\n", pkt->llid, pkt->flow, pkt->payload_length);
+        if (s->tun) {                                                            /* :248-263 */
+            uint64_t addr = ((uint64_t)(unsigned)pkt->uap << 24) | pkt->lap;
+            if (q->have_nap) { addr |= (uint64_t)q->nap << 32; pkt->have_nap = 1; }
+            uint8_t data[9 + 3000 / 8 + 8];
+            unsigned n = packet_tun_format(pkt, data);
+            tap_write(s, data, n, 0, addr, 0xFFF0);
+        }
         if (pkt->type == 2) sn_fhs(s, pkt, log, cap);
         bto_packet_free(pkt);
     } else if (first_run) {
@@ -627,6 +670,7 @@ void bto_sniffer_ac(bto_sniffer *s, const char *symbols, int len, uint32_t clkn,
         if (lap == 0x9e8b33 || lap == 0x9e8b00) pn_erase(s, lap);
     } else {
         LOGF("ID\n");
+        tap_write(s, NULL, 0, 0, lap, 0xFFF0);                                   /* id(): :229-235 */
         bto_packet_free(pkt);
     }
 }

@@ -141,6 +141,10 @@ def lib():
     L.bto_sniffer_new.argtypes = []
     L.bto_sniffer_free.restype = None
     L.bto_sniffer_free.argtypes = [vp]
+    L.bto_sniffer_set_tun.restype = None
+    L.bto_sniffer_set_tun.argtypes = [vp, ctypes.c_int]
+    L.bto_sniffer_tap.restype = ctypes.c_size_t
+    L.bto_sniffer_tap.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
     L.bto_sniffer_ac.restype = None
     L.bto_sniffer_ac.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_double,
                                  ctypes.c_char_p, ctypes.c_size_t]
@@ -309,8 +313,17 @@ class Sniffer:
     lib/multi_sniffer_impl.cc:169-365): feed classic hits in the order work() reports them, get the
     text the reference prints."""
 
-    def __init__(self):
+    def __init__(self, tun=False):
         self.h = lib().bto_sniffer_new()
+        if tun:
+            lib().bto_sniffer_set_tun(self.h, 1)
+
+    def tap(self):
+        """the frames written to the TAP device so far (each after its uint32 LE length)"""
+        n = lib().bto_sniffer_tap(self.h, None, 0)
+        buf = ctypes.create_string_buffer(max(n, 1))
+        lib().bto_sniffer_tap(self.h, buf, n)
+        return buf.raw[:n]
 
     def __del__(self):
         try:

@@ -11,10 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BTRX = os.path.join(ROOT, "gr-bluetooth_amd", "host", "btrx_amd")
 
 
-def _sniffer_text(po, o, iq, hits):
+def _sniffer_text(po, o, iq, hits, tap=None):
     """stdout of multi_sniffer for the oracle's hit list: the oracle's packet handlers
     (multi_sniffer_impl::ac and below) fed with the symbols each hit hands over, LE lines as aa() prints."""
-    sn = po.Sniffer()
+    sn = po.Sniffer(tun=tap is not None)
     text = ""
     for h in hits:
         ch_iq, _ = o.channel_samples(o.window(iq, h.slot), h.channel)
@@ -23,6 +23,8 @@ def _sniffer_text(po, o, iq, hits):
             text += "time %6d, snr=%.1f, " % (h.slot, h.snr) + po.le_print(sym[h.offset:h.offset + max(h.nsym, 0)], 2402e6 + 1e6 * h.channel)
             continue
         text += sn.ac(sym[h.offset:h.offset + min(h.nsym, 3125)], h.slot, h.channel, h.snr)
+    if tap is not None:
+        tap.append(sn.tap())
     return text
 
 
@@ -97,11 +99,18 @@ def test_btrx_amd_uap_discovery_on_captured_symbols(po, synth, tmp_path):
         synth.add_burst(iq, bits[off - 8:off + 3000], (off - 8) * 8, fs, fc, 73, rng, cfo_hz=5e3)
     path = str(tmp_path / "c37.cfile")
     iq.tofile(path)
-    out = subprocess.run([BTRX, "-f", "2476.5M", "-r", "8M", "-i", path, "-S"], capture_output=True, text=True, timeout=300)
+    tap_path = str(tmp_path / "tap.bin")        # -w: the Wireshark TAP frames (no TUN device here: BTGPU_TAP_FILE)
+    out = subprocess.run([BTRX, "-f", "2476.5M", "-r", "8M", "-i", path, "-S", "-w"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, BTGPU_TAP_FILE=tap_path))
     assert out.returncode == 0, out.stderr
     o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER, le=True)
     hits, _ = o.run_stream(iq, threads=16)
-    want = _sniffer_text(po, o, iq, hits)
+    frames = []
+    want = _sniffer_text(po, o, iq, hits, tap=frames)
+    got_frames = open(tap_path, "rb").read()
+    # Ethernet-framed packets as lib/tun.cc writes them: ethertype 0xFFF0, destination MAC = 00:00:UAP:LAP
+    assert len(frames[0]) > 200 and got_frames == frames[0]
+    assert bytes.fromhex("0000af24d952" + "000000000000" + "fff0") in got_frames
     got = out.stdout.split("\n", 1)[1]
     assert "We have a winner! UAP = 0xaf" in want and "Decoding queued packets" in want
     assert got == want
