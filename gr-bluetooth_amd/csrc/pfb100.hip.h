@@ -216,17 +216,18 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 6 : 1)) void pfb100_kernel(PfbParams 
     // phase-A lane roles and branch taps (fixed for the whole group)
     cf a[Q];
 
-    // Noise-bank roles: 500 tasks (instant i, branch pp) of 15 complex taps.  The channel branches
-    // occupy waves 0..3; the fifth wave (NTH = 320) takes instants 0..3 of branches 0..63 and the
-    // other lanes one task each, so that every wave carries about the same number of FMAs and a
-    // lane needs the taps of one branch only (fetched once, behind the input staging).
+    // Noise-bank roles: 500 tasks (instant i, branch pp) of 15 complex taps, spread so that every
+    // SIMD carries about the same number of FMAs in phase A and a lane needs the taps of one branch
+    // only (fetched once, behind the input staging).
     int nz_pp = 0, nz_i0 = 0, nz_cnt = 0;
     cf an[FUSEN ? NQ : 1];
     if (FUSEN) {
         if (NTH > 256) {
-            if (l0 >= 256) { nz_pp = l0 - 256; nz_i0 = 0; nz_cnt = 4; }
-            else if (l0 < 64) { nz_pp = l0; nz_i0 = 4; nz_cnt = 1; }
-            else if (l0 < 64 + 36 * NU) { nz_pp = 64 + (l0 - 64) % 36; nz_i0 = (l0 - 64) / 36; nz_cnt = 1; }
+            // Five waves land 2 + 1 + 1 + 1 on the four SIMDs (waves 0 and 4 share one): wave 0, which
+            // also has channel branches, takes one noise task per lane, the others two
+            if (l0 < 64) { nz_pp = l0; nz_i0 = 4; nz_cnt = 1; }                       // instant 4, branches 0..63
+            else if (l0 < 264) { nz_pp = (l0 - 64) % 100; nz_i0 = 2 * ((l0 - 64) / 100); nz_cnt = 2; }   // instants (0,1) / (2,3)
+            else if (l0 < 300) { nz_pp = 64 + (l0 - 264); nz_i0 = 4; nz_cnt = 1; }    // instant 4, branches 64..99
         } else {
             // 256 lanes: branch pp = l % 100 for l < 200, instants split 3 / 2
             if (l0 < 200) { nz_pp = l0 % 100; nz_i0 = l0 < 100 ? 0 : 3; nz_cnt = l0 < 100 ? 3 : 2; }
