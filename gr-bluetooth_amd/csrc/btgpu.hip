@@ -805,6 +805,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, kFuseThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, kFuseThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
+    if (getenv("BTGPU_VERBOSE"))
+        fprintf(stderr, "btgpu_create: d=%p d2=%p,%p Z=%p ptile=%p\n", h->d_d.p, h->tc[0].d_d2.p, h->tc[1].d_d2.p, h->d_Z.p, h->d_ptile.p);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]
     *out = h;

@@ -806,3 +806,26 @@ void sniffer_handlers::fhs(classic_packet &pkt, std::string &out)
 }  // namespace host
 }  // namespace bluetooth
 }  // namespace gr
+
+extern "C" int bt_host_crc_check(const uint8_t *symbols, int length, int clock, int type, int uap)
+{
+    btgpu_header none;
+    std::memset(&none, 0, sizeof none);
+    gr::bluetooth::host::classic_packet pkt(symbols, length, 0, 0, none);
+    pkt.force_header(type, (uint8_t)uap);
+    return pkt.crc_check(clock);
+}
+
+extern "C" int bt_host_decode_print(const uint8_t *symbols, int length, int uap, uint32_t clock, int have27, char *out, int cap)
+{
+    btgpu_header none;
+    std::memset(&none, 0, sizeof none);
+    gr::bluetooth::host::classic_packet pkt(symbols, length, 0, 0, none);
+    pkt.set_uap((uint8_t)uap);
+    pkt.set_clock(clock, have27 != 0);
+    std::string text;
+    pkt.decode(text);
+    pkt.print(text);
+    if (out && cap > 0) { std::strncpy(out, text.c_str(), (size_t)cap - 1); out[cap - 1] = 0; }
+    return pkt.got_payload() ? 1 : 0;
+}

@@ -65,6 +65,7 @@ public:
     void print(std::string &out) const;                // :1168-1179
     std::vector<uint8_t> tun_format() const;           // :1181-1210: 6 bytes meta data, 3 bytes header, payload
     void set_nap() { d_have_nap = true; }
+    void force_header(int type, uint8_t uap) { d_type = type; d_uap = uap; }   // what a try_clock() left behind (tests)
     int payload_length() const { return d_payload_length; }
     uint8_t uap() const { return d_uap; }
     // FHS payload fields (:1245-1281)
@@ -199,4 +200,10 @@ private:
 }  // namespace host
 }  // namespace bluetooth
 }  // namespace gr
+
+// C entry points onto the packet parsers, for differential tests against the oracle
+extern "C" {
+int bt_host_crc_check(const uint8_t *symbols, int length, int clock, int type, int uap);
+int bt_host_decode_print(const uint8_t *symbols, int length, int uap, uint32_t clock, int have27, char *out, int cap);
+}
 #endif

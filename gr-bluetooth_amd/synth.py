@@ -181,6 +181,58 @@ def classic_poll_bits(lap, uap, slot_clock, lt_addr=1, flow=1, arqn=0, seqn=0, p
     return np.concatenate([access_code_bits(lap), np.repeat(header, 3)])
 
 
+def fec23_encode(bits):
+    """(15,10) shortened Hamming code of the basic-rate FEC 2/3: ten data bits, then the five parity
+    bits of g(D) = (D + 1)(D^4 + D + 1) (register taps at positions 0, 1 and 3), zero padded to whole blocks."""
+    bits = list(int(b) for b in bits)
+    bits += [0] * ((-len(bits)) % 10)
+    out = []
+    for k in range(0, len(bits), 10):
+        d = bits[k:k + 10]
+        reg = [0] * 5
+        for i in range(9, -1, -1):
+            fb = d[i] ^ reg[4]
+            reg = [fb, reg[0] ^ fb, reg[1], reg[2] ^ fb, reg[3]]
+        out += d + reg
+    return np.array(out, dtype=np.uint8)
+
+
+def _classic_header(lap, uap, slot_clock, ptype, lt_addr, flow, arqn, seqn):
+    fields = (lt_addr & 7) | ((ptype & 15) << 3) | ((flow & 1) << 7) | ((arqn & 1) << 8) | ((seqn & 1) << 9)
+    hec = next(h for h in range(256) if _uap_of_hec(fields, h) == (uap & 0xFF))
+    return np.array([(fields >> i) & 1 for i in range(10)] + [(hec >> i) & 1 for i in range(8)], np.uint8)
+
+
+def classic_dm1_bits(lap, uap, slot_clock, body, lt_addr=1, llid=2, flow=1, arqn=0, seqn=0):
+    """DM1: like DH1 (TYPE 3) with the whitened payload FEC-2/3 encoded."""
+    body = bytes(body)
+    assert len(body) <= 17
+    ph = (llid & 3) | ((flow & 1) << 2) | (len(body) << 3)
+    pay = [(ph >> i) & 1 for i in range(8)]
+    for byte in body:
+        pay += [(byte >> i) & 1 for i in range(8)]
+    crc = _crc16(pay, uap)
+    pay += [(crc >> i) & 1 for i in range(16)]
+    wh = whitening_bits(slot_clock & 0x3F, 18 + len(pay))
+    header = _classic_header(lap, uap, slot_clock, 3, lt_addr, flow, arqn, seqn) ^ wh[:18]
+    return np.concatenate([access_code_bits(lap), np.repeat(header, 3), fec23_encode(np.array(pay, np.uint8) ^ wh[18:])])
+
+
+def classic_fhs_bits(lap, uap, slot_clock, fhs_lap, fhs_uap, fhs_nap, fhs_clk27_2, lt_addr=0):
+    """FHS (TYPE 2): 144 information bits (parity 34, LAP 24, EIR/SR/SP 6, UAP 8, NAP 16, class 24,
+    LT_ADDR 3, CLK27-2 26, page scan mode 3) + CRC, whitened, FEC 2/3."""
+    info = [0] * 144
+    def put(at, value, n):
+        for i in range(n):
+            info[at + i] = (value >> i) & 1
+    put(34, fhs_lap, 24); put(64, fhs_uap, 8); put(72, fhs_nap, 16); put(112, 1, 3); put(115, fhs_clk27_2, 26)
+    crc = _crc16(info, uap)
+    pay = np.array(info + [(crc >> i) & 1 for i in range(16)], np.uint8)
+    wh = whitening_bits(slot_clock & 0x3F, 18 + len(pay))
+    header = _classic_header(lap, uap, slot_clock, 2, lt_addr, 1, 0, 0) ^ wh[:18]
+    return np.concatenate([access_code_bits(lap), np.repeat(header, 3), fec23_encode(pay ^ wh[18:])])
+
+
 def classic_dh1_bits(lap, uap, slot_clock, body, lt_addr=1, llid=2, flow=1, arqn=0, seqn=0):
     """Air-order bits of a DH1 packet: 72-bit access code, FEC-1/3 header (LT_ADDR, TYPE 4, FLOW,
     ARQN, SEQN, HEC(UAP)), payload header + body + CRC(UAP); header and payload whitened with CLK6..1."""

@@ -137,3 +137,30 @@ def test_btrx_amd_hopper_follows_a_hopping_piconet(po, synth, tmp_path):
     got = out.stdout.split("\n", 1)[1]
     assert "Acquired CLK1-27 offset = 0x%07x" % ((clk0 - 6) & 0x7FFFFFF) in want
     assert got == want
+
+
+def test_btrx_amd_fhs_after_discovery(po, synth, tmp_path):
+    """A piconet seen through header-only packets until UAP / CLK1-6 are known, then an FHS and a DM1
+    packet: the sniffer block prints the decoded types, the FHS contents (BD_ADDR, CLK) and adopts
+    them -- text equal to the oracle pipeline."""
+    fs, fc = 8e6, 2476.5e6
+    lap, uap, clk0, nsl = 0x4831DD, 0x6B, 0x155AA00, 90
+    rng = np.random.default_rng(21)
+    iq = (0.05 * (rng.standard_normal(nsl * 5000) + 1j * rng.standard_normal(nsl * 5000))).astype(np.complex64)
+    for k in range(4, 60, 4):
+        bits = synth.classic_poll_bits(lap, uap, clk0 + k, lt_addr=int(rng.integers(1, 8)), flow=int(rng.integers(0, 2)),
+                                       arqn=int(rng.integers(0, 2)), seqn=int(rng.integers(0, 2)), ptype=int(rng.integers(0, 2)))
+        synth.add_burst(iq, bits, k * 5000 + 320, fs, fc, 72 + k % 5, rng, cfo_hz=4e3)
+    synth.add_burst(iq, synth.classic_fhs_bits(lap, uap, clk0 + 64, 0xABCDEF, 0x47, 0x1234, 0x1F2E3D4 >> 1), 64 * 5000 + 320, fs, fc, 75, rng)
+    synth.add_burst(iq, synth.classic_dm1_bits(lap, uap, clk0 + 70, b"hello dm1"), 70 * 5000 + 320, fs, fc, 73, rng)
+    path = str(tmp_path / "fhs.cfile")
+    iq.tofile(path)
+    out = subprocess.run([BTRX, "-f", "2476.5M", "-r", "8M", "-i", path, "-S"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER, le=True)
+    hits, _ = o.run_stream(iq, threads=16)
+    want = _sniffer_text(po, o, iq, hits)
+    # packets every fourth slot leave six CLK1-6 candidates; the FHS payload CRC settles it
+    assert "Correct CRC! UAP = 0x6b found after 15 total packets." in want
+    assert "FHS contents: BD_ADDR 00:34:47:ab:cd:ef, CLK 1f2e3d4" in want and "DM1\n  LLID: 2\n" in want
+    assert out.stdout.split("\n", 1)[1] == want
