@@ -30,7 +30,7 @@ using namespace btgpu;
 
 namespace {
 
-constexpr int kFuseThreads = 320;   // fused bank kernel: 310 DFT tasks per pass in one sweep
+constexpr int kFuseThreads = 256;   // fused bank kernel: 310 DFT tasks per pass in one sweep
 
 struct DevBuf {
     void *p = nullptr;

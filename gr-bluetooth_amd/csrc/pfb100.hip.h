@@ -149,7 +149,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 }
 
 template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false>
-__global__ __launch_bounds__(NTH, (FUSEN ? 6 : 1)) void pfb100_kernel(PfbParams p)
+__global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100_kernel(PfbParams p)
 {
     constexpr int DH = S * 50;                               // hop: 2 D = S * 100
     constexpr int NQ = 15, NR = 250, NU = 5;                 // fused noise bank: taps/branch, hop, instants per tile
@@ -230,6 +230,8 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 6 : 1)) void pfb100_kernel(PfbParams 
             else if (l0 < 300) { nz_pp = 64 + (l0 - 264); nz_i0 = 4; nz_cnt = 1; }    // instant 4, branches 64..99
         } else {
             // 256 lanes: branch pp = l % 100 for l < 200, instants split 3 / 2
+            // 256 lanes, one wave per SIMD: branch l % 100, instants 0..2 in lanes 0..99 and 3..4 in lanes
+            // 100..199 (an even 2-2-1 split needs a second tap set per lane and measured slower)
             if (l0 < 200) { nz_pp = l0 % 100; nz_i0 = l0 < 100 ? 0 : 3; nz_cnt = l0 < 100 ? 3 : 2; }
         }
     }
