@@ -213,6 +213,22 @@ def main():
         except Exception:
             pass
 
+        # The bank kernel is bounded by VALU issue rather than by HBM: report that roofline too, from the
+        # committed SQ_INSTS_VALU count (wave instructions; two launches in the counter run), 4 cycles
+        # per wave64 instruction on each of the 1024 SIMDs at 2.4 GHz
+        try:
+            import glob, re
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")), reverse=True):
+                m = re.search(r"^pfb100_kernel<7.*SQ_INSTS_VALU=([0-9.e+]+)M", open(path).read(), re.M)
+                if m and names[dom] == "ddc_channel" and args.workload == "c79" and S == 2048 and not direct:
+                    insts = float(m.group(1)) * 1e6 / 2.0
+                    bound_ms = insts * 4.0 / (1024 * 2.4e9) * 1e3
+                    roof["valu"] = {"wave_insts_per_launch": insts, "issue_bound_ms": round(bound_ms, 4),
+                                    "frac": round(bound_ms / avg[dom], 4), "source": "profiles/" + os.path.basename(path)}
+                    break
+        except Exception:
+            pass
+
         # ---- cpu_baseline: the oracle (a port, NOT the upstream binary) on a bounded sample ----
         cpu = None
         oracle_ok = None
