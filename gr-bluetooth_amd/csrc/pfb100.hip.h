@@ -130,13 +130,14 @@ __device__ __forceinline__ float demod_fast(const float *__restrict__ tab, float
     const float t0 = tab[index];
     const float interp = t0 + (tab[index + 1] - t0) * alpha;
     const float base = z < 0.003921569f ? z : interp;
-    const bool xbig = xa > ya;
+    // x-dominant when |x| >= |y| (so that (0, 0) falls through to angle 0 without a special case; at
+    // |x| == |y| both forms give pi/4 exactly)
+    const bool xbig = xa >= ya;
     // x-dominant: pr >= 0 ? base : pi - base ; y-dominant: pr >= 0 ? pi/2 - base : pi/2 + base
     const float k = xbig ? (pr >= 0.0f ? 0.0f : 3.14159265358979323846f) : 1.57079632679489661923f;
     const float sgn = (xbig == (pr >= 0.0f)) ? 1.0f : -1.0f;     // +base for (x-dom, pr>=0) and (y-dom, pr<0)
     float ang = k + sgn * base;
     ang = pi >= 0.0f ? ang : -ang;
-    ang = mx > 0.0f ? ang : 0.0f;
     return gain * ang;
 }
 
