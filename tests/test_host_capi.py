@@ -98,3 +98,16 @@ def test_product_never_imports_oracle():
                 if "pyoracle" in txt or "bt_oracle.h" in txt or "libbt_oracle" in txt or "bto_" in txt:
                     bad.append(os.path.join(d, f))
     assert bad == []
+
+
+def test_odd_samples_per_symbol_rates_are_refused_not_mishandled(pkg):
+    """625 * sps must be a multiple of the decimation floor(sps / 2) for the shared output grid:
+    5, 7, 25 Msps are refused by the design query (and by btgpu_create) instead of being computed
+    on a wrong grid; even sps and 3 Msps are accepted."""
+    for fs in (5e6, 7e6, 25e6):
+        with pytest.raises(pkg.BtgpuError) as e:
+            pkg.design_query(fs, 2450e6)
+        assert e.value.code == pkg.EUNSUPPORTED
+    for fs in (2e6, 3e6, 4e6, 6e6, 10e6, 16e6, 50e6):
+        d = pkg.design_query(fs, 2450e6)
+        assert d.samples_per_slot % d.decimation == 0
