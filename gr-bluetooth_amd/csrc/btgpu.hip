@@ -195,7 +195,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     const int nch = d.high_channel - d.low_channel + 1;
     const int ops = des.outs_per_slot;
     const long long G = (long long)ops * (S - 1) + d.ddc_out;
-    const long long Gn = (long long)ops * S;
+    const int ops_n = des.segmented ? d.noise_out : ops;       // noise outputs per slot
+    const long long Gn = (long long)ops_n * S;
+    const int seg_ch = des.segmented ? d.ddc_out : 0, seg_n = des.segmented ? d.noise_out : 0;
+    const long long seg_stride = d.samples_per_slot;
     const int nb = (int)((G + ops - 1) / ops);
     last_S = S;
     last_G = G;
@@ -265,11 +268,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            des.tail / TT, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     } else {
         const LaunchShape &s = shape_ch;
-        dim3 grid((unsigned)((G + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
+        const unsigned gx = seg_ch ? (unsigned)(((seg_ch + s.T - 1) / s.T) * S) : (unsigned)((G + s.T - 1) / s.T);
+        dim3 grid(gx, (unsigned)((nch + 1) / 2));
         hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len,
                            w0 + (long long)d.first_channel_sample, d.decimation, des.channel.ntp, s.JC,
                            (const float2 *)d_taps_ch.p, (const float2 *)d_rot_ch.p, des.channel.rot_period,
-                           (const double *)d_rotstep_ch.p, (float2 *)d_Y.p, G, ystride, nch);
+                           (const double *)d_rotstep_ch.p, (float2 *)d_Y.p, G, ystride, nch, seg_ch, seg_stride);
         HIPCHK(this, hipEventRecord(ev[1], st));
         dim3 g2((unsigned)nb, (unsigned)nch);
         hipLaunchKernelGGL(demod_energy_kernel<true>, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
@@ -306,7 +310,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             dim3 grid((unsigned)((Tn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
             hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, ns_st, d_x, (long long)x_len, xs0, ns.R,
                                ns.direct.ntp, s.JC, (const float2 *)d_taps_s1.p, (const float2 *)d_rot_s1.p,
-                               ns.direct.rot_period, (const double *)d_rotstep_s1.p, (float2 *)d_Z.p, Tn, zstride, nch);
+                               ns.direct.rot_period, (const double *)d_rotstep_s1.p, (float2 *)d_Z.p, Tn, zstride, nch, 0, 0LL);
         }
         HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
         const int run = ns.outs * (kS2Slots - 1) + ns.nw;
@@ -316,15 +320,16 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (const double *)d_w.p, (double *)d_Q.p, S);
     } else {
         const LaunchShape &s = shape_n;
-        dim3 grid((unsigned)((Gn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
+        const unsigned gx = seg_n ? (unsigned)(((seg_n + s.T - 1) / s.T) * S) : (unsigned)((Gn + s.T - 1) / s.T);
+        dim3 grid(gx, (unsigned)((nch + 1) / 2));
         hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, ns_st, d_x, (long long)x_len,
                            w0 + (long long)d.first_noise_sample, d.decimation, des.noise.ntp, s.JC,
                            (const float2 *)d_taps_n.p, (const float2 *)d_rot_n.p, des.noise.rot_period,
-                           (const double *)d_rotstep_n.p, (float2 *)d_Yn.p, Gn, ystride_n, nch);
+                           (const double *)d_rotstep_n.p, (float2 *)d_Yn.p, Gn, ystride_n, nch, seg_n, seg_stride);
         HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
         dim3 g2((unsigned)S, (unsigned)nch);
         hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, ns_st, (const float2 *)d_Yn.p, Gn,
-                           ystride_n, ops, 0, (const float *)nullptr, 0.f, (float *)nullptr,
+                           ystride_n, ops_n, 0, (const float *)nullptr, 0.f, (float *)nullptr,
                            (double *)d_Q.p, (double *)nullptr, S, nch, (float *)nullptr, 0LL);
     }
     HIPCHK(this, hipEventRecord(t.evn[2], ns_st));
@@ -621,10 +626,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     {
         FastPath *fp = &h->fp;
         int frc = make_fast_path(h->des, *fp);
-        const bool pfb_ok = (frc == BTGPU_OK || frc == BTGPU_EUNSUPPORTED) && fp->channel.available && fp->channel.Q == 7 && fp->channel.S == 1 &&
+        const bool pfb_ok = !h->des.segmented && (frc == BTGPU_OK || frc == BTGPU_EUNSUPPORTED) && fp->channel.available && fp->channel.Q == 7 && fp->channel.S == 1 &&
                             h->des.outs_per_slot % 25 == 0;
         const bool noise_pfb_ok = fp->noise.available && fp->noise.pfb.available && fp->noise.pfb.Q == 15 && fp->noise.pfb.S == 5;
-        const bool staged_ok = fp->noise.available &&
+        const bool staged_ok = !h->des.segmented && fp->noise.available &&
                                (noise_pfb_ok || pick_shape(fp->noise.R, fp->noise.direct.ntp, h->shape_s1));
         h->noise_pfb = noise_pfb_ok;
         h->fuse_noise = false;
@@ -676,7 +681,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
 
     const long long G = (long long)ops * (S - 1) + d.ddc_out;
     h->ystride = (G + 63) / 64 * 64;
-    h->ystride_n = ((long long)ops * S + 63) / 64 * 64;
+    h->ystride_n = ((long long)(des.segmented ? d.noise_out : ops) * S + 63) / 64 * 64;
     h->nb_max = (int)((G + ops - 1) / ops);
     h->in_cap = (size_t)d.history + (size_t)(S - 1) * d.samples_per_slot;
 

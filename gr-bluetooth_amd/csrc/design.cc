@@ -298,10 +298,18 @@ int make_design(const btgpu_config &cfg, Design &o)
     d.noise_out = d.samples_per_slot / d.decimation;
 
     // the shared output grid needs whole outputs per slot
-    if (d.samples_per_slot % d.decimation != 0) return BTGPU_EUNSUPPORTED;
-    o.outs_per_slot = d.samples_per_slot / d.decimation;
-    o.blocks_per_window = d.ddc_out / o.outs_per_slot;
-    o.tail = d.ddc_out % o.outs_per_slot;
+    if (d.samples_per_slot % d.decimation != 0) {
+        // consecutive windows sit on different decimation phases (odd samples per symbol >= 5): no
+        // shared output grid; every window is filtered on its own, like the reference does
+        o.segmented = true;
+        o.outs_per_slot = d.ddc_out;
+        o.blocks_per_window = 1;
+        o.tail = 0;
+    } else {
+        o.outs_per_slot = d.samples_per_slot / d.decimation;
+        o.blocks_per_window = d.ddc_out / o.outs_per_slot;
+        o.tail = d.ddc_out % o.outs_per_slot;
+    }
 
     for (int i = 0; i <= 255; i++) o.atan_tab[i] = (float)std::atan((double)i / 255.0);
     o.atan_tab[256] = o.atan_tab[255];

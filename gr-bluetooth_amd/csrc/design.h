@@ -62,7 +62,8 @@ struct Design {
     ClassicWhitening wh;
     int blocks_per_window = 0;           // ddc_out / (slot/decim)
     int tail = 0;                        // ddc_out % (slot/decim)
-    int outs_per_slot = 0;               // slot / decim
+    int outs_per_slot = 0;               // slot / decim; segmented: ddc_out (rows from one window to the next)
+    bool segmented = false;              // 625 * sps is not a multiple of decim: every window on its own grid
 };
 
 // returns BTGPU_OK or a negative error code; never throws

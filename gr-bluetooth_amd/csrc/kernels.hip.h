@@ -58,11 +58,18 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
     const float2 *__restrict__ x, long long x_len, long long first, int D, int ntp, int JC,
     const float2 *__restrict__ taps, const float2 *__restrict__ rot, int Q,
     const double *__restrict__ rot_step_turns,   // used when Q == 0
-    float2 *__restrict__ Y, long long G, long long ystride, int nch)
+    float2 *__restrict__ Y, long long G, long long ystride, int nch,
+    int seg_len, long long seg_stride)           // seg_len > 0: segmented outputs (one segment per window)
 {
+    // Segmented addressing (sample rates where consecutive windows sit on different decimation phases,
+    // 625 * sps not a multiple of D): output n = seg * seg_len + i reads x[first + seg * seg_stride + i * D + j]
+    // and is de-rotated with phase index i -- every window restarts its rotator like the reference.
     extern __shared__ float2 tile[];
     const int T = blockDim.x;
-    const long long g0 = (long long)blockIdx.x * T;
+    const int tiles_per_seg = seg_len > 0 ? (seg_len + T - 1) / T : 0;
+    const long long seg = seg_len > 0 ? (long long)(blockIdx.x / tiles_per_seg) : 0;
+    const long long g0 = seg_len > 0 ? (long long)(blockIdx.x % tiles_per_seg) * T : (long long)blockIdx.x * T;
+    first += seg * seg_stride;
     const int c0 = blockIdx.y * CPB;
     const int o = threadIdx.x;
 
@@ -108,8 +115,9 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
         }
     }
 
-    const long long g = g0 + o;
-    if (g >= G) return;
+    const long long g = g0 + o;                      // index inside the segment (or on the shared grid)
+    if (seg_len > 0 ? g >= seg_len : g >= G) return;
+    const long long gout = seg_len > 0 ? seg * seg_len + g : g;
 #pragma unroll
     for (int cc = 0; cc < CPB; cc++) {
         const int c = c0 + cc;
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
         float2 out;
         out.x = fmaf(-yi, ri, yr * rr);
         out.y = fmaf(yi, rr, yr * ri);
-        Y[(size_t)c * ystride + g] = out;
+        Y[(size_t)c * ystride + gout] = out;
     }
 }
 

@@ -32,6 +32,8 @@ CONFIGS = [
     (4e6, 2476e6, 30, 0.5),
     (8e6, 2476.5e6, 24, 0.4),
     (20e6, 2441e6, 12, 0.5),
+    (5e6, 2470e6, 24, 0.5),          # odd samples per symbol: 625 * sps is not a multiple of the decimation,
+    (25e6, 2441e6, 10, 0.5),         # every window is filtered on its own grid ("segmented" addressing)
 ]
 
 

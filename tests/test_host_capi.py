@@ -40,8 +40,8 @@ def test_design_query_rejects_bad_configs(pkg):
         pkg.design_query(8e6, 2476.5e6, 10.0, mode=7)
     with pytest.raises(pkg.BtgpuError):
         pkg.design_query(8e6, 2300e6)              # no Bluetooth channel in the span
-    with pytest.raises(pkg.BtgpuError) as e:
-        pkg.design_query(5e6, 2441e6)              # slot not a whole number of DDC outputs
+    with pytest.raises(pkg.BtgpuError) as e:       # the libbtbb-style search belongs to multi_LAP only
+        pkg.design_query(8e6, 2476.5e6, 10.0, mode=pkg.MODE_SNIFFER, correlator=pkg.CORRELATOR_BTBB)
     assert e.value.code == pkg.EUNSUPPORTED
 
 
@@ -100,14 +100,13 @@ def test_product_never_imports_oracle():
     assert bad == []
 
 
-def test_odd_samples_per_symbol_rates_are_refused_not_mishandled(pkg):
-    """625 * sps must be a multiple of the decimation floor(sps / 2) for the shared output grid:
-    5, 7, 25 Msps are refused by the design query (and by btgpu_create) instead of being computed
-    on a wrong grid; even sps and 3 Msps are accepted."""
-    for fs in (5e6, 7e6, 25e6):
-        with pytest.raises(pkg.BtgpuError) as e:
-            pkg.design_query(fs, 2450e6)
-        assert e.value.code == pkg.EUNSUPPORTED
-    for fs in (2e6, 3e6, 4e6, 6e6, 10e6, 16e6, 50e6):
-        d = pkg.design_query(fs, 2450e6)
-        assert d.samples_per_slot % d.decimation == 0
+def test_design_of_odd_samples_per_symbol_rates_matches_oracle(pkg, po):
+    """5, 7, 15, 25 Msps: 625 * sps is not a multiple of the decimation (no shared output grid, the
+    banks run window by window); the constructor arithmetic is the reference's all the same."""
+    for fs, fc in ((5e6, 2470e6), (7e6, 2450e6), (15e6, 2450e6), (25e6, 2441e6)):
+        for mode in (pkg.MODE_LAP, pkg.MODE_SNIFFER):
+            d = pkg.design_query(fs, fc, 10.0, mode)
+            o = po.Oracle(fs, fc, 10.0, mode)
+            assert d.samples_per_slot % d.decimation != 0
+            assert (d.history, d.ddc_out, d.noise_out, d.decimation, d.low_channel, d.high_channel) == \
+                (o.history, o.ddc_out, o.noise_out, o.decim, o.low_ch, o.high_ch)
