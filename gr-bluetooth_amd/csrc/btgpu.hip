@@ -106,7 +106,7 @@ struct btgpu_handle {
     // device memory
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
-    DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index;
+    DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index, d_winbits;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
     LaunchShape shape_s1;
@@ -154,7 +154,7 @@ struct btgpu_handle {
     {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
-                         &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index,
+                         &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -350,6 +350,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.syms = want_syms ? 1 : 0;
         p.btbb = d.correlator == BTGPU_CORRELATOR_BTBB ? 1 : 0;
         p.btbb_pcol = (const uint64_t *)d_pcol.p;
+        { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
         hipLaunchKernelGGL(window_kernel, dim3((S + kWinSlots - 1) / kWinSlots), dim3(kWinThreads), 0, st, p, (const float *)d_d.p, G,
                            (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
                            (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
@@ -357,7 +358,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
                            (unsigned int *)d_hitcount.p + 1, (const uint8_t *)d_le_hdr.p,
                            (const uint16_t *)d_le_whiten.p, (const int8_t *)d_le_index.p, (int *)d_winfin.p,
-                           (uint32_t *)d_symbits.p);
+                           (uint32_t *)d_symbits.p, (uint32_t *)d_winbits.p);
         HIPCHK(this, hipEventRecord(ev[5], st));
         // ---- tail: finish + nsym on the tail stream, overlapping the next batch's banks ----
         HIPCHK(this, hipEventRecord(t.detect_done, st));
@@ -776,6 +777,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_eon, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_eoff, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_snr, (size_t)S * nch * sizeof(double)));
+    TRY(h->alloc(h->d_winbits, (size_t)((S + kWinSlots - 1) / kWinSlots) * kBitWords * kWinThreads * sizeof(uint32_t)));
     for (int i = 0; i < (h->async ? 2 : 1); i++) {
         auto &t = h->tc[i];
         TRY(h->alloc(t.d_winlen, (size_t)S * nch * sizeof(int)));

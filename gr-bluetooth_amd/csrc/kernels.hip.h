@@ -269,6 +269,7 @@ struct WindowParams {
     int low_channel;
     int btbb;                   // multi_LAP: libbtbb-style search (BTGPU_CORRELATOR_BTBB)
     const uint64_t *btbb_pcol;  // [24] parity column of each LAP bit (device memory)
+    int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
 };
 
 __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
@@ -277,9 +278,15 @@ __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
     return da < db ? da : db;
 }
 
-constexpr int kWinSlots = 2;         // slots per workgroup: 2 x 79 lanes fill 3 waves to 82 % (1 x 79: 62 %)
-constexpr int kWinThreads = 192;     // >= kWinSlots * 79; lane = (slot, channel)
-constexpr int kWinRows = 64;         // demod rows staged per chunk and slot
+constexpr int kWinSlots = 3;         // slots per workgroup: 3 x 79 lanes fill 4 waves to 92.6 % (one wave per SIMD; 4 x 79 in 5 waves measured slower)
+constexpr int kWinThreads = 256;     // >= kWinSlots * 79; lane = (slot, channel)
+constexpr int kWinRows = 38;         // demod rows staged per chunk and slot
+constexpr int kWinRowStride = 96;    // LDS row stride (floats): a multiple of 32, so lane c always reads bank c mod 32
+                                     // whatever its input index (with the stream's own 80 the lanes c, c + 16
+                                     // collide whenever their indices differ by an odd number)
+constexpr int kTileFloats = kWinRows * kWinRowStride + 16;
+constexpr int kMmseStride = 12;      // floats per interpolator row in LDS: 16-byte slot 3 imu mod 16 instead of
+                                     // 2 imu mod 16 (eight classes for the sixteen lanes of a 16-byte read group)
 constexpr int kDetectSyms = 693;     // 625 search offsets + 68-symbol access code
 constexpr int kBitWords = 24;        // 32-bit words of sliced symbols kept per lane (>= 693 + 99 bits)
 
@@ -290,12 +297,15 @@ __device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { r
 //
 // Phase 1 -- clock recovery.  The demodulated stream is time-major [g][80], so the rows a slot's
 // windows need are shared by all its lanes: they are staged through LDS in chunks of kWinRows
-// rows with contiguous 16-byte copies and the strictly sequential M&M recursion of each lane
-// (multi_block::mm_cr, lib/multi_block.cc:128-155; windowed reset) runs out of LDS.  Lanes drift
-// apart by a few samples only (omega is clipped to 2 +- 0.005), so a slot's chunk starts at the
-// minimum input index over its live lanes.  Only the first 693 symbols can hold a reportable
-// access code (lib/multi_sniffer_impl.cc:108-126), so the recursion stops there; sliced symbols
-// are packed one bit each into a per-lane LDS bit buffer.
+// rows (16-byte copies, LDS row stride 96 so that lane c always reads bank c mod 32) and the
+// strictly sequential M&M recursion of each lane (multi_block::mm_cr, lib/multi_block.cc:128-155;
+// windowed reset) runs out of LDS.  A lane leaves a chunk with its input index just past the last
+// usable row, so the chunk schedule is static: the rows of chunk n + 1 are fetched into registers
+// (unconditional loads) before the recursion over chunk n starts.  Only the first 693 symbols can
+// hold a reportable access code (lib/multi_sniffer_impl.cc:108-126), so the recursion stops there;
+// sliced symbols are packed one bit each, leave through a small HBM scratch and come back into
+// the dead tile for phase 2 -- the LDS footprint (51 KB) lets three workgroups of four waves
+// share a CU, one wave of each per SIMD, which keeps every window of a 2048-slot batch resident.
 //
 // Phase 2 -- access-code search (classic_packet::sniff_ac, lib/packet_impl.cc:247-268) on the
 // packed bits, 32 offsets at a time: the 5-bit preamble and 7-bit Barker distance LUTs are
@@ -313,18 +323,24 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     int *__restrict__ win_len, DeviceHit *__restrict__ hits, unsigned int *__restrict__ hit_count,
     FinishRec *__restrict__ fin, unsigned int *__restrict__ fin_count,
     const uint8_t *__restrict__ le_hdr_g, const uint16_t *__restrict__ le_whiten_g,
-    const int8_t *__restrict__ le_index_g, int *__restrict__ win_fin, uint32_t *__restrict__ symbits)
+    const int8_t *__restrict__ le_index_g, int *__restrict__ win_fin, uint32_t *__restrict__ symbits,
+    uint32_t *winbits)
 {
     __shared__ uint8_t le_hdr[4 * 256];
-    __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
-    __shared__ uint64_t ac_lo[3 * 256];
-    __shared__ uint32_t ac_hi[3 * 256];
-    __shared__ __attribute__((aligned(16))) float tile[kWinSlots][kWinRows * 80];
-    __shared__ uint32_t bits[kBitWords * kWinThreads];
-    __shared__ int s_min[kWinSlots];
-    for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
-    for (int i = threadIdx.x; i < 768; i += blockDim.x) { ac_lo[i] = ac_lo_g[i]; ac_hi[i] = ac_hi_g[i]; }
-    for (int i = threadIdx.x; i < kBitWords * kWinThreads; i += blockDim.x) bits[i] = 0u;
+    __shared__ __attribute__((aligned(16))) float mmse[129 * kMmseStride];
+    // slot s's rows start 16 s floats into their bank row: the wave that holds the last lanes of one
+    // slot and the first of the next then still reads 32 different banks
+    __shared__ __attribute__((aligned(16))) float tile[kWinSlots * kTileFloats];
+    // After phase 1 the demod rows are dead and the same LDS holds the sliced symbols of every lane
+    // and the access-code tables of phase 2: the footprint stays under 40 KB, four workgroups per CU,
+    // which keeps every window of a 2048-slot batch resident at once (the M&M recursion is a chain
+    // of dependent operations -- only other waves hide its latency).
+    static_assert(kWinSlots * kTileFloats * 4 >= kBitWords * kWinThreads * 4 + 3 * 256 * 12, "phase-2 tables must fit the dead tile");
+    uint32_t *bits = (uint32_t *)tile;                                        // [kBitWords][kWinThreads]
+    uint64_t *ac_lo = (uint64_t *)(tile + kBitWords * kWinThreads);           // [3][256]
+    uint32_t *ac_hi = (uint32_t *)(ac_lo + 3 * 256);                          // [3][256]
+    __shared__ int s_live[2];
+    for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[(i >> 3) * kMmseStride + (i & 7)] = mmse_g[i];
     if (p.le) for (int i = threadIdx.x; i < 1024; i += blockDim.x) le_hdr[i] = le_hdr_g[i];
 
     const int nch = p.nch;
@@ -349,6 +365,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         if (snr >= p.target_snr) nmax = kDetectSyms;
     }
 
+    if (p.dbg_stop == 1) return;
     // ---- phase 1: M&M ----
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
@@ -357,68 +374,73 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     unsigned int ii = 0;
     int oo = 0;
     uint32_t cur = 0;
-    uint32_t *mybits = bits + threadIdx.x;
-    const float *mytile = tile[sl < kWinSlots ? sl : 0];
+    // sliced symbols leave phase 1 through a per-workgroup scratch in HBM ([word][lane], one
+    // coalesced store per 32 symbols) and come back into the dead tile for phase 2
+    uint32_t *gbits = winbits + (size_t)blockIdx.x * (kBitWords * kWinThreads) + threadIdx.x;
+    const float *mytile = tile + (sl < kWinSlots ? sl : 0) * kTileFloats;
 
-    for (;;) {
-        if (threadIdx.x < kWinSlots) s_min[threadIdx.x] = 0x7fffffff;
-        __syncthreads();
-        if (oo < nmax && ii < ni) atomicMin(&s_min[sl], (int)ii);
-        __syncthreads();
-        int bases[kWinSlots];
-        bool any = false;
+    // Chunk schedule.  A lane leaves a chunk with its input index just past the chunk's last usable
+    // row (index + 8 rows must be staged), so the next chunk always starts kWinRows - 7 rows further:
+    // the schedule is static and the rows of chunk n + 1 are fetched into registers before the
+    // recursion over chunk n starts -- the HBM round trip hides under the dependent arithmetic.
+    // Every load is unconditional (clamped row, value selected at the LDS store): a load under a
+    // lane-dependent branch would be waited for at the end of that branch, nine round trips per chunk.
+    constexpr int kAdv = kWinRows - 7;
+    constexpr int kVec = kWinRows * 20;                          // float4 per chunk and slot (80 floats per row)
+    constexpr int kTot = kVec * kWinSlots;
+    constexpr int kPer = (kTot + kWinThreads - 1) / kWinThreads;
+    float4 v[kPer];
+    unsigned int okm = 0;
+    auto fetch = [&](int base) {
+        okm = 0;
 #pragma unroll
-        for (int s = 0; s < kWinSlots; s++) { bases[s] = s_min[s]; any |= bases[s] != 0x7fffffff; }
-        if (!any) break;                                         // no live lane left (uniform)
-        {
-            constexpr int kVec = kWinRows * 80 / 4;              // float4 per chunk and slot
-            constexpr int kTot = kVec * kWinSlots;
-            constexpr int kPer = (kTot + kWinThreads - 1) / kWinThreads;
-            float4 v[kPer];
-#pragma unroll
-            for (int j = 0; j < kPer; j++) {
-                const int i = threadIdx.x + j * kWinThreads;
-                const int s = i / kVec, iv = i - s * kVec;
-                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < kTot && bases[s < kWinSlots ? s : 0] != 0x7fffffff) {
-                    const int base = bases[s];
-                    const long long r_first = ((long long)blockIdx.x * kWinSlots + s) * p.outs_per_slot + base;
-                    long long rows_ok = d_rows - r_first;
-                    const long long win_ok = (long long)p.ddc_out - base;
-                    if (win_ok < rows_ok) rows_ok = win_ok;
-                    const int vec_ok = rows_ok <= 0 ? 0 : (rows_ok >= kWinRows ? kVec : (int)rows_ok * 20);
-                    // policy Q1: demod_out[0] = 0 -- row 0 of the window is float4 index 0..19 of chunk 0
-                    if (iv < vec_ok && !(base == 0 && iv < 20))
-                        v[j] = ((const float4 *)(d + (size_t)r_first * 80))[iv];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kPer; j++) {
-                const int i = threadIdx.x + j * kWinThreads;
-                if (i < kTot) ((float4 *)&tile[0][0])[i] = v[j];
-            }
+        for (int j = 0; j < kPer; j++) {
+            const int i = (int)threadIdx.x + j * kWinThreads;
+            const int ic = i < kTot ? i : kTot - 1;
+            const int s = ic / kVec, iv = ic - s * kVec;
+            const int r = iv / 20, q4 = iv - r * 20;
+            const long long row = ((long long)blockIdx.x * kWinSlots + s) * p.outs_per_slot + base + r;
+            // policy Q1: demod_out[0] = 0 (row 0 of the window); rows past the window or the stream read as 0
+            const bool ok = i < kTot && row < d_rows && base + r < p.ddc_out && base + r != 0;
+            const long long rc = row < d_rows ? row : d_rows - 1;
+            v[j] = ((const float4 *)(d + (size_t)rc * 80))[q4];
+            okm |= (ok ? 1u : 0u) << j;
         }
+    };
+    int base = 0;
+    fetch(0);
+    for (int it = 0;; it++) {
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int i = (int)threadIdx.x + j * kWinThreads;
+            const int s = i / kVec, iv = i - s * kVec;
+            const int r = iv / 20, q4 = iv - r * 20;
+            const bool ok = (okm >> j) & 1u;
+            const float4 t = make_float4(ok ? v[j].x : 0.f, ok ? v[j].y : 0.f, ok ? v[j].z : 0.f, ok ? v[j].w : 0.f);
+            if (i < kTot) ((float4 *)(tile + s * kTileFloats))[r * (kWinRowStride / 4) + q4] = t;
+        }
+        if (threadIdx.x == 0) s_live[it & 1] = 0;
         __syncthreads();
-        const int base = bases[sl < kWinSlots ? sl : 0];
+        fetch(base + kAdv);
         unsigned int lim = (unsigned int)(base + kWinRows - 8);
         if (lim > ni - 1) lim = ni - 1;                          // while (ii < ni) of the reference
-        const float *col = mytile + c - base * 80;
+        const float *col = mytile + c - base * kWinRowStride;
         while (ii <= lim && oo < nmax) {
             // interpolate: sum_q T[imu][7-q] * in[ii+q], q ascending
             int imu = (int)rintf(mu * 128.0f);
             imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
-            const float4 ta = *(const float4 *)&mmse[imu * 8 + 4];   // T[4..7]
-            const float4 tb = *(const float4 *)&mmse[imu * 8];       // T[0..3]
-            const float *in = col + ii * 80;
+            const float4 ta = *(const float4 *)&mmse[imu * kMmseStride + 4];   // T[4..7]
+            const float4 tb = *(const float4 *)&mmse[imu * kMmseStride];       // T[0..3]
+            const float *in = col + ii * kWinRowStride;
             float acc = 0.f;
-            acc = fmaf(ta.w, in[0 * 80], acc);
-            acc = fmaf(ta.z, in[1 * 80], acc);
-            acc = fmaf(ta.y, in[2 * 80], acc);
-            acc = fmaf(ta.x, in[3 * 80], acc);
-            acc = fmaf(tb.w, in[4 * 80], acc);
-            acc = fmaf(tb.z, in[5 * 80], acc);
-            acc = fmaf(tb.y, in[6 * 80], acc);
-            acc = fmaf(tb.x, in[7 * 80], acc);
+            acc = fmaf(ta.w, in[0 * kWinRowStride], acc);
+            acc = fmaf(ta.z, in[1 * kWinRowStride], acc);
+            acc = fmaf(ta.y, in[2 * kWinRowStride], acc);
+            acc = fmaf(ta.x, in[3 * kWinRowStride], acc);
+            acc = fmaf(tb.w, in[4 * kWinRowStride], acc);
+            acc = fmaf(tb.z, in[5 * kWinRowStride], acc);
+            acc = fmaf(tb.y, in[6 * kWinRowStride], acc);
+            acc = fmaf(tb.x, in[7 * kWinRowStride], acc);
             const float out = acc;
             // slice(x) = (x < 0) ? -1 : +1; neither operand can be -0.0 (sums starting from +0)
             const float s_last = __builtin_copysignf(1.0f, last);
@@ -437,14 +459,40 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             mu = mu - fl;
             // slicer: one bit per symbol
             cur |= (out < 0.f ? 0u : 1u) << (oo & 31);
-            if ((oo & 31) == 31) { mybits[(oo >> 5) * kWinThreads] = cur; cur = 0u; }
+            if ((oo & 31) == 31) { gbits[(oo >> 5) * kWinThreads] = cur; cur = 0u; }
             oo++;
         }
+        if (oo < nmax && ii < ni) s_live[it & 1] = 1;            // this lane needs another chunk
+        __syncthreads();
+        if (!s_live[it & 1]) break;                              // uniform
+        base += kAdv;
     }
+    if (oo & 31) gbits[(oo >> 5) * kWinThreads] = cur;
+    if (p.dbg_stop == 2) return;
+    {
+        // every lane reads back the words it wrote itself (all loads in flight together)
+        const int nw = (oo + 31) >> 5;
+        uint32_t wv[kBitWords];
+#pragma unroll
+        for (int j = 0; j < kBitWords; j++) wv[j] = gbits[(j < nw ? j : 0) * kWinThreads];
+        uint64_t tl[4]; uint32_t th[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = (int)threadIdx.x + j * kWinThreads;
+            tl[j] = ac_lo_g[i < 768 ? i : 767]; th[j] = ac_hi_g[i < 768 ? i : 767];
+        }
+#pragma unroll
+        for (int j = 0; j < kBitWords; j++) bits[j * kWinThreads + threadIdx.x] = j < nw ? wv[j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = (int)threadIdx.x + j * kWinThreads;
+            if (i < 768) { ac_lo[i] = tl[j]; ac_hi[i] = th[j]; }
+        }
+    }
+    __syncthreads();
     if (nmax == 0) return;
-    if (oo & 31) mybits[(oo >> 5) * kWinThreads] = cur;
-    // all symbols of this lane are in LDS; the search below is lane-private (no barrier needed:
-    // every lane reads only the words it wrote)
+    uint32_t *mybits = bits + threadIdx.x;
+    // the search below is lane-private: every lane reads only its own words
 
     // ---- phase 2: access-code search over offsets [0, limit) ----
     const int len1 = oo;                                         // 693, or the whole window if shorter
@@ -568,6 +616,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         }
         r0 = r1; r1 = r2; r2 = r3;
     }
+    if (p.dbg_stop == 3) return;
     // ---- LE pass: le_packet::sniff_aa (lib/packet_impl.cc:1452-1527) with the loop of
     // lib/multi_sniffer_impl.cc:129-149.  `len` keeps what the classic pass left (Q6): the search
     // limit is min(len' - 68, 625) with len' = len - (last classic hit + 68); records carry

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
 
     // one workgroup = one tile; XCD-aware order (pre-tiles of the fused noise bank come first)
     const int ntl = p.ntiles + (FUSEN ? p.pre_tiles : 0);
-    const int tile = xcd_remap(blockIdx.x, ntl) - (FUSEN ? p.pre_tiles : 0);
+    const int tile_u = xcd_remap(blockIdx.x, ntl);
+    const int tile = tile_u - (FUSEN ? p.pre_tiles : 0);
+    const int l = l0;
 
     unsigned long long tprev = p.prof ? clock64() : 0ULL;
     auto mark = [&](int k) {
@@ -233,11 +235,10 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
             // 256 lanes: branch pp = l % 100 for l < 200, instants split 3 / 2
             // 256 lanes, one wave per SIMD: branch l % 100, instants 0..2 in lanes 0..99 and 3..4 in lanes
             // 100..199 (an even 2-2-1 split needs a second tap set per lane and measured slower)
-            if (l0 < 200) { nz_pp = l0 % 100; nz_i0 = l0 < 100 ? 0 : 3; nz_cnt = l0 < 100 ? 3 : 2; }
+            if (l < 200) { nz_pp = l % 100; nz_i0 = l < 100 ? 0 : 3; nz_cnt = l < 100 ? 3 : 2; }
         }
     }
 
-    const int l = l0;
     const int a_pp = l & 127, a_r = l >> 7;
     const bool a_on = a_pp < M && a_r < 2;
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
             const int nkr = p.nsel * p.rot_period;
 #pragma unroll
             for (int k = 0; k < NK; k++) kr[k] = ((const cf *)p.krot)[l0 + k * NTH < nkr ? l0 + k * NTH : nkr - 1];
-            const int pp = l0 & 127;
+            const int pp = l & 127;
 #pragma unroll
             for (int q = 0; q < Q; q++) a[q] = ((const cf *)p.taps)[q * M + (pp < M ? pp : 0)];
             if (FUSEN) {
