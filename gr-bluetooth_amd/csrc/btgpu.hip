@@ -276,9 +276,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (const double *)d_rotstep_ch.p, (float2 *)d_Y.p, G, ystride, nch, seg_ch, seg_stride);
         HIPCHK(this, hipEventRecord(ev[1], st));
         dim3 g2((unsigned)nb, (unsigned)nch);
-        hipLaunchKernelGGL(demod_energy_kernel<true>, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
-                           ystride, ops, des.tail, (const float *)d_atan.p, des.demod_gain,
-                           (float *)d_d.p, (double *)d_P.p, (double *)d_Pt.p, nb, nch, (float *)d_d2.p, ystride);
+        hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
+                           ystride, ops, des.tail, (const float *)nullptr, 0.f,
+                           (float *)nullptr, (double *)d_P.p, (double *)d_Pt.p, nb, nch, (float *)nullptr, 0LL);
+        hipLaunchKernelGGL(demod_rows_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st, (const float2 *)d_Y.p, G,
+                           ystride, nch, (const float *)d_atan.p, des.demod_gain, (float *)d_d.p,
+                           (float *)d_d2.p, ystride);
     }
     HIPCHK(this, hipEventRecord(ev[2], st));
 

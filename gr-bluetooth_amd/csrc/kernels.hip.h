@@ -91,11 +91,22 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
         const int need = (T - 1) * D + jc;
         const long long base = first + g0 * D + j0;
         __syncthreads();
-        for (int s = o; s < need; s += T) {
-            long long a = base + s;
-            float2 v = make_float2(0.f, 0.f);
-            if (a >= 0 && a < x_len) v = x[a];
-            tile[s] = v;
+        // unconditional (clamped) loads, four per lane in flight: a load under a lane-dependent
+        // branch is waited for at the end of that branch, one memory round trip per element
+        for (int s0 = o; s0 < need; s0 += 4 * T) {
+            float2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const long long a = base + s0 + k * T;
+                const long long ac = a < 0 ? 0 : (a < x_len ? a : x_len - 1);
+                v[k] = x[ac];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int s = s0 + k * T;
+                const long long a = base + s;
+                if (s < need) tile[s] = (a >= 0 && a < x_len) ? v[k] : make_float2(0.f, 0.f);
+            }
         }
         __syncthreads();
         const float2 *px = tile + o * D;
@@ -240,6 +251,41 @@ __global__ __launch_bounds__(256) void demod_energy_kernel(
         for (int w = 0; w < nw; w++) { a += red[0][w]; t += red[1][w]; }
         P[(size_t)c * nb + b] = a;
         if (Pt) Pt[(size_t)c * nb + b] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2b: quadrature demodulation of the channel streams Y[c][g] (multi_block::demod,
+// lib/multi_block.cc:158-173) into the time-major stream d[g][80] the window kernel reads and
+// the channel-major copy d2[c][g] of finish_kernel.  One workgroup = 64 consecutive grid points
+// of every channel: wave w takes channels w, w + 4, ... with lane = grid point (coalesced reads
+// along g), the values cross an LDS tile and leave as whole rows (a lane-per-grid-point store
+// into d would touch 64 different rows per instruction).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void demod_rows_kernel(
+    const float2 *__restrict__ Y, long long G, long long ystride, int nch,
+    const float *__restrict__ atan_tab, float gain, float *__restrict__ d,
+    float *__restrict__ d2, long long d2stride)
+{
+    __shared__ float atab[257];
+    __shared__ float tile[64 * 81];
+    for (int i = threadIdx.x; i < 257; i += blockDim.x) atab[i] = atan_tab[i];
+    __syncthreads();
+    const long long g0 = (long long)blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long g = g0 + lane;
+    const long long gc = g < G ? g : G - 1;
+    for (int c = w; c < nch; c += 4) {
+        const float2 *y = Y + (size_t)c * ystride;
+        const float2 v = y[gc], vp = y[gc > 0 ? gc - 1 : 0];
+        const float dv = (g > 0 && g < G) ? demod_one(atab, gain, v, vp) : 0.f;   // policy Q1: d[0] = 0
+        tile[lane * 81 + c] = dv;
+        if (d2 && g < G) d2[(size_t)c * d2stride + g] = dv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * nch; i += blockDim.x) {
+        const int r = i / nch, cc = i - r * nch;
+        if (g0 + r < G) d[(size_t)(g0 + r) * 80 + cc] = tile[r * 81 + cc];
     }
 }
 
