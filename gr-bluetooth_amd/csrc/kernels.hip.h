@@ -797,7 +797,9 @@ __global__ __launch_bounds__(64) void finish_kernel(
     {
         float v[RING];
 #pragma unroll
-        for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = idx < nvalid ? col[idx] : 0.f; }
+        for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = col[idx < nvalid ? idx : nvalid - 1]; }
+#pragma unroll
+        for (unsigned int j = 0; j < RING; j++) v[j] = hi + j < nvalid ? v[j] : 0.f;       // loads unconditional, values selected
 #pragma unroll
         for (unsigned int j = 0; j < RING; j++) { const unsigned int s = (hi + j) & MASK; my[s] = v[j]; my[s + RING] = v[j]; }
         hi += RING;
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
         // issue the loads of the next kFinRows rows now; they land while the steps below run
         float v[kFinRows];
 #pragma unroll
-        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = idx < nvalid ? col[idx] : 0.f; }
+        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[idx < nvalid ? idx : nvalid - 1]; }   // unconditional
         // consume every step whose 8-tap window lies inside the resident rows [.., hi)
         while (ii + 8 <= hi && ii < ni && oo < demod_n) {
             const int imu = (int)rintf(mu * 128.0f);             // mu in [0, 1) -> 0..128
@@ -846,7 +848,11 @@ __global__ __launch_bounds__(64) void finish_kernel(
         // here ii + 8 > hi (or the window is done): the ring slots of rows [hi-RING, hi-RING+kFinRows)
         // are all below ii and can take rows [hi, hi + kFinRows)
 #pragma unroll
-        for (int j = 0; j < kFinRows; j++) { const unsigned int s = (hi + j) & MASK; my[s] = v[j]; my[s + RING] = v[j]; }
+        for (int j = 0; j < kFinRows; j++) {
+            const unsigned int s = (hi + j) & MASK;
+            const float t = hi + j < nvalid ? v[j] : 0.f;        // rows past the stream read as 0
+            my[s] = t; my[s + RING] = t;
+        }
         hi += kFinRows;
     }
     if (SYMS && (oo & 31) && (oo >> 5) < kSymWords) sb[oo >> 5] = cur;
