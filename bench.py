@@ -83,7 +83,9 @@ def main():
 
     wl = WORKLOADS[args.workload]
     fs, fc = wl["sample_rate"], wl["center_freq"]
-    S = args.slots or 2048      # 1.28 s of signal per step at C79: 1024 window-kernel workgroups = two full rounds of 512
+    # C79: 1.28 s of signal per step, 683 window-kernel workgroups = one resident round.  C8: the same
+    # number of input samples per second of signal is 12.5x smaller, so a step takes 8x the slots
+    S = args.slots or (2048 if args.workload == "c79" else 16384)
     laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(args.piconets))
 
     blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,

@@ -354,14 +354,24 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.btbb = d.correlator == BTGPU_CORRELATOR_BTBB ? 1 : 0;
         p.btbb_pcol = (const uint64_t *)d_pcol.p;
         { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
-        hipLaunchKernelGGL(window_kernel, dim3((S + kWinSlots - 1) / kWinSlots), dim3(kWinThreads), 0, st, p, (const float *)d_d.p, G,
-                           (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
-                           (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
-                           (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
-                           (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
-                           (unsigned int *)d_hitcount.p + 1, (const uint8_t *)d_le_hdr.p,
-                           (const uint16_t *)d_le_whiten.p, (const int8_t *)d_le_index.p, (int *)d_winfin.p,
-                           (uint32_t *)d_symbits.p, (uint32_t *)d_winbits.p);
+        auto launch_window = [&](auto lay) {
+            using LAY = decltype(lay);
+            hipLaunchKernelGGL(window_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, st, p,
+                               (const float *)d_d.p, G,
+                               (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
+                               (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
+                               (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
+                               (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
+                               (unsigned int *)d_hitcount.p + 1, (const uint8_t *)d_le_hdr.p,
+                               (const uint16_t *)d_le_whiten.p, (const int8_t *)d_le_index.p, (int *)d_winfin.p,
+                               (uint32_t *)d_symbits.p, (uint32_t *)d_winbits.p);
+        };
+        // layout by channel count (kernels.hip.h): as many slots per workgroup as fill its 256 lanes
+        if (nch > 40) launch_window(WinLayout<3, 96, 20>{});
+        else if (nch > 20) launch_window(WinLayout<6, 40, 10>{});
+        else if (nch > 8) launch_window(WinLayout<12, 20, 5>{});
+        else if (nch > 4) launch_window(WinLayout<32, 8, 2>{});
+        else launch_window(WinLayout<64, 4, 1>{});
         HIPCHK(this, hipEventRecord(ev[5], st));
         // ---- tail: finish + nsym on the tail stream, overlapping the next batch's banks ----
         HIPCHK(this, hipEventRecord(t.detect_done, st));
@@ -780,7 +790,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_eon, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_eoff, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_snr, (size_t)S * nch * sizeof(double)));
-    TRY(h->alloc(h->d_winbits, (size_t)((S + kWinSlots - 1) / kWinSlots) * kBitWords * kWinThreads * sizeof(uint32_t)));
+    TRY(h->alloc(h->d_winbits, (size_t)((S + 2) / 3) * kBitWords * kWinThreads * sizeof(uint32_t)));   // most workgroups: 3 slots each
     for (int i = 0; i < (h->async ? 2 : 1); i++) {
         auto &t = h->tc[i];
         TRY(h->alloc(t.d_winlen, (size_t)S * nch * sizeof(int)));

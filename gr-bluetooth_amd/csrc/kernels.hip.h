@@ -324,13 +324,24 @@ __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
     return da < db ? da : db;
 }
 
-constexpr int kWinSlots = 3;         // slots per workgroup: 3 x 79 lanes fill 4 waves to 92.6 % (one wave per SIMD; 4 x 79 in 5 waves measured slower)
-constexpr int kWinThreads = 256;     // >= kWinSlots * 79; lane = (slot, channel)
+constexpr int kWinThreads = 256;     // lane = (slot, channel), slots per workgroup * channels <= 256
 constexpr int kWinRows = 38;         // demod rows staged per chunk and slot
-constexpr int kWinRowStride = 96;    // LDS row stride (floats): a multiple of 32, so lane c always reads bank c mod 32
-                                     // whatever its input index (with the stream's own 80 the lanes c, c + 16
-                                     // collide whenever their indices differ by an odd number)
-constexpr int kTileFloats = kWinRows * kWinRowStride + 16;
+// Window-kernel layouts, by channel count.  NSL slots per workgroup, rows of NCP4 float4 (the used
+// columns of the 80-float rows of d) at an LDS row stride of RS floats.
+//   <3, 96, 20>  41..80 channels (C79): 3 x 79 lanes fill four waves to 93 %, one wave per SIMD (2 x 79 in
+//                three waves and 4 x 79 in five both leave the SIMDs unevenly loaded: 1.4-1.6x slower);
+//                RS is a multiple of 32, so lane c always reads bank c mod 32 whatever its input index
+//                (with the stream's own 80 the lanes c, c + 16 collide whenever their indices differ
+//                by an odd number); slot s starts 16 s floats into its bank row so that the wave
+//                holding the end of one slot and the start of the next still reads 32 different banks
+//   <6, 40, 10> <12, 20, 5> <32, 8, 2> <64, 4, 1>   narrower captures (20, 8, 4, 2 Msps): compact rows,
+//                as many slots as fill the 256 lanes; the per-slot pad of 8 floats spreads the slots
+//                over the four 8-bank groups
+template <int NSL, int RS, int NCP4>
+struct WinLayout {
+    static constexpr int kSlots = NSL, kRowStride = RS, kVecPerRow = NCP4;
+    static constexpr int kTileFloats = kWinRows * RS + (RS % 32 == 0 ? 16 : 8);
+};
 constexpr int kMmseStride = 12;      // floats per interpolator row in LDS: 16-byte slot 3 imu mod 16 instead of
                                      // 2 imu mod 16 (eight classes for the sixteen lanes of a 16-byte read group)
 constexpr int kDetectSyms = 693;     // 625 search offsets + 68-symbol access code
@@ -360,6 +371,7 @@ __device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { r
 // compare against the affine access code AC(0) ^ cols(LAP) with popcount < 7
 // (check_ac, lib/packet_impl.cc:471-510).  Hits are taken greedily with resume at c + 68 and
 // limit = min(len - 68, 625), which is what the reference's while (limit >= 0) loop does.
+template <class LAY>
 __global__ __launch_bounds__(kWinThreads) void window_kernel(
     WindowParams p, const float *__restrict__ d, long long d_rows, const double *__restrict__ P,
     const double *__restrict__ Pt, const double *__restrict__ Qn,
@@ -372,6 +384,8 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int8_t *__restrict__ le_index_g, int *__restrict__ win_fin, uint32_t *__restrict__ symbits,
     uint32_t *winbits)
 {
+    constexpr int kWinSlots = LAY::kSlots, kWinRowStride = LAY::kRowStride, kTileFloats = LAY::kTileFloats;
+    constexpr int kVecPerRow = LAY::kVecPerRow;
     __shared__ uint8_t le_hdr[4 * 256];
     __shared__ __attribute__((aligned(16))) float mmse[129 * kMmseStride];
     // slot s's rows start 16 s floats into their bank row: the wave that holds the last lanes of one
@@ -432,7 +446,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     // Every load is unconditional (clamped row, value selected at the LDS store): a load under a
     // lane-dependent branch would be waited for at the end of that branch, nine round trips per chunk.
     constexpr int kAdv = kWinRows - 7;
-    constexpr int kVec = kWinRows * 20;                          // float4 per chunk and slot (80 floats per row)
+    constexpr int kVec = kWinRows * kVecPerRow;                  // float4 per chunk and slot (the used part of the 80-float rows)
     constexpr int kTot = kVec * kWinSlots;
     constexpr int kPer = (kTot + kWinThreads - 1) / kWinThreads;
     float4 v[kPer];
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             const int i = (int)threadIdx.x + j * kWinThreads;
             const int ic = i < kTot ? i : kTot - 1;
             const int s = ic / kVec, iv = ic - s * kVec;
-            const int r = iv / 20, q4 = iv - r * 20;
+            const int r = iv / kVecPerRow, q4 = iv - r * kVecPerRow;
             const long long row = ((long long)blockIdx.x * kWinSlots + s) * p.outs_per_slot + base + r;
             // policy Q1: demod_out[0] = 0 (row 0 of the window); rows past the window or the stream read as 0
             const bool ok = i < kTot && row < d_rows && base + r < p.ddc_out && base + r != 0;
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         for (int j = 0; j < kPer; j++) {
             const int i = (int)threadIdx.x + j * kWinThreads;
             const int s = i / kVec, iv = i - s * kVec;
-            const int r = iv / 20, q4 = iv - r * 20;
+            const int r = iv / kVecPerRow, q4 = iv - r * kVecPerRow;
             const bool ok = (okm >> j) & 1u;
             const float4 t = make_float4(ok ? v[j].x : 0.f, ok ? v[j].y : 0.f, ok ? v[j].z : 0.f, ok ? v[j].w : 0.f);
             if (i < kTot) ((float4 *)(tile + s * kTileFloats))[r * (kWinRowStride / 4) + q4] = t;
