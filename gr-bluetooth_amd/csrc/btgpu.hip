@@ -70,6 +70,7 @@ struct btgpu_handle {
     std::vector<float> pre;          // the `margin` samples preceding the next work() buffer
     int device = 0;
     hipStream_t stream = nullptr;
+    int drow = 80;                               // row stride (floats) of the time-major demodulated stream
     hipStream_t tail_stream = nullptr;
     struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
         DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_d2, d_winfin, d_symbits, d_hdr;
@@ -280,7 +281,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            ystride, ops, des.tail, (const float *)nullptr, 0.f,
                            (float *)nullptr, (double *)d_P.p, (double *)d_Pt.p, nb, nch, (float *)nullptr, 0LL);
         hipLaunchKernelGGL(demod_rows_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st, (const float2 *)d_Y.p, G,
-                           ystride, nch, (const float *)d_atan.p, des.demod_gain, (float *)d_d.p,
+                           ystride, nch, (const float *)d_atan.p, des.demod_gain, (float *)d_d.p, drow,
                            (float *)d_d2.p, ystride);
     }
     HIPCHK(this, hipEventRecord(ev[2], st));
@@ -367,10 +368,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                (uint32_t *)d_symbits.p, (uint32_t *)d_winbits.p);
         };
         // layout by channel count (kernels.hip.h): as many slots per workgroup as fill its 256 lanes
-        if (nch > 40) launch_window(WinLayout<3, 96, 20>{});
-        else if (nch > 20) launch_window(WinLayout<6, 40, 10>{});
-        else if (nch > 8) launch_window(WinLayout<12, 20, 5>{});
-        else if (nch > 4) launch_window(WinLayout<32, 8, 2>{});
+        if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
+        else if (drow == 40) launch_window(WinLayout<6, 40, 10>{});
+        else if (drow == 20) launch_window(WinLayout<12, 20, 5>{});
+        else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});
         else launch_window(WinLayout<64, 4, 1>{});
         HIPCHK(this, hipEventRecord(ev[5], st));
         // ---- tail: finish + nsym on the tail stream, overlapping the next batch's banks ----
@@ -769,7 +770,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_h3, ns.h3.data(), ns.h3.size() * sizeof(float)));
         TRY(h->upload(h->d_w, ns.weights.data(), ns.weights.size() * sizeof(double)));
     }
-    TRY(h->alloc(h->d_d, (size_t)80 * (h->ystride + 64) * sizeof(float)));
+    h->drow = h->use_pfb ? 80 : win_drow(nch);            // the polyphase epilogue writes 80-float rows
+    TRY(h->alloc(h->d_d, (size_t)h->drow * (h->ystride + 64) * sizeof(float)));   // [G][drow], time-major
     if (nch > 80) return fail(BTGPU_EUNSUPPORTED);
     TRY(h->alloc(h->d_P, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Pt, (size_t)nch * h->nb_max * sizeof(double)));
@@ -1021,7 +1023,7 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
             if (first >= avail) return 0;
             count = std::min(count, avail - first);
             if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
-            if (hipMemcpy2D(out, sizeof(float), (const float *)h->d_d.p + first * 80 + c, (size_t)80 * sizeof(float),
+            if (hipMemcpy2D(out, sizeof(float), (const float *)h->d_d.p + first * h->drow + c, (size_t)h->drow * sizeof(float),
                             sizeof(float), count, hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
             return (long)count;
         }

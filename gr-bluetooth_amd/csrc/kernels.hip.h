@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void demod_energy_kernel(
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void demod_rows_kernel(
     const float2 *__restrict__ Y, long long G, long long ystride, int nch,
-    const float *__restrict__ atan_tab, float gain, float *__restrict__ d,
+    const float *__restrict__ atan_tab, float gain, float *__restrict__ d, int drow,
     float *__restrict__ d2, long long d2stride)
 {
     __shared__ float atab[257];
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void demod_rows_kernel(
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * nch; i += blockDim.x) {
         const int r = i / nch, cc = i - r * nch;
-        if (g0 + r < G) d[(size_t)(g0 + r) * 80 + cc] = tile[r * 81 + cc];
+        if (g0 + r < G) d[(size_t)(g0 + r) * drow + cc] = tile[r * 81 + cc];
     }
 }
 
@@ -337,6 +337,9 @@ constexpr int kWinRows = 38;         // demod rows staged per chunk and slot
 //   <6, 40, 10> <12, 20, 5> <32, 8, 2> <64, 4, 1>   narrower captures (20, 8, 4, 2 Msps): compact rows,
 //                as many slots as fill the 256 lanes; the per-slot pad of 8 floats spreads the slots
 //                over the four 8-bank groups
+// row stride (floats) of the time-major stream d for a capture of nch channels = 4 * NCP4 of its layout
+inline int win_drow(int nch) { return nch > 40 ? 80 : nch > 20 ? 40 : nch > 8 ? 20 : nch > 4 ? 8 : 4; }
+
 template <int NSL, int RS, int NCP4>
 struct WinLayout {
     static constexpr int kSlots = NSL, kRowStride = RS, kVecPerRow = NCP4;
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             // policy Q1: demod_out[0] = 0 (row 0 of the window); rows past the window or the stream read as 0
             const bool ok = i < kTot && row < d_rows && base + r < p.ddc_out && base + r != 0;
             const long long rc = row < d_rows ? row : d_rows - 1;
-            v[j] = ((const float4 *)(d + (size_t)rc * 80))[q4];
+            v[j] = ((const float4 *)(d + (size_t)rc * (kVecPerRow * 4)))[q4];   // rows of d are kVecPerRow * 4 floats apart
             okm |= (ok ? 1u : 0u) << j;
         }
     };
