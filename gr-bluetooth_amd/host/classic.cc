@@ -682,7 +682,9 @@ std::string hopper_handlers::hit(const btgpu_hit &hit, const btgpu_header &sweep
         const uint32_t clock27 = (clkn + d_piconet.offset()) & 0x7ffffff;
         const int hop = d_piconet.hop(clock27);
         const int obs = d_aliased ? basic_rate_piconet::aliased_channel(hop) : hop;
-        if (obs < d_low || obs > d_high || hit.channel != hop) return out;
+        // the reference tunes to the true hop frequency (lib/multi_hopper_impl.cc:166); in an aliasing capture
+        // that offset equals, modulo the sample rate, the observed channel's -- the hit to take is the one on `obs`
+        if (obs < d_low || obs > d_high || hit.channel != obs) return out;
         d_slot_done = true;
         classic_packet pkt(symbols, nsymbols, 0, obs, sweep);
         if (pkt.lap() != d_lap) return out;

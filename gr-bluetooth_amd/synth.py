@@ -255,10 +255,12 @@ def classic_dh1_bits(lap, uap, slot_clock, body, lt_addr=1, llid=2, flow=1, arqn
 
 
 def make_hopping_capture(sample_rate, center_freq, n_slots, lap, uap, clk0, seed=1, snr_db=24.0, occupancy=0.9,
-                         cfo_hz=5e3, start_symbol=40, dh1_fraction=1.0):
+                         cfo_hz=5e3, start_symbol=40, dh1_fraction=1.0, aliased=False):
     """One master hopping over all 79 channels by the real selection kernel, a DH1 packet in each of
     its transmit slots (even CLK1) with probability `occupancy` (a POLL packet instead with
-    probability 1 - dh1_fraction); only the channels inside the capture's band are rendered.  Slot k of the capture carries master clock clk0 + k.
+    probability 1 - dh1_fraction); only the channels inside the capture's band are rendered -- or, with
+    `aliased`, all of them at their true offsets, which a 25 Msps capture folds into its band exactly as an
+    aliasing receiver does.  Slot k of the capture carries master clock clk0 + k.
     Returns (iq, truth) with truth = [(slot, clock, channel)] of the rendered packets."""
     rng = np.random.default_rng(seed)
     sps = int(round(sample_rate / SYMBOL_RATE))
@@ -279,7 +281,7 @@ def make_hopping_capture(sample_rate, center_freq, n_slots, lap, uap, clk0, seed
         body = bytes(rng.integers(0, 256, int(rng.integers(4, 27)), dtype=np.uint8))
         poll = rng.random() >= dh1_fraction
         lt, flow, arqn, seqn = int(rng.integers(1, 8)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
-        if lo <= ch <= hi:
+        if aliased or lo <= ch <= hi:
             if poll:
                 bits = classic_poll_bits(lap, uap, clk, lt_addr=lt, flow=flow, arqn=arqn, seqn=seqn, ptype=int(rng.integers(0, 2)))
             else:

@@ -224,7 +224,11 @@ void bto_hopper_block_slot(bto_hopper_block *b, uint32_t clkn, int nhits, const 
         int obs = b->aliased ? bto_aliased_channel(hop) : hop;
         if (obs < low_channel || obs > high_channel) return;
         for (int i = 0; i < nhits; i++) {
-            if (channels[i] != hop) continue;                  /* the front end runs on the true hop frequency */
+            /* The reference tunes its DDC to the true hop frequency (:166); with an aliasing receiver
+             * (25 Msps, every channel folded into 26..50) that offset is congruent, modulo the sample
+             * rate, to the offset of the observed channel: the samples are those of channel `obs` (the
+             * rotator increment and the tap phases differ by whole turns only). */
+            if (channels[i] != obs) continue;
             bto_packet *pkt = bto_packet_new(symbols[i], lens[i], 0, obs);
             if (bto_packet_lap(pkt) == b->lap) {
                 HLOG("clock 0x%07x, channel %2d: ", clock27, obs);

@@ -139,6 +139,29 @@ def test_btrx_amd_hopper_follows_a_hopping_piconet(po, synth, tmp_path):
     assert got == want
 
 
+def test_btrx_amd_hopper_with_an_aliasing_receiver(po, synth, tmp_path):
+    """btrx_amd -l LAP -p --aliased on a 25 Msps capture that folds all 79 channels into 26..50 (odd
+    samples per symbol: the segmented DIRECT path): hop reversal on aliased channel numbers, then one
+    line per followed packet on the channel it was observed on -- text equal to the oracle pipeline."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("toh", os.path.join(ROOT, "tests", "test_oracle_hop.py"))
+    toh = importlib.util.module_from_spec(spec); spec.loader.exec_module(toh)
+    fs, fc = 25e6, 2440e6
+    lap, uap, clk0, nsl = 0x24D952, 0xAF, 0x1B3C5D2, 200
+    iq, truth = synth.make_hopping_capture(fs, fc, nsl, lap, uap, clk0, seed=8, dh1_fraction=0.0, aliased=True)
+    path = str(tmp_path / "alias.cfile")
+    iq.tofile(path)
+    out = subprocess.run([BTRX, "-f", "2440M", "-r", "25M", "-i", path, "-l", "%06x" % lap, "-p", "--aliased"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    hits, _ = o.run_stream(iq, threads=16)
+    want, hb = toh._hopper_text(po, o, iq, hits, lap, nsl, aliased=True)
+    got = out.stdout.split("\n", 1)[1]
+    assert "Acquired CLK1-27 offset = 0x%07x" % ((clk0 - 6) & 0x7FFFFFF) in want
+    assert got == want
+
+
 def test_btrx_amd_fhs_after_discovery(po, synth, tmp_path):
     """A piconet seen through header-only packets until UAP / CLK1-6 are known, then an FHS and a DM1
     packet: the sniffer block prints the decoded types, the FHS contents (BD_ADDR, CLK) and adopts

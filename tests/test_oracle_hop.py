@@ -49,10 +49,10 @@ def test_winnowing_converges_on_the_true_clock(po):
     assert m == 1 and int(hp2.candidates()[0]) == clk
 
 
-def _hopper_text(po, o, iq, hits, lap, n_slots):
+def _hopper_text(po, o, iq, hits, lap, n_slots, aliased=False):
     """stdout of multi_hopper for the oracle front end's hit list (first classic hit of each channel
     per slot, ascending channels) through the oracle's hopper block."""
-    hb = po.HopperBlock(lap)
+    hb = po.HopperBlock(lap, aliased=aliased)
     by_slot = {}
     for h in hits:
         if h.kind == 0:
@@ -105,3 +105,29 @@ def test_hopper_block_crc_success_quirk(po, synth):
     text, hb = _hopper_text(po, o, iq, hits, lap, nsl)
     assert "Correct CRC! UAP = 0xaf found after 1 total packets." in text
     assert "no candidates remaining! starting over . . ." in text and not hb.piconet.have_clk27
+
+
+def test_hopper_block_with_an_aliasing_receiver(po, synth):
+    """multi_hopper's aliased mode (apps/btrx -a, lib/piconet_impl.cc:520-523): a 25 Msps capture folds
+    all 79 channels into channels 26..50, every packet of the piconet is seen, the hop reversal runs on
+    aliased channel numbers, and hopalong reports each followed packet on the channel it was observed
+    on -- which is aliased_channel() of the channel it was sent on."""
+    fs, fc = 25e6, 2440e6
+    lap, uap, clk0, nsl = 0x24D952, 0xAF, 0x1B3C5D2, 200
+    iq, truth = synth.make_hopping_capture(fs, fc, nsl, lap, uap, clk0, seed=8, dh1_fraction=0.0, aliased=True)
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    assert (o.low_ch, o.high_ch) == (26, 50)
+    hits, _ = o.run_stream(iq, threads=16)
+    text, hb = _hopper_text(po, o, iq, hits, lap, nsl, aliased=True)
+    pn = hb.piconet
+    assert pn.have_clk27 and pn.uap == uap and pn.clk_offset == (clk0 - 6) & 0x7FFFFFF, text[-600:]
+    tail = text.split("Acquired CLK1-27 offset")[1].splitlines()[1:]
+    sent = {clk: ch for k, clk, ch in truth}
+    followed = 0
+    for line in tail:
+        if not line.startswith("clock 0x"):
+            continue
+        clk, ch = int(line[6:15], 16), int(line[25:27])
+        assert ch == ((sent[clk] + 24) % 25) + 26
+        followed += 1
+    assert followed > 10
