@@ -210,8 +210,9 @@ def main():
                 pmc = json.load(open(path))
                 key = {"ddc_channel": "pfb100_kernel<7, 1, 26, true, true", "window": "window_kernel",
                        "finish": "finish_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
-                if args.workload == "c79" and S == pmc["slots"] and key in pmc["kernels"] and not direct:
-                    roof["traffic"] = pmc["kernels"][key]["hbm_bytes"]
+                match = [k for k in pmc["kernels"] if key and k.startswith(key)]
+                if args.workload == "c79" and S == pmc["slots"] and match and not direct:
+                    roof["traffic"] = pmc["kernels"][match[0]]["hbm_bytes"]
                     roof["traffic_source"] = "profiles/" + os.path.basename(path)
                     break
         except Exception:
