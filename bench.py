@@ -85,9 +85,10 @@ def main():
 
     wl = WORKLOADS[args.workload]
     fs, fc = wl["sample_rate"], wl["center_freq"]
-    # C79: 1.28 s of signal per step, 683 window-kernel workgroups = one resident round.  C8: the same
-    # number of input samples per second of signal is 12.5x smaller, so a step takes 8x the slots
-    S = args.slots or (2048 if args.workload == "c79" else 16384)
+    # C79: 1.44 s of signal per step = 768 window-kernel workgroups of three slots, exactly the number
+    # that is resident at once (three per CU).  C8: the same number of input samples per second of
+    # signal is 12.5x smaller, so a step takes more slots
+    S = args.slots or (2304 if args.workload == "c79" else 16384)
     laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(args.piconets))
 
     blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
@@ -225,7 +226,7 @@ def main():
             import glob, re
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")), reverse=True):
                 m = re.search(r"^pfb100_kernel<7.*SQ_INSTS_VALU=([0-9.e+]+)M", open(path).read(), re.M)
-                if m and names[dom] == "ddc_channel" and args.workload == "c79" and S == 2048 and not direct:
+                if m and names[dom] == "ddc_channel" and args.workload == "c79" and S == 2304 and not direct:
                     insts = float(m.group(1)) * 1e6 / 2.0
                     bound_ms = insts * 4.0 / (1024 * 2.4e9) * 1e3
                     roof["valu"] = {"wave_insts_per_launch": insts, "issue_bound_ms": round(bound_ms, 4),

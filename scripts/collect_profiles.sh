@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-SLOTS=${SLOTS:-2048}
+SLOTS=${SLOTS:-2304}
 python $R/bench.py --slots $SLOTS > "$OUT/bench.json" 2> "$OUT/bench.err"
 rm -rf /tmp/kt /tmp/p1 /tmp/p2 /tmp/p3
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/bench.py --slots $SLOTS --no-cpu > "$OUT/bench_under_rocprof.json" 2>> "$OUT/bench.err"
