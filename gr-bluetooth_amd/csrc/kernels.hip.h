@@ -446,28 +446,39 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     // row (index + 8 rows must be staged), so the next chunk always starts kWinRows - 7 rows further:
     // the schedule is static and the rows of chunk n + 1 are fetched into registers before the
     // recursion over chunk n starts -- the HBM round trip hides under the dependent arithmetic.
-    // Every load is unconditional (clamped row, value selected at the LDS store): a load under a
-    // lane-dependent branch would be waited for at the end of that branch, nine round trips per chunk.
+    // Every load is unconditional (clamped address): a load under a lane-dependent branch would be
+    // waited for at the end of that branch, nine round trips per chunk.
     constexpr int kAdv = kWinRows - 7;
     constexpr int kVec = kWinRows * kVecPerRow;                  // float4 per chunk and slot (the used part of the 80-float rows)
     constexpr int kTot = kVec * kWinSlots;
     constexpr int kPer = (kTot + kWinThreads - 1) / kWinThreads;
     float4 v[kPer];
-    unsigned int okm = 0;
+    // Per-thread constants of the staging copy, computed once: byte offset of element j from the
+    // workgroup's first row (chunk 0) and its float4 index in the LDS tile; bit 31 marks row 0 of a
+    // window (policy Q1: demod_out[0] = 0).  Per chunk an element then costs one add and one clamp.
+    // The clamp only keeps the address inside the stream: rows past the end belong to no window of
+    // this batch (every window's ddc_out rows exist) and are never consumed.
+    constexpr int kRowBytes = kVecPerRow * 16;
+    uint32_t goff[kPer], loff[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        const int i = (int)threadIdx.x + j * kWinThreads;
+        const int ic = i < kTot ? i : kTot - 1;
+        const int s = ic / kVec, iv = ic - s * kVec;
+        const int r = iv / kVecPerRow, q4 = iv - r * kVecPerRow;
+        goff[j] = (uint32_t)((s * p.outs_per_slot + r) * kRowBytes + q4 * 16);
+        loff[j] = (uint32_t)(s * (kTileFloats / 4) + r * (kWinRowStride / 4) + q4) | (r == 0 ? 0x80000000u : 0u);
+    }
+    const long long wg_row0 = (long long)blockIdx.x * kWinSlots * p.outs_per_slot;
+    const char *wgb = (const char *)(d + (size_t)wg_row0 * (kVecPerRow * 4));
+    const long long span = (d_rows - wg_row0) * kRowBytes - 16;             // last float4 of the stream (d_rows > wg_row0)
+    const uint32_t max_off = span > 0xFFFFFFF0LL ? 0xFFFFFFF0u : (uint32_t)span;
     auto fetch = [&](int base) {
-        okm = 0;
+        const uint32_t boff = (uint32_t)base * (uint32_t)kRowBytes;
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
-            const int i = (int)threadIdx.x + j * kWinThreads;
-            const int ic = i < kTot ? i : kTot - 1;
-            const int s = ic / kVec, iv = ic - s * kVec;
-            const int r = iv / kVecPerRow, q4 = iv - r * kVecPerRow;
-            const long long row = ((long long)blockIdx.x * kWinSlots + s) * p.outs_per_slot + base + r;
-            // policy Q1: demod_out[0] = 0 (row 0 of the window); rows past the window or the stream read as 0
-            const bool ok = i < kTot && row < d_rows && base + r < p.ddc_out && base + r != 0;
-            const long long rc = row < d_rows ? row : d_rows - 1;
-            v[j] = ((const float4 *)(d + (size_t)rc * (kVecPerRow * 4)))[q4];   // rows of d are kVecPerRow * 4 floats apart
-            okm |= (ok ? 1u : 0u) << j;
+            const uint32_t o = goff[j] + boff;
+            v[j] = *(const float4 *)(wgb + (o < max_off ? o : max_off));
         }
     };
     int base = 0;
@@ -476,11 +487,9 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
             const int i = (int)threadIdx.x + j * kWinThreads;
-            const int s = i / kVec, iv = i - s * kVec;
-            const int r = iv / kVecPerRow, q4 = iv - r * kVecPerRow;
-            const bool ok = (okm >> j) & 1u;
-            const float4 t = make_float4(ok ? v[j].x : 0.f, ok ? v[j].y : 0.f, ok ? v[j].z : 0.f, ok ? v[j].w : 0.f);
-            if (i < kTot) ((float4 *)(tile + s * kTileFloats))[r * (kWinRowStride / 4) + q4] = t;
+            const bool zero = base == 0 && (loff[j] >> 31);
+            const float4 t = make_float4(zero ? 0.f : v[j].x, zero ? 0.f : v[j].y, zero ? 0.f : v[j].z, zero ? 0.f : v[j].w);
+            if (i < kTot) ((float4 *)tile)[loff[j] & 0x7fffffffu] = t;
         }
         if (threadIdx.x == 0) s_live[it & 1] = 0;
         __syncthreads();
