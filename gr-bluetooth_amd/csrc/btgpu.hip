@@ -277,9 +277,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (const double *)d_rotstep_ch.p, (float2 *)d_Y.p, G, ystride, nch, seg_ch, seg_stride);
         HIPCHK(this, hipEventRecord(ev[1], st));
         dim3 g2((unsigned)nb, (unsigned)nch);
-        hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
-                           ystride, ops, des.tail, (const float *)nullptr, 0.f,
-                           (float *)nullptr, (double *)d_P.p, (double *)d_Pt.p, nb, nch, (float *)nullptr, 0LL);
+        hipLaunchKernelGGL(energy_kernel, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
+                           ystride, ops, des.tail, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
         hipLaunchKernelGGL(demod_rows_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st, (const float2 *)d_Y.p, G,
                            ystride, nch, (const float *)d_atan.p, des.demod_gain, (float *)d_d.p, drow,
                            (float *)d_d2.p, ystride);
@@ -332,9 +331,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (const double *)d_rotstep_n.p, (float2 *)d_Yn.p, Gn, ystride_n, nch, seg_n, seg_stride);
         HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
         dim3 g2((unsigned)S, (unsigned)nch);
-        hipLaunchKernelGGL(demod_energy_kernel<false>, g2, dim3(256), 0, ns_st, (const float2 *)d_Yn.p, Gn,
-                           ystride_n, ops_n, 0, (const float *)nullptr, 0.f, (float *)nullptr,
-                           (double *)d_Q.p, (double *)nullptr, S, nch, (float *)nullptr, 0LL);
+        hipLaunchKernelGGL(energy_kernel, g2, dim3(256), 0, ns_st, (const float2 *)d_Yn.p, Gn,
+                           ystride_n, ops_n, 0, (double *)d_Q.p, (double *)nullptr, S, nch);
     }
     HIPCHK(this, hipEventRecord(t.evn[2], ns_st));
     if (overlap_noise) HIPCHK(this, hipStreamWaitEvent(st, t.evn[2], 0));      // join before the window kernel

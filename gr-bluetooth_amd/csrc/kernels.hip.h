@@ -201,25 +201,17 @@ __device__ __forceinline__ float demod_one(const float *__restrict__ atab, float
 }
 
 // ------------------------------------------------------------------------------------
-// K2: demodulate the channel stream and reduce |Y|^2 per slot-block.
-// One workgroup per (block b of `bs` outputs, channel).  DEMOD=false: energy only
-// (noise bank).  Sums are float mag^2 accumulated in double like multi_block.cc:206-218.
+// K2: |Y|^2 sums per slot-block (and over the first `tail` outputs of the block).  One workgroup
+// per (block b of `bs` outputs, channel).  Float mag^2 accumulated in double like
+// multi_block.cc:206-218; fixed reduction order.
 // ------------------------------------------------------------------------------------
-template <bool DEMOD>
-__global__ __launch_bounds__(256) void demod_energy_kernel(
+__global__ __launch_bounds__(256) void energy_kernel(
     const float2 *__restrict__ Y, long long G, long long ystride, int bs, int tail,
-    const float *__restrict__ atan_tab, float gain, float *__restrict__ d,
-    double *__restrict__ P, double *__restrict__ Pt, int nb, int nch, float *__restrict__ d2,
-    long long d2stride)
+    double *__restrict__ P, double *__restrict__ Pt, int nb, int nch)
 {
-    __shared__ float atab[257];
     __shared__ double red[2][4];
     const int c = blockIdx.y;
     const int b = blockIdx.x;
-    if (DEMOD) {
-        for (int i = threadIdx.x; i < 257; i += blockDim.x) atab[i] = atan_tab[i];
-        __syncthreads();
-    }
     const float2 *y = Y + (size_t)c * ystride;
     const long long gb = (long long)b * bs;
     double s_full = 0.0, s_tail = 0.0;
@@ -230,12 +222,6 @@ __global__ __launch_bounds__(256) void demod_energy_kernel(
         const float m = (v.x * v.x) + (v.y * v.y);
         s_full += (double)m;
         if (i < tail) s_tail += (double)m;
-        if (DEMOD) {
-            float dv = 0.f;
-            if (g > 0) dv = demod_one(atab, gain, v, y[g - 1]);
-            d[(size_t)g * 80 + c] = dv;
-            if (d2) d2[(size_t)c * d2stride + g] = dv;
-        }
     }
     // wave reduce (64 lanes) then across the 4 waves
     for (int off = 32; off > 0; off >>= 1) {
