@@ -4,6 +4,7 @@
 // documented in DESIGN.md.
 #include "design.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -294,8 +295,17 @@ int make_design(const btgpu_config &cfg, Design &o)
     const int nsym = cfg.mode == BTGPU_MODE_SNIFFER ? kSymbolsHistorySniffer : kSymbolsShortAC;
     d.history = (int)(history + (nsym * d.samples_per_symbol));
 
-    d.ddc_out = (d.history - (d.ntaps_channel - 1) - d.first_channel_sample) / d.decimation;
-    d.noise_out = d.samples_per_slot / d.decimation;
+    // lib/multi_block.cc:194-200 and :269 hand (ninput - (history() - 1) - first) resp. one slot to
+    // the DDC's fixed_rate_ninput_to_noutput(), and gr::sync_decimator [EXT] answers
+    // max(0, n - history() + 1) / decimation with history() = ntaps: the filter length comes off a
+    // second time, so a window yields 7494/7495 channel outputs (not 7508) and 850 noise outputs
+    // (not 1250) at every integer rate.
+    {
+        const int ddc_samples = d.history - (d.ntaps_channel - 1) - d.first_channel_sample;
+        d.ddc_out = std::max(0, ddc_samples - d.ntaps_channel + 1) / d.decimation;
+        d.noise_out = std::max(0, d.samples_per_slot - d.ntaps_noise + 1) / d.decimation;
+    }
+    if (d.ddc_out < 2 * kMmseTaps || d.noise_out < 1) return BTGPU_EINVAL;
 
     // the shared output grid needs whole outputs per slot
     if (d.samples_per_slot % d.decimation != 0) {

@@ -235,7 +235,9 @@ int make_fast_path(const Design &des, FastPath &fp)
         }
         for (double &v : phi) v *= U / sum;
     }
-    ns.nw = ns.outs + 2 * ns.Jm;
+    // the reference averages noise_out (850 of a slot's 1250) fine-rate outputs: only the stage-2
+    // outputs under that span carry weight
+    ns.nw = (d.noise_out + U - 1) / U + 2 * ns.Jm;
     ns.weights.assign(ns.nw, 0.0);
     for (int a = 0; a < ns.nw; a++) {
         const int J = a - ns.Jm;

@@ -360,12 +360,23 @@ const float *bto_noise_taps(const bto_ctx *c) { return c->h_noise; }
 const float *bto_mmse_taps(const bto_ctx *c) { return &c->mmse[0][0]; }
 const float *bto_atan_table(const bto_ctx *c) { return c->atan_tab; }
 
+/* [EXT] gr::sync_decimator::fixed_rate_ninput_to_noutput(n) = max(0, n - history() + 1) / decimation,
+ * and freq_xlating_fir_filter_ccf sets history() = ntaps.  The reference has already taken
+ * (history() - 1) off before it asks (multi_block.cc:194), so the filter length comes off twice. */
+static int sync_decimator_noutput(int ninput, int ntaps, int decim)
+{
+    int n = ninput - ntaps + 1;
+    return (n < 0 ? 0 : n) / decim;
+}
 int bto_ddc_out(const bto_ctx *c)
 {
     int ddc_samples = c->history - (c->ntaps_ch - 1) - c->first_ch;   /* multi_block.cc:194 */
-    return ddc_samples / c->decim;                                    /* :200 [EXT] n/decim */
+    return sync_decimator_noutput(ddc_samples, c->ntaps_ch, c->decim); /* :200 */
 }
-int bto_noise_out(const bto_ctx *c) { return (int)c->samples_per_slot / c->decim; }  /* :269 */
+int bto_noise_out(const bto_ctx *c)                                    /* :269 */
+{
+    return sync_decimator_noutput((int)c->samples_per_slot, c->ntaps_noise, c->decim);
+}
 
 /* ------------------------------------------------------------------------- */
 /* [EXT] freq_xlating_fir_filter_ccf::work restated, fixed summation order     */

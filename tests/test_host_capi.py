@@ -70,13 +70,13 @@ def test_no_cpu_fallback(pkg):
 def test_staged_squelch_design_fit(pkg):
     """The two-stage squelch filter's composite impulse response must equal the reference's
     low_pass(1, fs, 22.5e3, 10e3, HANN) to ~1e-6 of its l1 norm at every supported rate, and the
-    quadrature weights must sum to the 1250 outputs they stand for."""
+    quadrature weights must sum to the 850 outputs (noise_out) they stand for."""
     for fs, fc in ((2e6, 2476e6), (4e6, 2476e6), (8e6, 2476.5e6), (20e6, 2441e6), (100e6, 2441e6)):
         s = pkg.staged_design(fs, fc)
         assert s["fit_l1_error"] < 5e-6, (fs, s)
         assert s["R"] == 5 * int(fs / 1e6) // 2 if fs > 2e6 else s["R"] == 5
-        assert s["nw"] == 262 and s["L3"] == 80
-        assert abs(s["weight_sum"] - 1250.0) < 1e-6
+        assert s["nw"] == 182 and s["L3"] == 80
+        assert abs(s["weight_sum"] - 850.0) < 1e-6
 
 
 def test_block_mirror_surface(pkg):

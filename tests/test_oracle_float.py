@@ -12,11 +12,11 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # fs, fc, sps, decim, ntaps ch/noise, slot, first_ch, channels, history LAP/sniffer, ddc_out LAP/sniffer
 A1 = [
-    (2e6, 2476e6, 1, 13, 401, 1250, 380, (74, 74), 1787, 7901, 1395, 7509),
-    (4e6, 2476e6, 2, 27, 801, 2500, 758, (73, 75), 3573, 15801, 1394, 7508),
-    (8e6, 2476.5e6, 4, 53, 1601, 5000, 1516, (71, 78), 7145, 31601, 1394, 7508),
-    (20e6, 2441e6, 10, 133, 4001, 12500, 3788, (30, 48), 17861, 79001, 1394, 7508),
-    (100e6, 2441e6, 50, 667, 20001, 62500, 18934, (0, 78), 89301, 395001, 1394, 7508),
+    (2e6, 2476e6, 1, 13, 401, 1250, 380, (74, 74), 1787, 7901, 1383, 7497),
+    (4e6, 2476e6, 2, 27, 801, 2500, 758, (73, 75), 3573, 15801, 1381, 7495),
+    (8e6, 2476.5e6, 4, 53, 1601, 5000, 1516, (71, 78), 7145, 31601, 1381, 7495),
+    (20e6, 2441e6, 10, 133, 4001, 12500, 3788, (30, 48), 17861, 79001, 1380, 7494),
+    (100e6, 2441e6, 50, 667, 20001, 62500, 18934, (0, 78), 89301, 395001, 1380, 7494),
 ]
 
 
@@ -28,11 +28,11 @@ def test_derived_sizes_table_A1(po, pkg, row):
         assert (o.decim, o.ntaps_ch, o.ntaps_noise, o.slot, o.first_ch, o.first_noise) == \
             (decim, nt_ch, nt_n, slot, first_ch, 0)
         assert (o.low_ch, o.high_ch) == chans
-        assert (o.history, o.ddc_out, o.noise_out) == (H, ddc, 1250)
+        assert (o.history, o.ddc_out, o.noise_out) == (H, ddc, 850)
         d = pkg.design_query(fs, fc, 10.0, mode)      # product host code must derive the same
         assert (d.decimation, d.ntaps_channel, d.ntaps_noise, d.samples_per_slot, d.first_channel_sample,
                 d.first_noise_sample, d.low_channel, d.high_channel, d.history, d.ddc_out, d.noise_out) == \
-            (decim, nt_ch, nt_n, slot, first_ch, 0, chans[0], chans[1], H, ddc, 1250)
+            (decim, nt_ch, nt_n, slot, first_ch, 0, chans[0], chans[1], H, ddc, 850)
 
 
 def test_firdes_low_pass_hann(po, pkg):
