@@ -78,7 +78,8 @@ EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_stre
            "btgpu_last_error", "btgpu_work", "btgpu_push", "btgpu_process_device", "btgpu_poll",
            "btgpu_poll_symbols", "btgpu_poll_headers", "btgpu_hopseq_create", "btgpu_hopseq_destroy",
            "btgpu_hopseq_init_candidates", "btgpu_hopseq_winnow", "btgpu_hopseq_candidates", "btgpu_hopseq_lookup",
-           "btgpu_hopseq_fetch", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch"]
+           "btgpu_hopseq_fetch", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch",
+           "btgpu_debug_scan_symbols", "btgpu_debug_lut"]
 
 
 class BtgpuError(RuntimeError):
@@ -183,6 +184,11 @@ def lib():
     L.btgpu_debug_tables.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(ctypes.c_float),
                                      ctypes.POINTER(ctypes.c_float), ctypes.c_uint32,
                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+    L.btgpu_debug_scan_symbols.restype = ctypes.c_long
+    L.btgpu_debug_scan_symbols.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(Hit), ctypes.c_long]
+    L.btgpu_debug_lut.restype = ctypes.c_int
+    L.btgpu_debug_lut.argtypes = [ctypes.c_char_p, vp, ctypes.c_int]
     _lib = L
     return L
 
@@ -231,6 +237,29 @@ def debug_tables(sample_rate, center_freq, lap=0):
     if rc != OK:
         raise BtgpuError(rc)
     return mmse, atab, lo.value, hi.value
+
+
+def debug_lut(name):
+    """One of the product's regenerated integer tables as bytes (see btgpu_debug_lut)."""
+    buf = ctypes.create_string_buffer(1024)
+    n = lib().btgpu_debug_lut(name.encode(), buf, 1024)
+    if n < 0:
+        raise BtgpuError(n, name)
+    return buf.raw[:n]
+
+
+def scan_symbols(symbols, policy=1, device=-1, cap=1 << 16):
+    """The window kernel's access-code search straight on a symbol stream (one 0/1 symbol per byte,
+    the format of the reference's samples/channel37.dem): list of (offset, lap, ac_errors).
+    policy 1 = stream scan resuming 68 symbols after a hit, 0 = every qualifying offset."""
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    out = (Hit * cap)()
+    n = lib().btgpu_debug_scan_symbols(s.tobytes(), len(s), device, policy, out, cap)
+    if n < 0:
+        raise BtgpuError(int(n))
+    if n > cap:
+        raise BtgpuError(EOVERFLOW, "%d records, cap %d" % (n, cap))
+    return [(out[i].offset, out[i].lap, out[i].ac_errors) for i in range(n)]
 
 
 def staged_design(sample_rate, center_freq):

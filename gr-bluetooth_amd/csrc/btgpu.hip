@@ -204,7 +204,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     last_S = S;
     last_G = G;
     TailCtx &t = tc[cur];
-    if (t.pending) { int hrc = harvest(t); if (hrc != BTGPU_OK && hrc != BTGPU_EOVERFLOW) return hrc; }
+    int carried = BTGPU_OK;                                      // overflow of the batch harvested here
+    if (t.pending) { int hrc = harvest(t); if (hrc == BTGPU_EOVERFLOW) carried = hrc; else if (hrc != BTGPU_OK) return hrc; }
     hipEvent_t *ev = t.ev;
     DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin, &d_d2 = t.d_d2;
     DevBuf &d_winfin = t.d_winfin, &d_symbits = t.d_symbits;
@@ -377,7 +378,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         HIPCHK(this, hipStreamWaitEvent(tail_stream, t.detect_done, 0));
         {
             // windows with hits: at most one FinishRec per window; lanes beyond fin_count exit
-            const long long cap = std::min<long long>((long long)S * nch, (long long)max_hits);
+            // (the kernel strides over the records: the grid only bounds the waves in flight)
+            const long long cap = (long long)S * nch;
             const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
             if (want_syms)
                 hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d2.p,
@@ -414,8 +416,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     HIPCHK(this, hipGetLastError());
     t.pending = true;
     cur ^= 1;
-    if (!async) return harvest(t);
-    return BTGPU_OK;
+    if (!async) { const int hrc = harvest(t); return hrc != BTGPU_OK ? hrc : carried; }
+    return carried;
 }
 
 // wait for a batch's tail, move its hit records to the host queue, account its kernel times
@@ -598,6 +600,32 @@ int btgpu_debug_tables(const btgpu_config *cfg, float *mmse /*129*8*/, float *at
                             d->ac.byte_lo[2][lap >> 16];
         if (ac_hi) *ac_hi = d->ac.a0_hi ^ d->ac.byte_hi[0][lap & 0xff] ^ d->ac.byte_hi[1][(lap >> 8) & 0xff] ^
                             d->ac.byte_hi[2][lap >> 16];
+    }
+    delete d;
+    return rc;
+}
+
+/* the regenerated integer tables the kernels use, by the reference's names / by the derived forms of
+ * tests/golden/make_lut_digests.py (CPU tests: digests against the reference's literals) */
+int btgpu_debug_lut(const char *name, void *out, int cap_bytes)
+{
+    if (!name || !out) return BTGPU_EINVAL;
+    Design *d = new (std::nothrow) Design();
+    if (!d) return BTGPU_ENOMEM;
+    btgpu_config cfg{};
+    cfg.sample_rate = 8e6; cfg.center_freq = 2476.5e6; cfg.squelch_db = 10.0; cfg.mode = BTGPU_MODE_SNIFFER;
+    int rc = make_design(cfg, *d);
+    if (rc == BTGPU_OK) {
+        const void *src = nullptr; int n = 0;
+        const std::string k(name);
+        if (k == "le_packet::ACCESS_HEADER_DISTANCE_LSB") { src = d->le.hdr[0]; n = 256; }
+        else if (k == "le_packet::ACCESS_HEADER_DISTANCE_MSB") { src = d->le.hdr[1]; n = 256; }
+        else if (k == "le_packet::DATA_HEADER_DISTANCE_LSB") { src = d->le.hdr[2]; n = 256; }
+        else if (k == "le_packet::DATA_HEADER_DISTANCE_MSB") { src = d->le.hdr[3]; n = 256; }
+        else if (k == "derived/classic_first18") { src = d->wh.first18; n = (int)sizeof d->wh.first18; }
+        else if (k == "derived/le_whiten16") { src = d->le.whiten16; n = (int)sizeof d->le.whiten16; }
+        if (!src || cap_bytes < n) rc = BTGPU_EINVAL;
+        else { std::memcpy(out, src, (size_t)n); rc = n; }
     }
     delete d;
     return rc;
@@ -800,7 +828,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->alloc(t.d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
         if (h->want_hdrs) TRY(h->alloc(t.d_hdr, (size_t)h->max_hits * sizeof(HeaderRec)));
         if (h->want_syms) {
-            const size_t maxfin = std::min<size_t>((size_t)S * nch, (size_t)h->max_hits);
+            const size_t maxfin = (size_t)S * nch;            // one FinishRec per hit window, whatever max_hits is
             TRY(h->alloc(t.d_winfin, (size_t)S * nch * sizeof(int)));
             TRY(h->alloc(t.d_symbits, std::max<size_t>(maxfin, btgpu_handle::kEagerFin) * kSymWords * sizeof(uint32_t)));
         }
@@ -1046,6 +1074,73 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
     if (hipMemcpy(out, (const char *)src + first * elem, count * elem, hipMemcpyDeviceToHost) != hipSuccess)
         return BTGPU_EDEVICE;
     return (long)count;
+}
+
+// ---------------------------------------------------------------------------------------
+// The correlator on a captured symbol stream (parity entry: samples/channel37.dem of the reference)
+// ---------------------------------------------------------------------------------------
+long btgpu_debug_scan_symbols(const uint8_t *symbols, size_t n, int device, int policy, btgpu_hit *out, long cap)
+{
+    if (!symbols || cap < 0 || (!out && cap > 0) || (policy != 0 && policy != 1) || n > 0x7fffffffull) return BTGPU_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BTGPU_ENODEVICE;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev || hipSetDevice(device) != hipSuccess) return BTGPU_EINVAL;
+    // access-code tables: the same host design the blocks use (they do not depend on the rate)
+    Design *des = new (std::nothrow) Design();
+    if (!des) return BTGPU_ENOMEM;
+    btgpu_config cfg{};
+    cfg.sample_rate = 8e6; cfg.center_freq = 2476.5e6; cfg.squelch_db = 10.0; cfg.mode = BTGPU_MODE_SNIFFER;
+    int rc = make_design(cfg, *des);
+    if (rc != BTGPU_OK) { delete des; return rc; }
+    const size_t nwords = (n + 31) / 32;
+    std::vector<uint32_t> words(nwords + 1, 0u);
+    for (size_t i = 0; i < n; i++) if (symbols[i] & 1) words[i >> 5] |= 1u << (i & 31);
+    const unsigned long long chunks = (n + 624) / 625;
+    const long max_hits = (long)std::min<unsigned long long>(chunks * 64 + 1024, 1ull << 24);
+    uint32_t *d_words = nullptr; uint64_t *d_lo = nullptr; uint32_t *d_hi = nullptr; DeviceHit *d_hits = nullptr; unsigned int *d_count = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_words); (void)hipFree(d_lo); (void)hipFree(d_hi); (void)hipFree(d_hits); (void)hipFree(d_count); delete des; };
+    if (hipMalloc((void **)&d_words, words.size() * 4) != hipSuccess || hipMalloc((void **)&d_lo, sizeof des->ac.byte_lo) != hipSuccess ||
+        hipMalloc((void **)&d_hi, sizeof des->ac.byte_hi) != hipSuccess || hipMalloc((void **)&d_hits, (size_t)max_hits * sizeof(DeviceHit)) != hipSuccess ||
+        hipMalloc((void **)&d_count, sizeof(unsigned int)) != hipSuccess) { cleanup(); return BTGPU_ENOMEM; }
+    long result = BTGPU_EDEVICE;
+    do {
+        if (hipMemcpy(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_lo, des->ac.byte_lo, sizeof des->ac.byte_lo, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_hi, des->ac.byte_hi, sizeof des->ac.byte_hi, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemset(d_count, 0, sizeof(unsigned int)) != hipSuccess) break;
+        const unsigned nblk = (unsigned)((chunks + kWinThreads - 1) / kWinThreads);
+        if (nblk)
+            hipLaunchKernelGGL(scan_symbols_kernel, dim3(nblk), dim3(kWinThreads), 0, 0, (const uint32_t *)d_words,
+                               (unsigned long long)n, 1, des->ac.a0_lo, des->ac.a0_hi, (const uint64_t *)d_lo,
+                               (const uint32_t *)d_hi, d_hits, d_count, (int)max_hits);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) break;
+        unsigned int count = 0;
+        if (hipMemcpy(&count, d_count, sizeof count, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if ((long)count > max_hits) { result = BTGPU_EOVERFLOW; break; }
+        std::vector<DeviceHit> hh(count);
+        if (count && hipMemcpy(hh.data(), d_hits, sizeof(DeviceHit) * count, hipMemcpyDeviceToHost) != hipSuccess) break;
+        std::vector<btgpu_hit> all(count);
+        for (unsigned int i = 0; i < count; i++) {
+            btgpu_hit o{};
+            o.slot = hh[i].slot;                                     // 625-offset chunk of the stream
+            o.offset = (int32_t)((long long)hh[i].slot * 625 + hh[i].offset);   // absolute symbol offset
+            o.lap = hh[i].lap; o.ac_errors = hh[i].ac_errors; o.kind = BTGPU_KIND_AC;
+            o.nsym = (int32_t)((long long)n - o.offset);
+            all[i] = o;
+        }
+        std::sort(all.begin(), all.end(), [](const btgpu_hit &a, const btgpu_hit &b) { return a.offset < b.offset; });
+        long m = 0, total = 0;
+        long long next = 0;                                          // policy 1: a hit moves the scan on by 68 symbols
+        for (const btgpu_hit &o : all) {
+            if (policy == 1) { if (o.offset < next) continue; next = (long long)o.offset + kSymbolsShortAC; }
+            if (m < cap) out[m++] = o;
+            total++;
+        }
+        result = total;
+    } while (0);
+    cleanup();
+    return result;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -339,6 +339,76 @@ constexpr int kBitWords = 24;        // 32-bit words of sliced symbols kept per 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
 __device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | (c & (a | b)); }
 
+constexpr int kSymbolsShortAcDev = 68;   // SYMBOLS_PER_BASIC_RATE_SHORTENED_ACCESS_CODE
+
+// classic_packet::sniff_ac (lib/packet_impl.cc:247-268) with check_ac (:471-510) over the offsets
+// [resume, limit) of one lane's packed symbols (word j of the lane at mybits[j * kWinThreads], LDS),
+// 32 offsets per pass: the gate PREAMBLE_DISTANCE[5 bits] + BARKER_DISTANCE[7 bits] <= 2 -- both
+// tables are "min Hamming distance to a pattern or its complement" -- is evaluated bit-sliced with
+// full adders over shifted copies of the stream; survivors get the 68-bit compare against the
+// affine access code AC(0) ^ cols(LAP) (three 256-entry LUTs) with popcount < 7.  A hit moves the
+// search on by `step` symbols (68: the loop of lib/multi_sniffer_impl.cc:107-127; 1: every
+// qualifying offset); first_only stops at the first one (multi_LAP).  Shared by window_kernel's
+// phase 2 and scan_symbols_kernel, which runs it on captured symbol streams.
+template <class Emit>
+__device__ __forceinline__ void search_classic(const uint32_t *mybits, int limit, int step, bool first_only,
+                                               uint64_t a0_lo, uint32_t a0_hi, const uint64_t *ac_lo,
+                                               const uint32_t *ac_hi, int &resume, int &nhits, Emit emit)
+{
+    uint32_t r0 = mybits[0], r1 = mybits[kWinThreads], r2 = mybits[2 * kWinThreads], r3;
+    for (int b = 0; b * 32 < limit; b++) {
+        r3 = mybits[(b + 3) * kWinThreads];
+        // W_k: bit j = symbol (32 b + j + k)
+        const uint32_t w0 = r0;
+        const uint32_t w1 = __funnelshift_r(r0, r1, 1), w2 = __funnelshift_r(r0, r1, 2);
+        const uint32_t w3 = __funnelshift_r(r0, r1, 3), w4 = __funnelshift_r(r0, r1, 4);
+        const uint32_t v61 = __funnelshift_r(r1, r2, 29), v62 = __funnelshift_r(r1, r2, 30);
+        const uint32_t v63 = __funnelshift_r(r1, r2, 31), v64 = r2;
+        const uint32_t v65 = __funnelshift_r(r2, r3, 1), v66 = __funnelshift_r(r2, r3, 2);
+        const uint32_t v67 = __funnelshift_r(r2, r3, 3);
+        // preamble: distance to 0x0a (symbols 0,1,0,1,0) or its complement
+        const uint32_t m0 = w0, m1 = ~w1, m2 = w2, m3 = ~w3, m4 = w4;
+        const uint32_t s1 = xor3(m0, m1, m2), c1 = maj3(m0, m1, m2);
+        const uint32_t s2 = m3 ^ m4, c2 = m3 & m4;
+        const uint32_t a0 = s1 ^ s2, c3 = s1 & s2;
+        const uint32_t a1 = xor3(c1, c2, c3), a2 = maj3(c1, c2, c3);
+        const uint32_t p1 = ~a2 & a1;                                  // min(d, 5 - d), bit 1
+        const uint32_t p0 = (~a2 & ~a1 & a0) | (a2 & ~a0);             //               bit 0
+        // Barker + LAP msb: distance to 0x27 (symbols 1,1,1,0,0,1,0) or its complement
+        const uint32_t n0 = ~v61, n1 = ~v62, n2 = ~v63, n3 = v64, n4 = v65, n5 = ~v66, n6 = v67;
+        const uint32_t t1 = xor3(n0, n1, n2), u1 = maj3(n0, n1, n2);
+        const uint32_t t2 = xor3(n3, n4, n5), u2 = maj3(n3, n4, n5);
+        const uint32_t d0 = xor3(t1, t2, n6), u3 = maj3(t1, t2, n6);
+        const uint32_t d1 = xor3(u1, u2, u3), d2 = maj3(u1, u2, u3);
+        const uint32_t b0 = d0 ^ d2, b1 = d1 ^ d2;                     // min(d, 7 - d) in 0..3
+        // PREAMBLE_DISTANCE + BARKER_DISTANCE <= 2
+        uint32_t ok = (~p1 & ~p0 & ~(b1 & b0)) | (~p1 & p0 & ~b1) | (p1 & ~p0 & ~b1 & ~b0);
+        while (ok) {
+            const int j = __ffs(ok) - 1;
+            ok &= ok - 1;
+            const int cpos = 32 * b + j;
+            if (cpos < resume || cpos >= limit) continue;
+            // 68-bit window at offset cpos
+            const uint32_t x0 = j ? ((r0 >> j) | (r1 << (32 - j))) : r0;
+            const uint32_t x1 = j ? ((r1 >> j) | (r2 << (32 - j))) : r1;
+            const uint32_t x2 = j ? ((r2 >> j) | (r3 << (32 - j))) : r2;
+            const uint64_t wlo = ((uint64_t)x1 << 32) | x0;
+            const uint32_t whi = x2 & 0xf;
+            const uint32_t lap = (uint32_t)(wlo >> 38) & 0xffffff;
+            const uint64_t elo = a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^ ac_lo[512 + (lap >> 16)];
+            const uint32_t ehi = a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^ ac_hi[512 + (lap >> 16)];
+            const int err = __popcll(elo ^ wlo) + __popc((ehi ^ whi) & 0xf);
+            if (err < 7) {
+                emit(cpos, lap, err);
+                nhits++;
+                resume = cpos + step;
+                if (first_only) limit = 0;                             // multi_LAP: first hit only
+            }
+        }
+        r0 = r1; r1 = r2; r2 = r3;
+    }
+}
+
 // One workgroup per kWinSlots consecutive slots, one lane per (slot, channel) window (nch <= 79).
 //
 // Phase 1 -- clock recovery.  The demodulated stream is time-major [g][80], so the rows a slot's
@@ -616,64 +686,16 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         }
         limit = 0;                                                 // skip the in-tree search below
     }
-    uint32_t r0 = mybits[0], r1 = mybits[kWinThreads], r2 = mybits[2 * kWinThreads], r3;
-    for (int b = 0; b * 32 < limit; b++) {
-        r3 = mybits[(b + 3) * kWinThreads];
-        // W_k: bit j = symbol (32 b + j + k)
-        const uint32_t w0 = r0;
-        const uint32_t w1 = __funnelshift_r(r0, r1, 1), w2 = __funnelshift_r(r0, r1, 2);
-        const uint32_t w3 = __funnelshift_r(r0, r1, 3), w4 = __funnelshift_r(r0, r1, 4);
-        const uint32_t v61 = __funnelshift_r(r1, r2, 29), v62 = __funnelshift_r(r1, r2, 30);
-        const uint32_t v63 = __funnelshift_r(r1, r2, 31), v64 = r2;
-        const uint32_t v65 = __funnelshift_r(r2, r3, 1), v66 = __funnelshift_r(r2, r3, 2);
-        const uint32_t v67 = __funnelshift_r(r2, r3, 3);
-        // preamble: distance to 0x0a (symbols 0,1,0,1,0) or its complement
-        const uint32_t m0 = w0, m1 = ~w1, m2 = w2, m3 = ~w3, m4 = w4;
-        const uint32_t s1 = xor3(m0, m1, m2), c1 = maj3(m0, m1, m2);
-        const uint32_t s2 = m3 ^ m4, c2 = m3 & m4;
-        const uint32_t a0 = s1 ^ s2, c3 = s1 & s2;
-        const uint32_t a1 = xor3(c1, c2, c3), a2 = maj3(c1, c2, c3);
-        const uint32_t p1 = ~a2 & a1;                                  // min(d, 5 - d), bit 1
-        const uint32_t p0 = (~a2 & ~a1 & a0) | (a2 & ~a0);             //               bit 0
-        // Barker + LAP msb: distance to 0x27 (symbols 1,1,1,0,0,1,0) or its complement
-        const uint32_t n0 = ~v61, n1 = ~v62, n2 = ~v63, n3 = v64, n4 = v65, n5 = ~v66, n6 = v67;
-        const uint32_t t1 = xor3(n0, n1, n2), u1 = maj3(n0, n1, n2);
-        const uint32_t t2 = xor3(n3, n4, n5), u2 = maj3(n3, n4, n5);
-        const uint32_t d0 = xor3(t1, t2, n6), u3 = maj3(t1, t2, n6);
-        const uint32_t d1 = xor3(u1, u2, u3), d2 = maj3(u1, u2, u3);
-        const uint32_t b0 = d0 ^ d2, b1 = d1 ^ d2;                     // min(d, 7 - d) in 0..3
-        // PREAMBLE_DISTANCE + BARKER_DISTANCE <= 2
-        uint32_t ok = (~p1 & ~p0 & ~(b1 & b0)) | (~p1 & p0 & ~b1) | (p1 & ~p0 & ~b1 & ~b0);
-        while (ok) {
-            const int j = __ffs(ok) - 1;
-            ok &= ok - 1;
-            const int cpos = 32 * b + j;
-            if (cpos < resume || cpos >= limit) continue;
-            // 68-bit window at offset cpos
-            const uint32_t x0 = j ? ((r0 >> j) | (r1 << (32 - j))) : r0;
-            const uint32_t x1 = j ? ((r1 >> j) | (r2 << (32 - j))) : r1;
-            const uint32_t x2 = j ? ((r2 >> j) | (r3 << (32 - j))) : r2;
-            const uint64_t wlo = ((uint64_t)x1 << 32) | x0;
-            const uint32_t whi = x2 & 0xf;
-            const uint32_t lap = (uint32_t)(wlo >> 38) & 0xffffff;
-            const uint64_t elo = p.a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^ ac_lo[512 + (lap >> 16)];
-            const uint32_t ehi = p.a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^ ac_hi[512 + (lap >> 16)];
-            const int err = __popcll(elo ^ wlo) + __popc((ehi ^ whi) & 0xf);
-            if (err < 7) {
-                const unsigned int slot_h = atomicAdd(hit_count, 1u);
-                if (slot_h < (unsigned int)p.max_hits) {
-                    DeviceHit h;
-                    h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
-                    h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0; h.sym = -1; h.pad_ = 0;
-                    hits[slot_h] = h;
-                }
-                nhits++;
-                resume = cpos + 68;
-                if (p.mode == 0) limit = 0;                            // multi_LAP: first hit only
-            }
-        }
-        r0 = r1; r1 = r2; r2 = r3;
-    }
+    search_classic(mybits, limit, kSymbolsShortAcDev, p.mode == 0, p.a0_lo, p.a0_hi, ac_lo, ac_hi, resume, nhits,
+                   [&](int cpos, uint32_t lap, int err) {
+                       const unsigned int slot_h = atomicAdd(hit_count, 1u);
+                       if (slot_h < (unsigned int)p.max_hits) {
+                           DeviceHit h;
+                           h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
+                           h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0; h.sym = -1; h.pad_ = 0;
+                           hits[slot_h] = h;
+                       }
+                   });
     if (p.dbg_stop == 3) return;
     // ---- LE pass: le_packet::sniff_aa (lib/packet_impl.cc:1452-1527) with the loop of
     // lib/multi_sniffer_impl.cc:129-149.  `len` keeps what the classic pass left (Q6): the search
@@ -784,15 +806,15 @@ __global__ __launch_bounds__(64) void finish_kernel(
     __shared__ float slab[64 * SLAB];
     const unsigned int n = *fin_count;
     if (blockIdx.x * blockDim.x >= n) return;                    // uniform: nothing for this workgroup
+    const unsigned int stride = gridDim.x * blockDim.x;          // records beyond the grid: next round
     // a few dozen strictly sequential waves next to the throughput kernels of the following batch:
     // give them the highest wave issue priority, they use a fraction of a percent of the issue slots
     __builtin_amdgcn_s_setprio(3);
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
     __syncthreads();
-    const unsigned int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
+  for (unsigned int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += stride) {
     const FinishRec r = fin[f];
-    if (r.done) return;
+    if (r.done) continue;
     const int k = r.w / p.nch, c = r.w - k * p.nch;
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
@@ -869,6 +891,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     }
     if (SYMS && (oo & 31) && (oo >> 5) < kSymWords) sb[oo >> 5] = cur;
     win_len[r.w] = oo;
+  }
 }
 
 // nsym = len - offset for every hit record, once finish_kernel has produced the window lengths
@@ -884,6 +907,50 @@ __global__ void nsym_patch_kernel(DeviceHit *__restrict__ hits, const unsigned i
         hits[i].nsym = win_len[w] - hits[i].sub - hits[i].offset;
         if (win_fin) hits[i].sym = win_fin[w];
     }
+}
+
+// ------------------------------------------------------------------------------------
+// The same search on a captured SYMBOL stream (one bit per symbol, LSB first in 32-bit words --
+// samples/channel37.dem of the reference, bit-packed): lane = a 625-offset chunk of the stream,
+// its 693 symbols aligned into the LDS layout of window_kernel's phase 2.  Records carry the
+// chunk index in `slot` and the offset inside the chunk; the caller adds 625 * slot.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWinThreads) void scan_symbols_kernel(
+    const uint32_t *__restrict__ words, unsigned long long nsym, int step, uint64_t a0_lo, uint32_t a0_hi,
+    const uint64_t *__restrict__ ac_lo_g, const uint32_t *__restrict__ ac_hi_g,
+    DeviceHit *__restrict__ hits, unsigned int *__restrict__ hit_count, int max_hits)
+{
+    __shared__ uint32_t bits[kBitWords * kWinThreads];
+    __shared__ uint64_t ac_lo[3 * 256];
+    __shared__ uint32_t ac_hi[3 * 256];
+    for (int i = threadIdx.x; i < 768; i += kWinThreads) { ac_lo[i] = ac_lo_g[i]; ac_hi[i] = ac_hi_g[i]; }
+    const unsigned long long chunk = (unsigned long long)blockIdx.x * kWinThreads + threadIdx.x;
+    const unsigned long long s0 = chunk * 625ull;                       // first symbol of this lane's chunk
+    const unsigned long long nwords = (nsym + 31) / 32;
+    const unsigned long long w0 = s0 >> 5;
+    const int sh = (int)(s0 & 31);
+    for (int j = 0; j < kBitWords; j++) {
+        const unsigned long long a = w0 + j, b = a + 1;
+        const uint32_t lo = a < nwords ? words[a] : 0u, hi = b < nwords ? words[b] : 0u;
+        bits[j * kWinThreads + threadIdx.x] = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+    }
+    __syncthreads();
+    if (s0 >= nsym) return;
+    const unsigned long long left = nsym - s0;
+    const int len1 = left < (unsigned long long)kDetectSyms ? (int)left : kDetectSyms;
+    // a stream scan may use the last 68 symbols too (no "one more symbol" rule as in the block's loop)
+    const int limit = len1 - 67 < 625 ? len1 - 67 : 625;
+    int resume = 0, nhits = 0;
+    search_classic(bits + threadIdx.x, limit, step, false, a0_lo, a0_hi, ac_lo, ac_hi, resume, nhits,
+                   [&](int cpos, uint32_t lap, int err) {
+                       const unsigned int slot_h = atomicAdd(hit_count, 1u);
+                       if (slot_h < (unsigned int)max_hits) {
+                           DeviceHit h;
+                           h.slot = (uint32_t)chunk; h.channel_idx = 0; h.offset = cpos;
+                           h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = 0.0; h.nsym = -1; h.sub = 0; h.sym = -1; h.pad_ = 0;
+                           hits[slot_h] = h;
+                       }
+                   });
 }
 
 // ------------------------------------------------------------------------------------

@@ -18,13 +18,15 @@ def partition_slots(total_slots, world_size, rank):
     return first, base + (1 if rank < rem else 0)
 
 
-def segment_bounds(first_slot, n_slots, history, samples_per_slot):
-    """Absolute sample range [start, start+n) a rank needs for its slots, halo included.
-    start may be negative (the zeros GNU Radio pre-fills before the stream)."""
+def segment_bounds(first_slot, n_slots, history, samples_per_slot, left_margin=0):
+    """Absolute sample range [start, start+n) a rank needs for its slots: the history()-1 halo
+    plus `left_margin` (btgpu_design.left_margin: what the staged squelch reads in front of a
+    segment; pass it to btgpu_process_device as left_margin).  start may be negative (the zeros
+    GNU Radio pre-fills before the stream)."""
     if n_slots <= 0:
         return first_slot * samples_per_slot, 0
-    start = first_slot * samples_per_slot - (history - 1)
-    return start, history + (n_slots - 1) * samples_per_slot
+    start = first_slot * samples_per_slot - (history - 1) - int(left_margin)
+    return start, int(left_margin) + history + (n_slots - 1) * samples_per_slot
 
 
 def hits_to_arrays(hits):

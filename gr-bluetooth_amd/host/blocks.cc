@@ -59,6 +59,8 @@ int multi_block::run_work(int noutput_items, gr_vector_const_void_star &input_it
     const float *in = (const float *)input_items[0];
     size_t consumed = 0;
     int rc = btgpu_work(d_gpu, in, (size_t)(history() - 1) + (size_t)noutput_items, &consumed);
+    if (rc == BTGPU_EOVERFLOW)                        // records were dropped: the reference would have printed them
+        fprintf(stderr, "Warning: hit buffer overflow, detections of this call were dropped (%s)\n", btgpu_last_error(d_gpu));
     if (rc != BTGPU_OK && rc != BTGPU_EOVERFLOW) {
         // reference convention for fatal errors: fprintf + abort (lib/multi_sniffer_impl.cc:36-40)
         fprintf(stderr, "Error: %s (%s)\n", btgpu_strerror(rc), btgpu_last_error(d_gpu));

@@ -809,6 +809,15 @@ void sniffer_handlers::fhs(classic_packet &pkt, std::string &out)
 }  // namespace bluetooth
 }  // namespace gr
 
+// the regenerated whitening tables by the reference's names (digest test against the reference's literals)
+extern "C" int bt_host_lut(const char *name, uint8_t *out, int cap)
+{
+    const gr::bluetooth::host::whitening_tables &t = gr::bluetooth::host::wt();
+    if (std::strcmp(name, "packet::WHITENING_DATA") == 0 && cap >= 127) { std::memcpy(out, t.seq, 127); return 127; }
+    if (std::strcmp(name, "classic_packet::INDICES") == 0 && cap >= 64) { std::memcpy(out, t.start, 64); return 64; }
+    return -1;
+}
+
 extern "C" int bt_host_crc_check(const uint8_t *symbols, int length, int clock, int type, int uap)
 {
     btgpu_header none;

@@ -6,11 +6,7 @@
 #include <cstdint>
 
 #include <gr_bluetooth/api.h>
-#ifdef HAVE_GNURADIO
-#include <gnuradio/sync_block.h>
-#else
-#include <gnuradio/sync_block.h>   // shim/ on the include path
-#endif
+#include <gnuradio/sync_block.h>   // GNU Radio's, or shim/gnuradio/sync_block.h when built without it (-Ishim)
 
 extern "C" {
 #include "btgpu.h"

@@ -1,5 +1,5 @@
 // Minimal stand-in for the parts of GNU Radio's runtime that gr::bluetooth::multi_block touches,
-// used ONLY when this tree is built without GNU Radio (-DHAVE_GNURADIO absent).  It exists so
+// used ONLY when this tree is built without GNU Radio (it is found through -Ishim).  It exists so
 // that OUR block classes (not the reference's sources) compile and can be driven by the
 // harness scheduler in btrx_amd.cc, which reproduces the scheduler contract the reference
 // relies on: history()-1 zero items before the stream, work() called with at least

@@ -206,6 +206,21 @@ int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out);
  * channel is a classic channel number (ignored for 2..4); returns elements copied. */
 long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, size_t count, void *out);
 
+/* Host-side copies of the integer tables the kernels use (header-byte distance tables of
+ * le_packet::sniff_aa under the reference's names, "derived/classic_first18", "derived/le_whiten16"):
+ * returns bytes written or <0.  For the digest test against the reference's literals. */
+int btgpu_debug_lut(const char *name, void *out, int cap_bytes);
+
+/* ---- parity entry: the access-code search on a captured SYMBOL stream ----
+ * Runs the window kernel's search (classic_packet::sniff_ac + check_ac, lib/packet_impl.cc:247-268,
+ * :471-510) straight on `n` sliced symbols, one per byte (0/1) -- the format of the reference's
+ * samples/channel37.dem -- without the float front end.  policy 0: every qualifying offset;
+ * policy 1: a stream scan that moves on by 68 symbols after a hit (the sniffer's loop,
+ * lib/multi_sniffer_impl.cc:107-127, applied to the whole stream).  Records: offset = absolute
+ * symbol offset, lap, ac_errors, nsym = n - offset; ordered by offset.  Returns the number of
+ * records (the first `cap` are written) or a negative error.  No handle needed. */
+long btgpu_debug_scan_symbols(const uint8_t *symbols, size_t n, int device, int policy, btgpu_hit *out, long cap);
+
 /* ---- hop reversal: the piconet's complete hopping sequence on the GPU ----
  * Replaces basic_rate_piconet_impl::init_hop_reversal's precalc + address_precalc + gen_hops
  * (lib/piconet_impl.cc:96-255: a 128 MiB table, one entry per 625 us slot, index = CLK27..1),

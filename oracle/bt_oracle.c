@@ -686,6 +686,35 @@ static void build_luts(void)
     luts_ready = 1;
 }
 
+/* The regenerated tables by the reference's names (lib/packet_impl.cc:84-90, :188-197, :1316-1450),
+ * for the digest test against the reference's literals (tests/golden/lut_digests.json). */
+int bto_lut(const char *name, uint8_t *out, int cap)
+{
+    build_luts();
+    static const struct { const char *name; const uint8_t *p; int n; } T[] = {
+        {"packet::WHITENING_DATA", WHITENING, 127},
+        {"classic_packet::PREAMBLE_DISTANCE", PREAMBLE_DISTANCE, 32},
+        {"classic_packet::BARKER_DISTANCE", BARKER_DISTANCE, 128},
+        {"le_packet::PREAMBLE_DISTANCE", LE_PREAMBLE_DISTANCE, 512},
+        {"le_packet::ACCESS_ADDRESS_DISTANCE_0", LE_AA_DISTANCE[0], 256},
+        {"le_packet::ACCESS_ADDRESS_DISTANCE_1", LE_AA_DISTANCE[1], 256},
+        {"le_packet::ACCESS_ADDRESS_DISTANCE_2", LE_AA_DISTANCE[2], 256},
+        {"le_packet::ACCESS_ADDRESS_DISTANCE_3", LE_AA_DISTANCE[3], 256},
+        {"le_packet::ACCESS_HEADER_DISTANCE_LSB", LE_ACC_HDR_LSB, 256},
+        {"le_packet::ACCESS_HEADER_DISTANCE_MSB", LE_ACC_HDR_MSB, 256},
+        {"le_packet::DATA_HEADER_DISTANCE_LSB", LE_DATA_HDR_LSB, 256},
+        {"le_packet::DATA_HEADER_DISTANCE_MSB", LE_DATA_HDR_MSB, 256},
+        {"le_packet::INDICES", LE_INDICES, 40},
+    };
+    for (size_t i = 0; i < sizeof T / sizeof T[0]; i++)
+        if (strcmp(name, T[i].name) == 0) {
+            if (cap < T[i].n) return -1;
+            memcpy(out, T[i].p, (size_t)T[i].n);
+            return T[i].n;
+        }
+    return -1;
+}
+
 int bto_sniff_ac(const char *stream, int stream_length)
 {
     build_luts();

@@ -121,6 +121,8 @@ int  bto_channel_symbols(bto_ctx *c, const float *iq, int n, char *symbols, floa
 void bto_acgen(uint32_t lap, uint8_t ac[9]);
 int  bto_ac_errors(const char *stream, uint32_t lap);      /* mismatches over 68 bits */
 int  bto_check_ac(const char *stream, uint32_t lap);
+int  bto_lut(const char *name, uint8_t *out, int cap);      /* regenerated LUT by the reference's name */
+int  bto_uap_lut(const char *name, uint8_t *out, int cap);  /* whitening sequence / classic INDICES (bt_uap.c) */
 int  bto_sniff_ac(const char *stream, int stream_length);
 int  bto_sniff_aa(const char *stream, int stream_length, double freq);
 /* [EXT libbtbb, unpinned] btbb_find_ac(stream, search_length, LAP_ANY, max_ac_errors, &pkt): returns the

@@ -369,6 +369,37 @@ def header_present(symbols, length=None):
     return bool(lib().bto_header_present(pad.tobytes(), n))
 
 
+def lut(name):
+    """A regenerated table of the oracle by the reference's name (bt_oracle.c / bt_uap.c), as bytes."""
+    L = lib()
+    buf = ctypes.create_string_buffer(1024)
+    for f in (L.bto_lut, L.bto_uap_lut):
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    if name == "classic_packet::INDICES":
+        n = L.bto_uap_lut(name.encode(), buf, 1024)
+    else:
+        n = L.bto_lut(name.encode(), buf, 1024)
+    if n < 0:
+        raise KeyError(name)
+    return buf.raw[:n]
+
+
+def qualifying_offsets(symbols):
+    """Every offset of a symbol stream at which classic_packet::sniff_ac would accept (no resume)."""
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    raw = s.tobytes()
+    L = lib()
+    out, pos, n = [], 0, len(s)
+    while pos + 68 <= n:
+        i = L.bto_sniff_ac(raw[pos:], n - pos - 67)
+        if i < 0:
+            break
+        out.append(pos + i)
+        pos += i + 1
+    return out
+
+
 def scan_symbols(symbols, max_hits=4096):
     s = np.ascontiguousarray(symbols, dtype=np.uint8)
     hits = (Hit * max_hits)()

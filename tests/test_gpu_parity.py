@@ -550,3 +550,23 @@ def test_hop_sequence_table_and_winnowing_equal_oracle(pkg, po):
                 assert np.array_equal(seq.candidates(), hp.candidates())
             assert int(seq.candidates()[0]) == clk and len(seq.candidates()) == 1
         seq.close()
+
+
+def test_hip_correlator_on_the_reference_symbol_capture(pkg, po):
+    """the HIP access-code search (window_kernel's phase 2, search_classic)
+    fed the reference's own fixture -- the 3 997 342 captured symbols of samples/channel37.dem,
+    committed bit-packed -- without the float front end.  Stream policy (resume 68 symbols after a
+    hit): the 33 hits / 3 LAPs of tests/golden/channel37_hits.json, offsets, LAPs and error counts;
+    and every qualifying offset (no resume) equals the oracle's classic_packet::sniff_ac answers."""
+    gold = json.load(open(os.path.join(G, "channel37_hits.json")))
+    dem = np.unpackbits(np.load(os.path.join(G, "channel37.bits.npy")))[:gold["n_symbols"]]
+    hits = pkg.scan_symbols(dem, policy=1)
+    assert [[o, "%06x" % lap, e] for o, lap, e in hits] == gold["hits"]
+    assert len(hits) == 33
+    every = pkg.scan_symbols(dem, policy=0)
+    assert [o for o, _, _ in every] == po.qualifying_offsets(dem)
+    # ragged ends: a stream shorter than an access code, and one ending right after one
+    assert pkg.scan_symbols(dem[:40], policy=1) == []
+    o0 = gold["hits"][0][0]
+    assert [o for o, _, _ in pkg.scan_symbols(dem[:o0 + 68], policy=1)] == [o0]
+    assert pkg.scan_symbols(dem[:o0 + 67], policy=1) == []
