@@ -4,16 +4,27 @@
 One "step" = one pass of the hot path (channel bank -> squelch -> demod -> M&M -> slicer ->
 access-code search -> hit records on the host) over one batch of synthetic wideband IQ that
 is already resident in HBM.  Workload = BASELINE.json configs[2]: multi_sniffer, 79 channels,
-100 Msps, centre 2441 MHz (C79).  N > 1: the stream is time-partitioned, each rank gets its
-own slot range plus a history()-1 halo and the hit records are gathered over RCCL (weak
-scaling: per-rank slots fixed).
+100 Msps, centre 2441 MHz (C79), synthetic capture per SURVEY.md section 8(d) (8 piconets,
+30 % slot occupancy, payload 0-2745 bits, CFO +-75 kHz).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
-`cpu_baseline` objects added.
+N > 1 (`--gpus N`): the stream is time-partitioned, rank r owns slots [r S, (r+1) S) plus a left
+halo of history()-1 (+ left_margin) samples, and the hit records travel to every rank with ONE
+asynchronous fixed-size all_gather per batch (RCCL over xGMI; gr-bluetooth_amd/dist.py
+HitGatherer) that overlaps the next batch -- weak scaling, per-rank slots fixed.  Started under
+torchrun (WORLD_SIZE / RANK / LOCAL_RANK in the environment) each process is one rank; started
+plainly with --gpus N > 1 this script spawns its own N ranks, one device each, and FAILS if it
+cannot see N devices.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`,
+`cpu_baseline` and `parity` objects added.  `parity` (N = 1) is a differential of the records of
+one step against the CPU oracle run on all host cores over the first --parity-slots slots of
+the same capture (tests/paritylib.py).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -33,7 +44,7 @@ WORKLOADS = {
 }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -43,9 +54,14 @@ def main():
     ap.add_argument("--squelch", type=float, default=10.0, help="SNR squelch threshold in dB (btrx -t default 10.0)")
     ap.add_argument("--snr", type=float, default=25.0, help="burst SNR in 1 MHz (dB) of the synthetic capture")
     ap.add_argument("--piconets", type=int, default=8)
+    ap.add_argument("--occupancy", type=float, default=0.3)
+    ap.add_argument("--cfo-hz", type=float, default=75e3, help="carrier offset range of the bursts (SURVEY 8(d): +-75 kHz)")
+    ap.add_argument("--max-payload-bits", type=int, default=2745, help="payload length range (SURVEY 8(d): 0-2745)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate budget of the cpu_baseline leg")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="approximate budget of the single-thread cpu_baseline sample")
+    ap.add_argument("--parity-slots", type=int, default=1600,
+                    help="slots of the capture the all-core oracle differential covers (N = 1; 0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
@@ -53,8 +69,49 @@ def main():
     ap.add_argument("--sync", action="store_true", help="harvest every batch before the next one is enqueued (no tail overlap)")
     ap.add_argument("--channelizer", type=int, default=0)
     ap.add_argument("--squelch-mode", type=int, default=0, help="0 auto, 1 direct, 2 staged")
-    args = ap.parse_args()
+    ap.add_argument("--pmc-json", default="", help="rocprofv3 PMC summary (scripts/pmc_hbm_json.py) of THIS build: its HBM bytes "
+                    "become roofline.traffic; refused when its build id differs from libbtgpu.so's")
+    return ap.parse_args(argv)
 
+
+def build_id():
+    """sha256 (16 hex) of the loaded libbtgpu.so: ties PMC files to the kernels they measured."""
+    so = os.path.join(ROOT, "gr-bluetooth_amd", "libbtgpu.so")
+    return hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+
+
+def _spawn_entry(rank, args, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["WORLD_SIZE"] = str(world)
+    os.environ["RANK"] = str(rank)
+    os.environ["LOCAL_RANK"] = str(rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run_rank(args)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" in os.environ:                  # torchrun / the driver's launcher: one rank per process
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        return run_rank(args)
+    if args.gpus > 1:                               # plain start: spawn our own ranks, one device each
+        import torch
+        import torch.multiprocessing as mp
+        have = torch.cuda.device_count()
+        if not args.all_on_device0 and have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (no silent fallback to fewer ranks; "
+                             "--all-on-device0 --backend gloo is the 1-GPU dry run)" % (args.gpus, have))
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        mp.spawn(_spawn_entry, args=(args, args.gpus, port), nprocs=args.gpus, join=True)
+        return
+    os.environ.pop("RANK", None)
+    return run_rank(args)
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
@@ -62,13 +119,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
-        args.no_cpu = True                          # cpu_baseline: rank 0 at N = 1 only
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        args.no_cpu = True                          # cpu_baseline / oracle differential: rank 0 at N = 1 only
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     if args.all_on_device0:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: device %d not visible (%d GPUs)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     coll_device = device if args.backend == "nccl" else torch.device("cpu")
@@ -90,6 +147,8 @@ def main():
     # signal is 12.5x smaller, so a step takes more slots
     S = args.slots or (2304 if args.workload == "c79" else 16384)
     laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(args.piconets))
+    gen = dict(laps=laps, seed=args.seed, snr_db=args.snr, occupancy=args.occupancy, cfo_hz=args.cfo_hz,
+               max_payload_bits=args.max_payload_bits)
 
     blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
                             channelizer=args.channelizer, squelch=args.squelch_mode,
@@ -98,25 +157,34 @@ def main():
     H, slot = des.history, des.samples_per_slot
     nch = des.high_channel - des.low_channel + 1
 
-    first = rank * S
+    first, _ = bdist.partition_slots(world * S, world, rank)        # rank r owns slots [r S, (r+1) S)
     margin = des.left_margin
-    seg, truth = synth.make_segment_torch(fs, fc, first, first + S, device, laps=laps, seed=args.seed,
-                                          snr_db=args.snr, left_pad=H - 1 + margin)
+    a0, n_need = bdist.segment_bounds(first, S, H, slot, margin)
+    seg, truth = synth.make_segment_torch(fs, fc, first, first + S, device, left_pad=H - 1 + margin, **gen)
     seg = seg.contiguous()
     n_complex = seg.shape[0]
+    assert n_complex == n_need and a0 == first * slot - (H - 1) - margin
     torch.cuda.synchronize()
+    gatherer = bdist.HitGatherer(cap=8192, device=coll_device)
 
     def step(last=False, gather=True):
         """One pass of the hot path over the rank's batch.  In the (default) pipelined mode the
         records of a batch are harvested while the next batch runs; the last step of a timed
-        region flushes, so every record of every step is on the host inside the timed region."""
+        region flushes, so every record of every step is on the host inside the timed region.
+        N > 1: the records this rank has ready are posted to one asynchronous all_gather; what
+        comes back here is the previous post (collected while this batch computes)."""
         blk.process_device(seg.data_ptr(), n_complex, first, S, left_margin=margin)
         if last:
             blk.flush()
         ints, snr = bdist.struct_to_arrays(blk.poll_arrays())
-        if world > 1 and gather:                    # RCCL gather of whatever records are ready
-            ints, snr = bdist.gather_hits(ints, snr, device=coll_device)
-        return ints, snr
+        if world == 1 or not gather:
+            return ints, snr
+        got = gatherer.collect() if gatherer.pending is not None else (ints[:0], snr[:0])
+        gatherer.post(ints, snr)
+        if last:
+            more = gatherer.collect(drain=True)
+            got = (np.concatenate([got[0], more[0]], axis=0), np.concatenate([got[1], more[1]], axis=0))
+        return got
 
     def tdiff(a, b):
         return np.array(list(b.kernel_ms)) - np.array(list(a.kernel_ms)), \
@@ -163,11 +231,12 @@ def main():
     total_samples = float(world) * S * slot * args.steps
     value = total_samples / elapsed / 1e6
 
-    # ---- correctness gate 1: every detectable ground-truth burst is reported ----
+    # ---- correctness gate 1: ground-truth bursts reported (recall of the synthetic capture) ----
     got = set((int(r[0]), int(r[1]), int(r[4])) for r in ints)           # (slot, channel, lap)
-    lo_slot, hi_slot = (0 if world > 1 else first), (world * S if world > 1 else first + S)
-    if world > 1:                                   # rank 0 only knows its own truth; regenerate all
-        truth, _ = synth.burst_schedule(fs, fc, 0, world * S, laps, args.seed, 0.3, 10e3, 240)
+    lo_slot, hi_slot = 0, world * S
+    if world > 1:                                   # a rank only knows its own truth; regenerate all
+        truth, _ = synth.burst_schedule(fs, fc, 0, world * S, laps, args.seed, args.occupancy, args.cfo_hz,
+                                        args.max_payload_bits)
     expected = found = 0
     for tr in truth:
         det = tr["slot"] + 6                        # sniffer window lag: (history()-1)/slot = 6.3
@@ -177,7 +246,6 @@ def main():
         if any((det + d, tr["channel"], tr["lap"]) in got for d in (-1, 0, 1)):
             found += 1
 
-    out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events inside libbtgpu, same stream) ----
         names = pkg.KERNEL_NAMES
@@ -194,6 +262,7 @@ def main():
         fma_noise = nch * des.ntaps_noise * 2.0 / des.decimation * 2
         roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(ach, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": round(avg[dom], 4),
                 "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(NK)},
                 "note": "ddc_channel = channel bank (+ noise stage 1 when fused); ddc_noise = 0 then"}
@@ -203,71 +272,60 @@ def main():
             fl = (fma_noise if names[dom] == "ddc_noise" else fma_ch) * 2.0 * S * slot
             roof["fp32_tflops"] = round(fl / (avg[dom] * 1e-3) / 1e12, 3)
             roof["fp32_frac"] = round(roof["fp32_tflops"] / FP32_PEAK_TFLOPS, 4)
-        # HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
-        # gfx950 + WRITE_SIZE), valid for the configuration they were collected on
-        try:
-            import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")), reverse=True):
-                pmc = json.load(open(path))
-                key = {"ddc_channel": "pfb100_kernel<7, 1, 26, true, true", "window": "window_kernel",
-                       "finish": "finish_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
-                match = [k for k in pmc["kernels"] if key and k.startswith(key)]
-                if args.workload == "c79" and S == pmc["slots"] and match and not direct:
-                    roof["traffic"] = pmc["kernels"][match[0]]["hbm_bytes"]
-                    roof["traffic_source"] = "profiles/" + os.path.basename(path)
-                    break
-        except Exception:
-            pass
+        roof["build_id"] = build_id()
+        if args.pmc_json:
+            # HBM bytes of the dominant kernel from rocprofv3 PMC passes of the SAME build and batch size
+            # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; scripts/collect_profiles.sh stamps the build id)
+            pmc = json.load(open(args.pmc_json))
+            if pmc.get("build_id") != roof["build_id"] or pmc.get("slots") != S:
+                raise SystemExit("--pmc-json %s was collected on build %s / %s slots, this run is build %s / %d slots"
+                                 % (args.pmc_json, pmc.get("build_id"), pmc.get("slots"), roof["build_id"], S))
+            key = {"ddc_channel": "pfb", "window": "window_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
+            match = [k for k in pmc["kernels"] if key and k.startswith(key)]
+            if match:
+                roof["traffic"] = pmc["kernels"][match[0]]["hbm_bytes"]
+                roof["traffic_source"] = os.path.basename(args.pmc_json)
 
-        # The bank kernel is bounded by VALU issue rather than by HBM: report that roofline too, from the
-        # committed SQ_INSTS_VALU count (wave instructions; two launches in the counter run), 4 cycles
-        # per wave64 instruction on each of the 1024 SIMDs at 2.4 GHz
-        try:
-            import glob, re
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")), reverse=True):
-                m = re.search(r"^pfb100_kernel<7.*SQ_INSTS_VALU=([0-9.e+]+)M", open(path).read(), re.M)
-                if m and names[dom] == "ddc_channel" and args.workload == "c79" and S == 2304 and not direct:
-                    insts = float(m.group(1)) * 1e6 / 2.0
-                    bound_ms = insts * 4.0 / (1024 * 2.4e9) * 1e3
-                    roof["valu"] = {"wave_insts_per_launch": insts, "issue_bound_ms": round(bound_ms, 4),
-                                    "frac": round(bound_ms / avg[dom], 4), "source": "profiles/" + os.path.basename(path)}
-                    break
-        except Exception:
-            pass
-
-        # ---- cpu_baseline: the oracle (a port, NOT the upstream binary) on a bounded sample ----
+        # ---- cpu_baseline + parity: the oracle (a port, NOT the upstream binary) ----
         cpu = None
-        oracle_ok = None
-        nsym_dev = None
+        parity = {"truth_detected": found, "truth_expected": expected, "hits": int(len(ints)),
+                  "records_sha256": hashlib.sha256(np.ascontiguousarray(ints, dtype=np.int64).tobytes()).hexdigest()[:16]}
         if not args.no_cpu:
             import pyoracle as po
+            import paritylib
             o = po.Oracle(fs, fc, args.squelch, po.MODE_SNIFFER)
+            ncores = os.cpu_count() or 1
+            P = max(2, min(S, args.parity_slots)) if args.parity_slots > 0 else 0
+            nhost = max(P, min(S, 64))
+            host = seg[margin + H - 1:margin + H - 1 + nhost * slot].cpu().numpy().reshape(-1)
+            # single thread (what GNU Radio gives one block), bounded sample
             probe = 2
-            host = seg[margin + H - 1:margin + H - 1 + min(S, 64) * slot].cpu().numpy().reshape(-1)
             t1 = time.perf_counter()
             o.run_stream(host[:2 * probe * slot])
             per_slot = (time.perf_counter() - t1) / probe
-            cs = int(max(2, min(len(host) // (2 * slot), args.cpu_seconds / max(per_slot, 1e-6))))
+            cs = int(max(2, min(nhost, args.cpu_seconds / max(per_slot, 1e-6))))
             t1 = time.perf_counter()
-            ohits, done = o.run_stream(host[:2 * cs * slot])
+            o.run_stream(host[:2 * cs * slot])
             dt = time.perf_counter() - t1
-            cpu = {"value": round(cs * slot / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1,
-                   "kind": "port",
+            cpu = {"value": round(cs * slot / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
                    "sample": "first %d slots (%d samples) of the same capture, oracle/bt_oracle.c single thread" % (cs, cs * slot)}
-            okeys = [h.key() for h in ohits]
-            gkeys = [tuple(int(v) for v in r) for r in ints if r[0] < cs]
-            # exact on (slot, channel, kind, offset, LAP, ac_errors); nsym (symbols left in the window
-            # after the hit = M&M run length over trailing noise) is exact on the DIRECT path and
-            # reported as a max deviation on the tolerance (polyphase) path -- DESIGN.md "Parity".
-            oracle_ok = [k[:6] for k in okeys] == [k[:6] for k in gkeys]
-            nsym_dev = max([abs(a[6] - b[6]) for a, b in zip(okeys, gkeys)], default=0) if oracle_ok else None
-            ncores = os.cpu_count() or 1
-            if ncores > 1:
-                cs2 = min(len(host) // (2 * slot), cs * min(ncores, 8))
+            if P:
+                # all host cores over the first P slots: the full-size differential AND the all-core rate
                 t1 = time.perf_counter()
-                o.run_stream(host[:2 * cs2 * slot], threads=ncores)
+                ohits, done = o.run_stream(host[:2 * P * slot], max_hits=1 << 20, threads=ncores)
                 dt2 = time.perf_counter() - t1
-                cpu["all_cores"] = {"value": round(cs2 * slot / dt2 / 1e6, 4), "cores": ncores, "slots": cs2}
+                cpu["all_cores"] = {"value": round(P * slot / dt2 / 1e6, 4), "cores": ncores, "slots": P,
+                                    "seconds": round(dt2, 2)}
+                oi, _ = bdist.sort_hits(*bdist.hits_to_arrays(ohits))
+                gi = ints[ints[:, 0] < P]
+                tr = [t for t in truth if t["slot"] < P]
+                parity["oracle_slots"] = P
+                parity["differential"] = paritylib.differential(gi, oi, tr)
+                parity["lap_list_equal_ref"] = ("planted records identical" if parity["differential"]["planted_identical"]
+                                                else "PLANTED RECORDS DIFFER") + \
+                    "; %d / %d other records on one side only" % (
+                        parity["differential"]["other_only_gpu"] + parity["differential"]["other_only_ref"],
+                        parity["differential"]["other_gpu"] + parity["differential"]["other_ref"])
 
         out = {
             "metric": "complex-IQ Msamples/s @ 79 ch" if args.workload == "c79" else "complex-IQ Msamples/s @ 8 ch",
@@ -278,14 +336,15 @@ def main():
             "config": {"workload": wl["name"], "sample_rate": fs, "center_freq": fc, "channels": nch,
                        "slots_per_rank_per_step": S, "samples_per_rank_per_step": S * slot,
                        "squelch_db": args.squelch, "burst_snr_db": args.snr, "piconets": args.piconets,
-                       "mode": "multi_sniffer", "partition": "time x%d, halo %d samples" % (world, H - 1),
+                       "occupancy": args.occupancy, "cfo_hz": args.cfo_hz, "max_payload_bits": args.max_payload_bits,
+                       "mode": "multi_sniffer",
+                       "partition": "time x%d, halo %d + margin %d samples" % (world, H - 1, margin),
+                       "gather": ("one async all_gather per batch (%s), %d rounds" % (args.backend, gatherer.rounds)) if world > 1 else "none",
                        "channelizer": {1: "direct", 2: "polyphase"}[int(des.channelizer)],
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},
             "roofline": roof,
             "cpu_baseline": cpu,
-            "parity": {"truth_detected": found, "truth_expected": expected, "hits": int(len(ints)),
-                       "hits_equal_oracle_on_sample": oracle_ok,
-                       "nsym_max_abs_dev": (nsym_dev if not args.no_cpu else None)},
+            "parity": parity,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

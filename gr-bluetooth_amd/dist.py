@@ -3,8 +3,10 @@
 The IQ stream is split into contiguous slot ranges, one per rank, each with a left halo of
 history()-1 samples (exactly what the reference's GNU Radio history provides at a window
 start: lib/multi_block.cc:102-119).  No collective touches the data path; the only
-exchange is one gather of the fixed-size hit records per batch (RCCL over xGMI on the
-GPU box via backend "nccl", gloo in the CPU tests).
+exchange is the gather of the fixed-size hit records (RCCL over xGMI on the GPU box via
+backend "nccl", gloo in the CPU tests): HitGatherer posts ONE fixed-size all_gather per batch
+(count and records in one buffer, no host round trip for sizes), asynchronously, and the
+records of batch n are unpacked while batch n+1 computes.
 """
 import numpy as np
 
@@ -85,3 +87,82 @@ def gather_hits(ints, snr, group=None, device="cpu"):
     gi = np.concatenate([all_i[r][:counts[r]].cpu().numpy() for r in range(world)], axis=0)
     gs = np.concatenate([all_s[r][:counts[r]].cpu().numpy() for r in range(world)], axis=0)
     return sort_hits(gi, gs)
+
+
+class HitGatherer:
+    """One collective per batch: every rank contributes a fixed-size int64 block
+    [1 + cap, 8] -- row 0 = (number of records this round, number still to come), rows 1.. =
+    the seven integer fields and the bits of snr_db -- to one asynchronous all_gather.  Nothing
+    about sizes crosses the host beforehand (no counts exchange, no .item()); post() returns at
+    once and collect() of the PREVIOUS post is called while the next batch computes.  More than
+    `cap` records in a batch (rare) spill into extra rounds that every rank agrees on from the
+    headers it received."""
+
+    def __init__(self, cap=8192, device="cpu", group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.cap, self.device = int(cap), device
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.pending = None                 # (work handle, receive buffers)
+        self.backlog_i = np.zeros((0, len(HIT_INT_FIELDS)), np.int64)
+        self.backlog_s = np.zeros((0,), np.float64)
+        self.rounds = 0
+
+    def _pack(self):
+        torch = self.torch
+        n = min(len(self.backlog_i), self.cap)
+        blockh = np.zeros((1 + self.cap, 8), np.int64)
+        blockh[0, 0] = n
+        blockh[0, 1] = len(self.backlog_i) - n
+        if n:
+            blockh[1:1 + n, :7] = self.backlog_i[:n]
+            blockh[1:1 + n, 7] = self.backlog_s[:n].view(np.int64)
+        self.backlog_i, self.backlog_s = self.backlog_i[n:], self.backlog_s[n:]
+        t = torch.from_numpy(blockh)
+        if str(self.device) != "cpu":
+            t = t.pin_memory().to(self.device, non_blocking=True)
+        return t
+
+    def post(self, ints, snr):
+        """Queue this rank's new records and start the gather of one round."""
+        if len(ints):
+            self.backlog_i = np.concatenate([self.backlog_i, np.ascontiguousarray(ints, dtype=np.int64)], axis=0)
+            self.backlog_s = np.concatenate([self.backlog_s, np.ascontiguousarray(snr, dtype=np.float64)], axis=0)
+        if not self.on:
+            return
+        assert self.pending is None, "collect() the previous round first"
+        send = self._pack()
+        recv = [self.torch.empty_like(send) for _ in range(self.world)]
+        work = self.dist.all_gather(recv, send, group=self.group, async_op=True)
+        self.pending = (work, recv, send)
+        self.rounds += 1
+
+    def collect(self, drain=False):
+        """Records of the posted round from every rank, sorted (slot, channel, kind, offset).  With
+        drain=True keeps going (synchronously) until no rank has records left."""
+        if not self.on:
+            i, s = self.backlog_i, self.backlog_s
+            self.backlog_i, self.backlog_s = i[:0], s[:0]
+            return sort_hits(i, s)
+        out_i, out_s = [], []
+        while True:
+            if self.pending is None:
+                self.post(self.backlog_i[:0], self.backlog_s[:0])
+            work, recv, _send = self.pending
+            work.wait()
+            self.pending = None
+            more = False
+            for r in range(self.world):
+                blk = recv[r].cpu().numpy()
+                n = int(blk[0, 0])
+                more = more or blk[0, 1] > 0
+                if n:
+                    out_i.append(blk[1:1 + n, :7].copy())
+                    out_s.append(blk[1:1 + n, 7].copy().view(np.float64))
+            if not (drain and more):
+                break
+        if not out_i:
+            return np.zeros((0, len(HIT_INT_FIELDS)), np.int64), np.zeros((0,), np.float64)
+        return sort_hits(np.concatenate(out_i, axis=0), np.concatenate(out_s, axis=0))

@@ -19,7 +19,13 @@ python $R/scripts/pmc_hbm_json.py "$(find /tmp/p1 -name '*counter_collection.csv
 # instruction mix of the kernels (own pass; SQ counters)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/p3 -o p -- python $R/bench.py --slots $SLOTS --steps 1 --warmup 0 --prewarm-ms 0 --no-cpu --sync > /dev/null 2>> "$OUT/bench.err"
 python $R/scripts/pmc_table.py "$(find /tmp/p3 -name '*counter_collection.csv' | head -1)" > "$OUT/pmc_sq.txt" 2>> "$OUT/bench.err"
-cat "$OUT/pmc_sq.txt"
+# where the waves' time goes (own pass): busy / waiting / issuing, LDS share
+rm -rf /tmp/p4
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/p4 -o p -- python $R/bench.py --slots $SLOTS --steps 1 --warmup 0 --prewarm-ms 0 --no-cpu --sync > /dev/null 2>> "$OUT/bench.err"
+python $R/scripts/pmc_table.py "$(find /tmp/p4 -name '*counter_collection.csv' | head -1)" > "$OUT/pmc_stall.txt" 2>> "$OUT/bench.err"
+# the bench line again with the measured HBM traffic of this very build embedded
+python $R/bench.py --slots $SLOTS --no-cpu --pmc-json "$OUT/pmc_hbm.json" > "$OUT/bench_with_traffic.json" 2>> "$OUT/bench.err"
+cat "$OUT/pmc_sq.txt" "$OUT/pmc_stall.txt"
 tail -c 600 "$OUT/bench.err"
 cat "$OUT/kernel_stats.csv"
 python -c "import json; d=json.load(open('$OUT/pmc_hbm.json')); [print(k, {a: round(b/1e6,1) for a,b in v.items()}) for k,v in d['kernels'].items()]"

@@ -5,7 +5,7 @@
 
 Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md: the counters are in KiB...
 FETCH_SIZE is doubled on gfx950 (it reports half of a wide coalesced streaming read)."""
-import collections, csv, json, sys
+import collections, csv, hashlib, json, os, sys
 
 
 def per_launch(path, counter):
@@ -19,13 +19,19 @@ def per_launch(path, counter):
     return {k: tot[k] / max(len(n[k]), 1) for k in tot}
 
 
+def build_id():
+    """sha256 (16 hex) of the libbtgpu.so the counters were collected on (bench.py --pmc-json checks it)"""
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gr-bluetooth_amd", "libbtgpu.so")
+    return hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+
+
 def main():
     fetch, write, slots = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE"), int(sys.argv[3])
     out = {"command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 1 "
                       "--warmup 0 --prewarm-ms 0 --no-cpu --sync --slots %d" % slots,
            "note": "counter unit KiB, averaged per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 "
                    "of a wide coalesced streaming read); algorithmic bytes per launch of a bank kernel = 8 * slots * 62500",
-           "slots": slots, "kernels": {}}
+           "slots": slots, "build_id": build_id(), "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, 0.0) * 1024.0, write.get(k, 0.0) * 1024.0
         out["kernels"][k] = {"fetch_bytes_raw": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "hbm_bytes": 2 * f + w}

@@ -1,0 +1,73 @@
+"""Differential of two hit-record lists (GPU FAST path vs CPU oracle) on a capture with known
+planted bursts -- used by tests/test_gpu_parity.py and by bench.py's parity gate.
+
+Records are rows (slot, channel, kind, offset, lap, ac_errors, nsym).  A record is PLANTED when it
+is a classic access-code hit with the LAP of a planted burst on that burst's channel, in a window
+that has the burst's access code in its search range (burst slot + 6 +- 1: a sniffer window lags
+its newest slot by (history()-1)/slot = 6.3 slots).  Everything else -- LAPs and access addresses
+"found" in noise or in random payload bits -- is OTHER.
+
+Contract of the tolerance (polyphase) path, DESIGN.md section 5:
+  * PLANTED records are identical on (slot, channel, kind, LAP, ac_errors): the reference's LAP list
+    for real packets.  `offset` counts symbols from the window start, ~85 of them noise before the
+    burst, and `nsym` runs over ~3000 noise symbols after it: both depend on what the clock
+    recovery loop does in noise, where a 1e-7 difference in the demodulated stream can flip a
+    1/128-sample rounding; they are reported (offset +-1, nsym +-8), not required equal.
+  * OTHER records depend on the loop's trajectory in noise only; they are counted on both sides and
+    the difference of the two LAP multisets is reported.
+"""
+import collections
+
+import numpy as np
+
+
+def classify(ints, truth, lag=6):
+    """Boolean mask: which rows of `ints` are PLANTED records."""
+    ints = np.asarray(ints, dtype=np.int64).reshape(-1, 7)
+    planted = collections.defaultdict(set)            # (channel, lap) -> set of burst slots
+    for t in truth:
+        planted[(int(t["channel"]), int(t["lap"]))].add(int(t["slot"]))
+    mask = np.zeros(len(ints), bool)
+    for i, r in enumerate(ints):
+        if r[2] != 0:
+            continue
+        slots = planted.get((int(r[1]), int(r[4])))
+        if slots and any((int(r[0]) - lag + d) in slots for d in (-1, 0, 1)):
+            mask[i] = True
+    return mask
+
+
+def _multiset(rows):
+    return collections.Counter(tuple(int(v) for v in r) for r in rows)
+
+
+def differential(gpu, ref, truth, lag=6):
+    """Compare two record arrays.  Returns a dict of plain ints/bools (JSON-ready)."""
+    gpu = np.asarray(gpu, dtype=np.int64).reshape(-1, 7)
+    ref = np.asarray(ref, dtype=np.int64).reshape(-1, 7)
+    mg, mr = classify(gpu, truth, lag), classify(ref, truth, lag)
+    key = [0, 1, 2, 4, 5]                              # slot, channel, kind, lap, ac_errors
+    pg, pr = _multiset(gpu[mg][:, key]), _multiset(ref[mr][:, key])
+    out = {"planted_gpu": int(mg.sum()), "planted_ref": int(mr.sum()),
+           "planted_identical": pg == pr,
+           "planted_only_gpu": int(sum((pg - pr).values())), "planted_only_ref": int(sum((pr - pg).values()))}
+    # offset / nsym of the planted records that pair up one to one
+    dg = {tuple(int(v) for v in r[key]): r for r in gpu[mg]}
+    dr = {tuple(int(v) for v in r[key]): r for r in ref[mr]}
+    common = [k for k in dg if k in dr]
+    out["planted_offset_differs"] = int(sum(dg[k][3] != dr[k][3] for k in common))
+    out["planted_offset_max_abs_dev"] = int(max([abs(int(dg[k][3]) - int(dr[k][3])) for k in common], default=0))
+    out["planted_nsym_max_abs_dev"] = int(max([abs(int(dg[k][6]) - int(dr[k][6])) for k in common], default=0))
+    og, orf = _multiset(gpu[~mg][:, key]), _multiset(ref[~mr][:, key])
+    out.update({"other_gpu": int((~mg).sum()), "other_ref": int((~mr).sum()),
+                "other_common": int(sum((og & orf).values())),
+                "other_only_gpu": int(sum((og - orf).values())), "other_only_ref": int(sum((orf - og).values()))})
+    # the LAP list as the reference prints it: multiset of classic LAPs, all records
+    lg = collections.Counter(int(r[4]) for r in gpu if r[2] == 0)
+    lr = collections.Counter(int(r[4]) for r in ref if r[2] == 0)
+    out["lap_multiset_only_gpu"] = int(sum((lg - lr).values()))
+    out["lap_multiset_only_ref"] = int(sum((lr - lg).values()))
+    out["lap_multiset_equal"] = lg == lr
+    out["records_gpu"] = int(len(gpu)); out["records_ref"] = int(len(ref))
+    out["records_identical_all_fields"] = bool(len(gpu) == len(ref) and _multiset(gpu) == _multiset(ref))
+    return out

@@ -23,6 +23,8 @@ def test_partition_and_segment_bounds(pkg):
             pos += n
     start, n = d.segment_bounds(10, 5, 31601, 5000)
     assert (start, n) == (10 * 5000 - 31600, 31601 + 4 * 5000)
+    start, n = d.segment_bounds(10, 5, 31601, 5000, left_margin=4096)      # staged squelch: margin in front
+    assert (start, n) == (10 * 5000 - 31600 - 4096, 4096 + 31601 + 4 * 5000)
     assert d.segment_bounds(0, 0, 31601, 5000)[1] == 0
 
 
@@ -53,6 +55,16 @@ def _worker(rank, world, port, tmp):
             hits.append(h)
     ints, snr = bd.hits_to_arrays(hits)
     gi, gs = bd.gather_hits(ints, snr, device="cpu")
+    # the bench's path: one fixed-size asynchronous all_gather per batch, here with a tiny capacity so
+    # that records spill into further rounds, posted in two batches
+    g = bd.HitGatherer(cap=3, device="cpu")
+    half = len(ints) // 2
+    g.post(ints[:half], snr[:half])
+    a_i, a_s = g.collect()
+    g.post(ints[half:], snr[half:])
+    b_i, b_s = g.collect(drain=True)
+    hi, hs = bd.sort_hits(np.concatenate([a_i, b_i], axis=0), np.concatenate([a_s, b_s], axis=0))
+    assert g.rounds >= 3 and np.array_equal(hi, gi) and np.array_equal(hs, gs)
     if rank == 0:
         np.save(os.path.join(tmp, "gathered.npy"), gi)
     dist.barrier()

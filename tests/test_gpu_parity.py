@@ -570,3 +570,112 @@ def test_hip_correlator_on_the_reference_symbol_capture(pkg, po):
     o0 = gold["hits"][0][0]
     assert [o for o, _, _ in pkg.scan_symbols(dem[:o0 + 68], policy=1)] == [o0]
     assert pkg.scan_symbols(dem[:o0 + 67], policy=1) == []
+
+
+def test_full_size_fast_path_vs_all_core_oracle_c79(pkg, po, synth):
+    """The benchmarked path at the benchmarked size: C79 (100 Msps, 79 channels, polyphase bank +
+    staged squelch, default 10 dB squelch so that every window runs clock recovery and the search),
+    1600 slots = 1e8 samples of the bench capture (SURVEY 8(d) spec: payload 0-2745 bits, CFO
+    +-75 kHz), against the oracle on all host cores (about a minute on the 256-core GPU host; a
+    host with few cores takes a 64-slot sample instead).  Contract (tests/paritylib.py, DESIGN.md
+    section 5): records of the planted packets identical on (slot, channel, kind, LAP, ac_errors);
+    records born from noise / random payload bits are counted on both sides, the difference is
+    printed and must stay a small fraction."""
+    import importlib
+    import torch
+    import paritylib
+    bdist = importlib.import_module("gr_bluetooth_amd.dist")
+    fs, fc = 100e6, 2441e6
+    ncores = os.cpu_count() or 1
+    S = 1600 if ncores >= 64 else 64
+    laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(8))
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, max_batch_slots=S)
+    assert blk.design.channelizer == pkg.CHANNELIZER_POLYPHASE and blk.design.squelch == pkg.SQUELCH_STAGED
+    H, slot, mg = blk.history(), blk.output_multiple(), blk.design.left_margin
+    seg, truth = synth.make_segment_torch(fs, fc, 0, S, "cuda", laps=laps, seed=1, snr_db=25.0, occupancy=0.3,
+                                          cfo_hz=75e3, max_payload_bits=2745, left_pad=H - 1 + mg)
+    seg = seg.contiguous()
+    blk.process_device(seg.data_ptr(), seg.shape[0], 0, S, left_margin=mg)
+    gi, _ = bdist.struct_to_arrays(blk.poll_arrays())
+    blk.close()
+    host = seg[mg + H - 1:].cpu().numpy().reshape(-1)
+    del seg
+    ohits, done = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(host, max_hits=1 << 20, threads=ncores)
+    assert done == S
+    oi, _ = bdist.sort_hits(*bdist.hits_to_arrays(ohits))
+    d = paritylib.differential(gi, oi, truth)
+    print("full-size differential (%d slots):" % S, json.dumps(d))
+    assert d["planted_ref"] > (800 if S == 1600 else 20)
+    assert d["planted_identical"], d
+    assert d["planted_offset_max_abs_dev"] <= 1 and d["planted_nsym_max_abs_dev"] <= 16, d
+    assert d["planted_offset_differs"] <= max(2, d["planted_ref"] // 100), d
+    other = d["other_gpu"] + d["other_ref"]
+    assert d["other_only_gpu"] + d["other_only_ref"] <= max(4, other // 10), d
+
+
+def test_c79_time_partition_with_left_margin_equals_whole_stream(pkg, synth):
+    """BASELINE configs[3] on one GPU: the C79 stream cut into contiguous slot ranges (halo history()-1
+    + left_margin for the staged squelch, dist.segment_bounds) gives, range by range, exactly the
+    records of the unpartitioned run -- every field, bit for bit (same kernels, same arithmetic per
+    output; only the tile a sample falls into changes)."""
+    import importlib
+    import torch
+    bdist = importlib.import_module("gr_bluetooth_amd.dist")
+    fs, fc = 100e6, 2441e6
+    S = 40
+    laps = tuple((0x24D952 + 0x10101 * i) & 0xFFFFFF for i in range(8))
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, max_batch_slots=S, flags=pkg.FLAG_LE)
+    H, slot, mg = blk.history(), blk.output_multiple(), blk.design.left_margin
+    assert mg > 0
+    seg, truth = synth.make_segment_torch(fs, fc, 0, S, "cuda", laps=laps, seed=5, snr_db=22.0, occupancy=0.5,
+                                          cfo_hz=75e3, max_payload_bits=2745, left_pad=H - 1 + mg)
+    seg = seg.contiguous()
+    a_all = -(H - 1) - mg                                           # absolute index of seg[0]
+    blk.process_device(seg.data_ptr(), seg.shape[0], 0, S, left_margin=mg)
+    whole = _keys(blk.poll())
+    assert len(whole) > 50
+    parts = []
+    for world in (2, 3, 8):
+        got = []
+        for r in range(world):
+            first, n = bdist.partition_slots(S, world, r)
+            start, cnt = bdist.segment_bounds(first, n, H, slot, mg)
+            lo = max(start, a_all)                                  # rank 0: the stream start (zeros in front)
+            part = seg[lo - a_all: start + cnt - a_all].contiguous()
+            blk.process_device(part.data_ptr(), part.shape[0], first, n, left_margin=mg - (lo - start))
+            got += _keys(blk.poll())
+        assert got == whole, "world %d" % world
+        parts.append(world)
+    blk.close()
+
+
+def test_bench_two_ranks_on_one_device_equal_one_rank(tmp_path):
+    """The N > 1 branch of bench.py executed for real: `python bench.py --gpus 2` spawns its own two
+    ranks (both on device 0, gloo standing in for RCCL on a 1-GPU box), each takes its slot range with
+    halo + margin, records travel through the HitGatherer; the record set of 2 x 24 slots equals the
+    one-rank run over 48 slots of the same stream.  Without enough devices and without the dry-run
+    flag it refuses instead of silently running one rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu",
+            "--prewarm-ms", "5", "--occupancy", "0.5"]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = subprocess.run(base + ["--gpus", "1", "--slots", "48"], capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run(base + ["--gpus", "2", "--slots", "24", "--all-on-device0", "--backend", "gloo"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert (j1["n_gpus"], j2["n_gpus"]) == (1, 2)
+    assert j2["config"]["gather"].startswith("one async all_gather per batch")
+    assert j1["parity"]["hits"] > 40
+    assert j1["parity"]["hits"] == j2["parity"]["hits"]
+    assert j1["parity"]["records_sha256"] == j2["parity"]["records_sha256"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run(base + ["--gpus", "2", "--slots", "24"], capture_output=True, text=True, env=env, timeout=300)
+        assert bad.returncode != 0 and "only" in (bad.stderr + bad.stdout)
