@@ -163,7 +163,7 @@ def run_rank(args):
     seg, truth = synth.make_segment_torch(fs, fc, first, first + S, device, left_pad=H - 1 + margin, **gen)
     seg = seg.contiguous()
     n_complex = seg.shape[0]
-    assert n_complex == n_need and a0 == first * slot - (H - 1) - margin
+    assert n_complex >= n_need and a0 == first * slot - (H - 1) - margin   # (the generator runs to the end of the last slot)
     torch.cuda.synchronize()
     gatherer = bdist.HitGatherer(cap=8192, device=coll_device)
 

@@ -279,7 +279,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         HIPCHK(this, hipEventRecord(ev[1], st));
         dim3 g2((unsigned)nb, (unsigned)nch);
         hipLaunchKernelGGL(energy_kernel, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
-                           ystride, ops, des.tail, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
+                           ystride, ops, des.tail, (double *)d_P.p, (double *)d_Pt.p, nb, nch, ops);
         hipLaunchKernelGGL(demod_rows_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st, (const float2 *)d_Y.p, G,
                            ystride, nch, (const float *)d_atan.p, des.demod_gain, (float *)d_d.p, drow,
                            (float *)d_d2.p, ystride);
@@ -333,7 +333,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
         dim3 g2((unsigned)S, (unsigned)nch);
         hipLaunchKernelGGL(energy_kernel, g2, dim3(256), 0, ns_st, (const float2 *)d_Yn.p, Gn,
-                           ystride_n, ops_n, 0, (double *)d_Q.p, (double *)nullptr, S, nch);
+                           ystride_n, ops_n, 0, (double *)d_Q.p, (double *)nullptr, S, nch, d.noise_out);
     }
     HIPCHK(this, hipEventRecord(t.evn[2], ns_st));
     if (overlap_noise) HIPCHK(this, hipStreamWaitEvent(st, t.evn[2], 0));      // join before the window kernel

@@ -207,15 +207,17 @@ __device__ __forceinline__ float demod_one(const float *__restrict__ atab, float
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void energy_kernel(
     const float2 *__restrict__ Y, long long G, long long ystride, int bs, int tail,
-    double *__restrict__ P, double *__restrict__ Pt, int nb, int nch)
+    double *__restrict__ P, double *__restrict__ Pt, int nb, int nch, int nsum)
 {
+    // nsum: outputs of a block that count towards P (the channel bank sums whole blocks, nsum = bs; the
+    // noise bank only the noise_out = 850 outputs of each slot the reference averages, multi_block.cc:269-286)
     __shared__ double red[2][4];
     const int c = blockIdx.y;
     const int b = blockIdx.x;
     const float2 *y = Y + (size_t)c * ystride;
     const long long gb = (long long)b * bs;
     double s_full = 0.0, s_tail = 0.0;
-    for (int i = threadIdx.x; i < bs; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nsum; i += blockDim.x) {
         const long long g = gb + i;
         if (g >= G) break;
         const float2 v = y[g];
