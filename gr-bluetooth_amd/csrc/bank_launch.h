@@ -1,0 +1,105 @@
+// bank_launch.h -- geometry and parameters of one launch of the polyphase bank kernels
+// (pfb100.hip.h), shared by the runtime (btgpu.hip) and by the host-emulation tests
+// (tests/emu), so that the tile / halo / noise-grid arithmetic that is checked on the CPU is the
+// very code that runs in production.
+#pragma once
+#include "design.h"
+#include "pfb100.hip.h"
+
+namespace btgpu {
+
+constexpr int kBankThreads = 256;
+constexpr int kBankNT = 26;                 // channel instants per tile (25 new + 1 halo for the demod)
+constexpr int kNoiseNT = 10;                // instants per tile of the stand-alone noise stage 1
+
+struct BankBuffers {                        // device (or emulated) memory
+    const float2 *x = nullptr;
+    const float2 *taps_ch = nullptr, *twiddle = nullptr, *krot_ch = nullptr, *rho_ch = nullptr;
+    const int *binpos_ch = nullptr, *binnat_ch = nullptr;
+    const uint16_t *b2map_fused = nullptr, *b2map_ch = nullptr, *b2map_noise = nullptr;
+    float *d = nullptr; double *ptile = nullptr, *phead = nullptr;
+    float2 *Ydebug = nullptr; long long ystride = 0;
+    const float2 *taps_n = nullptr, *krot_n = nullptr; const int *binpos_n = nullptr;
+    float2 *Z = nullptr; long long zstride = 0;
+    unsigned long long *prof = nullptr;
+};
+
+inline size_t bank_lds_bytes(int span_samples, int nt, int nrows, bool chan)
+{
+    const int span = 2 * ((span_samples + 3) / 2);
+    const int ysz = chan ? nt * kPfbYst : 0;
+    const int asz = ((span > ysz ? span : ysz) + 1) & ~1;
+    return (size_t)(asz + nrows * kPfbUst) * sizeof(float2);
+}
+
+// Channel bank (+ fused noise stage 1).  L(kernel, grid, threads, lds_bytes, params) performs the launch.
+// Returns the number of channel tiles.
+template <class Launcher>
+inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_noise, const BankBuffers &b,
+                               size_t x_len, long long w0, int S, long long G, int nb, Launcher &&L)
+{
+    const btgpu_design &d = des.d;
+    const PfbBank &bk = fp.channel;
+    const int nch = d.high_channel - d.low_channel + 1;
+    const int ops = des.outs_per_slot;
+    constexpr int NT = kBankNT, TT = NT - 1;
+    PfbParams p{};
+    p.x = b.x; p.x_len = (long long)x_len; p.x0 = w0 + d.first_channel_sample;
+    p.D = bk.D; p.T = G;
+    p.taps = b.taps_ch; p.twiddle = b.twiddle;
+    p.nsel = nch; p.binpos = b.binpos_ch; p.binnat = b.binnat_ch; p.krot = b.krot_ch;
+    p.rot_period = bk.rot_period; p.rho = b.rho_ch; p.rho_real = bk.rho_real ? 1 : 0;
+    p.ntiles = (int)((G + TT - 1) / TT);
+    p.d = b.d; p.ptile = b.ptile; p.phead = b.phead;
+    p.tiles_per_block = ops / TT; p.tail = des.tail; p.nb = nb;
+    p.gain = des.demod_gain;
+    p.Z = b.Ydebug; p.zstride = b.ystride;
+    p.prof = b.prof;
+    if (fuse_noise) {
+        const NoiseStage &ns = fp.noise;
+        const long long xn0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
+        const long long delta0 = (p.x0 - bk.D) - xn0;                      // tile-0 start minus noise origin
+        const long long c0 = (delta0 + ns.R - 1) / ns.R;                   // delta0 >= 0
+        p.n_taps = b.taps_n; p.n_binpos = b.binpos_n; p.n_krot = b.krot_n; p.n_period = ns.pfb.rot_period;
+        p.n_off = (int)(c0 * ns.R - delta0); p.n_u0 = (int)c0; p.pre_tiles = (int)((c0 + 4) / 5);
+        p.n_T = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+        p.n_Z = b.Z; p.n_zstride = b.zstride;
+        p.b2map = b.b2map_fused;
+        const size_t lds = bank_lds_bytes((250 - 1) + 250 * 4 + 15 * 100, NT, NT + 5, true);
+        const int grid = p.ntiles + p.pre_tiles;
+        if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreads, true>, grid, kBankThreads, lds, p);
+        else L(pfb100_kernel<7, 1, NT, false, true, kBankThreads, true>, grid, kBankThreads, lds, p);
+    } else {
+        p.b2map = b.b2map_ch;
+        const size_t lds = bank_lds_bytes(bk.D * (NT - 1) + bk.Q * 100, NT, NT, true);
+        if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreads>, p.ntiles, kBankThreads, lds, p);
+        else L(pfb100_kernel<7, 1, NT, false, true, kBankThreads>, p.ntiles, kBankThreads, lds, p);
+    }
+    return p.ntiles;
+}
+
+// Stand-alone noise stage 1 as a polyphase bank (staged squelch without the fused kernel)
+template <class Launcher>
+inline void launch_noise_bank(const Design &des, const FastPath &fp, const BankBuffers &b, size_t x_len,
+                              long long w0, int S, Launcher &&L)
+{
+    const btgpu_design &d = des.d;
+    const NoiseStage &ns = fp.noise;
+    const PfbBank &bk = ns.pfb;
+    const int nch = d.high_channel - d.low_channel + 1;
+    constexpr int NT = kNoiseNT;
+    const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+    PfbParams p{};
+    p.x = b.x; p.x_len = (long long)x_len;
+    p.x0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
+    p.D = bk.D; p.T = Tn;
+    p.taps = b.taps_n; p.twiddle = b.twiddle;
+    p.nsel = nch; p.binpos = b.binpos_n; p.krot = b.krot_n; p.rot_period = bk.rot_period;
+    p.ntiles = (int)((Tn + NT - 1) / NT);
+    p.Z = b.Z; p.zstride = b.zstride;
+    p.b2map = b.b2map_noise;
+    const size_t lds = bank_lds_bytes(bk.D * (NT - 1) + bk.Q * 100, NT, NT, false);
+    L(pfb100_kernel<15, 5, NT, false, false, kBankThreads>, p.ntiles, kBankThreads, lds, p);
+}
+
+}  // namespace btgpu

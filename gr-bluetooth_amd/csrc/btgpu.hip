@@ -15,6 +15,7 @@
 #include "design.h"
 #include "kernels.hip.h"
 #include "pfb100.hip.h"
+#include "bank_launch.h"
 #include "hopseq.hip.h"
 
 using namespace btgpu;
@@ -30,7 +31,6 @@ using namespace btgpu;
 
 namespace {
 
-constexpr int kFuseThreads = 256;   // fused bank kernel: 310 DFT tasks per pass in one sweep
 
 struct DevBuf {
     void *p = nullptr;
@@ -73,7 +73,7 @@ struct btgpu_handle {
     int drow = 80;                               // row stride (floats) of the time-major demodulated stream
     hipStream_t tail_stream = nullptr;
     struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
-        DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_d2, d_winfin, d_symbits, d_hdr;
+        DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_winfin, d_symbits, d_hdr;
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
@@ -108,7 +108,7 @@ struct btgpu_handle {
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index, d_winbits;
-    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_krot_ch, d_ptile, d_phead;
+    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_ch, d_b2map_noise;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
     LaunchShape shape_s1;
     bool noise_pfb = false;
@@ -156,13 +156,13 @@ struct btgpu_handle {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
-                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_krot_ch, &d_ptile, &d_phead,
+                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_ch, &d_b2map_noise,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
-        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d2.p = nullptr;
+        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = nullptr;
                       tc[1].d_winfin.p = tc[1].d_symbits.p = tc[1].d_hdr.p = nullptr; }
         for (TailCtx &t : tc) {
-            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_d2, &t.d_winfin, &t.d_symbits, &t.d_hdr};
+            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -181,6 +181,23 @@ struct btgpu_handle {
         if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
     }
 
+    BankBuffers bank_buffers(const float2 *d_x) const
+    {
+        BankBuffers b;
+        b.x = d_x;
+        b.taps_ch = (const float2 *)d_pfb_taps_ch.p; b.twiddle = (const float2 *)d_pfb_tw.p;
+        b.krot_ch = (const float2 *)d_krot_ch.p; b.rho_ch = (const float2 *)d_rho_ch.p;
+        b.binpos_ch = (const int *)d_binpos_ch.p; b.binnat_ch = (const int *)d_binnat_ch.p;
+        b.b2map_fused = (const uint16_t *)d_b2map_fused.p; b.b2map_ch = (const uint16_t *)d_b2map_ch.p;
+        b.b2map_noise = (const uint16_t *)d_b2map_noise.p;
+        b.d = (float *)d_d.p; b.ptile = (double *)d_ptile.p; b.phead = (double *)d_phead.p;
+        b.Ydebug = (keep_Y && use_pfb) ? (float2 *)d_Y.p : nullptr; b.ystride = ystride;
+        b.taps_n = (const float2 *)d_pfb_taps_n.p; b.krot_n = (const float2 *)d_krot_n.p;
+        b.binpos_n = (const int *)d_binpos_n.p;
+        b.Z = (float2 *)d_Z.p; b.zstride = zstride;
+        b.prof = (unsigned long long *)d_prof.p;
+        return b;
+    }
     int process_batch(const float2 *d_x, size_t x_len, long long w0, uint64_t abs_first_slot, int S, hipStream_t st);
     int harvest(TailCtx &t);
     int harvest_all(bool block);
@@ -207,7 +224,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     int carried = BTGPU_OK;                                      // overflow of the batch harvested here
     if (t.pending) { int hrc = harvest(t); if (hrc == BTGPU_EOVERFLOW) carried = hrc; else if (hrc != BTGPU_OK) return hrc; }
     hipEvent_t *ev = t.ev;
-    DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin, &d_d2 = t.d_d2;
+    DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin;
     DevBuf &d_winfin = t.d_winfin, &d_symbits = t.d_symbits;
     t.S = S; t.abs_first_slot = abs_first_slot;
 
@@ -222,51 +239,15 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
 
     // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 block sums P, Pt ----
     if (use_pfb) {
-        const PfbBank &b = fp.channel;
-        constexpr int NT = 26, TT = NT - 1;
-        PfbParams p{};
-        p.x = d_x; p.x_len = (long long)x_len; p.x0 = w0 + d.first_channel_sample;
-        p.D = b.D; p.T = G;
-        p.taps = (const float2 *)d_pfb_taps_ch.p; p.twiddle = (const float2 *)d_pfb_tw.p;
-        p.nsel = nch; p.binpos = (const int *)d_binpos_ch.p; p.krot = (const float2 *)d_krot_ch.p;
-        p.rot_period = b.rot_period;
-        p.ntiles = (int)((G + TT - 1) / TT);
-        p.d = (float *)d_d.p; p.ptile = (double *)d_ptile.p; p.phead = (double *)d_phead.p;
-        p.d2 = (float *)d_d2.p; p.d2stride = ystride;
-        p.tiles_per_block = ops / TT; p.tail = des.tail; p.nb = nb;
-        p.atan_tab = (const float *)d_atan.p; p.gain = des.demod_gain;
-        p.Z = keep_Y ? (float2 *)d_Y.p : nullptr; p.zstride = ystride;
-        p.prof = (unsigned long long *)d_prof.p;
-        const int span = 2 * ((b.D * (NT - 1) + b.Q * 100 + 3) / 2), wsz = nch * NT;
-        const int asz = ((span > wsz ? span : wsz) + 1) & ~1;
-        const size_t lds = (size_t)(asz + NT * kPfbUst + 1) * sizeof(float2) + (size_t)257 * sizeof(float);
-        static_assert(NT * 79 + (256 / 80) * 80 * 2 <= 2 * 2 * (50 * 25 + 700), "epilogue scratch (floats) of the 256-lane variant must fit the dead input tile");
-        if (fuse_noise) {
-            const NoiseStage &ns = fp.noise;
-            const long long xn0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
-            const long long delta0 = (p.x0 - b.D) - xn0;                       // tile-0 start minus noise origin
-            const long long c0 = (delta0 + ns.R - 1) / ns.R;                   // delta0 >= 0
-            p.n_taps = (const float2 *)d_pfb_taps_n.p; p.n_binpos = (const int *)d_binpos_n.p;
-            p.n_krot = (const float2 *)d_krot_n.p; p.n_period = ns.pfb.rot_period;
-            p.n_off = (int)(c0 * ns.R - delta0); p.n_u0 = (int)c0; p.pre_tiles = (int)((c0 + 4) / 5);
-            p.n_T = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
-            p.n_Z = (float2 *)d_Z.p; p.n_zstride = zstride;
-            const int spanf = 2 * (((250 - 1) + 250 * 4 + 15 * 100 + 3) / 2);
-            const int aszf = ((spanf > wsz ? spanf : wsz) + 1) & ~1;
-            const size_t ldsf = (size_t)(aszf + NT * kPfbUst + 1) * sizeof(float2) + (size_t)258 * sizeof(float) +
-                                (size_t)5 * kPfbUst * sizeof(float2);
-            const dim3 gridf(p.ntiles + p.pre_tiles);
-            if (b.real_taps)
-                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, kFuseThreads, true>), gridf, dim3(kFuseThreads), ldsf, st, p);
-            else
-                hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, kFuseThreads, true>), gridf, dim3(kFuseThreads), ldsf, st, p);
-        } else if (b.real_taps)
-            hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, true, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
-        else
-            hipLaunchKernelGGL((pfb100_kernel<7, 1, NT, false, true, 256>), dim3(p.ntiles), dim3(256), lds, st, p);
+        constexpr int TT = kBankNT - 1;
+        BankBuffers bb = bank_buffers(d_x);
+        auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
+        };
+        const int ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L);
         HIPCHK(this, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, st,
-                           (const double *)d_ptile.p, (const double *)d_phead.p, p.ntiles, p.tiles_per_block,
+                           (const double *)d_ptile.p, (const double *)d_phead.p, ntiles, ops / TT,
                            des.tail / TT, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     } else {
         const LaunchShape &s = shape_ch;
@@ -281,8 +262,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         hipLaunchKernelGGL(energy_kernel, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
                            ystride, ops, des.tail, (double *)d_P.p, (double *)d_Pt.p, nb, nch, ops);
         hipLaunchKernelGGL(demod_rows_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st, (const float2 *)d_Y.p, G,
-                           ystride, nch, (const float *)d_atan.p, des.demod_gain, (float *)d_d.p, drow,
-                           (float *)d_d2.p, ystride);
+                           ystride, nch, (const float *)d_atan.p, des.demod_gain, (float *)d_d.p, drow);
     }
     HIPCHK(this, hipEventRecord(ev[2], st));
 
@@ -295,19 +275,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         if (fuse_noise) {
             // stage 1 already ran inside the channel-bank kernel
         } else if (noise_pfb) {
-            const PfbBank &b = ns.pfb;
-            constexpr int NT = 10;
-            PfbParams p{};
-            p.x = d_x; p.x_len = (long long)x_len; p.x0 = xs0;
-            p.D = b.D; p.T = Tn;
-            p.taps = (const float2 *)d_pfb_taps_n.p; p.twiddle = (const float2 *)d_pfb_tw.p;
-            p.nsel = nch; p.binpos = (const int *)d_binpos_n.p; p.krot = (const float2 *)d_krot_n.p;
-            p.rot_period = b.rot_period;
-            p.ntiles = (int)((Tn + NT - 1) / NT);
-            p.Z = (float2 *)d_Z.p; p.zstride = zstride;
-            const int span = 2 * ((b.D * (NT - 1) + b.Q * 100 + 3) / 2);
-            const size_t lds = (size_t)(span + NT * kPfbUst + 1) * sizeof(float2);
-            hipLaunchKernelGGL((pfb100_kernel<15, 5, NT, false, false, 256>), dim3(p.ntiles), dim3(256), lds, ns_st, p);
+            BankBuffers bb = bank_buffers(d_x);
+            auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, ns_st, p);
+            };
+            launch_noise_bank(des, fp, bb, x_len, w0, S, L);
         } else {
             // stage 1 as a direct-form bank: B-spline prototype (a few hundred taps at most), hop R
             const LaunchShape &s = shape_s1;
@@ -382,12 +354,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             const long long cap = (long long)S * nch;
             const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
             if (want_syms)
-                hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d2.p,
-                                   ystride, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
+                hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d.p,
+                                   drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)d_symbits.p);
             else
-                hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d2.p,
-                                   ystride, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
+                hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d.p,
+                                   drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)nullptr);
             hipLaunchKernelGGL(nsym_patch_kernel, dim3(32), dim3(256), 0, tail_stream, (DeviceHit *)d_hits.p,
                                (const unsigned int *)d_hitcount.p, max_hits, (const int *)d_winlen.p, nch,
@@ -772,6 +744,15 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_pfb_taps_ch, b.taps.data(), b.taps.size() * sizeof(float)));
         TRY(h->upload(h->d_pfb_tw, b.twiddle.data(), b.twiddle.size() * sizeof(float)));
         TRY(h->upload(h->d_binpos_ch, b.binpos.data(), b.binpos.size() * sizeof(int)));
+        TRY(h->upload(h->d_binnat_ch, b.binnat.data(), b.binnat.size() * sizeof(int)));
+        TRY(h->upload(h->d_rho_ch, b.rho.data(), b.rho.size() * sizeof(float)));
+        {
+            const std::vector<uint16_t> mf = make_dft_pass2_map(kBankNT + 5, kBankThreads, 2);
+            const std::vector<uint16_t> mc = make_dft_pass2_map(kBankNT, kBankThreads, 2);
+            if (mf.empty() || mc.empty()) return fail(BTGPU_EUNSUPPORTED);
+            TRY(h->upload(h->d_b2map_fused, mf.data(), mf.size() * sizeof(uint16_t)));
+            TRY(h->upload(h->d_b2map_ch, mc.data(), mc.size() * sizeof(uint16_t)));
+        }
         TRY(h->upload(h->d_krot_ch, b.krot.data(), b.krot.size() * sizeof(float)));
         TRY(h->alloc(h->d_ptile, (size_t)nch * h->ntiles_max * sizeof(double)));
         TRY(h->alloc(h->d_phead, (size_t)nch * h->ntiles_max * sizeof(double)));
@@ -784,6 +765,11 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             TRY(h->upload(h->d_pfb_taps_n, ns.pfb.taps.data(), ns.pfb.taps.size() * sizeof(float)));
             if (!h->d_pfb_tw.p) TRY(h->upload(h->d_pfb_tw, ns.pfb.twiddle.data(), ns.pfb.twiddle.size() * sizeof(float)));
             TRY(h->upload(h->d_binpos_n, ns.pfb.binpos.data(), ns.pfb.binpos.size() * sizeof(int)));
+            {
+                const std::vector<uint16_t> mn = make_dft_pass2_map(kNoiseNT, kBankThreads, 2);
+                if (mn.empty()) return fail(BTGPU_EUNSUPPORTED);
+                TRY(h->upload(h->d_b2map_noise, mn.data(), mn.size() * sizeof(uint16_t)));
+            }
             TRY(h->upload(h->d_krot_n, ns.pfb.krot.data(), ns.pfb.krot.size() * sizeof(float)));
         } else {
             TRY(h->upload(h->d_taps_s1, ns.direct.taps.data(), ns.direct.taps.size() * sizeof(float)));
@@ -825,7 +811,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->alloc(t.d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
         TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
         TRY(h->alloc(t.d_fin, (size_t)S * nch * sizeof(FinishRec)));
-        TRY(h->alloc(t.d_d2, (size_t)nch * (h->ystride + 64) * sizeof(float)));
         if (h->want_hdrs) TRY(h->alloc(t.d_hdr, (size_t)h->max_hits * sizeof(HeaderRec)));
         if (h->want_syms) {
             const size_t maxfin = (size_t)S * nch;            // one FinishRec per hit window, whatever max_hits is
@@ -841,7 +826,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     if (!h->async) {                      // synchronous mode: one context, used for every batch
         h->tc[1].d_winlen = h->tc[0].d_winlen; h->tc[1].d_hits = h->tc[0].d_hits;
-        h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d2 = h->tc[0].d_d2;
+        h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin;
         h->tc[1].d_winfin = h->tc[0].d_winfin; h->tc[1].d_symbits = h->tc[0].d_symbits; h->tc[1].d_hdr = h->tc[0].d_hdr;
     }
 #undef TRY
@@ -850,11 +835,11 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, kFuseThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, kFuseThreads, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))
-        fprintf(stderr, "btgpu_create: d=%p d2=%p,%p Z=%p ptile=%p\n", h->d_d.p, h->tc[0].d_d2.p, h->tc[1].d_d2.p, h->d_Z.p, h->d_ptile.p);
+        fprintf(stderr, "btgpu_create: d=%p Z=%p ptile=%p\n", h->d_d.p, h->d_Z.p, h->d_ptile.p);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]
     *out = h;
@@ -1053,9 +1038,6 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
                             sizeof(float), count, hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
             return (long)count;
         }
-        case 6:
-            if (c < 0 || c >= nch) return BTGPU_EINVAL;
-            src = (const float *)h->tc[h->cur ^ 1].d_d2.p + (size_t)c * h->ystride; elem = sizeof(float); avail = (size_t)h->last_G; break;
         case 7: src = h->tc[h->cur ^ 1].d_winlen.p; elem = sizeof(int); avail = (size_t)h->last_S * nch; break;
         case 8: src = h->tc[h->cur ^ 1].d_fin.p; elem = sizeof(FinishRec); avail = (size_t)h->last_S * nch; break;
         case 9: if (!h->d_prof.p) return BTGPU_EINVAL; src = h->d_prof.p; elem = sizeof(unsigned long long); avail = (size_t)(h->ntiles_max + 64) * 8; break;

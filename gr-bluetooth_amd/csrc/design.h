@@ -94,10 +94,20 @@ struct PfbBank {
     bool real_taps = false;
     std::vector<float> taps;            // [Q*100][2]  a[j] = proto[L-1-j] * exp(-j 2 pi delta j / 100)
     std::vector<float> twiddle;         // [100][2]    exp(-j 2 pi m1 p2 / 100) at index m1*10 + p2
-    std::vector<int> binpos;            // [nch] position of the channel's bin in the 10x10 FFT output
+    std::vector<int> binpos;            // [nch] position of the channel's bin in the in-place 10x10 FFT output
+    std::vector<int> binnat;            // [nch] the bin itself, m in 0..99 (channel epilogue: Y[t][m])
     int rot_period = 0;
     std::vector<float> krot;            // [nch][rot_period][2]  C_m * exp(-j 2 pi f D t / fs)
+    std::vector<float> rho;             // [nch][2]  exp(-j 2 pi f D / fs): y[t] conj(y[t-1]) = Y[t] conj(Y[t-1]) rho
+    bool rho_real = false;              // every rho is +-1 (integer-MHz offsets at D = 50)
 };
+
+// Lane -> task table of the second DFT pass over `rows` instants (tasks (row, m1), row-contiguous
+// 80-byte reads at LDS pitch kPfbUst): each half-wave gets two tasks of every residue
+// (row + m1) mod 16, placed so that both the 16-lane groups of ds_read_b128 / ds_write_b128 and the
+// contiguous 16-lane groups of ds_write_b64 see sixteen different residues -> no bank conflicts.
+// Entry = row << 4 | m1, 0xffff = idle lane.  `sweeps` * `lanes` entries.
+std::vector<uint16_t> make_dft_pass2_map(int rows, int lanes, int sweeps);
 
 struct NoiseStage {
     bool available = false;

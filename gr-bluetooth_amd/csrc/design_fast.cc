@@ -86,6 +86,9 @@ bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::v
     }
     b.rot_period = (int)period;
     b.binpos.resize(nch);
+    b.binnat.resize(nch);
+    b.rho.resize((size_t)nch * 2);
+    b.rho_real = true;
     b.krot.resize((size_t)nch * period * 2);
     for (int c = 0; c < nch; c++) {
         const double off = foff_hz[c] / 1e6;             // (m + delta)
@@ -93,6 +96,16 @@ bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::v
         if (std::fabs(off - (m + delta)) > 1e-9) return false;
         const int mm = (int)(((m % M) + M) % M);
         b.binpos[c] = 10 * (mm % 10) + mm / 10;
+        b.binnat[c] = mm;
+        {
+            // one-step rotation: exp(-j 2 pi foff D / fs), exact on the quarter-turn grid
+            long long num1 = (long long)std::llround(foff_hz[c]) * D, den1 = (long long)std::llround(fs);
+            long long r1 = ((num1 % den1) + den1) % den1;
+            float rr1, ri1;
+            phasor_turns(-(double)r1 / (double)den1, rr1, ri1);
+            b.rho[2 * c] = rr1; b.rho[2 * c + 1] = ri1;
+            if (ri1 != 0.f || std::fabs(rr1) != 1.f) b.rho_real = false;
+        }
         // C_m = exp(+j 2 pi (m+delta)(L-1)/M)
         const double cturn = off * (b.L - 1) / M;
         for (long long t = 0; t < period; t++) {
@@ -115,6 +128,31 @@ bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::v
     b.available = true;
     return true;
 }
+
+}  // namespace
+
+std::vector<uint16_t> make_dft_pass2_map(int rows, int lanes, int sweeps)
+{
+    // residue classes of the tasks
+    std::vector<std::vector<uint16_t>> cls(16);
+    for (int row = 0; row < rows; row++)
+        for (int m1 = 0; m1 < 10; m1++) cls[(row + m1) & 15].push_back((uint16_t)(row << 4 | m1));
+    std::vector<size_t> next(16, 0);
+    std::vector<uint16_t> map((size_t)lanes * sweeps, 0xffff);
+    // lane j of a half-wave: residues 0..7 on {0-3, 12-15} and {16-19, 28-31}, residues 8..15 on
+    // {4-11} and {20-27}
+    static const int res_of_lane[32] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7,
+                                        0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7};
+    for (size_t i = 0; i < map.size(); i++) {
+        const int r = res_of_lane[i & 31];
+        if (next[r] < cls[r].size()) map[i] = cls[r][next[r]++];
+    }
+    for (int r = 0; r < 16; r++)
+        if (next[r] != cls[r].size()) return std::vector<uint16_t>();      // does not fit: caller refuses
+    return map;
+}
+
+namespace {
 
 double bessel_i0(double x)
 {

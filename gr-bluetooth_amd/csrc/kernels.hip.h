@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
     // Segmented addressing (sample rates where consecutive windows sit on different decimation phases,
     // 625 * sps not a multiple of D): output n = seg * seg_len + i reads x[first + seg * seg_stride + i * D + j]
     // and is de-rotated with phase index i -- every window restarts its rotator like the reference.
-    extern __shared__ float2 tile[];
+    HIP_DYNAMIC_SHARED(float2, tile)
     const int T = blockDim.x;
     const int tiles_per_seg = seg_len > 0 ? (seg_len + T - 1) / T : 0;
     const long long seg = seg_len > 0 ? (long long)(blockIdx.x / tiles_per_seg) : 0;
@@ -244,16 +244,15 @@ __global__ __launch_bounds__(256) void energy_kernel(
 
 // ------------------------------------------------------------------------------------
 // K2b: quadrature demodulation of the channel streams Y[c][g] (multi_block::demod,
-// lib/multi_block.cc:158-173) into the time-major stream d[g][80] the window kernel reads and
-// the channel-major copy d2[c][g] of finish_kernel.  One workgroup = 64 consecutive grid points
+// lib/multi_block.cc:158-173) into the time-major stream d[g][drow] the window and finish kernels read.
+// One workgroup = 64 consecutive grid points
 // of every channel: wave w takes channels w, w + 4, ... with lane = grid point (coalesced reads
 // along g), the values cross an LDS tile and leave as whole rows (a lane-per-grid-point store
 // into d would touch 64 different rows per instruction).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void demod_rows_kernel(
     const float2 *__restrict__ Y, long long G, long long ystride, int nch,
-    const float *__restrict__ atan_tab, float gain, float *__restrict__ d, int drow,
-    float *__restrict__ d2, long long d2stride)
+    const float *__restrict__ atan_tab, float gain, float *__restrict__ d, int drow)
 {
     __shared__ float atab[257];
     __shared__ float tile[64 * 81];
@@ -268,7 +267,6 @@ __global__ __launch_bounds__(256) void demod_rows_kernel(
         const float2 v = y[gc], vp = y[gc > 0 ? gc - 1 : 0];
         const float dv = (g > 0 && g < G) ? demod_one(atab, gain, v, vp) : 0.f;   // policy Q1: d[0] = 0
         tile[lane * 81 + c] = dv;
-        if (d2 && g < G) d2[(size_t)c * d2stride + g] = dv;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * nch; i += blockDim.x) {
@@ -790,14 +788,16 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     }
 }
 
-// Continue the M&M recursion of the windows that reported hits to the end of their window and
-// store len.  One lane per window; each lane stages its own column of the time-major stream
-// (row stride 80 floats) into a private LDS slab, kFinRows rows at a time, all loads of a chunk
-// in flight together.  No cross-lane data => no barriers.
+// Continue the M&M recursion of the windows that reported hits (a few per cent) to the end of their
+// window and store len.  One lane per window; each lane stages its own column of the time-major
+// stream d[g][drow] into a private LDS slab, kFinRows rows at a time, all loads of a chunk in
+// flight together (a strided column costs one cache line per row, but it is only read for the hit
+// windows and off the critical path: a channel-major copy of the whole stream, which the bank
+// kernel used to write for this, cost more than it saved).  No cross-lane data => no barriers.
 constexpr int kFinRows = 32;
 template <bool SYMS>
 __global__ __launch_bounds__(64) void finish_kernel(
-    WindowParams p, const float *__restrict__ d2, long long d2stride, long long d_rows,
+    WindowParams p, const float *__restrict__ d, int drow, long long d_rows,
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
     const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits)
 {
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
     const long long row0 = (long long)k * p.outs_per_slot;
-    const float *col = d2 + (size_t)c * d2stride + row0;         // this window's demod samples, contiguous
+    const float *col = d + (size_t)row0 * drow + c;              // this window's demod samples: every drow-th float
     const unsigned int nvalid = (unsigned int)((d_rows - row0) < p.ddc_out ? (d_rows - row0) : p.ddc_out);
     float mu = r.mu, omega = r.omega, last = r.last;
     unsigned int ii = r.ii;
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     {
         float v[RING];
 #pragma unroll
-        for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = col[idx < nvalid ? idx : nvalid - 1]; }
+        for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * drow]; }
 #pragma unroll
         for (unsigned int j = 0; j < RING; j++) v[j] = hi + j < nvalid ? v[j] : 0.f;       // loads unconditional, values selected
 #pragma unroll
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
         // issue the loads of the next kFinRows rows now; they land while the steps below run
         float v[kFinRows];
 #pragma unroll
-        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[idx < nvalid ? idx : nvalid - 1]; }   // unconditional
+        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * drow]; }   // unconditional
         // consume every step whose 8-tap window lies inside the resident rows [.., hi)
         while (ii + 8 <= hi && ii < ni && oo < demod_n) {
             const int imu = (int)rintf(mu * 128.0f);             // mu in [0, 1) -> 0..128

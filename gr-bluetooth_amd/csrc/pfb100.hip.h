@@ -2,11 +2,13 @@
 //
 // For every output instant t the bank needs, for each of the 100 polyphase branches p,
 //   u_p[t] = sum_q a[100 q + p] * x[x0 + D t + 100 q + p]               (Q taps per branch)
-// followed by a 100-point DFT over p (10 x 10 Cooley-Tukey) and, per selected channel,
-// one complex multiply by C_m * rot(t).  This is algebraically the reference's per-channel
-// "complex band-pass FIR, decimate, de-rotate" (freq_xlating_fir_filter_ccf [EXT], called
-// from lib/multi_block.cc:204,275) for all channels at once: ~27 FMA + ~70 flop per input
-// sample instead of ~2100 FMA.
+// followed by a 100-point DFT over p (10 x 10 Cooley-Tukey).  This is algebraically the
+// reference's per-channel "complex band-pass FIR, decimate, de-rotate" (freq_xlating_fir_filter_ccf
+// [EXT], called from lib/multi_block.cc:204,275) for all channels at once: ~27 FMA + ~70 flop per
+// input sample instead of ~2100 FMA.  The de-rotation itself is never applied on the channel
+// path: quadrature demodulation (multi_block::demod, lib/multi_block.cc:158-168) only needs
+// y[t] conj(y[t-1]) = Y[t] conj(Y[t-1]) * rho with the per-channel constant rho = exp(-j 2 pi f D / fs)
+// (+-1 on the integer-MHz grid), and |y|^2 = |Y|^2.
 //
 // Work decomposition (one workgroup = NT consecutive output instants, NTH = 256 lanes):
 //   0  the input span of the tile is staged through LDS with aligned 16-byte loads, all loads of
@@ -15,12 +17,19 @@
 //   A  lanes (p, r): branch p, instants of parity r.  Because 2 D is a multiple of 100 the
 //      samples a branch needs for instant t+2 are the ones of instant t shifted by S = 2D/100
 //      taps: each lane keeps a Q-deep register window and reads every input sample from LDS
-//      exactly once.
-//   B  two passes of 10-point DFTs over the LDS matrix U[t][100], twiddle in between.
-//   C  epilogue.  CHANNEL bank: lane (run, channel) walks <= 9 consecutive instants: de-rotate,
-//      quadrature demod against the previous instant (multi_block::demod), |y|^2 sums; d is
-//      written time-major [g][80] (the window kernel's lanes = channels read it coalesced) and
-//      channel-major [c][g] (finish_kernel streams single windows).  NOISE bank: stage-1 output Z.
+//      exactly once.  Rows U[t][0..99] at a pitch of 106 complex.
+//   B1 lane (t, p2): 10-point DFT over p1 (p = 10 p1 + p2), twiddle, in place.  The pitch of 106
+//      (= 10 mod 32 eight-byte banks) makes the stride-10 accesses of consecutive lanes hit
+//      consecutive banks.
+//   B2 lane (t, m1) by a host-built table (design.h make_dft_pass2_map): 80 contiguous bytes in,
+//      10-point DFT over p2, bin m = m1 + 10 m2 out -- channel rows to Y[t][m] (pitch 113, in the
+//      dead input tile), noise rows in place.  The table gives every 16-lane access group sixteen
+//      different (t + m1) mod 16, which is what keeps both access shapes conflict-free.
+//   C  epilogue.  CHANNEL bank: lane (run, channel) walks <= 9 consecutive instants of Y:
+//      quadrature demod against the previous instant (odd minimax polynomial for the arctangent,
+//      quadrant logic on sign bits -- no table, no compare/select chains), |Y|^2 sums; d is
+//      written time-major [g][80] (the window kernel's lanes = channels read it coalesced).
+//      NOISE bank: stage-1 output Z.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,7 +41,8 @@
 
 namespace btgpu {
 
-constexpr int kPfbUst = 107;
+constexpr int kPfbUst = 106;     // LDS pitch (complex) of the DFT rows U
+constexpr int kPfbYst = 113;     // LDS pitch (complex) of the bin rows Y (= 1 mod 16)
 
 struct PfbParams {
     const float2 *x; long long x_len; long long x0;   // x index of tap 0 for output instant 0
@@ -41,18 +51,21 @@ struct PfbParams {
     const float2 *taps;          // [Q*100]
     const float2 *twiddle;       // [100]
     int nsel;
-    const int *binpos;           // [nsel]
-    const float2 *krot;          // [nsel][rot_period]
+    const int *binpos;           // [nsel] position of the channel's bin in the in-place DFT output (noise banks)
+    const int *binnat;           // [nsel] the bin itself, 0..99 (channel epilogue)
+    const float2 *krot;          // [nsel][rot_period] de-rotation (noise banks; channel bank: BTGPU_FLAG_DEBUG_Y only)
     int rot_period;
+    const float2 *rho;           // [nsel] per-step rotation of the channel (channel epilogue)
+    int rho_real;                // every rho is +-1
+    const uint16_t *b2map;       // [2][NTH] lane -> (row << 4 | m1) of DFT pass 2, 0xffff = idle
     int ntiles;
     // channel epilogue
     float *d;                    // [T][80] time-major (row stride 80 floats)
-    float *d2; long long d2stride;  // optional channel-major copy [nsel][d2stride] for finish_kernel
     double *ptile;               // [nsel][ntiles]
     double *phead;               // [nsel][ntiles]  sum of the first (tail % TT) instants of each tile
     int tiles_per_block, tail, nb;
-    const float *atan_tab; float gain;
-    // noise epilogue
+    float gain;
+    // noise epilogue / debug copy of the de-rotated channel output
     float2 *Z; long long zstride;   // [nsel][zstride]
     // fused noise stage 1 (FUSEN): the channel tile's staged input also feeds the NU = 5 noise-bank
     // instants whose first tap lies in the tile's 1250 new samples
@@ -72,6 +85,7 @@ struct PfbParams {
 // v_pk_fma_f32 (two FMAs per lane per issue); swizzles and sign flips map onto the packed
 // instructions' op_sel / neg modifiers.
 typedef float cf __attribute__((ext_vector_type(2)));
+typedef float cf2 __attribute__((ext_vector_type(4)));       // two complex values = one 16-byte LDS access
 __device__ __forceinline__ cf mk(float re, float im) { cf v = {re, im}; return v; }
 __device__ __forceinline__ cf cmulf(cf a, cf b)
 {
@@ -114,31 +128,45 @@ __device__ __forceinline__ void dft10(cf *v)
     v[4] = E[4] + o4; v[9] = E[4] - o4;
 }
 
-// fast_atan2f with v_rcp_f32 instead of the IEEE divide (1 ulp on the ratio; tolerance path only),
-// written branch-free: both the small-angle value and the table interpolation are formed and
-// one is selected, the quadrant fix-ups are selects.
-__device__ __forceinline__ float demod_fast(const float *__restrict__ tab, float gain, cf a, cf b)
+// Quadrature demodulation of the tolerance path: gain * atan2(pi, pr) of (pr, pi), the product
+// a conj(b) already rotated by rho.  gr::fast_atan2f [EXT] is a 256-interval table with linear
+// interpolation (1.3e-6 rad off the true arctangent); here an odd degree-13 minimax polynomial
+// (3.4e-7 rad in float) stands in for it, and the octant / quadrant unfolding works on sign bits:
+//   A = atan(min/max) in [0, pi/4],  q = pi/4 - A
+//   first quadrant   a1 = pi/4 - q sgn(|pr| - |pi|)       (x-dominant: A, y-dominant: pi/2 - A)
+//   left half plane  a2 = pi/2 + (a1 - pi/2) sgn(pr)       (pr < 0: pi - a1)
+//   lower half plane a2 sgn(pi)
+// with every constant and coefficient pre-multiplied by the gain.  (0, 0) gives 0 like the
+// reference; zeros are made positive first so that their sign bits decide like ">= 0" does.
+struct DemodConst { float c[7]; float q4, q2; };
+__device__ __forceinline__ DemodConst demod_constants(float gain)
 {
-    const cf pp = b.xx * a + b.yy * mk(a.y, -a.x);              // a conj(b) = (pr, pi)
-    const float pr = pp.x, pi = pp.y;
-    const float ya = fabsf(pi), xa = fabsf(pr);
-    const float mx = fmaxf(xa, ya), mn = fminf(xa, ya);
-    const float z = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-37f));
-    const float alpha0 = z * 255.0f;
-    const int index = ((int)alpha0) & 0xff;
-    const float alpha = alpha0 - (float)index;
-    const float t0 = tab[index];
-    const float interp = t0 + (tab[index + 1] - t0) * alpha;
-    const float base = z < 0.003921569f ? z : interp;
-    // x-dominant when |x| >= |y| (so that (0, 0) falls through to angle 0 without a special case; at
-    // |x| == |y| both forms give pi/4 exactly)
-    const bool xbig = xa >= ya;
-    // x-dominant: pr >= 0 ? base : pi - base ; y-dominant: pr >= 0 ? pi/2 - base : pi/2 + base
-    const float k = xbig ? (pr >= 0.0f ? 0.0f : 3.14159265358979323846f) : 1.57079632679489661923f;
-    const float sgn = (xbig == (pr >= 0.0f)) ? 1.0f : -1.0f;     // +base for (x-dom, pr>=0) and (y-dom, pr<0)
-    float ang = k + sgn * base;
-    ang = pi >= 0.0f ? ang : -ang;
-    return gain * ang;
+    DemodConst k;
+    k.c[0] = gain * 9.9999611154e-01f; k.c[1] = gain * -3.3317368021e-01f; k.c[2] = gain * 1.9807815191e-01f;
+    k.c[3] = gain * -1.3233340512e-01f; k.c[4] = gain * 7.9623641276e-02f; k.c[5] = gain * -3.3604192045e-02f;
+    k.c[6] = gain * 6.8117834093e-03f;
+    k.q4 = gain * 0.78539816339744831f;
+    k.q2 = 2.0f * k.q4;                                           // exactly twice q4: (0, 0) comes out as 0
+    return k;
+}
+__device__ __forceinline__ float demod_poly(const DemodConst &k, float pr, float pi)
+{
+    const uint32_t SIGN = 0x80000000u;
+    pr = pr + 0.0f; pi = pi + 0.0f;                               // -0 -> +0
+    const float ax = fabsf(pr), ay = fabsf(pi);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
+    const float z = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = z * z;
+    float P = k.c[6];
+    P = P * s + k.c[5]; P = P * s + k.c[4]; P = P * s + k.c[3];
+    P = P * s + k.c[2]; P = P * s + k.c[1]; P = P * s + k.c[0];
+    const float q = k.q4 - z * P;                                 // gain (pi/4 - atan z) >= 0
+    const float dd = ax - ay;                                     // >= 0: x-dominant
+    const uint32_t t1 = __float_as_uint(q) ^ (__float_as_uint(dd) & SIGN);
+    const float w = -k.q4 - __uint_as_float(t1);                  // gain (a1 - pi/2) <= 0
+    const uint32_t t2 = __float_as_uint(w) ^ (__float_as_uint(pr) & SIGN);
+    const float a2 = k.q2 + __uint_as_float(t2);
+    return __uint_as_float(__float_as_uint(a2) ^ (__float_as_uint(pi) & SIGN));
 }
 
 // XCD-aware tile order: consecutive tiles (which share the filter-length halo of their input
@@ -150,48 +178,46 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 }
 
 template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false>
-__global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100_kernel(PfbParams p)
+__global__ __launch_bounds__(NTH, (FUSEN ? 3 : 1)) void pfb100_kernel(PfbParams p)
 {
     constexpr int DH = S * 50;                               // hop: 2 D = S * 100
     constexpr int NQ = 15, NR = 250, NU = 5;                 // fused noise bank: taps/branch, hop, instants per tile
     static_assert(!FUSEN || (CHAN && DH == 50 && NT == 26), "fused noise stage needs the C79 channel geometry");
-    // NTH lanes: the DFT tasks of a pass (10 per row) should fit in one sweep (310 tasks -> 320
-    // lanes), otherwise one wave runs the whole DFT body twice for a handful of tasks
+    static_assert(NTH == 256, "lane roles below are laid out for four waves");
     constexpr int M = 100;
-    constexpr int UST = kPfbUst;                             // LDS row stride of U (complex): 107 spreads the
-                                                             // DFT passes' strided rows over the banks
-    constexpr int TT = CHAN ? NT - 1 : NT;      // new output instants per tile
+    constexpr int UST = kPfbUst, YST = kPfbYst;
+    constexpr int TT = CHAN ? NT - 1 : NT;                   // new output instants per tile
+    constexpr int NROWS = NT + (FUSEN ? NU : 0);             // DFT rows: channel instants, then the noise instants
     static_assert(NT % 2 == 0, "NT must be even");
-    extern __shared__ float4 lds4[];
+    HIP_DYNAMIC_SHARED(float4, lds4)
     cf *lds = (cf *)lds4;
     constexpr int SPAN_C = DH * (NT - 1) + Q * M;            // input samples the channel instants need
     constexpr int SPAN_N = (NR - 1) + NR * (NU - 1) + NQ * M;   // ... and the owned noise instants
     constexpr int SPAN = (FUSEN && SPAN_N > SPAN_C) ? SPAN_N : SPAN_C;
     constexpr int N4 = (SPAN + 3) / 2;                       // 16-byte pieces staged (aligned start: +1 sample)
     constexpr int span = 2 * N4;                             // samples resident in LDS
-    const int wsz = CHAN ? p.nsel * NT : 0;
-    const int asz = span > wsz ? span : wsz;                 // the head of xs is dead after phase A -> reused as Db
-    cf *xs = lds;                                        // [span]
-    cf *U = lds + ((asz + 1) & ~1);                      // [NT][UST]
-    float *atab = (float *)(U + NT * UST);                   // [257]               (CHAN)
-    cf *Un = (cf *)(atab + 258);                     // [NU][UST] noise branch outputs (FUSEN)
+    constexpr int YSZ = CHAN ? NT * YST : 0;                 // the input tile is dead after phase A -> bin rows Y
+    constexpr int ASZ = ((span > YSZ ? span : YSZ) + 1) & ~1;
+    cf *xs = lds;                                            // [span]
+    cf *Y = lds;                                             // [NT][YST]      (after phase A)
+    cf *U = lds + ASZ;                                       // [NROWS][UST]
     __shared__ cf s_tw[100];
-    __shared__ cf s_krot[80 * 4];
-    __shared__ int s_binpos[80];
-    const bool krot_lds = p.rot_period <= 4 && p.nsel <= 80;
-    const int l0 = threadIdx.x;
+    __shared__ cf s_krot[CHAN ? 1 : 80 * 4];
+    __shared__ int s_binpos[CHAN ? 1 : 80];
+    __shared__ float s_part[CHAN ? (NTH / 80) * 80 * 2 : 1];
+    const bool krot_lds = !CHAN && p.rot_period <= 4 && p.nsel <= 80;
+    const int l = threadIdx.x;
 
     // one workgroup = one tile; XCD-aware order (pre-tiles of the fused noise bank come first)
     const int ntl = p.ntiles + (FUSEN ? p.pre_tiles : 0);
     const int tile_u = xcd_remap(blockIdx.x, ntl);
     const int tile = tile_u - (FUSEN ? p.pre_tiles : 0);
-    const int l = l0;
 
     unsigned long long tprev = p.prof ? clock64() : 0ULL;
     auto mark = [&](int k) {
         if (p.prof) {
             const unsigned long long now = clock64();
-            if (l0 == 0) p.prof[(size_t)blockIdx.x * 8 + k] += now - tprev;   // wave 0 of each tile
+            if (l == 0) p.prof[(size_t)blockIdx.x * 8 + k] += now - tprev;   // wave 0 of each tile
             tprev = now;
         }
     };
@@ -199,9 +225,8 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
     // Every global load of the prologue is unconditional (indices clamped, values selected
     // afterwards): a load under a lane-dependent branch is waited for at the end of that branch,
     // which would serialise the ~30 loads of a lane into as many memory round trips.
-    auto load_piece = [&](long long a0, int i, bool interior) -> float4 {
-        // 16-byte piece i (two samples) of the span starting at the even sample a0
-        if (interior) return *(const float4 *)(p.x + a0 + 2 * (long long)i);       // block-uniform branch
+    auto load_piece_edge = [&](long long a0, int i) -> float4 {
+        // 16-byte piece i (two samples) of the span starting at the even sample a0, stream edges included
         const long long a = a0 + 2 * (long long)i;
         const long long ac = a < 0 ? 0 : (a + 1 < p.x_len ? a : (p.x_len >= 2 ? p.x_len - 2 : 0));
         const long long bc = ac + 1 < p.x_len ? ac + 1 : ac;
@@ -216,86 +241,59 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
         return v;
     };
 
-    // phase-A lane roles and branch taps (fixed for the whole group)
+    // phase-A lane roles and branch taps (fixed for the whole tile)
     cf a[Q];
 
-    // Noise-bank roles: 500 tasks (instant i, branch pp) of 15 complex taps, spread so that every
-    // SIMD carries about the same number of FMAs in phase A and a lane needs the taps of one branch
-    // only (fetched once, behind the input staging).
+    // Noise-bank roles: 500 tasks (instant i, branch pp) of 15 complex taps: branch l % 100, instants
+    // 0..2 in lanes 0..99 and 3..4 in lanes 100..199 (a lane needs the taps of one branch only; an
+    // even 2-2-1 split needs a second tap set per lane and measured slower)
     int nz_pp = 0, nz_i0 = 0, nz_cnt = 0;
     cf an[FUSEN ? NQ : 1];
-    if (FUSEN) {
-        if (NTH > 256) {
-            // Five waves land 2 + 1 + 1 + 1 on the four SIMDs (waves 0 and 4 share one): wave 0, which
-            // also has channel branches, takes one noise task per lane, the others two
-            if (l0 < 64) { nz_pp = l0; nz_i0 = 4; nz_cnt = 1; }                       // instant 4, branches 0..63
-            else if (l0 < 264) { nz_pp = (l0 - 64) % 100; nz_i0 = 2 * ((l0 - 64) / 100); nz_cnt = 2; }   // instants (0,1) / (2,3)
-            else if (l0 < 300) { nz_pp = 64 + (l0 - 264); nz_i0 = 4; nz_cnt = 1; }    // instant 4, branches 64..99
-        } else {
-            // 256 lanes: branch pp = l % 100 for l < 200, instants split 3 / 2
-            // 256 lanes, one wave per SIMD: branch l % 100, instants 0..2 in lanes 0..99 and 3..4 in lanes
-            // 100..199 (an even 2-2-1 split needs a second tap set per lane and measured slower)
-            if (l < 200) { nz_pp = l % 100; nz_i0 = l < 100 ? 0 : 3; nz_cnt = l < 100 ? 3 : 2; }
-        }
-    }
+    if (FUSEN && l < 200) { nz_pp = l % 100; nz_i0 = l < 100 ? 0 : 3; nz_cnt = l < 100 ? 3 : 2; }
 
     const int a_pp = l & 127, a_r = l >> 7;
-    const bool a_on = a_pp < M && a_r < 2;
+    const bool a_on = a_pp < M;
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
+
+    // roles of the later phases, fetched behind the input loads
+    constexpr int NZT = FUSEN ? (80 * NU + NTH - 1) / NTH : 1;   // noise outputs per lane (phase C')
+    const int nz_u0 = FUSEN ? p.n_u0 + NU * tile : 0;            // first noise instant owned by this tile
+    int nz_pos[NZT]; cf nz_rot[NZT];
+    uint32_t b2task = 0xffffffffu;                               // both sweeps of pass 2: lo | hi << 16
+    constexpr int CH = NTH / 80;                                 // epilogue: CH runs of <= RUN instants per channel
+    constexpr int RUN = (TT + CH - 1) / CH;
+    const int e_chunk = l / 80, e_c = l % 80;
+    const bool e_on = CHAN && e_chunk < CH && e_c < p.nsel;
+    int e_pos = 0; cf e_rho = mk(1.f, 0.f);
 
     // ---- stage the input span.  The tile starts at the even sample a0 <= gs so that every piece is
     // a 16-byte aligned load; all loads of a lane are issued before its first LDS store (one
     // memory latency per tile instead of one per loop trip).
-    constexpr int NZT = FUSEN ? (80 * NU + NTH - 1) / NTH : 1;   // noise outputs per lane (phase C')
-    const int nz_u0 = FUSEN ? p.n_u0 + NU * tile : 0;            // first noise instant owned by this tile
-    int nz_pos[NZT]; cf nz_rot[NZT];
     const long long gs = p.x0 + (long long)DH * t0;
     const long long a0 = gs & ~1LL;
     const int shift = (int)(gs - a0);
     {
         constexpr int PER = (N4 + NTH - 1) / NTH;
         float4 v[PER];
-        {
-            const bool interior = a0 >= 0 && a0 + 2LL * N4 <= p.x_len;
-            if (interior) {                                      // block-uniform: one straight run of loads
+        const bool interior = a0 >= 0 && a0 + 2LL * N4 <= p.x_len;
+        if (interior) {                                      // block-uniform: one straight run of loads
+            const float4 *xb = (const float4 *)(p.x + a0);
 #pragma unroll
-                for (int j = 0; j < PER; j++) v[j] = load_piece(a0, l + j * NTH < N4 ? l + j * NTH : N4 - 1, true);
-            } else {
+            for (int j = 0; j < PER; j++) v[j] = xb[l + j * NTH < N4 ? l + j * NTH : N4 - 1];
+        } else {
 #pragma unroll
-                for (int j = 0; j < PER; j++) v[j] = load_piece(a0, l + j * NTH < N4 ? l + j * NTH : N4 - 1, false);
-            }
-            // tables -> LDS and the branch taps of this lane's roles (fixed for the group), issued
-            // behind the input loads: memory returns in order, so the staging wait excludes them
-            constexpr int NA = (257 + NTH - 1) / NTH, NK = (80 * 4 + NTH - 1) / NTH;
-            float at[NA]; cf kr[NK];
-#pragma unroll
-            for (int k = 0; k < NA; k++) at[k] = CHAN ? p.atan_tab[l0 + k * NTH < 257 ? l0 + k * NTH : 256] : 0.f;
-            const cf tw = ((const cf *)p.twiddle)[l0 < 100 ? l0 : 99];
-            const int bp = p.binpos[l0 < p.nsel ? l0 : p.nsel - 1];
-            const int nkr = p.nsel * p.rot_period;
-#pragma unroll
-            for (int k = 0; k < NK; k++) kr[k] = ((const cf *)p.krot)[l0 + k * NTH < nkr ? l0 + k * NTH : nkr - 1];
-            const int pp = l & 127;
-#pragma unroll
-            for (int q = 0; q < Q; q++) a[q] = ((const cf *)p.taps)[q * M + (pp < M ? pp : 0)];
-            if (FUSEN) {
-#pragma unroll
-                for (int q = 0; q < NQ; q++) an[q] = ((const cf *)p.n_taps)[q * M + nz_pp];
-            }
-#pragma unroll
-            for (int k = 0; k < NA; k++) asm volatile("" : "+v"(at[k]));   // keep the load out of the branch below
-#pragma unroll
-            for (int k = 0; k < NA; k++) if (CHAN && l0 + k * NTH < 257) atab[l0 + k * NTH] = at[k];
-            if (l0 < 100) s_tw[l0] = tw;
-            if (l0 < p.nsel && l0 < 80) s_binpos[l0] = bp;
-            if (krot_lds) {
-#pragma unroll
-                for (int k = 0; k < NK; k++) if (l0 + k * NTH < nkr) s_krot[l0 + k * NTH] = kr[k];
-            }
+            for (int j = 0; j < PER; j++) v[j] = load_piece_edge(a0, l + j * NTH < N4 ? l + j * NTH : N4 - 1);
         }
+        // tables -> LDS and the constants of this lane's roles, issued behind the input loads:
+        // memory returns in order, so the staging wait excludes them
+        const cf tw = ((const cf *)p.twiddle)[l < 100 ? l : 99];
+        b2task = (uint32_t)p.b2map[l] | ((uint32_t)p.b2map[NTH + l] << 16);
+#pragma unroll
+        for (int q = 0; q < Q; q++) a[q] = ((const cf *)p.taps)[q * M + (a_on ? a_pp : 0)];
         if (FUSEN) {
-            // bin position and de-rotation factor of this lane's noise outputs (phase C'): fetched
-            // here so that their latency overlaps the input staging
+#pragma unroll
+            for (int q = 0; q < NQ; q++) an[q] = ((const cf *)p.n_taps)[q * M + nz_pp];
+            // bin position and de-rotation factor of this lane's noise outputs (phase C')
             const int np = p.n_period;
             const int ph0 = ((nz_u0 % np) + np) % np;             // block-uniform
 #pragma unroll
@@ -308,6 +306,25 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
                 nz_rot[j] = ((const cf *)p.n_krot)[(size_t)c * np + ph];
             }
         }
+        if (CHAN) {
+            const int cc = e_c < p.nsel ? e_c : p.nsel - 1;
+            e_pos = p.binnat[cc];
+            e_rho = ((const cf *)p.rho)[cc];
+        } else {
+            constexpr int NK = (80 * 4 + NTH - 1) / NTH;
+            const int nkr = p.nsel * p.rot_period;
+            const int bp = p.binpos[l < p.nsel ? l : p.nsel - 1];
+            if (l < p.nsel && l < 80) s_binpos[l] = bp;
+            if (krot_lds) {
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+                    const int i = l + k * NTH;
+                    const cf kr = ((const cf *)p.krot)[i < nkr ? i : nkr - 1];
+                    if (i < nkr) s_krot[i] = kr;
+                }
+            }
+        }
+        if (l < 100) s_tw[l] = tw;
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const int i = l + j * NTH;
@@ -318,33 +335,31 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
     mark(0);
 
     // ---- phase A: polyphase branch filters ----
-    {
+    if (a_on && tile >= 0) {
         const int pp = a_pp, r = a_r;
-        if (a_on && tile >= 0) {
-            const cf *z = xs + shift + DH * r + pp;
-            cf zw[Q];
+        const cf *z = xs + shift + DH * r + pp;
+        cf zw[Q];
 #pragma unroll
-            for (int q = 0; q < Q; q++) zw[q] = z[q * M];
+        for (int q = 0; q < Q; q++) zw[q] = z[q * M];
 #pragma unroll
-            for (int tau = 0; tau < NT / 2; tau++) {
-                cf u = mk(0.f, 0.f);
+        for (int tau = 0; tau < NT / 2; tau++) {
+            cf u = mk(0.f, 0.f);
 #pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    if (REAL) u = a[q].xx * zw[q] + u;
-                    else { u = a[q].xx * zw[q] + u; u = mk(-a[q].y, a[q].y) * zw[q].yx + u; }
-                }
-                U[(2 * tau + r) * UST + pp] = u;
-                if (tau + 1 < NT / 2) {
+            for (int q = 0; q < Q; q++) {
+                if (REAL) u = a[q].xx * zw[q] + u;
+                else { u = a[q].xx * zw[q] + u; u = mk(-a[q].y, a[q].y) * zw[q].yx + u; }
+            }
+            U[(2 * tau + r) * UST + pp] = u;
+            if (tau + 1 < NT / 2) {
 #pragma unroll
-                    for (int q = 0; q + S < Q; q++) zw[q] = zw[q + S];
+                for (int q = 0; q + S < Q; q++) zw[q] = zw[q + S];
 #pragma unroll
-                    for (int q = (Q - S > 0 ? Q - S : 0); q < Q; q++) zw[q] = z[(q + S * (tau + 1)) * M];
-                }
+                for (int q = (Q - S > 0 ? Q - S : 0); q < Q; q++) zw[q] = z[(q + S * (tau + 1)) * M];
             }
         }
     }
     if (FUSEN) {
-        // noise bank branches (taps preloaded above): nz_cnt instants of branch nz_pp
+        // noise bank branches (taps preloaded above): nz_cnt instants of branch nz_pp -> rows NT..
         for (int i = nz_i0; i < nz_i0 + nz_cnt; i++) {
             const cf *zz = xs + shift + p.n_off + NR * i + nz_pp;
             cf u = mk(0.f, 0.f);
@@ -354,36 +369,50 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
                 u = an[q].xx * v + u;
                 u = mk(-an[q].y, an[q].y) * v.yx + u;
             }
-            Un[i * UST + nz_pp] = u;
+            U[(NT + i) * UST + nz_pp] = u;
         }
     }
     __syncthreads();
     mark(1);
 
-    // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100} ----
-    constexpr int NTASK = NT * 10 + (FUSEN ? NU * 10 : 0);
+    // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100}, in place ----
+    constexpr int NTASK = NROWS * 10;
     for (int i = l; i < NTASK; i += NTH) {
-        const int tl = i / 10, p2 = i % 10;
+        const int row = i / 10, p2 = i - 10 * row;
+        cf *col = U + row * UST + p2;
+        const cf *tw = s_tw + p2;
         cf v[10];
-        cf *row = (FUSEN && tl >= NT) ? Un + (tl - NT) * UST + p2 : U + tl * UST + p2;
 #pragma unroll
-        for (int k = 0; k < 10; k++) v[k] = row[10 * k];
+        for (int k = 0; k < 10; k++) v[k] = col[10 * k];
         dft10(v);
+        col[0] = v[0];                                           // m1 = 0: twiddle 1
 #pragma unroll
-        for (int k = 0; k < 10; k++) row[10 * k] = cmulf(v[k], s_tw[k * 10 + p2]);
+        for (int k = 1; k < 10; k++) col[10 * k] = cmulf(v[k], tw[10 * k]);
     }
     __syncthreads();
     mark(2);
-    // ---- phase B2: DFT over p2; bin m = m1 + 10 m2 ends up at position 10 m1 + m2 ----
-    for (int i = l; i < NTASK; i += NTH) {
-        const int tl = i / 10, m1 = i % 10;
-        cf v[10];
-        cf *row = (FUSEN && tl >= NT) ? Un + (tl - NT) * UST + 10 * m1 : U + tl * UST + 10 * m1;
+
+    // ---- phase B2: DFT over p2.  Channel rows: bin m = m1 + 10 m2 -> Y[row][m] (the input tile is
+    // dead); noise rows (and the noise-only bank) stay in place: bin at position 10 m1 + m2 ----
 #pragma unroll
-        for (int k = 0; k < 10; k++) v[k] = row[k];
-        dft10(v);
+    for (int sw = 0; sw < 2; sw++) {
+        const uint32_t task = sw == 0 ? (b2task & 0xffffu) : (b2task >> 16);
+        if (task != 0xffffu) {
+            const int row = (int)(task >> 4), m1 = (int)(task & 15u);
+            cf2 *src = (cf2 *)(U + row * UST + 10 * m1);         // 16-byte aligned: UST and 10 m1 are even
+            cf v[10];
 #pragma unroll
-        for (int k = 0; k < 10; k++) row[k] = v[k];
+            for (int k = 0; k < 5; k++) { const cf2 t = src[k]; v[2 * k] = t.xy; v[2 * k + 1] = t.zw; }
+            dft10(v);
+            if (CHAN && row < NT) {
+                cf *dst = Y + row * YST + m1;
+#pragma unroll
+                for (int k = 0; k < 10; k++) dst[10 * k] = v[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) { cf2 t; t.xy = v[2 * k]; t.zw = v[2 * k + 1]; src[k] = t; }
+            }
+        }
     }
     __syncthreads();
     mark(3);
@@ -398,15 +427,13 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
             const int c = i / NU, ui = i % NU;
             const int u = nz_u0 + ui;
             if (u < 0 || u >= p.n_T) continue;
-            ((cf *)p.n_Z)[(size_t)c * p.n_zstride + u] = cmulf(Un[ui * UST + nz_pos[j]], nz_rot[j]);
+            ((cf *)p.n_Z)[(size_t)c * p.n_zstride + u] = cmulf(U[(NT + ui) * UST + nz_pos[j]], nz_rot[j]);
         }
-        __syncthreads();                                          // Un is reused for the run partial sums
     }
     mark(4);
-    const uint32_t period = (uint32_t)p.rot_period;
-    // phase index of local instant 0: (t0 mod period) in 32-bit arithmetic (t0 >= -1)
-    const uint32_t ph_t0 = (uint32_t)(((uint32_t)tile * (uint32_t)TT % period + period - (CHAN ? 1u : 0u)) % period);
     if (!CHAN) {
+        const uint32_t period = (uint32_t)p.rot_period;
+        const uint32_t ph_t0 = (uint32_t)(((uint32_t)tile * (uint32_t)TT) % period);   // phase index of local instant 0
         for (int i = l; i < p.nsel * NT; i += NTH) {
             const int c = i / NT, tl = i % NT;
             const long long t = t0 + tl;
@@ -418,79 +445,88 @@ __global__ __launch_bounds__(NTH, (FUSEN ? (NTH > 256 ? 6 : 3) : 1)) void pfb100
             ((cf *)p.Z)[(size_t)c * p.zstride + t] = y;
         }
     }
-    // Channel epilogue.  Lane (chunk, c): channel c, a run of <= 9 consecutive instants, walking
-    // forward in time with the previous instant's Y in registers: de-rotate, demodulate against
-    // the previous instant (multi_block::demod), |Y|^2 partial sums (combined in double, fixed order).
-    if (CHAN && tile >= 0) {                                     // pre-tiles hold no channel instants
-        constexpr int CH = NTH / 80, RUN = (TT + CH - 1) / CH;   // 320 lanes: runs of 7, 7, 7, 4 instants
-        float *Db = (float *)xs;                                 // [nsel][NT] demod values for the d2 copy
-        float *part = FUSEN ? (float *)Un : Db + p.nsel * NT;    // [CH][80][2] (sum, head)
-        const int chunk = l / 80, c = l % 80;
-        if (chunk < CH && c < p.nsel) {
-            const int pos = s_binpos[c];
-            const int tl0 = 1 + chunk * RUN;
-            const int hr = p.tail % TT;                          // head length inside a tile
+    // Channel epilogue.  Lane (run, c): channel c, <= RUN consecutive instants, the previous instant's
+    // bin in registers.  Runs cover local instants 1 .. NT-1 (local 0 is the halo instant).
+    if (CHAN && tile >= 0) {
+        if (e_on) {
+            const int tl0 = 1 + e_chunk * RUN;
+            const DemodConst kc = demod_constants(p.gain);
+            const cf *yc = Y + e_pos;
+            // rows past the tile's last instant (the last run is shorter) read on into the DFT rows: finite
+            // values that are never used
+            cf y[RUN + 1];
+#pragma unroll
+            for (int k = 0; k <= RUN; k++) y[k] = yc[(tl0 - 1 + k) * YST];
+            float sum = 0.f;
+            float *drow = p.d + (size_t)(t0 + tl0) * 80 + e_c;
+            // one output: |Y|^2 into the tile sum, Y[t] conj(Y[t-1]) rho -> angle -> d[t][c]
+            auto one_real = [&](int k) {
+                const cf ya = y[k + 1], yb = y[k] * e_rho.xx;                  // rho = +-1
+                sum += ya.x * ya.x + ya.y * ya.y;
+                const cf pp = yb.xx * ya + yb.yy * mk(ya.y, -ya.x);
+                drow[k * 80] = demod_poly(kc, pp.x, pp.y);
+            };
+            auto one_any = [&](int k) {
+                const cf ya = y[k + 1], yb = cmulf(y[k], mk(e_rho.x, -e_rho.y));   // conj(Y[t-1] conj(rho)) = conj(Y[t-1]) rho
+                sum += ya.x * ya.x + ya.y * ya.y;
+                const cf pp = yb.xx * ya + yb.yy * mk(ya.y, -ya.x);
+                drow[k * 80] = demod_poly(kc, pp.x, pp.y);
+            };
+            constexpr int LAST = TT - (CH - 1) * RUN;            // instants of the last run
+            const bool whole = t0 + NT <= p.T;                   // block-uniform: every instant of the tile exists
             // instants of this run that exist: inside the tile and inside the stream
             const long long left = p.T - (t0 + tl0);
             int nval = NT - tl0 < RUN ? NT - tl0 : RUN;
             nval = left < nval ? (int)(left < 0 ? 0 : left) : nval;
-            float sum = 0.f, head = 0.f;                         // <= 9 terms per run
-            float dv[RUN];
-            // the run, instantiated once per address space of the de-rotation table so that the
-            // LDS copy is read with ds_read (a generic pointer would force flat loads + full waits).
-            // Fully unrolled: all bins of the run are fetched and de-rotated first, the demods
-            // are independent chains.
-            auto run = [&](const cf *krc) {
-                uint32_t ph = ph_t0 + (uint32_t)(tl0 - 1);
-                ph = ph >= period ? ph % period : ph;
-                cf y[RUN + 1];
+            if (whole && p.rho_real) {
 #pragma unroll
-                for (int k = 0; k <= RUN; k++) {
-                    const int tl = tl0 - 1 + k < NT ? tl0 - 1 + k : NT - 1;
-                    y[k] = cmulf(U[tl * UST + pos], krc[ph]);
+                for (int k = 0; k < LAST; k++) one_real(k);
+                if (e_chunk < CH - 1) {
+#pragma unroll
+                    for (int k = LAST; k < RUN; k++) one_real(k);
+                }
+            } else if (whole) {
+#pragma unroll
+                for (int k = 0; k < LAST; k++) one_any(k);
+                if (e_chunk < CH - 1) {
+#pragma unroll
+                    for (int k = LAST; k < RUN; k++) one_any(k);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RUN; k++) if (k < nval) one_any(k);
+            }
+            s_part[(e_chunk * 80 + e_c) * 2 + 0] = sum;
+            // head sum (first tail % TT instants of the tile): only the tile that holds the end of a
+            // window's last partial block is ever asked for it (block_sum_kernel)
+            const int hr = p.tail % TT;
+            float head = 0.f;
+            if (hr > 0 && tile % p.tiles_per_block == p.tail / TT) {            // block-uniform
+#pragma unroll
+                for (int k = 0; k < RUN; k++)
+                    if (k < nval && tl0 + k - 1 < hr) head += y[k + 1].x * y[k + 1].x + y[k + 1].y * y[k + 1].y;
+            }
+            s_part[(e_chunk * 80 + e_c) * 2 + 1] = head;
+            if (p.Z) {                                          // BTGPU_FLAG_DEBUG_Y: the de-rotated channel output
+                const int period = p.rot_period;
+                int ph = (int)((t0 + tl0) % period);
+                for (int k = 0; k < nval; k++) {
+                    const cf kr = ((const cf *)p.krot)[e_c * period + ph];
+                    ((cf *)p.Z)[(size_t)e_c * p.zstride + (t0 + tl0 + k)] = cmulf(yc[(tl0 + k) * YST], kr);
                     ph = ph + 1 == period ? 0 : ph + 1;
                 }
-                float *drow = p.d + (size_t)(t0 + tl0) * 80 + c;
-#pragma unroll
-                for (int k = 0; k < RUN; k++) {
-                    dv[k] = 0.f;
-                    if (k < nval) {
-                        const float m = y[k + 1].x * y[k + 1].x + y[k + 1].y * y[k + 1].y;
-                        sum += m;
-                        if (tl0 + k - 1 < hr) head += m;
-                        dv[k] = demod_fast(atab, p.gain, y[k + 1], y[k]);
-                        drow[k * 80] = dv[k];
-                        if (p.Z) ((cf *)p.Z)[(size_t)c * p.zstride + (t0 + tl0 + k)] = y[k + 1];   // BTGPU_FLAG_DEBUG_Y
-                    }
-                }
-            };
-            if (krot_lds) run(&s_krot[c * p.rot_period]);
-            else run((const cf *)p.krot + (size_t)c * p.rot_period);
-            part[(chunk * 80 + c) * 2 + 0] = sum;
-            part[(chunk * 80 + c) * 2 + 1] = head;
-#pragma unroll
-            for (int k = 0; k < RUN; k++) if (tl0 + k < NT) Db[c * NT + tl0 + k] = dv[k];
+            }
         }
         __syncthreads();
         mark(5);
         if (l < p.nsel) {
             double sum = 0.0, head = 0.0;
             for (int k = 0; k < CH; k++) {
-                sum += (double)part[(k * 80 + l) * 2];
-                head += (double)part[(k * 80 + l) * 2 + 1];
+                sum += (double)s_part[(k * 80 + l) * 2];
+                head += (double)s_part[(k * 80 + l) * 2 + 1];
             }
             p.ptile[(size_t)l * p.ntiles + tile] = sum;
             p.phead[(size_t)l * p.ntiles + tile] = head;         // first (tail % TT) instants of this tile
-        }
-        if (p.d2) {
-            // channel-major copy for finish_kernel, time fastest.  (Storing each run straight from
-            // its lane -- 64 different rows per store instruction -- clogs the CU's memory pipeline:
-            // measured 1.3x slower overall.)
-            for (int i = l; i < p.nsel * TT; i += NTH) {
-                const int cc = i / TT, tl = 1 + i % TT;
-                const long long t = t0 + tl;
-                if (t < p.T) p.d2[(size_t)cc * p.d2stride + t] = Db[cc * NT + tl];
-            }
         }
         mark(6);
     }
@@ -537,7 +573,7 @@ __global__ __launch_bounds__(256) void noise_stage2_kernel(
     const float2 *__restrict__ Z, long long zstride, int outs, int nw, int L3,
     const float *__restrict__ h3, const double *__restrict__ w, double *__restrict__ Qn, int S)
 {
-    extern __shared__ float4 lds4[];
+    HIP_DYNAMIC_SHARED(float4, lds4)
     const int k0 = blockIdx.x * kS2Slots, c = blockIdx.y;
     const int ks = (S - k0) < kS2Slots ? (S - k0) : kS2Slots;        // slots in this run
     const int nout = outs * (ks - 1) + nw;                            // y^ needed

@@ -1,0 +1,63 @@
+// Fiber scheduler of the host emulation (see hip/hip_runtime.h).  TEST INFRASTRUCTURE.
+#include <hip/hip_runtime.h>
+
+namespace emu {
+thread_local dim3 t_idx, b_idx, b_dim, g_dim;
+alignas(64) char dyn_lds[160 * 1024];
+
+namespace {
+constexpr size_t kStack = 256 * 1024;
+struct Fiber { ucontext_t ctx; char *stack = nullptr; bool done = false, waiting = false; dim3 tid; };
+std::vector<Fiber> fibers;
+ucontext_t sched_ctx;
+int cur = -1;
+const std::function<void()> *cur_body = nullptr;
+
+void trampoline()
+{
+    (*cur_body)();
+    fibers[cur].done = true;
+    swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+}  // namespace
+
+void barrier()
+{
+    fibers[cur].waiting = true;
+    swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()> &body)
+{
+    const unsigned nt = block.x * block.y * block.z;
+    fibers.resize(nt);
+    for (auto &f : fibers) if (!f.stack) f.stack = (char *)std::malloc(kStack);
+    cur_body = &body;
+    g_dim = grid; b_dim = block;
+    for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+    for (unsigned bx = 0; bx < grid.x; bx++) {
+        for (unsigned t = 0; t < nt; t++) {
+            Fiber &f = fibers[t];
+            f.done = f.waiting = false;
+            f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, trampoline, 0);
+        }
+        for (;;) {
+            unsigned alive = 0;
+            for (unsigned t = 0; t < nt; t++) {
+                Fiber &f = fibers[t];
+                if (f.done || f.waiting) continue;
+                cur = (int)t; t_idx = f.tid; b_idx = dim3(bx, by, bz);
+                swapcontext(&sched_ctx, &f.ctx);
+            }
+            for (auto &f : fibers) if (!f.done) alive++;
+            if (!alive) break;
+            // every live fiber sits at the barrier: release them (exited threads do not take part)
+            for (auto &f : fibers) f.waiting = false;
+        }
+    }
+}
+}  // namespace emu

@@ -1,0 +1,122 @@
+// Host emulation of the polyphase bank kernels (TEST INFRASTRUCTURE; see hip/hip_runtime.h):
+// runs pfb100_kernel -- the same source hipcc compiles for gfx950, launched through the same
+// bank_launch.h the runtime uses -- thread by thread on the CPU and hands the demodulated stream,
+// the tile energy sums and the noise stage-1 output back to the Python tests, which compare them
+// with the oracle.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+#include "bank_launch.h"
+
+using namespace btgpu;
+
+extern "C" {
+
+// iq: interleaved complex64, x_len samples; window 0 of the batch starts at sample w0 (margin in front).
+// mode: BTGPU_MODE_*; fuse: 1 = channel bank + fused noise stage 1, 0 = channel bank alone, 2 = also run the
+// stand-alone noise bank into Z.
+// Outputs (caller-allocated): d [G][80] float, P/Pt [nch][nb] double (block sums as block_sum_kernel forms them),
+// Z [nch][zstride] complex64 (noise stage 1), Y [nch][ystride] complex64 (de-rotated channel output, optional).
+// sizes[]: G, nb, nch, zstride, ystride, Tn (filled in).  Returns 0 or a negative error.
+int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_len, long long w0, int S, int fuse,
+                 float *d_out, double *P_out, double *Pt_out, float *Z_out, float *Y_out, long long *sizes)
+{
+    btgpu_config cfg{};
+    cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = 10.0; cfg.mode = mode;
+    static Design des; static FastPath fp;
+    int rc = make_design(cfg, des);
+    if (rc) return rc;
+    rc = make_fast_path(des, fp);
+    if (rc) return rc;
+    if (!fp.channel.available || !fp.noise.available || !fp.noise.pfb.available) return BTGPU_EUNSUPPORTED;
+    const btgpu_design &d = des.d;
+    const int nch = d.high_channel - d.low_channel + 1;
+    const int ops = des.outs_per_slot;
+    const long long G = (long long)ops * (S - 1) + d.ddc_out;
+    const int nb = (int)((G + ops - 1) / ops);
+    const NoiseStage &ns = fp.noise;
+    const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+    const long long zstride = (Tn + 10 + 63) / 64 * 64, ystride = (G + 63) / 64 * 64;
+    sizes[0] = G; sizes[1] = nb; sizes[2] = nch; sizes[3] = zstride; sizes[4] = ystride; sizes[5] = Tn;
+    if (!d_out) return 0;                                  // size query
+
+    const std::vector<uint16_t> mf = make_dft_pass2_map(kBankNT + 5, kBankThreads, 2);
+    const std::vector<uint16_t> mc = make_dft_pass2_map(kBankNT, kBankThreads, 2);
+    const std::vector<uint16_t> mn = make_dft_pass2_map(kNoiseNT, kBankThreads, 2);
+    if (mf.empty() || mc.empty() || mn.empty()) return BTGPU_EUNSUPPORTED;
+    const int ntiles_max = (int)((G + 24) / 25);
+    std::vector<double> ptile((size_t)nch * ntiles_max, 0.0), phead((size_t)nch * ntiles_max, 0.0);
+    // x must be readable as float4 at even sample offsets: keep a 16-byte aligned copy with slack
+    std::vector<float4> xbuf((size_t)x_len / 2 + 16);
+    std::memcpy(xbuf.data(), iq, (size_t)x_len * sizeof(float2));
+    BankBuffers b;
+    b.x = (const float2 *)xbuf.data();
+    b.taps_ch = (const float2 *)fp.channel.taps.data(); b.twiddle = (const float2 *)fp.channel.twiddle.data();
+    b.krot_ch = (const float2 *)fp.channel.krot.data(); b.rho_ch = (const float2 *)fp.channel.rho.data();
+    b.binpos_ch = fp.channel.binpos.data(); b.binnat_ch = fp.channel.binnat.data();
+    b.b2map_fused = mf.data(); b.b2map_ch = mc.data(); b.b2map_noise = mn.data();
+    b.d = d_out; b.ptile = ptile.data(); b.phead = phead.data();
+    b.Ydebug = (float2 *)Y_out; b.ystride = ystride;
+    b.taps_n = (const float2 *)ns.pfb.taps.data(); b.krot_n = (const float2 *)ns.pfb.krot.data();
+    b.binpos_n = ns.pfb.binpos.data();
+    b.Z = (float2 *)Z_out; b.zstride = zstride;
+    auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
+        if (lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", lds); std::abort(); }
+        std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);      // NaN pattern: reads of unwritten LDS show up
+        emu::launch(dim3((unsigned)grid), dim3((unsigned)threads), [&]() { kern(p); });
+    };
+    const int ntiles = launch_channel_bank(des, fp, fuse == 1, b, (size_t)x_len, w0, S, G, nb, L);
+    if (fuse == 2) launch_noise_bank(des, fp, b, (size_t)x_len, w0, S, L);
+    // block sums exactly as block_sum_kernel orders them (per block: tiles ascending)
+    const int tpb = ops / 25, tail_tiles = des.tail / 25;
+    for (int c = 0; c < nch; c++)
+        for (int bi = 0; bi < nb; bi++) {
+            double s = 0.0, h = 0.0;
+            for (int k = 0; k < tpb; k++) {
+                const int t = bi * tpb + k;
+                if (t < ntiles) {
+                    const double v = ptile[(size_t)c * ntiles + t];
+                    s += v;
+                    if (k < tail_tiles) h += v;
+                    else if (k == tail_tiles) h += phead[(size_t)c * ntiles + t];
+                }
+            }
+            P_out[(size_t)c * nb + bi] = s;
+            Pt_out[(size_t)c * nb + bi] = h;
+        }
+    return 0;
+}
+
+// staged-squelch stage 2 constants (host design) for the tests' numpy restatement of noise_stage2_kernel
+int emu_stage2_design(double fs, double fc, int mode, float *h3, double *w, int *ints /* outs, nw, L3, R, pad, Jm */)
+{
+    btgpu_config cfg{};
+    cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = 10.0; cfg.mode = mode;
+    static Design des; static FastPath fp;
+    int rc = make_design(cfg, des);
+    if (rc) return rc;
+    rc = make_fast_path(des, fp);
+    if (rc || !fp.noise.available) return BTGPU_EUNSUPPORTED;
+    const NoiseStage &ns = fp.noise;
+    ints[0] = ns.outs; ints[1] = ns.nw; ints[2] = ns.L3; ints[3] = ns.R; ints[4] = ns.pad; ints[5] = ns.Jm;
+    if (h3) std::memcpy(h3, ns.h3.data(), ns.h3.size() * sizeof(float));
+    if (w) std::memcpy(w, ns.weights.data(), ns.weights.size() * sizeof(double));
+    return 0;
+}
+
+// the pass-2 lane map, for the bank-conflict check of the tests
+int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
+{
+    const std::vector<uint16_t> m = make_dft_pass2_map(rows, lanes, sweeps);
+    if (m.empty()) return -1;
+    std::memcpy(out, m.data(), m.size() * sizeof(uint16_t));
+    return (int)m.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// tests/emu/hip/hip_runtime.h -- TEST INFRASTRUCTURE, not product code.
+//
+// A stand-in for <hip/hip_runtime.h> that lets the kernel sources under gr-bluetooth_amd/csrc be
+// compiled for the HOST (clang++, x86) and executed thread by thread: the build container has no
+// GPU, and the index arithmetic of the LDS-tiled kernels (tile spans, bank-aware layouts, lane ->
+// task tables, halo handling) is exactly what goes wrong first.  Every thread of a workgroup is
+// a ucontext fiber; __syncthreads() parks the fiber until all live fibers of the block arrive,
+// so LDS hazards that a missing barrier would cause show up as wrong results here too.  Only
+// what the kernels use is provided.  The product is built by hipcc for gfx950 only; nothing
+// under gr-bluetooth_amd/ includes this file.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)emu::dyn_lds;
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+namespace emu {
+extern thread_local dim3 t_idx, b_idx, b_dim, g_dim;
+extern char dyn_lds[160 * 1024];
+void barrier();
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+}  // namespace emu
+
+#define threadIdx emu::t_idx
+#define blockIdx emu::b_idx
+#define blockDim emu::b_dim
+#define gridDim emu::g_dim
+static inline void __syncthreads() { emu::barrier(); }
+static inline unsigned long long clock64() { return 0ULL; }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+static inline unsigned __funnelshift_r(unsigned lo, unsigned hi, unsigned sh)
+{
+    sh &= 31;
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+}
+static inline unsigned __brev(unsigned v)
+{
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+static inline float __fdiv_rn(float a, float b) { return a / b; }
+static inline void sincospi(double x, double *s, double *c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
+template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }   // fibers: one OS thread
+// wave-level exchanges are not emulated: kernels that need them are not run under the emulator
+template <class T> static inline T __shfl_down(T, int, int = 64) { std::fprintf(stderr, "emu: __shfl_down\n"); std::abort(); }
+static inline unsigned long long __ballot(int) { std::fprintf(stderr, "emu: __ballot\n"); std::abort(); }
