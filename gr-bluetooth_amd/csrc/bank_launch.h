@@ -8,7 +8,8 @@
 
 namespace btgpu {
 
-constexpr int kBankThreads = 256;
+constexpr int kBankThreads = 256;            // lanes per tile of the non-fused banks
+constexpr int kBankThreadsWide = 512;        // fused channel + noise bank: eight waves per tile
 constexpr int kBankNT = 26;                 // channel instants per tile (25 new + 1 halo for the demod)
 constexpr int kNoiseNT = 10;                // instants per tile of the stand-alone noise stage 1
 
@@ -16,7 +17,7 @@ struct BankBuffers {                        // device (or emulated) memory
     const float2 *x = nullptr;
     const float2 *taps_ch = nullptr, *twiddle = nullptr, *krot_ch = nullptr, *rho_ch = nullptr;
     const int *binpos_ch = nullptr, *binnat_ch = nullptr;
-    const uint16_t *b2map_fused = nullptr, *b2map_ch = nullptr, *b2map_noise = nullptr;
+    const uint16_t *b2map_fused = nullptr, *b2map_fused_wide = nullptr, *b2map_ch = nullptr, *b2map_noise = nullptr;
     float *d = nullptr; double *ptile = nullptr, *phead = nullptr;
     float2 *Ydebug = nullptr; long long ystride = 0;
     const float2 *taps_n = nullptr, *krot_n = nullptr; const int *binpos_n = nullptr;
@@ -36,7 +37,7 @@ inline size_t bank_lds_bytes(int span_samples, int nt, int nrows, bool chan)
 // Returns the number of channel tiles.
 template <class Launcher>
 inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_noise, const BankBuffers &b,
-                               size_t x_len, long long w0, int S, long long G, int nb, Launcher &&L)
+                               size_t x_len, long long w0, int S, long long G, int nb, Launcher &&L, bool wide = true)
 {
     const btgpu_design &d = des.d;
     const PfbBank &bk = fp.channel;
@@ -64,11 +65,16 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
         p.n_off = (int)(c0 * ns.R - delta0); p.n_u0 = (int)c0; p.pre_tiles = (int)((c0 + 4) / 5);
         p.n_T = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
         p.n_Z = b.Z; p.n_zstride = b.zstride;
-        p.b2map = b.b2map_fused;
+        p.b2map = wide ? b.b2map_fused_wide : b.b2map_fused;
         const size_t lds = bank_lds_bytes((250 - 1) + 250 * 4 + 15 * 100, NT, NT + 5, true);
         const int grid = p.ntiles + p.pre_tiles;
-        if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreads, true>, grid, kBankThreads, lds, p);
-        else L(pfb100_kernel<7, 1, NT, false, true, kBankThreads, true>, grid, kBankThreads, lds, p);
+        if (wide) {
+            if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreadsWide, true>, grid, kBankThreadsWide, lds, p);
+            else L(pfb100_kernel<7, 1, NT, false, true, kBankThreadsWide, true>, grid, kBankThreadsWide, lds, p);
+        } else {
+            if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreads, true>, grid, kBankThreads, lds, p);
+            else L(pfb100_kernel<7, 1, NT, false, true, kBankThreads, true>, grid, kBankThreads, lds, p);
+        }
     } else {
         p.b2map = b.b2map_ch;
         const size_t lds = bank_lds_bytes(bk.D * (NT - 1) + bk.Q * 100, NT, NT, true);

@@ -74,6 +74,7 @@ struct btgpu_handle {
     hipStream_t tail_stream = nullptr;
     struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
         DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_winfin, d_symbits, d_hdr;
+        DevBuf d_d;                           // demodulated stream of the batch: the tail reads it under the next batch's banks
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
@@ -106,9 +107,9 @@ struct btgpu_handle {
 
     // device memory
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
-    DevBuf d_Y, d_Yn, d_d, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
+    DevBuf d_Y, d_Yn, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index, d_winbits;
-    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_ch, d_b2map_noise;
+    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
     LaunchShape shape_s1;
     bool noise_pfb = false;
@@ -154,15 +155,15 @@ struct btgpu_handle {
     void release()
     {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
-                         &d_Y, &d_Yn, &d_d, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
+                         &d_Y, &d_Yn, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
-                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_ch, &d_b2map_noise,
+                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
-        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = nullptr;
+        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d.p = nullptr;
                       tc[1].d_winfin.p = tc[1].d_symbits.p = tc[1].d_hdr.p = nullptr; }
         for (TailCtx &t : tc) {
-            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr};
+            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -181,14 +182,15 @@ struct btgpu_handle {
         if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
     }
 
-    BankBuffers bank_buffers(const float2 *d_x) const
+    BankBuffers bank_buffers(const float2 *d_x, const DevBuf &d_d) const
     {
         BankBuffers b;
         b.x = d_x;
         b.taps_ch = (const float2 *)d_pfb_taps_ch.p; b.twiddle = (const float2 *)d_pfb_tw.p;
         b.krot_ch = (const float2 *)d_krot_ch.p; b.rho_ch = (const float2 *)d_rho_ch.p;
         b.binpos_ch = (const int *)d_binpos_ch.p; b.binnat_ch = (const int *)d_binnat_ch.p;
-        b.b2map_fused = (const uint16_t *)d_b2map_fused.p; b.b2map_ch = (const uint16_t *)d_b2map_ch.p;
+        b.b2map_fused = (const uint16_t *)d_b2map_fused.p; b.b2map_fused_wide = (const uint16_t *)d_b2map_fused_wide.p;
+        b.b2map_ch = (const uint16_t *)d_b2map_ch.p;
         b.b2map_noise = (const uint16_t *)d_b2map_noise.p;
         b.d = (float *)d_d.p; b.ptile = (double *)d_ptile.p; b.phead = (double *)d_phead.p;
         b.Ydebug = (keep_Y && use_pfb) ? (float2 *)d_Y.p : nullptr; b.ystride = ystride;
@@ -224,7 +226,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     int carried = BTGPU_OK;                                      // overflow of the batch harvested here
     if (t.pending) { int hrc = harvest(t); if (hrc == BTGPU_EOVERFLOW) carried = hrc; else if (hrc != BTGPU_OK) return hrc; }
     hipEvent_t *ev = t.ev;
-    DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin;
+    DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin, &d_d = t.d_d;
     DevBuf &d_winfin = t.d_winfin, &d_symbits = t.d_symbits;
     t.S = S; t.abs_first_slot = abs_first_slot;
 
@@ -240,11 +242,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 block sums P, Pt ----
     if (use_pfb) {
         constexpr int TT = kBankNT - 1;
-        BankBuffers bb = bank_buffers(d_x);
+        BankBuffers bb = bank_buffers(d_x, d_d);
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
         };
-        const int ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L);
+        static const bool wide = !(getenv("BTGPU_BANK_THREADS") && atoi(getenv("BTGPU_BANK_THREADS")) == 256);
+        const int ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, wide);
         HIPCHK(this, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, st,
                            (const double *)d_ptile.p, (const double *)d_phead.p, ntiles, ops / TT,
@@ -275,7 +278,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         if (fuse_noise) {
             // stage 1 already ran inside the channel-bank kernel
         } else if (noise_pfb) {
-            BankBuffers bb = bank_buffers(d_x);
+            BankBuffers bb = bank_buffers(d_x, d_d);
             auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
                 hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, ns_st, p);
             };
@@ -749,7 +752,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         {
             const std::vector<uint16_t> mf = make_dft_pass2_map(kBankNT + 5, kBankThreads, 2);
             const std::vector<uint16_t> mc = make_dft_pass2_map(kBankNT, kBankThreads, 2);
-            if (mf.empty() || mc.empty()) return fail(BTGPU_EUNSUPPORTED);
+            const std::vector<uint16_t> mw = make_dft_pass2_map(kBankNT + 5, kBankThreadsWide, 1);
+            if (mf.empty() || mc.empty() || mw.empty()) return fail(BTGPU_EUNSUPPORTED);
+            TRY(h->upload(h->d_b2map_fused_wide, mw.data(), mw.size() * sizeof(uint16_t)));
             TRY(h->upload(h->d_b2map_fused, mf.data(), mf.size() * sizeof(uint16_t)));
             TRY(h->upload(h->d_b2map_ch, mc.data(), mc.size() * sizeof(uint16_t)));
         }
@@ -783,7 +788,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_w, ns.weights.data(), ns.weights.size() * sizeof(double)));
     }
     h->drow = h->use_pfb ? 80 : win_drow(nch);            // the polyphase epilogue writes 80-float rows
-    TRY(h->alloc(h->d_d, (size_t)h->drow * (h->ystride + 64) * sizeof(float)));   // [G][drow], time-major
     if (nch > 80) return fail(BTGPU_EUNSUPPORTED);
     TRY(h->alloc(h->d_P, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Pt, (size_t)nch * h->nb_max * sizeof(double)));
@@ -811,6 +815,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->alloc(t.d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
         TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
         TRY(h->alloc(t.d_fin, (size_t)S * nch * sizeof(FinishRec)));
+        TRY(h->alloc(t.d_d, (size_t)h->drow * (h->ystride + 64) * sizeof(float)));   // [G][drow], time-major
         if (h->want_hdrs) TRY(h->alloc(t.d_hdr, (size_t)h->max_hits * sizeof(HeaderRec)));
         if (h->want_syms) {
             const size_t maxfin = (size_t)S * nch;            // one FinishRec per hit window, whatever max_hits is
@@ -826,7 +831,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     if (!h->async) {                      // synchronous mode: one context, used for every batch
         h->tc[1].d_winlen = h->tc[0].d_winlen; h->tc[1].d_hits = h->tc[0].d_hits;
-        h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin;
+        h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d = h->tc[0].d_d;
         h->tc[1].d_winfin = h->tc[0].d_winfin; h->tc[1].d_symbits = h->tc[0].d_symbits; h->tc[1].d_hdr = h->tc[0].d_hdr;
     }
 #undef TRY
@@ -836,10 +841,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))
-        fprintf(stderr, "btgpu_create: d=%p Z=%p ptile=%p\n", h->d_d.p, h->d_Z.p, h->d_ptile.p);
+        fprintf(stderr, "btgpu_create: d=%p,%p Z=%p ptile=%p\n", h->tc[0].d_d.p, h->tc[1].d_d.p, h->d_Z.p, h->d_ptile.p);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]
     *out = h;
@@ -1034,7 +1041,7 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
             if (first >= avail) return 0;
             count = std::min(count, avail - first);
             if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
-            if (hipMemcpy2D(out, sizeof(float), (const float *)h->d_d.p + first * h->drow + c, (size_t)h->drow * sizeof(float),
+            if (hipMemcpy2D(out, sizeof(float), (const float *)h->tc[h->cur ^ 1].d_d.p + first * h->drow + c, (size_t)h->drow * sizeof(float),
                             sizeof(float), count, hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
             return (long)count;
         }

@@ -178,12 +178,17 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 }
 
 template <int Q, int S, int NT, bool REAL, bool CHAN, int NTH, bool FUSEN = false>
-__global__ __launch_bounds__(NTH, (FUSEN ? 3 : 1)) void pfb100_kernel(PfbParams p)
+__global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kernel(PfbParams p)
 {
     constexpr int DH = S * 50;                               // hop: 2 D = S * 100
     constexpr int NQ = 15, NR = 250, NU = 5;                 // fused noise bank: taps/branch, hop, instants per tile
     static_assert(!FUSEN || (CHAN && DH == 50 && NT == 26), "fused noise stage needs the C79 channel geometry");
-    static_assert(NTH == 256, "lane roles below are laid out for four waves");
+    // NTH = 256: four waves, one per SIMD; the fused noise branches and the second sweeps of the DFT passes
+    // run behind the channel work.  NTH = 512: eight waves share one tile -- channel branches on waves 0-3,
+    // noise branches on waves 4-7, every DFT pass in one sweep, epilogue runs of five instants -- the
+    // tile lives half as long on the same LDS footprint, i.e. twice the waves per SIMD hide latency.
+    static_assert(NTH == 256 || NTH == 512, "lane roles below are laid out for four or eight waves");
+    constexpr int NSW = NTH == 256 ? 2 : 1;                  // sweeps of DFT pass 2 (host table: [NSW][NTH])
     constexpr int M = 100;
     constexpr int UST = kPfbUst, YST = kPfbYst;
     constexpr int TT = CHAN ? NT - 1 : NT;                   // new output instants per tile
@@ -201,10 +206,11 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 : 1)) void pfb100_kernel(PfbParams 
     cf *xs = lds;                                            // [span]
     cf *Y = lds;                                             // [NT][YST]      (after phase A)
     cf *U = lds + ASZ;                                       // [NROWS][UST]
+    float *s_part = (float *)U;                              // [NTH / 80][80][2] run sums: the channel rows of U are dead after pass 2
+    static_assert(!CHAN || (NTH / 80) * 80 * 2 <= 2 * NT * UST, "run sums must fit the dead DFT rows");
     __shared__ cf s_tw[100];
     __shared__ cf s_krot[CHAN ? 1 : 80 * 4];
     __shared__ int s_binpos[CHAN ? 1 : 80];
-    __shared__ float s_part[CHAN ? (NTH / 80) * 80 * 2 : 1];
     const bool krot_lds = !CHAN && p.rot_period <= 4 && p.nsel <= 80;
     const int l = threadIdx.x;
 
@@ -249,10 +255,11 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 : 1)) void pfb100_kernel(PfbParams 
     // even 2-2-1 split needs a second tap set per lane and measured slower)
     int nz_pp = 0, nz_i0 = 0, nz_cnt = 0;
     cf an[FUSEN ? NQ : 1];
-    if (FUSEN && l < 200) { nz_pp = l % 100; nz_i0 = l < 100 ? 0 : 3; nz_cnt = l < 100 ? 3 : 2; }
+    const int ln = NTH == 256 ? l : l - 256;                     // noise role index
+    if (FUSEN && ln >= 0 && ln < 200) { nz_pp = ln % 100; nz_i0 = ln < 100 ? 0 : 3; nz_cnt = ln < 100 ? 3 : 2; }
 
-    const int a_pp = l & 127, a_r = l >> 7;
-    const bool a_on = a_pp < M;
+    const int a_pp = l & 127, a_r = (l >> 7) & 1;
+    const bool a_on = a_pp < M && l < 256;
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
 
     // roles of the later phases, fetched behind the input loads
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 : 1)) void pfb100_kernel(PfbParams 
         // tables -> LDS and the constants of this lane's roles, issued behind the input loads:
         // memory returns in order, so the staging wait excludes them
         const cf tw = ((const cf *)p.twiddle)[l < 100 ? l : 99];
-        b2task = (uint32_t)p.b2map[l] | ((uint32_t)p.b2map[NTH + l] << 16);
+        b2task = (uint32_t)p.b2map[l] | ((uint32_t)(NSW == 2 ? p.b2map[NTH + l] : (uint16_t)0xffffu) << 16);
 #pragma unroll
         for (int q = 0; q < Q; q++) a[q] = ((const cf *)p.taps)[q * M + (a_on ? a_pp : 0)];
         if (FUSEN) {
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 : 1)) void pfb100_kernel(PfbParams 
     // ---- phase B2: DFT over p2.  Channel rows: bin m = m1 + 10 m2 -> Y[row][m] (the input tile is
     // dead); noise rows (and the noise-only bank) stay in place: bin at position 10 m1 + m2 ----
 #pragma unroll
-    for (int sw = 0; sw < 2; sw++) {
+    for (int sw = 0; sw < NSW; sw++) {
         const uint32_t task = sw == 0 ? (b2task & 0xffffu) : (b2task >> 16);
         if (task != 0xffffu) {
             const int row = (int)(task >> 4), m1 = (int)(task & 15u);

@@ -49,7 +49,8 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     const std::vector<uint16_t> mf = make_dft_pass2_map(kBankNT + 5, kBankThreads, 2);
     const std::vector<uint16_t> mc = make_dft_pass2_map(kBankNT, kBankThreads, 2);
     const std::vector<uint16_t> mn = make_dft_pass2_map(kNoiseNT, kBankThreads, 2);
-    if (mf.empty() || mc.empty() || mn.empty()) return BTGPU_EUNSUPPORTED;
+    const std::vector<uint16_t> mw = make_dft_pass2_map(kBankNT + 5, kBankThreadsWide, 1);
+    if (mf.empty() || mc.empty() || mn.empty() || mw.empty()) return BTGPU_EUNSUPPORTED;
     const int ntiles_max = (int)((G + 24) / 25);
     std::vector<double> ptile((size_t)nch * ntiles_max, 0.0), phead((size_t)nch * ntiles_max, 0.0);
     // x must be readable as float4 at even sample offsets: keep a 16-byte aligned copy with slack
@@ -60,7 +61,7 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     b.taps_ch = (const float2 *)fp.channel.taps.data(); b.twiddle = (const float2 *)fp.channel.twiddle.data();
     b.krot_ch = (const float2 *)fp.channel.krot.data(); b.rho_ch = (const float2 *)fp.channel.rho.data();
     b.binpos_ch = fp.channel.binpos.data(); b.binnat_ch = fp.channel.binnat.data();
-    b.b2map_fused = mf.data(); b.b2map_ch = mc.data(); b.b2map_noise = mn.data();
+    b.b2map_fused = mf.data(); b.b2map_fused_wide = mw.data(); b.b2map_ch = mc.data(); b.b2map_noise = mn.data();
     b.d = d_out; b.ptile = ptile.data(); b.phead = phead.data();
     b.Ydebug = (float2 *)Y_out; b.ystride = ystride;
     b.taps_n = (const float2 *)ns.pfb.taps.data(); b.krot_n = (const float2 *)ns.pfb.krot.data();
@@ -71,7 +72,8 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);      // NaN pattern: reads of unwritten LDS show up
         emu::launch(dim3((unsigned)grid), dim3((unsigned)threads), [&]() { kern(p); });
     };
-    const int ntiles = launch_channel_bank(des, fp, fuse == 1, b, (size_t)x_len, w0, S, G, nb, L);
+    // fuse: 1 = fused, eight waves per tile (the default); 3 = fused, four waves
+    const int ntiles = launch_channel_bank(des, fp, fuse == 1 || fuse == 3, b, (size_t)x_len, w0, S, G, nb, L, fuse != 3);
     if (fuse == 2) launch_noise_bank(des, fp, b, (size_t)x_len, w0, S, L);
     // block sums exactly as block_sum_kernel orders them (per block: tiles ascending)
     const int tpb = ops / 25, tail_tiles = des.tail / 25;
