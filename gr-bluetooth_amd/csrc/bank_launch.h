@@ -3,6 +3,8 @@
 // (tests/emu), so that the tile / halo / noise-grid arithmetic that is checked on the CPU is the
 // very code that runs in production.
 #pragma once
+#include <cstdlib>
+
 #include "design.h"
 #include "pfb100.hip.h"
 
@@ -56,6 +58,7 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
     p.gain = des.demod_gain;
     p.Z = b.Ydebug; p.zstride = b.ystride;
     p.prof = b.prof;
+    { static const int dbg = getenv("BTGPU_PFB_DBG") ? atoi(getenv("BTGPU_PFB_DBG")) : 0; p.dbg = dbg; }
     if (fuse_noise) {
         const NoiseStage &ns = fp.noise;
         const long long xn0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;

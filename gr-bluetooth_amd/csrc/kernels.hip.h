@@ -791,13 +791,46 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 // Continue the M&M recursion of the windows that reported hits (a few per cent) to the end of their
 // window and store len.  One lane per window; each lane stages its own column of the time-major
 // stream d[g][drow] into a private LDS slab, kFinRows rows at a time, all loads of a chunk in
-// flight together (a strided column costs one cache line per row, but it is only read for the hit
-// windows and off the critical path: a channel-major copy of the whole stream, which the bank
-// kernel used to write for this, cost more than it saved).  No cross-lane data => no barriers.
+// flight together.  The columns come packed from gather_columns_kernel (a channel-major copy of the
+// whole stream, which the bank kernel used to write for this, cost more than it saved); records
+// beyond the packed capacity are read straight from the stream, one cache line per row.  No
+// cross-lane data => no barriers.
+// Columns of the hit windows, made contiguous: the windows that continue (a few per cent) need the rest
+// of their column of the time-major stream, one float per 4 * drow bytes.  A latency-bound consumer
+// reading that stride pays a cache line per row per lane; this kernel pays it once, with every lane of
+// the machine in flight (one workgroup per window and pass, lanes = rows), and leaves col[f][r] =
+// d[row0 + r][c] for finish_kernel to stream.  Records beyond `cap` stay where they are (finish_kernel
+// then reads them strided).
+__global__ __launch_bounds__(256) void gather_columns_kernel(
+    WindowParams p, const float *__restrict__ d, int drow, long long d_rows, const FinishRec *__restrict__ fin,
+    const unsigned int *__restrict__ fin_count, float *__restrict__ col, int colstride, unsigned int cap)
+{
+    unsigned int n = *fin_count;
+    if (n > cap) n = cap;
+    for (unsigned int f = blockIdx.x; f < n; f += gridDim.x) {
+        const FinishRec r = fin[f];
+        if (r.done) continue;                                        // block-uniform
+        const int k = r.w / p.nch, c = r.w - k * p.nch;
+        const long long row0 = (long long)k * p.outs_per_slot;
+        const int nvalid = (int)((d_rows - row0) < p.ddc_out ? (d_rows - row0) : p.ddc_out);
+        const float *src = d + (size_t)row0 * drow + c;
+        float *dst = col + (size_t)f * colstride;
+        const int first = (int)(r.ii & ~63u);                        // rows below the window's position are never read again
+        for (int i = first + (int)threadIdx.x; i < nvalid; i += 4 * 256) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int q = i + j * 256; v[j] = src[(size_t)(q < nvalid ? q : nvalid - 1) * drow]; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int q = i + j * 256; if (q < nvalid) dst[q] = v[j]; }
+        }
+    }
+}
+
 constexpr int kFinRows = 32;
 template <bool SYMS>
 __global__ __launch_bounds__(64) void finish_kernel(
     WindowParams p, const float *__restrict__ d, int drow, long long d_rows,
+    const float *__restrict__ colbuf, int colstride, unsigned int colcap,
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
     const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits)
 {
@@ -821,7 +854,10 @@ __global__ __launch_bounds__(64) void finish_kernel(
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
     const long long row0 = (long long)k * p.outs_per_slot;
-    const float *col = d + (size_t)row0 * drow + c;              // this window's demod samples: every drow-th float
+    // this window's demod samples: contiguous in the gathered columns, every drow-th float of the stream otherwise
+    const bool packed = colbuf != nullptr && f < colcap;
+    const float *col = packed ? colbuf + (size_t)f * colstride : d + (size_t)row0 * drow + c;
+    const int estride = packed ? 1 : drow;
     const unsigned int nvalid = (unsigned int)((d_rows - row0) < p.ddc_out ? (d_rows - row0) : p.ddc_out);
     float mu = r.mu, omega = r.omega, last = r.last;
     unsigned int ii = r.ii;
@@ -833,7 +869,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     {
         float v[RING];
 #pragma unroll
-        for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * drow]; }
+        for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * estride]; }
 #pragma unroll
         for (unsigned int j = 0; j < RING; j++) v[j] = hi + j < nvalid ? v[j] : 0.f;       // loads unconditional, values selected
 #pragma unroll
@@ -844,7 +880,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
         // issue the loads of the next kFinRows rows now; they land while the steps below run
         float v[kFinRows];
 #pragma unroll
-        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * drow]; }   // unconditional
+        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * estride]; }   // unconditional
         // consume every step whose 8-tap window lies inside the resident rows [.., hi)
         while (ii + 8 <= hi && ii < ni && oo < demod_n) {
             const int imu = (int)rintf(mu * 128.0f);             // mu in [0, 1) -> 0..128

@@ -79,6 +79,7 @@ struct PfbParams {
     long long n_T;               // noise instants in total
     float2 *n_Z; long long n_zstride;
     unsigned long long *prof;    // optional [grid][8] per-phase cycle sums of wave 0 (BTGPU_PFB_PROF diagnostics)
+    int dbg;                     // timing experiments only (BTGPU_PFB_DBG): 1 no input loads, 2 no d stores, 4 no Z stores
 };
 
 // Complex values are two-float ext vectors: with contraction enabled a * b + c on them is one
@@ -283,7 +284,10 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
         constexpr int PER = (N4 + NTH - 1) / NTH;
         float4 v[PER];
         const bool interior = a0 >= 0 && a0 + 2LL * N4 <= p.x_len;
-        if (interior) {                                      // block-uniform: one straight run of loads
+        if (p.dbg & 1) {
+#pragma unroll
+            for (int j = 0; j < PER; j++) v[j] = make_float4(1.f, 0.5f, -0.25f, 0.125f);
+        } else if (interior) {                               // block-uniform: one straight run of loads
             const float4 *xb = (const float4 *)(p.x + a0);
 #pragma unroll
             for (int j = 0; j < PER; j++) v[j] = xb[l + j * NTH < N4 ? l + j * NTH : N4 - 1];
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
             if (i >= p.nsel * NU) break;
             const int c = i / NU, ui = i % NU;
             const int u = nz_u0 + ui;
-            if (u < 0 || u >= p.n_T) continue;
+            if (u < 0 || u >= p.n_T || (p.dbg & 4)) continue;
             ((cf *)p.n_Z)[(size_t)c * p.n_zstride + u] = cmulf(U[(NT + ui) * UST + nz_pos[j]], nz_rot[j]);
         }
     }
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
 #pragma unroll
             for (int k = 0; k <= RUN; k++) y[k] = yc[(tl0 - 1 + k) * YST];
             float sum = 0.f;
-            float *drow = p.d + (size_t)(t0 + tl0) * 80 + e_c;
+            float *drow = (p.dbg & 2) ? p.d + l : p.d + (size_t)(t0 + tl0) * 80 + e_c;
             // one output: |Y|^2 into the tile sum, Y[t] conj(Y[t-1]) rho -> angle -> d[t][c]
             auto one_real = [&](int k) {
                 const cf ya = y[k + 1], yb = y[k] * e_rho.xx;                  // rho = +-1

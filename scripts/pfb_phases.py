@@ -31,7 +31,7 @@ for _ in range(nb):
     blk.poll_arrays()
 c = blk.debug_fetch(9, 0, 0, 1 << 24).astype(np.float64).reshape(-1, 8).sum(axis=0)
 names = ["stage input", "A branch FIR (+noise)", "B1 DFT pass + twiddle", "B2 DFT pass", "C noise store",
-         "epilogue runs", "tile sums + d2 copy", "carry shift"]
+         "epilogue runs", "tile sums", "-"]
 tot = c.sum()
 for n, v in zip(names, c):
     print("%-24s %6.2f %%" % (n, 100.0 * v / tot))
