@@ -208,7 +208,9 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
     cf *Y = lds;                                             // [NT][YST]      (after phase A)
     cf *U = lds + ASZ;                                       // [NROWS][UST]
     float *s_part = (float *)U;                              // [NTH / 80][80][2] run sums: the channel rows of U are dead after pass 2
-    static_assert(!CHAN || (NTH / 80) * 80 * 2 <= 2 * NT * UST, "run sums must fit the dead DFT rows");
+    float *s_d = (float *)U + (NTH / 80) * 80 * 2;           // [TT][80] angles of the tile on their way to d
+    static_assert(!CHAN || ((NTH / 80) * 80 * 2) % 4 == 0, "s_d must be 16-byte aligned");
+    static_assert(!CHAN || (NTH / 80) * 80 * 2 + TT * 80 <= 2 * NT * UST, "run sums and the angle tile must fit the dead DFT rows");
     __shared__ cf s_tw[100];
     __shared__ cf s_krot[CHAN ? 1 : 80 * 4];
     __shared__ int s_binpos[CHAN ? 1 : 80];
@@ -429,16 +431,15 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
     mark(3);
 
     // ---- phase C ----
+    // owned noise instants -> stage-1 output Z (de-rotated; consumed by noise_stage2_kernel): the bins are
+    // fetched here, unconditionally, and leave after the channel epilogue, whose arithmetic covers the
+    // LDS round trip
+    cf nz_val[NZT];
     if (FUSEN) {
-        // owned noise instants -> stage-1 output Z (de-rotated; consumed by noise_stage2_kernel)
 #pragma unroll
         for (int j = 0; j < NZT; j++) {
-            const int i = l + j * NTH;
-            if (i >= p.nsel * NU) break;
-            const int c = i / NU, ui = i % NU;
-            const int u = nz_u0 + ui;
-            if (u < 0 || u >= p.n_T || (p.dbg & 4)) continue;
-            ((cf *)p.n_Z)[(size_t)c * p.n_zstride + u] = cmulf(U[(NT + ui) * UST + nz_pos[j]], nz_rot[j]);
+            const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
+            nz_val[j] = U[(NT + i % NU) * UST + nz_pos[j]];
         }
     }
     mark(4);
@@ -469,7 +470,10 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
 #pragma unroll
             for (int k = 0; k <= RUN; k++) y[k] = yc[(tl0 - 1 + k) * YST];
             float sum = 0.f;
-            float *drow = (p.dbg & 2) ? p.d + l : p.d + (size_t)(t0 + tl0) * 80 + e_c;
+            // The TT rows of d this tile owns are one contiguous block of 320 TT bytes: the angles cross the
+            // LDS tile s_d[TT][80] (lanes = channels: consecutive banks) and leave as 16-byte pieces below,
+            // a quarter of the store instructions a lane-per-angle store needs
+            float *drow = s_d + (tl0 - 1) * 80 + e_c;
             // one output: |Y|^2 into the tile sum, Y[t] conj(Y[t-1]) rho -> angle -> d[t][c]
             auto one_real = [&](int k) {
                 const cf ya = y[k + 1], yb = y[k] * e_rho.xx;                  // rho = +-1
@@ -528,8 +532,28 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
                 }
             }
         }
+    }
+    if (FUSEN) {                                                 // (pre-tiles too: they own noise instants only)
+#pragma unroll
+        for (int j = 0; j < NZT; j++) {
+            const int i = l + j * NTH;
+            const int c = i / NU, ui = i % NU;
+            const int u = nz_u0 + ui;
+            if (i < p.nsel * NU && u >= 0 && u < p.n_T && !(p.dbg & 4))
+                ((cf *)p.n_Z)[(size_t)c * p.n_zstride + u] = cmulf(nz_val[j], nz_rot[j]);
+        }
+    }
+    if (CHAN && tile >= 0) {
         __syncthreads();
         mark(5);
+        {
+            // d rows of the tile: TT * 20 pieces of 16 bytes, contiguous in HBM (row stride = row size)
+            const long long g1 = t0 + 1;                             // first owned instant
+            const long long rows = p.T - g1 < TT ? p.T - g1 : TT;    // ... inside the stream
+            float4 *dst = (float4 *)(p.d + (size_t)g1 * 80);
+            if (!(p.dbg & 2))
+                for (int i = l; i < (int)rows * 20; i += NTH) dst[i] = ((const float4 *)s_d)[i];
+        }
         if (l < p.nsel) {
             double sum = 0.0, head = 0.0;
             for (int k = 0; k < CH; k++) {
