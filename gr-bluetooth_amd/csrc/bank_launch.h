@@ -25,9 +25,6 @@ struct BankBuffers {                        // device (or emulated) memory
     const float2 *taps_n = nullptr, *krot_n = nullptr; const int *binpos_n = nullptr;
     float2 *Z = nullptr; long long zstride = 0;
     unsigned long long *prof = nullptr;
-    unsigned int *tile_ctr = nullptr;       // [16] per-XCD tile counters, zeroed by the caller before every batch: 0..7 channel
-                                            // (+ fused noise) bank, 8..15 stand-alone noise bank; null = one tile per workgroup
-    int resident_wgs = 0;                   // workgroups the device keeps resident (persistent launch size)
 };
 
 inline size_t bank_lds_bytes(int span_samples, int nt, int nrows, bool chan)
@@ -61,7 +58,6 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
     p.gain = des.demod_gain;
     p.Z = b.Ydebug; p.zstride = b.ystride;
     p.prof = b.prof;
-    p.tile_ctr = b.tile_ctr;
     { static const int dbg = getenv("BTGPU_PFB_DBG") ? atoi(getenv("BTGPU_PFB_DBG")) : 0; p.dbg = dbg; }
     if (fuse_noise) {
         const NoiseStage &ns = fp.noise;
@@ -74,9 +70,7 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
         p.n_Z = b.Z; p.n_zstride = b.zstride;
         p.b2map = wide ? b.b2map_fused_wide : b.b2map_fused;
         const size_t lds = bank_lds_bytes((250 - 1) + 250 * 4 + 15 * 100, NT, NT + 5, true);
-        const int ntl = p.ntiles + p.pre_tiles;
-        const int grid = (b.tile_ctr && b.resident_wgs > 0 && b.resident_wgs < ntl) ? b.resident_wgs : ntl;
-        if (grid == ntl) p.tile_ctr = nullptr;
+        const int grid = p.ntiles + p.pre_tiles;
         if (wide) {
             if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreadsWide, true>, grid, kBankThreadsWide, lds, p);
             else L(pfb100_kernel<7, 1, NT, false, true, kBankThreadsWide, true>, grid, kBankThreadsWide, lds, p);
@@ -87,10 +81,8 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
     } else {
         p.b2map = b.b2map_ch;
         const size_t lds = bank_lds_bytes(bk.D * (NT - 1) + bk.Q * 100, NT, NT, true);
-        const int grid = (b.tile_ctr && b.resident_wgs > 0 && b.resident_wgs < p.ntiles) ? b.resident_wgs : p.ntiles;
-        if (grid == p.ntiles) p.tile_ctr = nullptr;
-        if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreads>, grid, kBankThreads, lds, p);
-        else L(pfb100_kernel<7, 1, NT, false, true, kBankThreads>, grid, kBankThreads, lds, p);
+        if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreads>, p.ntiles, kBankThreads, lds, p);
+        else L(pfb100_kernel<7, 1, NT, false, true, kBankThreads>, p.ntiles, kBankThreads, lds, p);
     }
     return p.ntiles;
 }
@@ -116,9 +108,7 @@ inline void launch_noise_bank(const Design &des, const FastPath &fp, const BankB
     p.Z = b.Z; p.zstride = b.zstride;
     p.b2map = b.b2map_noise;
     const size_t lds = bank_lds_bytes(bk.D * (NT - 1) + bk.Q * 100, NT, NT, false);
-    const int grid = (b.tile_ctr && b.resident_wgs > 0 && b.resident_wgs < p.ntiles) ? b.resident_wgs : p.ntiles;
-    p.tile_ctr = grid == p.ntiles ? nullptr : b.tile_ctr + 8;
-    L(pfb100_kernel<15, 5, NT, false, false, kBankThreads>, grid, kBankThreads, lds, p);
+    L(pfb100_kernel<15, 5, NT, false, false, kBankThreads>, p.ntiles, kBankThreads, lds, p);
 }
 
 }  // namespace btgpu

@@ -70,7 +70,6 @@ struct btgpu_handle {
     std::vector<float> pre;          // the `margin` samples preceding the next work() buffer
     int device = 0;
     hipStream_t stream = nullptr;
-    int resident_wgs = 0; bool persistent = true; // bank kernels: workgroups launched (they pull tiles from per-XCD counters)
     int drow = 80;                               // row stride (floats) of the time-major demodulated stream
     int colstride = 0; unsigned int colcap = 0;  // packed hit-window columns: floats per column, columns per batch
     hipStream_t tail_stream = nullptr;
@@ -112,7 +111,7 @@ struct btgpu_handle {
     DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index, d_winbits;
-    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise, d_tilectr;
+    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
     LaunchShape shape_s1;
     bool noise_pfb = false;
@@ -160,7 +159,7 @@ struct btgpu_handle {
         DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
-                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_tilectr,
+                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d.p = tc[1].d_col.p = nullptr;
@@ -201,8 +200,6 @@ struct btgpu_handle {
         b.binpos_n = (const int *)d_binpos_n.p;
         b.Z = (float2 *)d_Z.p; b.zstride = zstride;
         b.prof = (unsigned long long *)d_prof.p;
-        b.tile_ctr = persistent ? (unsigned int *)d_tilectr.p : nullptr;
-        b.resident_wgs = resident_wgs;
         return b;
     }
     int process_batch(const float2 *d_x, size_t x_len, long long w0, uint64_t abs_first_slot, int S, hipStream_t st);
@@ -236,7 +233,6 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     t.S = S; t.abs_first_slot = abs_first_slot;
 
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
-    if (use_pfb || noise_pfb) HIPCHK(this, hipMemsetAsync(d_tilectr.p, 0, 16 * sizeof(unsigned int), st));   // per-XCD tile counters
     HIPCHK(this, hipEventRecord(ev[0], st));
     // fork: the noise bank only needs the input, it runs on its own stream beside the channel bank
     hipStream_t ns_st = overlap_noise ? noise_stream : st;
@@ -362,10 +358,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             // (the kernel strides over the records: the grid only bounds the waves in flight)
             const long long cap = (long long)S * nch;
             const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
-            // the hit windows' columns, packed: a strided gather with many loads in flight, kept to one workgroup
-            // per CU so that it does not crowd the next batch's bank kernel off the machine
-            static const unsigned gather_grid = getenv("BTGPU_GATHER_GRID") ? (unsigned)atoi(getenv("BTGPU_GATHER_GRID")) : 256u;
-            hipLaunchKernelGGL(gather_columns_kernel, dim3(gather_grid), dim3(256), 0, tail_stream, p, (const float *)d_d.p, drow, G,
+            // the hit windows' columns, packed (throughput-bound strided gather, every CU)
+            hipLaunchKernelGGL(gather_columns_kernel, dim3(2048), dim3(256), 0, tail_stream, p, (const float *)d_d.p, drow, G,
                                (const FinishRec *)d_fin.p, (const unsigned int *)d_hitcount.p + 1, (float *)t.d_col.p,
                                colstride, colcap);
             if (want_syms)
@@ -810,11 +804,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_Pt, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Q, (size_t)nch * S * sizeof(double)));
     TRY(h->upload(h->d_mmse, des.mmse, sizeof des.mmse));
-    TRY(h->alloc(h->d_tilectr, 16 * sizeof(unsigned int)));
-    // persistent bank kernels: a few workgroups per CU are enough (three fit the LDS; a late extra one finds the
-    // counters exhausted and leaves)
-    h->resident_wgs = 4 * prop.multiProcessorCount;
-    h->persistent = !(getenv("BTGPU_BANK_PERSIST") && atoi(getenv("BTGPU_BANK_PERSIST")) == 0);
     TRY(h->upload(h->d_atan, des.atan_tab, sizeof des.atan_tab));
     if (getenv("BTGPU_PFB_PROF")) {                       // per-phase cycle sums of the bank kernel (diagnostics)
         TRY(h->alloc(h->d_prof, (size_t)(h->ntiles_max + 64) * 8 * sizeof(unsigned long long)));

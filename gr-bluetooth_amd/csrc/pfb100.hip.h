@@ -80,7 +80,6 @@ struct PfbParams {
     float2 *n_Z; long long n_zstride;
     unsigned long long *prof;    // optional [grid][8] per-phase cycle sums of wave 0 (BTGPU_PFB_PROF diagnostics)
     int dbg;                     // timing experiments only (BTGPU_PFB_DBG): 1 no input loads, 2 no d stores, 4 no Z stores
-    unsigned int *tile_ctr;      // [8] per-XCD tile counters (zeroed before the launch): persistent workgroups; null: one tile each
 };
 
 // Complex values are two-float ext vectors: with contraction enabled a * b + c on them is one
@@ -218,18 +217,10 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
     const bool krot_lds = !CHAN && p.rot_period <= 4 && p.nsel <= 80;
     const int l = threadIdx.x;
 
-    // Persistent workgroups (p.tile_ctr): a workgroup takes tile after tile from the share of the XCD it
-    // runs on (consecutive tiles share the filter-length halo of their input span: kept in one L2), through
-    // that XCD's counter -- whoever is resident works, nobody waits for a late starter.  Staying resident
-    // keeps the tables, taps and lane roles in registers, and the stores of a tile drain under the input
-    // loads of the next one instead of holding up the workgroup's exit.  Pre-tiles of the fused noise
-    // bank come first.  Without counters: one tile per workgroup (blockIdx picks it).
+    // one workgroup = one tile; XCD-aware order (pre-tiles of the fused noise bank come first)
     const int ntl = p.ntiles + (FUSEN ? p.pre_tiles : 0);
-    __shared__ int s_tile[2];
-    const int xcd = blockIdx.x & 7;
-    const int x_first = xcd_remap(xcd, ntl);                     // first tile of this XCD's share
-    const int x_count = ntl / 8 + (xcd < ntl % 8 ? 1 : 0);
-    if (l == 0) s_tile[0] = p.tile_ctr ? (int)atomicAdd(&p.tile_ctr[xcd], 1u) : (int)(blockIdx.x >> 3);
+    const int tile_u = xcd_remap(blockIdx.x, ntl);
+    const int tile = tile_u - (FUSEN ? p.pre_tiles : 0);
 
     unsigned long long tprev = p.prof ? clock64() : 0ULL;
     auto mark = [&](int k) {
@@ -272,60 +263,18 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
 
     const int a_pp = l & 127, a_r = (l >> 7) & 1;
     const bool a_on = a_pp < M && l < 256;
+    const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
 
-    // ---- once per workgroup: tables -> LDS, branch taps and the constants of this lane's roles -> registers
+    // roles of the later phases, fetched behind the input loads
     constexpr int NZT = FUSEN ? (80 * NU + NTH - 1) / NTH : 1;   // noise outputs per lane (phase C')
-    int nz_pos[NZT], nz_c[NZT], nz_ui[NZT];
+    const int nz_u0 = FUSEN ? p.n_u0 + NU * tile : 0;            // first noise instant owned by this tile
+    int nz_pos[NZT]; cf nz_rot[NZT];
     uint32_t b2task = 0xffffffffu;                               // both sweeps of pass 2: lo | hi << 16
     constexpr int CH = NTH / 80;                                 // epilogue: CH runs of <= RUN instants per channel
     constexpr int RUN = (TT + CH - 1) / CH;
     const int e_chunk = l / 80, e_c = l % 80;
     const bool e_on = CHAN && e_chunk < CH && e_c < p.nsel;
     int e_pos = 0; cf e_rho = mk(1.f, 0.f);
-    const DemodConst kc = demod_constants(p.gain);
-    {
-        const cf tw = ((const cf *)p.twiddle)[l < 100 ? l : 99];
-        b2task = (uint32_t)p.b2map[l] | ((uint32_t)(NSW == 2 ? p.b2map[NTH + l] : (uint16_t)0xffffu) << 16);
-#pragma unroll
-        for (int q = 0; q < Q; q++) a[q] = ((const cf *)p.taps)[q * M + (a_on ? a_pp : 0)];
-        if (FUSEN) {
-#pragma unroll
-            for (int q = 0; q < NQ; q++) an[q] = ((const cf *)p.n_taps)[q * M + nz_pp];
-#pragma unroll
-            for (int j = 0; j < NZT; j++) {
-                const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
-                nz_c[j] = i / NU; nz_ui[j] = i % NU;
-                nz_pos[j] = p.n_binpos[nz_c[j]];                 // bin position of this lane's noise outputs (phase C')
-            }
-        }
-        if (CHAN) {
-            const int cc = e_c < p.nsel ? e_c : p.nsel - 1;
-            e_pos = p.binnat[cc];
-            e_rho = ((const cf *)p.rho)[cc];
-        } else {
-            constexpr int NK = (80 * 4 + NTH - 1) / NTH;
-            const int nkr = p.nsel * p.rot_period;
-            const int bp = p.binpos[l < p.nsel ? l : p.nsel - 1];
-            if (l < p.nsel && l < 80) s_binpos[l] = bp;
-            if (krot_lds) {
-#pragma unroll
-                for (int k = 0; k < NK; k++) {
-                    const int i = l + k * NTH;
-                    const cf kr = ((const cf *)p.krot)[i < nkr ? i : nkr - 1];
-                    if (i < nkr) s_krot[i] = kr;
-                }
-            }
-        }
-        if (l < 100) s_tw[l] = tw;
-    }
-    __syncthreads();
-
-  for (int it = 0, idx = s_tile[0]; idx < x_count; it++) {      // block-uniform
-    const int tile_u = x_first + idx;
-    const int tile = tile_u - (FUSEN ? p.pre_tiles : 0);
-    const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);   // global instant of local 0
-    const int nz_u0 = FUSEN ? p.n_u0 + NU * tile : 0;            // first noise instant owned by this tile
-    cf nz_rot[NZT];
 
     // ---- stage the input span.  The tile starts at the even sample a0 <= gs so that every piece is
     // a 16-byte aligned load; all loads of a lane are issued before its first LDS store (one
@@ -348,19 +297,47 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
 #pragma unroll
             for (int j = 0; j < PER; j++) v[j] = load_piece_edge(a0, l + j * NTH < N4 ? l + j * NTH : N4 - 1);
         }
-        // issued behind the input loads (memory returns in order: the staging wait excludes them): the
-        // de-rotation factors of this lane's noise outputs, and the next tile of this workgroup
+        // tables -> LDS and the constants of this lane's roles, issued behind the input loads:
+        // memory returns in order, so the staging wait excludes them
+        const cf tw = ((const cf *)p.twiddle)[l < 100 ? l : 99];
+        b2task = (uint32_t)p.b2map[l] | ((uint32_t)(NSW == 2 ? p.b2map[NTH + l] : (uint16_t)0xffffu) << 16);
+#pragma unroll
+        for (int q = 0; q < Q; q++) a[q] = ((const cf *)p.taps)[q * M + (a_on ? a_pp : 0)];
         if (FUSEN) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) an[q] = ((const cf *)p.n_taps)[q * M + nz_pp];
+            // bin position and de-rotation factor of this lane's noise outputs (phase C')
             const int np = p.n_period;
             const int ph0 = ((nz_u0 % np) + np) % np;             // block-uniform
 #pragma unroll
             for (int j = 0; j < NZT; j++) {
-                int ph = ph0 + nz_ui[j];
+                const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
+                const int c = i / NU;
+                int ph = ph0 + i % NU;
                 ph = ph >= np ? ph - np : ph;
-                nz_rot[j] = ((const cf *)p.n_krot)[(size_t)nz_c[j] * np + ph];
+                nz_pos[j] = p.n_binpos[c];
+                nz_rot[j] = ((const cf *)p.n_krot)[(size_t)c * np + ph];
             }
         }
-        if (l == 0) s_tile[(it + 1) & 1] = p.tile_ctr ? (int)atomicAdd(&p.tile_ctr[xcd], 1u) : x_count;
+        if (CHAN) {
+            const int cc = e_c < p.nsel ? e_c : p.nsel - 1;
+            e_pos = p.binnat[cc];
+            e_rho = ((const cf *)p.rho)[cc];
+        } else {
+            constexpr int NK = (80 * 4 + NTH - 1) / NTH;
+            const int nkr = p.nsel * p.rot_period;
+            const int bp = p.binpos[l < p.nsel ? l : p.nsel - 1];
+            if (l < p.nsel && l < 80) s_binpos[l] = bp;
+            if (krot_lds) {
+#pragma unroll
+                for (int k = 0; k < NK; k++) {
+                    const int i = l + k * NTH;
+                    const cf kr = ((const cf *)p.krot)[i < nkr ? i : nkr - 1];
+                    if (i < nkr) s_krot[i] = kr;
+                }
+            }
+        }
+        if (l < 100) s_tw[l] = tw;
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const int i = l + j * NTH;
@@ -461,7 +438,8 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
     if (FUSEN) {
 #pragma unroll
         for (int j = 0; j < NZT; j++) {
-            nz_val[j] = U[(NT + nz_ui[j]) * UST + nz_pos[j]];
+            const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
+            nz_val[j] = U[(NT + i % NU) * UST + nz_pos[j]];
         }
     }
     mark(4);
@@ -484,6 +462,7 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
     if (CHAN && tile >= 0) {
         if (e_on) {
             const int tl0 = 1 + e_chunk * RUN;
+            const DemodConst kc = demod_constants(p.gain);
             const cf *yc = Y + e_pos;
             // rows past the tile's last instant (the last run is shorter) read on into the DFT rows: finite
             // values that are never used
@@ -557,9 +536,11 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
     if (FUSEN) {                                                 // (pre-tiles too: they own noise instants only)
 #pragma unroll
         for (int j = 0; j < NZT; j++) {
-            const int u = nz_u0 + nz_ui[j];
-            if (l + j * NTH < p.nsel * NU && u >= 0 && u < p.n_T && !(p.dbg & 4))
-                ((cf *)p.n_Z)[(size_t)nz_c[j] * p.n_zstride + u] = cmulf(nz_val[j], nz_rot[j]);
+            const int i = l + j * NTH;
+            const int c = i / NU, ui = i % NU;
+            const int u = nz_u0 + ui;
+            if (i < p.nsel * NU && u >= 0 && u < p.n_T && !(p.dbg & 4))
+                ((cf *)p.n_Z)[(size_t)c * p.n_zstride + u] = cmulf(nz_val[j], nz_rot[j]);
         }
     }
     if (CHAN && tile >= 0) {
@@ -584,11 +565,6 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
         }
         mark(6);
     }
-    // next tile of this workgroup (fetched while the input loads were in flight).  Whatever this tile still
-    // reads after its last barrier -- the angle tile and the run sums in the DFT rows -- is written again
-    // only behind the first barrier of the next round; the input span (bin rows Y) is dead by now.
-    idx = s_tile[(it + 1) & 1];
-  }
 }
 
 // tile sums -> per-slot-block sums P[c][b] and block-head sums Pt[c][b] (first `tail` instants of

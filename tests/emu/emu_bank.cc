@@ -67,11 +67,6 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     b.taps_n = (const float2 *)ns.pfb.taps.data(); b.krot_n = (const float2 *)ns.pfb.krot.data();
     b.binpos_n = ns.pfb.binpos.data();
     b.Z = (float2 *)Z_out; b.zstride = zstride;
-    // fuse + 8: persistent workgroups (16 of them pull every tile through the per-XCD counters)
-    unsigned int ctr[16] = {0};
-    const bool persist = (fuse & 8) != 0;
-    fuse &= 7;
-    if (persist) { b.tile_ctr = ctr; b.resident_wgs = 16; }
     auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
         if (lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", lds); std::abort(); }
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);      // NaN pattern: reads of unwritten LDS show up

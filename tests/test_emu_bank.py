@@ -101,10 +101,9 @@ def c79_capture(synth):
     return fs, fc, S, iq
 
 
-@pytest.mark.parametrize("fuse", [1, 9, 3, 11, 0, 8])
+@pytest.mark.parametrize("fuse", [1, 3, 0])
 def test_channel_bank_vs_oracle_c79(emu, po, c79_capture, fuse):
-    """fuse: 1 fused channel + noise bank on eight waves, 3 on four waves, 0 channel bank alone; + 8 = persistent
-    workgroups pulling tiles from the per-XCD counters.  Demodulated stream, window energies and (fused) the squelch energies of the emulated kernels
+    """Demodulated stream, window energies and (fused) the squelch energies of the emulated kernels
     against the oracle's direct-form restatement: demod within 1e-4 rad x gain where the channel
     carries signal, E_on / E_off within 1e-5 relative (the FAST path's stated tolerances)."""
     fs, fc, S, iq = c79_capture
@@ -131,7 +130,7 @@ def test_channel_bank_vs_oracle_c79(emu, po, c79_capture, fuse):
         assert np.linalg.norm(yk - y) / np.linalg.norm(y) <= 1e-5
         e_gpu = (r["P"][ch, k:k + 5].sum() + r["Pt"][ch, k + 5]) / o.ddc_out
         assert abs(e_gpu - e_on) / e_on <= 1e-5, (ch, e_gpu, e_on)
-        if fuse & 3:
+        if fuse in (1, 3):
             ints = (ctypes.c_int * 6)()
             emu.emu_stage2_design(fs, fc, 1, None, None, ints)
             outs, nw, L3 = ints[0], ints[1], ints[2]
@@ -151,10 +150,8 @@ def test_fused_and_standalone_noise_banks_agree(emu, c79_capture):
     fs, fc, S, iq = c79_capture
     H = 395001
     x = np.concatenate([np.zeros(4096 + H - 1, np.complex64), iq.astype(np.complex64)])
-    a = _run(emu, fs, fc, 1, x, 4096, S, 9)              # fused, persistent workgroups
-    b = _run(emu, fs, fc, 1, x, 4096, S, 2)              # stand-alone noise bank, one tile per workgroup
-    c = _run(emu, fs, fc, 1, x, 4096, S, 10)             # stand-alone noise bank, persistent
-    assert np.array_equal(b["Z"][:, :b["Tn"]], c["Z"][:, :c["Tn"]])
+    a = _run(emu, fs, fc, 1, x, 4096, S, 1)
+    b = _run(emu, fs, fc, 1, x, 4096, S, 2)
     Tn = a["Tn"]
     assert np.isfinite(a["Z"][:, :Tn]).all() and np.isfinite(b["Z"][:, :Tn]).all()
     assert np.abs(a["Z"][:, :Tn] - b["Z"][:, :Tn]).max() <= 1e-6 * np.abs(b["Z"][:, :Tn]).max()
