@@ -39,7 +39,7 @@ inline size_t bank_lds_bytes(int span_samples, int nt, int nrows, bool chan)
 // Returns the number of channel tiles.
 template <class Launcher>
 inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_noise, const BankBuffers &b,
-                               size_t x_len, long long w0, int S, long long G, int nb, Launcher &&L, bool wide = true)
+                               size_t x_len, long long w0, int S, long long G, int nb, Launcher &&L, bool wide = false)
 {
     const btgpu_design &d = des.d;
     const PfbBank &bk = fp.channel;

@@ -248,7 +248,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
         };
-        static const bool wide = !(getenv("BTGPU_BANK_THREADS") && atoi(getenv("BTGPU_BANK_THREADS")) == 256);
+        // four waves per tile measured faster than eight (BTGPU_BANK_THREADS=512 keeps the wide variant reachable)
+        static const bool wide = getenv("BTGPU_BANK_THREADS") && atoi(getenv("BTGPU_BANK_THREADS")) == 512;
         const int ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, wide);
         HIPCHK(this, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, st,
@@ -358,8 +359,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             // (the kernel strides over the records: the grid only bounds the waves in flight)
             const long long cap = (long long)S * nch;
             const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
-            // the hit windows' columns, packed (throughput-bound strided gather, every CU)
-            hipLaunchKernelGGL(gather_columns_kernel, dim3(2048), dim3(256), 0, tail_stream, p, (const float *)d_d.p, drow, G,
+            static const bool tail_off = getenv("BTGPU_TAIL_OFF") != nullptr;   // timing experiments only: records lose nsym
+            if (!tail_off) {
+            // the hit windows' columns, packed: a strided gather with many loads in flight, kept to one workgroup
+            // per CU so that it does not crowd the next batch's bank kernel off the machine
+            static const unsigned gather_grid = getenv("BTGPU_GATHER_GRID") ? (unsigned)atoi(getenv("BTGPU_GATHER_GRID")) : 256u;
+            hipLaunchKernelGGL(gather_columns_kernel, dim3(gather_grid), dim3(256), 0, tail_stream, p, (const float *)d_d.p, drow, G,
                                (const FinishRec *)d_fin.p, (const unsigned int *)d_hitcount.p + 1, (float *)t.d_col.p,
                                colstride, colcap);
             if (want_syms)
@@ -370,6 +375,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                 hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)t.d_col.p, colstride, colcap, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)nullptr);
+            }
             hipLaunchKernelGGL(nsym_patch_kernel, dim3(32), dim3(256), 0, tail_stream, (DeviceHit *)d_hits.p,
                                (const unsigned int *)d_hitcount.p, max_hits, (const int *)d_winlen.p, nch,
                                want_syms ? (const int *)d_winfin.p : (const int *)nullptr);

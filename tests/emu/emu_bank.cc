@@ -72,8 +72,8 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);      // NaN pattern: reads of unwritten LDS show up
         emu::launch(dim3((unsigned)grid), dim3((unsigned)threads), [&]() { kern(p); });
     };
-    // fuse: 1 = fused, eight waves per tile (the default); 3 = fused, four waves
-    const int ntiles = launch_channel_bank(des, fp, fuse == 1 || fuse == 3, b, (size_t)x_len, w0, S, G, nb, L, fuse != 3);
+    // fuse: 1 = fused, four waves per tile (the default); 3 = fused, eight waves
+    const int ntiles = launch_channel_bank(des, fp, fuse == 1 || fuse == 3, b, (size_t)x_len, w0, S, G, nb, L, fuse == 3);
     if (fuse == 2) launch_noise_bank(des, fp, b, (size_t)x_len, w0, S, L);
     // block sums exactly as block_sum_kernel orders them (per block: tiles ascending)
     const int tpb = ops / 25, tail_tiles = des.tail / 25;
