@@ -31,8 +31,8 @@ inline size_t bank_lds_bytes(int span_samples, int nt, int nrows, bool chan)
 {
     const int span = 2 * ((span_samples + 3) / 2);
     const int ysz = chan ? nt * kPfbYst : 0;
-    const int asz = ((span > ysz ? span : ysz) + 1) & ~1;
-    return (size_t)(asz + nrows * kPfbUst) * sizeof(float2);
+    const int asz = kPfbRegion(span, ysz);
+    return (size_t)(asz + nrows * kPfbUst) * sizeof(float2) + (chan ? 0 : (80 * 4) * sizeof(float2) + 80 * sizeof(int));
 }
 
 // Channel bank (+ fused noise stage 1).  L(kernel, grid, threads, lds_bytes, params) performs the launch.

@@ -358,7 +358,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             // windows with hits: at most one FinishRec per window; lanes beyond fin_count exit
             // (the kernel strides over the records: the grid only bounds the waves in flight)
             const long long cap = (long long)S * nch;
-            const unsigned nblk = (unsigned)std::min<long long>((cap + 63) / 64, 4096);
+            const unsigned nblk = (unsigned)std::min<long long>((cap + kFinLanes - 1) / kFinLanes, 4096);
             static const bool tail_off = getenv("BTGPU_TAIL_OFF") != nullptr;   // timing experiments only: records lose nsym
             if (!tail_off) {
             // the hit windows' columns, packed: a strided gather with many loads in flight, kept to one workgroup
@@ -368,11 +368,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                (const FinishRec *)d_fin.p, (const unsigned int *)d_hitcount.p + 1, (float *)t.d_col.p,
                                colstride, colcap);
             if (want_syms)
-                hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d.p,
+                hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)t.d_col.p, colstride, colcap, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)d_symbits.p);
             else
-                hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(64), 0, tail_stream, p, (const float *)d_d.p,
+                hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)t.d_col.p, colstride, colcap, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)nullptr);
             }

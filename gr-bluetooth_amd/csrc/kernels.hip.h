@@ -826,7 +826,12 @@ __global__ __launch_bounds__(256) void gather_columns_kernel(
     }
 }
 
-constexpr int kFinRows = 32;
+constexpr int kFinRows = 16;       // rows per refill
+constexpr int kFinRing = 32;       // rows resident per lane
+constexpr int kFinSlab = kFinRing + 8 + 1;   // + the first eight slots again behind the ring (the 8-tap window never wraps),
+                                             // + 1: an odd lane pitch keeps equal offsets of different lanes on different banks
+constexpr int kFinLanes = 48;      // windows per workgroup.  48 * 41 * 4 + 4128 bytes = 12 KB of LDS: what a CU has left
+                                   // beside three bank workgroups, so the tail does not push one of them off the CU
 template <bool SYMS>
 __global__ __launch_bounds__(64) void finish_kernel(
     WindowParams p, const float *__restrict__ d, int drow, long long d_rows,
@@ -834,20 +839,18 @@ __global__ __launch_bounds__(64) void finish_kernel(
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
     const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits)
 {
-    constexpr unsigned int RING = 2 * kFinRows, MASK = RING - 1;
-    constexpr int SLAB = 2 * RING + 1;           // every row is stored twice (r and r + RING): the 8-tap
-                                                 // window [pos, pos + 8) never wraps, one address per step
+    constexpr unsigned int RING = kFinRing, MASK = RING - 1;
     __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
-    __shared__ float slab[64 * SLAB];
+    __shared__ float slab[kFinLanes * kFinSlab];
     const unsigned int n = *fin_count;
-    if (blockIdx.x * blockDim.x >= n) return;                    // uniform: nothing for this workgroup
-    const unsigned int stride = gridDim.x * blockDim.x;          // records beyond the grid: next round
+    if (blockIdx.x * kFinLanes >= n) return;                     // uniform: nothing for this workgroup
+    const unsigned int stride = gridDim.x * kFinLanes;           // records beyond the grid: next round
     // a few dozen strictly sequential waves next to the throughput kernels of the following batch:
     // give them the highest wave issue priority, they use a fraction of a percent of the issue slots
     __builtin_amdgcn_s_setprio(3);
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
     __syncthreads();
-  for (unsigned int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += stride) {
+  for (unsigned int f = blockIdx.x * kFinLanes + threadIdx.x; f < n; f += stride) {
     const FinishRec r = fin[f];
     if (r.done) continue;
     const int k = r.w / p.nch, c = r.w - k * p.nch;
@@ -862,25 +865,50 @@ __global__ __launch_bounds__(64) void finish_kernel(
     float mu = r.mu, omega = r.omega, last = r.last;
     unsigned int ii = r.ii;
     int oo = r.oo;
-    float *my = slab + threadIdx.x * SLAB;
+    float *my = slab + threadIdx.x * kFinSlab;
     uint32_t *sb = SYMS ? symbits + (size_t)f * kSymWords : nullptr;
     uint32_t cur = (SYMS && (oo & 31)) ? sb[oo >> 5] : 0u;       // partially filled word left by the window kernel
-    unsigned int hi = ii;                                        // rows [.., hi) are resident
+    // rows [hi - RING, hi) are resident, row q in slot q & 31 (slots 0..7 also at 32..39); refills are whole
+    // 16-row blocks, so a block is either slots 0..15 (guard copy of its first half) or 16..31
+    unsigned int hi = ii & ~(unsigned int)(kFinRows - 1);
+    auto fetch = [&](float *v) {                                 // rows [hi, hi + 16): unconditional loads, values selected later
+        if (packed) {                                            // 64 contiguous, 64-byte aligned bytes
+            const unsigned int b0 = hi + kFinRows <= nvalid ? hi : (nvalid >= (unsigned)kFinRows ? (nvalid - kFinRows) & ~3u : 0u);
+            const float4 *src = (const float4 *)(col + b0);
+            float4 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = src[j];
+            if (b0 == hi) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[4 * j] = q[j].x; v[4 * j + 1] = q[j].y; v[4 * j + 2] = q[j].z; v[4 * j + 3] = q[j].w; }
+            } else {                                             // the last, partial block of the window: element by element
+#pragma unroll
+                for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[idx < nvalid ? idx : nvalid - 1]; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * estride]; }
+        }
+    };
+    auto put = [&](const float *v) {                             // rows [hi, hi + 16) -> ring; rows past the stream read as 0
+        const unsigned int s0 = hi & MASK;                       // 0 or 16
+#pragma unroll
+        for (int j = 0; j < kFinRows; j++) my[s0 + j] = hi + j < nvalid ? v[j] : 0.f;
+        if (s0 == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) my[RING + j] = hi + j < nvalid ? v[j] : 0.f;
+        }
+        hi += kFinRows;
+    };
     {
-        float v[RING];
-#pragma unroll
-        for (unsigned int j = 0; j < RING; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * estride]; }
-#pragma unroll
-        for (unsigned int j = 0; j < RING; j++) v[j] = hi + j < nvalid ? v[j] : 0.f;       // loads unconditional, values selected
-#pragma unroll
-        for (unsigned int j = 0; j < RING; j++) { const unsigned int s = (hi + j) & MASK; my[s] = v[j]; my[s + RING] = v[j]; }
-        hi += RING;
+        float v0[kFinRows], v1[kFinRows];
+        fetch(v0); put(v0);
+        fetch(v1); put(v1);
     }
     while (ii < ni && oo < demod_n) {
-        // issue the loads of the next kFinRows rows now; they land while the steps below run
+        // issue the loads of the next block now; they land while the steps below run
         float v[kFinRows];
-#pragma unroll
-        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * estride]; }   // unconditional
+        fetch(v);
         // consume every step whose 8-tap window lies inside the resident rows [.., hi)
         while (ii + 8 <= hi && ii < ni && oo < demod_n) {
             const int imu = (int)rintf(mu * 128.0f);             // mu in [0, 1) -> 0..128
@@ -917,15 +945,9 @@ __global__ __launch_bounds__(64) void finish_kernel(
             }
             oo++;
         }
-        // here ii + 8 > hi (or the window is done): the ring slots of rows [hi-RING, hi-RING+kFinRows)
-        // are all below ii and can take rows [hi, hi + kFinRows)
-#pragma unroll
-        for (int j = 0; j < kFinRows; j++) {
-            const unsigned int s = (hi + j) & MASK;
-            const float t = hi + j < nvalid ? v[j] : 0.f;        // rows past the stream read as 0
-            my[s] = t; my[s + RING] = t;
-        }
-        hi += kFinRows;
+        // here ii + 8 > hi (or the window is done): the block of slots that holds rows [hi - RING, hi - RING + 16)
+        // lies below ii and takes rows [hi, hi + 16)
+        put(v);
     }
     if (SYMS && (oo & 31) && (oo >> 5) < kSymWords) sb[oo >> 5] = cur;
     win_len[r.w] = oo;

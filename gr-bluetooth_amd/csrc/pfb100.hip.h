@@ -43,6 +43,8 @@ namespace btgpu {
 
 constexpr int kPfbUst = 106;     // LDS pitch (complex) of the DFT rows U
 constexpr int kPfbYst = 113;     // LDS pitch (complex) of the bin rows Y (= 1 mod 16)
+// size (complex) of the LDS region shared by the input span, the pass-1 twiddles behind it and the bin rows
+constexpr int kPfbRegion(int span, int ysz) { return (((span + 100 > ysz ? span + 100 : ysz)) + 1) & ~1; }
 
 struct PfbParams {
     const float2 *x; long long x_len; long long x0;   // x index of tap 0 for output instant 0
@@ -203,17 +205,18 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
     constexpr int N4 = (SPAN + 3) / 2;                       // 16-byte pieces staged (aligned start: +1 sample)
     constexpr int span = 2 * N4;                             // samples resident in LDS
     constexpr int YSZ = CHAN ? NT * YST : 0;                 // the input tile is dead after phase A -> bin rows Y
-    constexpr int ASZ = ((span > YSZ ? span : YSZ) + 1) & ~1;
+    constexpr int ASZ = kPfbRegion(span, YSZ);
     cf *xs = lds;                                            // [span]
     cf *Y = lds;                                             // [NT][YST]      (after phase A)
+    cf *s_tw = lds + ASZ - 100;                              // [100] twiddles of pass 1, behind the input span (pass 2 may overwrite them)
     cf *U = lds + ASZ;                                       // [NROWS][UST]
+    // no static LDS at all: the channel banks must leave room for a tail workgroup beside three of them
+    cf *s_krot = U + NROWS * UST;                            // [80 * 4]  (noise-only bank)
+    int *s_binpos = (int *)(s_krot + 80 * 4);                // [80]      (noise-only bank)
     float *s_part = (float *)U;                              // [NTH / 80][80][2] run sums: the channel rows of U are dead after pass 2
     float *s_d = (float *)U + (NTH / 80) * 80 * 2;           // [TT][80] angles of the tile on their way to d
     static_assert(!CHAN || ((NTH / 80) * 80 * 2) % 4 == 0, "s_d must be 16-byte aligned");
     static_assert(!CHAN || (NTH / 80) * 80 * 2 + TT * 80 <= 2 * NT * UST, "run sums and the angle tile must fit the dead DFT rows");
-    __shared__ cf s_tw[100];
-    __shared__ cf s_krot[CHAN ? 1 : 80 * 4];
-    __shared__ int s_binpos[CHAN ? 1 : 80];
     const bool krot_lds = !CHAN && p.rot_period <= 4 && p.nsel <= 80;
     const int l = threadIdx.x;
 
