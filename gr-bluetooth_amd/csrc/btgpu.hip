@@ -71,12 +71,10 @@ struct btgpu_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     int drow = 80;                               // row stride (floats) of the time-major demodulated stream
-    int colstride = 0; unsigned int colcap = 0;  // packed hit-window columns: floats per column, columns per batch
     hipStream_t tail_stream = nullptr;
     struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
         DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_winfin, d_symbits, d_hdr;
         DevBuf d_d;                           // demodulated stream of the batch: the tail reads it under the next batch's banks
-        DevBuf d_col;                         // packed columns of the hit windows (gather_columns_kernel -> finish_kernel)
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
@@ -162,10 +160,10 @@ struct btgpu_handle {
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
-        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d.p = tc[1].d_col.p = nullptr;
+        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d.p = nullptr;
                       tc[1].d_winfin.p = tc[1].d_symbits.p = tc[1].d_hdr.p = nullptr; }
         for (TailCtx &t : tc) {
-            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_col};
+            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -332,6 +330,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         p.btbb = d.correlator == BTGPU_CORRELATOR_BTBB ? 1 : 0;
         p.btbb_pcol = (const uint64_t *)d_pcol.p;
         { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
+        { static const int fp_ = getenv("BTGPU_FIN_PRIO") ? atoi(getenv("BTGPU_FIN_PRIO")) : 3; p.fin_prio = fp_; }
         auto launch_window = [&](auto lay) {
             using LAY = decltype(lay);
             hipLaunchKernelGGL(window_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, st, p,
@@ -361,19 +360,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             const unsigned nblk = (unsigned)std::min<long long>((cap + kFinLanes - 1) / kFinLanes, 4096);
             static const bool tail_off = getenv("BTGPU_TAIL_OFF") != nullptr;   // timing experiments only: records lose nsym
             if (!tail_off) {
-            // the hit windows' columns, packed: a strided gather with many loads in flight, kept to one workgroup
-            // per CU so that it does not crowd the next batch's bank kernel off the machine
-            static const unsigned gather_grid = getenv("BTGPU_GATHER_GRID") ? (unsigned)atoi(getenv("BTGPU_GATHER_GRID")) : 256u;
-            hipLaunchKernelGGL(gather_columns_kernel, dim3(gather_grid), dim3(256), 0, tail_stream, p, (const float *)d_d.p, drow, G,
-                               (const FinishRec *)d_fin.p, (const unsigned int *)d_hitcount.p + 1, (float *)t.d_col.p,
-                               colstride, colcap);
             if (want_syms)
                 hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
-                                   drow, G, (const float *)t.d_col.p, colstride, colcap, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
+                                   drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)d_symbits.p);
             else
                 hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
-                                   drow, G, (const float *)t.d_col.p, colstride, colcap, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
+                                   drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)nullptr);
             }
             hipLaunchKernelGGL(nsym_patch_kernel, dim3(32), dim3(256), 0, tail_stream, (DeviceHit *)d_hits.p,
@@ -800,11 +793,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_w, ns.weights.data(), ns.weights.size() * sizeof(double)));
     }
     h->drow = h->use_pfb ? 80 : win_drow(nch);            // the polyphase epilogue writes 80-float rows
-    // packed columns for one window in eight (hits are a few per cent of the windows; more than that overflow
-    // into finish_kernel's strided path), at most 1 GiB per in-flight batch
-    h->colstride = (d.ddc_out + 63) / 64 * 64;
-    h->colcap = (unsigned int)std::min<size_t>(std::max<size_t>((size_t)S * nch / 8, 256), ((size_t)1 << 30) / ((size_t)h->colstride * sizeof(float)));
-    if (getenv("BTGPU_COLCAP")) h->colcap = (unsigned int)std::max(1, atoi(getenv("BTGPU_COLCAP")));   // tests: force the overflow path
     if (nch > 80) return fail(BTGPU_EUNSUPPORTED);
     TRY(h->alloc(h->d_P, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Pt, (size_t)nch * h->nb_max * sizeof(double)));
@@ -833,7 +821,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
         TRY(h->alloc(t.d_fin, (size_t)S * nch * sizeof(FinishRec)));
         TRY(h->alloc(t.d_d, (size_t)h->drow * (h->ystride + 64) * sizeof(float)));   // [G][drow], time-major
-        TRY(h->alloc(t.d_col, (size_t)h->colcap * h->colstride * sizeof(float)));
         if (h->want_hdrs) TRY(h->alloc(t.d_hdr, (size_t)h->max_hits * sizeof(HeaderRec)));
         if (h->want_syms) {
             const size_t maxfin = (size_t)S * nch;            // one FinishRec per hit window, whatever max_hits is
@@ -849,7 +836,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     if (!h->async) {                      // synchronous mode: one context, used for every batch
         h->tc[1].d_winlen = h->tc[0].d_winlen; h->tc[1].d_hits = h->tc[0].d_hits;
-        h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d = h->tc[0].d_d; h->tc[1].d_col = h->tc[0].d_col;
+        h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d = h->tc[0].d_d;
         h->tc[1].d_winfin = h->tc[0].d_winfin; h->tc[1].d_symbits = h->tc[0].d_symbits; h->tc[1].d_hdr = h->tc[0].d_hdr;
     }
 #undef TRY

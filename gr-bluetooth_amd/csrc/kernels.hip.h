@@ -301,6 +301,7 @@ struct WindowParams {
     int low_channel;
     int btbb;                   // multi_LAP: libbtbb-style search (BTGPU_CORRELATOR_BTBB)
     const uint64_t *btbb_pcol;  // [24] parity column of each LAP bit (device memory)
+    int fin_prio;               // wave priority of finish_kernel (0..3)
     int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
 };
 
@@ -791,41 +792,12 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 // Continue the M&M recursion of the windows that reported hits (a few per cent) to the end of their
 // window and store len.  One lane per window; each lane stages its own column of the time-major
 // stream d[g][drow] into a private LDS slab, kFinRows rows at a time, all loads of a chunk in
-// flight together.  The columns come packed from gather_columns_kernel (a channel-major copy of the
-// whole stream, which the bank kernel used to write for this, cost more than it saved); records
-// beyond the packed capacity are read straight from the stream, one cache line per row.  No
-// cross-lane data => no barriers.
-// Columns of the hit windows, made contiguous: the windows that continue (a few per cent) need the rest
-// of their column of the time-major stream, one float per 4 * drow bytes.  A latency-bound consumer
-// reading that stride pays a cache line per row per lane; this kernel pays it once, with every lane of
-// the machine in flight (one workgroup per window and pass, lanes = rows), and leaves col[f][r] =
-// d[row0 + r][c] for finish_kernel to stream.  Records beyond `cap` stay where they are (finish_kernel
-// then reads them strided).
-__global__ __launch_bounds__(256) void gather_columns_kernel(
-    WindowParams p, const float *__restrict__ d, int drow, long long d_rows, const FinishRec *__restrict__ fin,
-    const unsigned int *__restrict__ fin_count, float *__restrict__ col, int colstride, unsigned int cap)
-{
-    unsigned int n = *fin_count;
-    if (n > cap) n = cap;
-    for (unsigned int f = blockIdx.x; f < n; f += gridDim.x) {
-        const FinishRec r = fin[f];
-        if (r.done) continue;                                        // block-uniform
-        const int k = r.w / p.nch, c = r.w - k * p.nch;
-        const long long row0 = (long long)k * p.outs_per_slot;
-        const int nvalid = (int)((d_rows - row0) < p.ddc_out ? (d_rows - row0) : p.ddc_out);
-        const float *src = d + (size_t)row0 * drow + c;
-        float *dst = col + (size_t)f * colstride;
-        const int first = (int)(r.ii & ~63u);                        // rows below the window's position are never read again
-        for (int i = first + (int)threadIdx.x; i < nvalid; i += 4 * 256) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) { const int q = i + j * 256; v[j] = src[(size_t)(q < nvalid ? q : nvalid - 1) * drow]; }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { const int q = i + j * 256; if (q < nvalid) dst[q] = v[j]; }
-        }
-    }
-}
-
+// flight together.  A strided column costs a cache line per row, but only the hit windows read it and
+// off the critical path; measured against the alternatives -- a channel-major copy of the whole stream
+// written by the bank kernel (round 1: 0.9 GB of writes and two LDS transposes on the critical path) and a
+// throughput-style gather of the hit columns in front of this kernel (its burst of strided reads slowed the
+// next batch's bank kernel by as much as it saved here) -- this is the cheapest.  No cross-lane data =>
+// no barriers.
 constexpr int kFinRows = 16;       // rows per refill
 constexpr int kFinRing = 32;       // rows resident per lane
 constexpr int kFinSlab = kFinRing + 8 + 1;   // + the first eight slots again behind the ring (the 8-tap window never wraps),
@@ -835,7 +807,6 @@ constexpr int kFinLanes = 48;      // windows per workgroup.  48 * 41 * 4 + 4128
 template <bool SYMS>
 __global__ __launch_bounds__(64) void finish_kernel(
     WindowParams p, const float *__restrict__ d, int drow, long long d_rows,
-    const float *__restrict__ colbuf, int colstride, unsigned int colcap,
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
     const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits)
 {
@@ -847,7 +818,9 @@ __global__ __launch_bounds__(64) void finish_kernel(
     const unsigned int stride = gridDim.x * kFinLanes;           // records beyond the grid: next round
     // a few dozen strictly sequential waves next to the throughput kernels of the following batch:
     // give them the highest wave issue priority, they use a fraction of a percent of the issue slots
-    __builtin_amdgcn_s_setprio(3);
+    if (p.fin_prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p.fin_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.fin_prio == 1) __builtin_amdgcn_s_setprio(1);
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[i] = mmse_g[i];
     __syncthreads();
   for (unsigned int f = blockIdx.x * kFinLanes + threadIdx.x; f < n; f += stride) {
@@ -857,10 +830,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     const int demod_n = p.ddc_out - 1;
     const unsigned int ni = (unsigned int)(demod_n - 8);
     const long long row0 = (long long)k * p.outs_per_slot;
-    // this window's demod samples: contiguous in the gathered columns, every drow-th float of the stream otherwise
-    const bool packed = colbuf != nullptr && f < colcap;
-    const float *col = packed ? colbuf + (size_t)f * colstride : d + (size_t)row0 * drow + c;
-    const int estride = packed ? 1 : drow;
+    const float *col = d + (size_t)row0 * drow + c;              // this window's demod samples: every drow-th float of the stream
     const unsigned int nvalid = (unsigned int)((d_rows - row0) < p.ddc_out ? (d_rows - row0) : p.ddc_out);
     float mu = r.mu, omega = r.omega, last = r.last;
     unsigned int ii = r.ii;
@@ -872,23 +842,13 @@ __global__ __launch_bounds__(64) void finish_kernel(
     // 16-row blocks, so a block is either slots 0..15 (guard copy of its first half) or 16..31
     unsigned int hi = ii & ~(unsigned int)(kFinRows - 1);
     auto fetch = [&](float *v) {                                 // rows [hi, hi + 16): unconditional loads, values selected later
-        if (packed) {                                            // 64 contiguous, 64-byte aligned bytes
-            const unsigned int b0 = hi + kFinRows <= nvalid ? hi : (nvalid >= (unsigned)kFinRows ? (nvalid - kFinRows) & ~3u : 0u);
-            const float4 *src = (const float4 *)(col + b0);
-            float4 q[4];
+        if (p.dbg_stop == 9) {                                   // timing experiment (BTGPU_WIN_STOP=9): no stream traffic
 #pragma unroll
-            for (int j = 0; j < 4; j++) q[j] = src[j];
-            if (b0 == hi) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) { v[4 * j] = q[j].x; v[4 * j + 1] = q[j].y; v[4 * j + 2] = q[j].z; v[4 * j + 3] = q[j].w; }
-            } else {                                             // the last, partial block of the window: element by element
-#pragma unroll
-                for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[idx < nvalid ? idx : nvalid - 1]; }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * estride]; }
+            for (int j = 0; j < kFinRows; j++) v[j] = 0.01f * (float)((hi + j) & 7) - 0.03f;
+            return;
         }
+#pragma unroll
+        for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * drow]; }
     };
     auto put = [&](const float *v) {                             // rows [hi, hi + 16) -> ring; rows past the stream read as 0
         const unsigned int s0 = hi & MASK;                       // 0 or 16

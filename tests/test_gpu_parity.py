@@ -679,17 +679,3 @@ def test_bench_two_ranks_on_one_device_equal_one_rank(tmp_path):
     if torch.cuda.device_count() < 2:
         bad = subprocess.run(base + ["--gpus", "2", "--slots", "24"], capture_output=True, text=True, env=env, timeout=300)
         assert bad.returncode != 0 and "only" in (bad.stderr + bad.stdout)
-
-
-def test_finish_overflow_path_reads_the_stream_directly(pkg, po, synth, monkeypatch):
-    """The tail packs the columns of at most colcap hit windows per batch; windows beyond that are continued
-    straight from the time-major stream.  With the capacity forced to 2 both paths run in one batch and the
-    records (nsym = run length to the end of the window) still equal the oracle's."""
-    monkeypatch.setenv("BTGPU_COLCAP", "2")
-    fs, fc = 8e6, 2476.5e6
-    iq, _ = synth.make_capture(fs, fc, 24, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=8, snr_db=24, occupancy=0.4)
-    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq, threads=8)
-    assert len(want) > 8
-    blk, got = _run_gpu(pkg, pkg.multi_sniffer, fs, fc, iq)
-    assert _keys(got) == _keys(want)
-    blk.close()
