@@ -79,7 +79,7 @@ EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_stre
            "btgpu_poll_symbols", "btgpu_poll_headers", "btgpu_hopseq_create", "btgpu_hopseq_destroy",
            "btgpu_hopseq_init_candidates", "btgpu_hopseq_winnow", "btgpu_hopseq_candidates", "btgpu_hopseq_lookup",
            "btgpu_hopseq_fetch", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch",
-           "btgpu_debug_scan_symbols", "btgpu_debug_lut"]
+           "btgpu_debug_scan_symbols", "btgpu_debug_lut", "btgpu_process_host"]
 
 
 class BtgpuError(RuntimeError):

@@ -106,7 +106,7 @@ struct btgpu_handle {
     size_t in_cap = 0;           // complex samples the staging buffer holds
 
     // device memory
-    DevBuf d_in, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
+    DevBuf d_in, d_in_b, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index, d_winbits;
     DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise;
@@ -154,7 +154,7 @@ struct btgpu_handle {
     }
     void release()
     {
-        DevBuf *all[] = {&d_in, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
+        DevBuf *all[] = {&d_in, &d_in_b, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise,
@@ -173,6 +173,11 @@ struct btgpu_handle {
             if (t.tail_done) { (void)hipEventDestroy(t.tail_done); t.tail_done = nullptr; }
             if (t.h_count) { (void)hipHostFree(t.h_count); t.h_count = nullptr; }
             if (t.h_hits) { (void)hipHostFree(t.h_hits); t.h_hits = nullptr; }
+        }
+        for (int k = 0; k < 2; k++) {
+            if (h_stage[k]) { (void)hipHostFree(h_stage[k]); h_stage[k] = nullptr; }
+            if (ev_copied[k]) { (void)hipEventDestroy(ev_copied[k]); ev_copied[k] = nullptr; }
+            if (ev_consumed[k]) { (void)hipEventDestroy(ev_consumed[k]); ev_consumed[k] = nullptr; }
         }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         if (tail_stream) { (void)hipStreamDestroy(tail_stream); tail_stream = nullptr; }
@@ -200,6 +205,14 @@ struct btgpu_handle {
         b.prof = (unsigned long long *)d_prof.p;
         return b;
     }
+    // host -> device staging of btgpu_work / btgpu_process_host: two pinned host buffers and two device input
+    // buffers, so that the copy of batch n+1 (host memcpy + DMA on the copy stream) overlaps the kernels of batch n
+    float2 *h_stage[2] = {nullptr, nullptr};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    unsigned stage_turn = 0;
+    int stage_batch(const float *head, size_t n_head_zero, const float *body, size_t n_body, long long w0,
+                    uint64_t abs_first_slot, int S);
     int process_batch(const float2 *d_x, size_t x_len, long long w0, uint64_t abs_first_slot, int S, hipStream_t st);
     int harvest(TailCtx &t);
     int harvest_all(bool block);
@@ -398,6 +411,41 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     cur ^= 1;
     if (!async) { const int hrc = harvest(t); return hrc != BTGPU_OK ? hrc : carried; }
     return carried;
+}
+
+// One batch from host memory: [n_head_zero zeros | body] (complex samples) -> pinned buffer -> device buffer ->
+// kernels.  `head` (may be null) supplies real samples for the first n_head samples instead of zeros when the
+// caller has them (the margin carried between btgpu_work calls).  Buffers alternate; a buffer is reused only
+// after the batch that read it has left the main stream.
+int btgpu_handle::stage_batch(const float *head, size_t n_head, const float *body, size_t n_body, long long w0,
+                              uint64_t abs_first_slot, int S)
+{
+    const unsigned k = stage_turn++ & 1u;
+    const size_t cap = in_cap + (size_t)margin + 64;
+    if (n_head + n_body > cap) { set_error("staging overflow"); return BTGPU_EINVAL; }
+    if (!h_stage[k]) {
+        if (hipHostMalloc((void **)&h_stage[k], cap * sizeof(float2), hipHostMallocDefault) != hipSuccess) {
+            set_error("hipHostMalloc (pinned staging buffer)"); return BTGPU_ENOMEM;
+        }
+        HIPCHK(this, hipEventCreateWithFlags(&ev_copied[k], hipEventDisableTiming));
+        HIPCHK(this, hipEventCreateWithFlags(&ev_consumed[k], hipEventDisableTiming));
+        if (k == 1 && !d_in_b.p) { int rc = alloc(d_in_b, cap * sizeof(float2)); if (rc) return rc; }
+    }
+    if (stage_used[k]) HIPCHK(this, hipEventSynchronize(ev_consumed[k]));        // the batch that used this pair is done with it
+    float *dst = (float *)h_stage[k];
+    if (n_head) {
+        if (head) std::memcpy(dst, head, n_head * sizeof(float2));
+        else std::memset(dst, 0, n_head * sizeof(float2));
+    }
+    std::memcpy(dst + 2 * n_head, body, n_body * sizeof(float2));
+    float2 *d_buf = (float2 *)(k == 0 ? d_in.p : d_in_b.p);
+    HIPCHK(this, hipMemcpyAsync(d_buf, h_stage[k], (n_head + n_body) * sizeof(float2), hipMemcpyHostToDevice, copy_stream));
+    HIPCHK(this, hipEventRecord(ev_copied[k], copy_stream));
+    HIPCHK(this, hipStreamWaitEvent(stream, ev_copied[k], 0));
+    const int rc = process_batch(d_buf, n_head + n_body, w0, abs_first_slot, S, stream);
+    HIPCHK(this, hipEventRecord(ev_consumed[k], stream));
+    stage_used[k] = true;
+    return rc;
 }
 
 // wait for a batch's tail, move its hit records to the host queue, account its kernel times
@@ -898,6 +946,28 @@ int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, si
     return rc_all;
 }
 
+int btgpu_process_host(btgpu_handle *h, const float *iq, size_t n_complex, size_t left_margin, uint64_t first_slot,
+                       uint64_t n_slots)
+{
+    if (!h || !iq) return BTGPU_EINVAL;
+    const btgpu_design &d = h->des.d;
+    if (n_slots == 0) return BTGPU_OK;
+    const size_t H = (size_t)d.history, slot = (size_t)d.samples_per_slot, mg = (size_t)h->margin;
+    if (n_complex < left_margin + H + (size_t)(n_slots - 1) * slot) return BTGPU_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc_all = BTGPU_OK;
+    for (uint64_t s0 = 0; s0 < n_slots; s0 += (uint64_t)h->max_slots) {
+        const int S = (int)std::min<uint64_t>((uint64_t)h->max_slots, n_slots - s0);
+        const size_t seg = H + (size_t)(S - 1) * slot;
+        const size_t i0 = left_margin + (size_t)s0 * slot;           // sample index of window 0 of this batch
+        const size_t have = std::min(mg, i0), zeros = mg - have;     // real samples in front, else implied zeros
+        int rc = h->stage_batch(nullptr, zeros, iq + 2 * (i0 - have), have + seg, (long long)mg, first_slot + s0, S);
+        if (rc == BTGPU_EOVERFLOW) rc_all = rc;
+        else if (rc != BTGPU_OK) return rc;
+    }
+    return rc_all;
+}
+
 int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *consumed)
 {
     if (!h || !items) return BTGPU_EINVAL;
@@ -914,14 +984,9 @@ int btgpu_work(btgpu_handle *h, const float *items, size_t n_items, size_t *cons
         const size_t i0 = (size_t)s0 * slot;                     // item index of window 0 of this batch
         // staging buffer = [margin samples preceding items[i0] | items[i0 .. i0+seg)]
         size_t from_items = std::min(mg, i0), from_pre = mg - from_items;
-        if (from_pre) {
-            // pre holds the mg samples before items[0]; we need its last from_pre samples
-            HIPCHK(h, hipMemcpyAsync(h->d_in.p, h->pre.data() + 2 * (mg - from_pre), from_pre * sizeof(float2),
-                                     hipMemcpyHostToDevice, h->stream));
-        }
-        HIPCHK(h, hipMemcpyAsync((float2 *)h->d_in.p + from_pre, items + 2 * (i0 - from_items),
-                                 (from_items + seg) * sizeof(float2), hipMemcpyHostToDevice, h->stream));
-        int rc = h->process_batch((const float2 *)h->d_in.p, mg + seg, (long long)mg, h->push_slot + s0, S, h->stream);
+        // pre holds the mg samples before items[0]; its last from_pre samples come first
+        int rc = h->stage_batch(from_pre ? h->pre.data() + 2 * (mg - from_pre) : nullptr, from_pre,
+                                items + 2 * (i0 - from_items), from_items + seg, (long long)mg, h->push_slot + s0, S);
         if (rc == BTGPU_EOVERFLOW) rc_all = rc;
         else if (rc != BTGPU_OK) return rc;
     }

@@ -5,8 +5,11 @@
 // the number of items consumed -- a whole number of slots (the reference always returns
 // exactly one slot; this block consumes every whole slot it was handed).
 #include <cstdio>
+#include <algorithm>
+#include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <gr_bluetooth/multi_LAP.h>
@@ -38,6 +41,7 @@ multi_block::multi_block(double sample_rate, double center_freq, double squelch_
     cfg.mode = mode;
     cfg.device = -1;
     cfg.flags = flags;
+    d_cfg = cfg;
     int rc = btgpu_create(&cfg, &d_gpu);
     if (rc != BTGPU_OK)      // no CPU fallback: fail loudly
         throw std::runtime_error(std::string("gr::bluetooth: btgpu_create failed: ") + btgpu_strerror(rc));
@@ -66,6 +70,13 @@ int multi_block::run_work(int noutput_items, gr_vector_const_void_star &input_it
         fprintf(stderr, "Error: %s (%s)\n", btgpu_strerror(rc), btgpu_last_error(d_gpu));
         abort();
     }
+    drain(d_gpu);
+    d_cumulative_count += consumed;
+    return (int)consumed;
+}
+
+void multi_block::drain(btgpu_handle *g)
+{
     std::vector<btgpu_hit> buf(256);
     if (d_headers) {
         const int cap = 3125;                         // classic_packet keeps at most MAX_SYMBOLS
@@ -73,19 +84,69 @@ int multi_block::run_work(int noutput_items, gr_vector_const_void_star &input_it
         std::vector<int> lens(buf.size());
         std::vector<btgpu_header> hdrs(buf.size());
         for (;;) {
-            int n = btgpu_poll_headers(d_gpu, buf.data(), hdrs.data(), syms.data(), cap, lens.data(), (int)buf.size());
+            int n = btgpu_poll_headers(g, buf.data(), hdrs.data(), syms.data(), cap, lens.data(), (int)buf.size());
             if (n <= 0) break;
             for (int i = 0; i < n; i++) handle_hit(buf[i], &hdrs[i], syms.data() + (size_t)i * cap, lens[i]);
         }
     } else {
         for (;;) {
-            int n = btgpu_poll(d_gpu, buf.data(), (int)buf.size());
+            int n = btgpu_poll(g, buf.data(), (int)buf.size());
             if (n <= 0) break;
             for (int i = 0; i < n; i++) handle_hit(buf[i], nullptr, nullptr, 0);
         }
     }
-    d_cumulative_count += consumed;
-    return (int)consumed;
+}
+
+long multi_block::run_partitioned(const gr_complex *items, size_t n_new, int ngpus, bool all_on_device0)
+{
+    const size_t H = (size_t)d_design.history, slot = (size_t)d_design.samples_per_slot, mg = (size_t)d_design.left_margin;
+    const uint64_t total = n_new / slot;
+    if (ngpus < 1) ngpus = 1;
+    if (total == 0) return 0;
+    const uint64_t first_abs = d_cumulative_count / slot;              // slot index of the first new slot
+    // one handle per range: range 0 on this block's own handle, the others on handles of their own devices
+    std::vector<btgpu_handle *> g((size_t)ngpus, nullptr);
+    g[0] = d_gpu;
+    for (int r = 1; r < ngpus; r++) {
+        btgpu_config cfg = d_cfg;
+        cfg.device = all_on_device0 ? d_cfg.device : r;
+        int rc = btgpu_create(&cfg, &g[(size_t)r]);
+        if (rc != BTGPU_OK) {
+            for (int q = 1; q < r; q++) btgpu_destroy(g[(size_t)q]);
+            throw std::runtime_error(std::string("gr::bluetooth: btgpu_create on device ") + std::to_string(cfg.device) +
+                                     " failed: " + btgpu_strerror(rc));
+        }
+    }
+    std::vector<int> rcs((size_t)ngpus, BTGPU_OK);
+    std::vector<std::thread> th;
+    const float *base = (const float *)items;                          // items[0] = absolute sample first_abs*slot - (H-1)
+    for (int r = 0; r < ngpus; r++) {
+        const uint64_t b = total / (uint64_t)ngpus, rem = total % (uint64_t)ngpus;
+        const uint64_t first = (uint64_t)r * b + std::min<uint64_t>((uint64_t)r, rem), cnt = b + ((uint64_t)r < rem ? 1 : 0);
+        th.emplace_back([=, &rcs, &g]() {
+            if (cnt == 0) return;
+            // window 0 of the range starts at items[first * slot]; the staged squelch wants mg more samples in front
+            const size_t w0 = (size_t)first * slot;
+            const size_t have = std::min(mg, w0);                      // the stream start has zeros there (implied)
+            int rc = btgpu_process_host(g[(size_t)r], base + 2 * (w0 - have), have + H + (size_t)(cnt - 1) * slot, have,
+                                        first_abs + first, cnt);
+            if (rc == BTGPU_OK || rc == BTGPU_EOVERFLOW) { int rf = btgpu_flush(g[(size_t)r]); if (rf != BTGPU_OK) rc = rf; }
+            rcs[(size_t)r] = rc;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int r = 0; r < ngpus; r++) {
+        if (rcs[(size_t)r] == BTGPU_EOVERFLOW)
+            fprintf(stderr, "Warning: hit buffer overflow on range %d, detections were dropped\n", r);
+        else if (rcs[(size_t)r] != BTGPU_OK) {
+            fprintf(stderr, "Error: %s (%s)\n", btgpu_strerror(rcs[(size_t)r]), btgpu_last_error(g[(size_t)r]));
+            abort();
+        }
+    }
+    for (int r = 0; r < ngpus; r++) drain(g[(size_t)r]);               // ranges ascend in time: stream order
+    for (int r = 1; r < ngpus; r++) btgpu_destroy(g[(size_t)r]);
+    d_cumulative_count += total * slot;
+    return (long)(total * slot);
 }
 
 // ---------------------------------------------------------------- multi_LAP

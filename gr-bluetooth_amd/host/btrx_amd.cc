@@ -2,8 +2,10 @@
 // blocks.  Same flag meanings (apps/btrx:22-60): -f centre frequency (default 2.476e9), -r sample
 // rate (required, >= 2e6), -i input file ('-' = stdin), -s input is interleaved int16, -N sample
 // limit, -S all-piconet sniffer (default: LAP sniffer), -t SNR squelch (default 10.0),
-// -w accepted (TAP sink not built).  The little scheduler below stands in for GNU Radio's:
-// history()-1 zeros first, work() called with a multiple of output_multiple() new items.
+// -w Wireshark TAP sink.  The little scheduler below stands in for GNU Radio's: history()-1 zeros first,
+// work() called with a multiple of output_multiple() new items.  --gpus N (no counterpart in apps/btrx)
+// reads the whole capture and time-partitions it over N devices of the node (multi_block::run_partitioned);
+// the output is the single-device output.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,7 +33,7 @@ static double eng(const char *s)
 
 static void usage()
 {
-    fprintf(stderr, "usage: btrx_amd -r RATE [-f FREQ] [-i FILE|-] [-s] [-N NSAMPLES] [-S] [-l LAP -p [--aliased]] [-t SNR] [-w] [-c CHUNK_SLOTS]\n");
+    fprintf(stderr, "usage: btrx_amd -r RATE [-f FREQ] [-i FILE|-] [-s] [-N NSAMPLES] [-S] [-l LAP -p [--aliased]] [-t SNR] [-w] [-c CHUNK_SLOTS] [--gpus N [--all-on-device0]]\n");
 }
 
 int main(int argc, char **argv)
@@ -40,7 +42,8 @@ int main(int argc, char **argv)
     bool sniff = false, shorts = false, tun = false, hop = false, aliased = false;
     long lap = -1;
     std::string file;
-    int chunk_slots = 64;
+    int chunk_slots = 64, gpus = 1;
+    bool all_on_device0 = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](const char *n) { if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", n); usage(); exit(1); } return argv[++i]; };
@@ -50,6 +53,8 @@ int main(int argc, char **argv)
         else if (a == "-N" || a == "--nsamples") nsamples = eng(need("-N"));
         else if (a == "-t" || a == "--snr") snr = eng(need("-t"));
         else if (a == "-c") chunk_slots = atoi(need("-c"));
+        else if (a == "--gpus") gpus = atoi(need("--gpus"));
+        else if (a == "--all-on-device0") all_on_device0 = true;
         else if (a == "-S" || a == "--sniff") sniff = true;
         else if (a == "-l" || a == "--lap") lap = strtol(need("-l"), nullptr, 16);     // apps/btrx:42-43
         else if (a == "-p" || a == "--hop") hop = true;                                // apps/btrx:46-47
@@ -78,6 +83,31 @@ int main(int argc, char **argv)
     const size_t H = blk->history(), mult = (size_t)blk->output_multiple();
     std::vector<gr_complex> buf(H - 1, gr_complex(0, 0));          // GNU Radio pre-fills history()-1 zeros
     std::vector<int16_t> sbuf;
+    if (gpus > 1) {
+        // whole capture in memory, one time range per device
+        for (;;) {
+            size_t want = (size_t)1 << 22;
+            if (nsamples >= 0 && (double)(buf.size() - (H - 1)) + (double)want > nsamples) want = (size_t)(nsamples - (double)(buf.size() - (H - 1)));
+            if (want == 0) break;
+            size_t old = buf.size(), got;
+            buf.resize(old + want);
+            if (shorts) {
+                sbuf.resize(2 * want);
+                got = fread(sbuf.data(), 2 * sizeof(int16_t), want, fp);
+                for (size_t i = 0; i < got; i++) buf[old + i] = gr_complex(sbuf[2 * i], sbuf[2 * i + 1]);
+            } else got = fread(&buf[old], sizeof(gr_complex), want, fp);
+            buf.resize(old + got);
+            if (got < want) break;
+        }
+        if (fp != stdin) fclose(fp);
+        try {
+            blk->run_partitioned(buf.data(), buf.size() - (H - 1), gpus, all_on_device0);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "%s\n", e.what());
+            return 2;
+        }
+        return 0;
+    }
     const size_t chunk = mult * (size_t)(chunk_slots > 0 ? chunk_slots : 1);
     double remaining = nsamples;
     bool eof = false;

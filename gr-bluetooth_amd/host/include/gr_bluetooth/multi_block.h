@@ -37,7 +37,18 @@ protected:
     // hdr: the GPU header sweep of a classic hit (multi_sniffer), else nullptr
     virtual void handle_hit(const btgpu_hit &h, const btgpu_header *hdr, const uint8_t *syms, int nsyms) = 0;
 
+    void drain(btgpu_handle *g);          // records of `g` -> handle_hit, in order
+    btgpu_config d_cfg{};                 // what d_gpu was created with (run_partitioned clones it per device)
+
 public:
+    // Time-partitioned run over `ngpus` devices of this node (no GNU Radio counterpart: a flowgraph hands a
+    // block one stream): `items` is what work() would get for the WHOLE capture -- history()-1 old items
+    // followed by n_new new ones.  The whole slots are cut into ngpus contiguous ranges; range r goes, with its
+    // left halo of history()-1 (+ left_margin) samples, to device r (one btgpu handle and one host thread
+    // each, no collective); the ranges' records, each already ordered, are concatenated in range order --
+    // i.e. in stream order -- and pass through the same per-record handlers on the calling thread.
+    // all_on_device0: every range on device 0 (dry run on a one-GPU box).  Returns the items consumed.
+    long run_partitioned(const gr_complex *items, size_t n_new, int ngpus, bool all_on_device0 = false);
     double samples_per_slot() const { return d_design.samples_per_slot; }
     int low_channel() const { return d_design.low_channel; }
     int high_channel() const { return d_design.high_channel; }

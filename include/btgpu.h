@@ -18,6 +18,7 @@
  *                        ones), but consumes every whole slot in the buffer at once
  *   btgpu_process_device same work on a device-resident stream segment (time-partitioned
  *                        multi-GPU and bench entry; no reference counterpart)
+ *   btgpu_process_host   ... on a host-resident segment (what btrx_amd --gpus N gives each device)
  *   btgpu_poll           replaces the printf side effect of work(): hit records in the
  *                        order the reference's loops print them (slot, channel, offset)
  *   btgpu_acgen          classic_packet::acgen (lib/packet_impl.cc:309-364)
@@ -171,6 +172,12 @@ int btgpu_push(btgpu_handle *h, const float *iq, size_t n_complex);
  * `hip_stream` is a hipStream_t (NULL = the handle's own stream). */
 int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, size_t left_margin,
                          uint64_t first_slot, uint64_t n_slots, void *hip_stream);
+
+/* The same for a segment in HOST memory (one rank of a time-partitioned run driven from C/C++): the library
+ * stages it batch by batch through two pinned buffers, the copy of one batch overlapping the kernels of the
+ * previous one (with BTGPU_FLAG_ASYNC).  Same layout and meaning of the arguments as btgpu_process_device. */
+int btgpu_process_host(btgpu_handle *h, const float *iq, size_t n_complex, size_t left_margin,
+                       uint64_t first_slot, uint64_t n_slots);
 
 /* Drain queued hits, ordered by (slot, channel, kind, offset). Returns count (>=0) or <0. */
 int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits);

@@ -187,3 +187,23 @@ def test_btrx_amd_fhs_after_discovery(po, synth, tmp_path):
     assert "Correct CRC! UAP = 0x6b found after 15 total packets." in want
     assert "FHS contents: BD_ADDR 00:34:47:ab:cd:ef, CLK 1f2e3d4" in want and "DM1\n  LLID: 2\n" in want
     assert out.stdout.split("\n", 1)[1] == want
+
+
+@pytest.mark.parametrize("rate,fc,sniff,nslots", [("8M", 2476.5e6, True, 23), ("8M", 2476.5e6, False, 23), ("100M", 2441e6, True, 11)])
+def test_btrx_amd_time_partitioned_over_devices_prints_the_same(synth, tmp_path, rate, fc, sniff, nslots):
+    """btrx_amd --gpus N (multi_block::run_partitioned): the capture cut into N contiguous slot ranges, one btgpu
+    handle and one host thread per range (every range on device 0 here: one-GPU box), halo of history()-1 plus
+    the staged squelch's margin in front of each range, records concatenated in range order -- stdout equals
+    the single-device run byte for byte, packet handlers (UAP discovery state, ID suffixes, LE lines) included."""
+    fs = 8e6 if rate == "8M" else 100e6
+    iq, _ = synth.make_capture(fs, fc, nslots, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=77, snr_db=24, occupancy=0.6)
+    path = str(tmp_path / "cap.cfile")
+    iq.astype(np.complex64).tofile(path)
+    base = [BTRX, "-f", "%.1fM" % (fc / 1e6), "-r", rate, "-i", path] + (["-S"] if sniff else [])
+    one = subprocess.run(base, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr
+    assert len(one.stdout.splitlines()) > 5
+    for n in (2, 3):
+        many = subprocess.run(base + ["--gpus", str(n), "--all-on-device0"], capture_output=True, text=True, timeout=300)
+        assert many.returncode == 0, many.stderr
+        assert many.stdout == one.stdout, n
