@@ -146,7 +146,7 @@ classic_packet::classic_packet(const uint8_t *symbols, int length, uint32_t clkn
 {
     if (length > MAX_SYMBOLS) length = MAX_SYMBOLS;
     if (length < 0) length = 0;
-    std::memcpy(d_symbols.data(), symbols, (size_t)length);
+    if (length > 0) std::memcpy(d_symbols.data(), symbols, (size_t)length);   // (a hit may hand over no symbols at all)
     d_length = length;
     d_lap = bits(&d_symbols[38], 24);
 }
@@ -248,8 +248,15 @@ void classic_packet::set_clock(uint32_t clock, bool have27)
 
 bool classic_packet::payload_crc() const
 {
-    const uint16_t crc = crcgen(d_payload.data(), (d_payload_length - 2) * 8, d_uap);
-    return crc == (uint16_t)bits(&d_payload[(size_t)(d_payload_length - 2) * 8], 16);
+    // EV4 starts with a payload length of 1: the reference then takes the 16 check bits from eight bytes in
+    // front of d_payload (lib/packet_impl.cc:675-686 called from :946-1001; undefined behaviour).  Policy, as
+    // in the oracle: bits in front of the payload read as 0, a negative length is an empty CRC input.
+    const int start = (d_payload_length - 2) * 8;
+    const uint16_t crc = crcgen(d_payload.data(), start, d_uap);
+    uint16_t chk = 0;
+    for (int i = 0; i < 16; i++)
+        if (start + i >= 0) chk |= (uint16_t)((d_payload[(size_t)(start + i)] & 1) << i);
+    return crc == chk;
 }
 
 int classic_packet::fhs(int clock)

@@ -203,8 +203,14 @@ int  bto_packet_uap(const bto_packet *p) { return p->uap; }
 
 static int payload_crc_ok(const bto_packet *p)                                  /* :675-686 */
 {
-    unsigned crc = bto_crcgen(p->payload, (p->payload_length - 2) * 8, p->uap);
-    unsigned chk = air_bits(&p->payload[(p->payload_length - 2) * 8], 16);
+    /* EV4 (:946-1001) starts with payload_length = 1: the reference then reads the 16 check bits from
+     * d_payload[-8 .. 7], eight bytes in front of the array (UB).  Policy: bits in front of the
+     * payload read as 0 (and a negative length is an empty CRC input, as the reference's loop makes it). */
+    int start = (p->payload_length - 2) * 8;
+    unsigned crc = bto_crcgen(p->payload, start, p->uap);
+    unsigned chk = 0;
+    for (int i = 0; i < 16; i++)
+        if (start + i >= 0) chk |= ((unsigned)(p->payload[start + i] & 1)) << i;
     return crc == chk;
 }
 
