@@ -7,6 +7,7 @@
 
 #include "design.h"
 #include "pfb100.hip.h"
+#include "pfbm.hip.h"
 
 namespace btgpu {
 
@@ -25,6 +26,9 @@ struct BankBuffers {                        // device (or emulated) memory
     const float2 *taps_n = nullptr, *krot_n = nullptr; const int *binpos_n = nullptr;
     float2 *Z = nullptr; long long zstride = 0;
     unsigned long long *prof = nullptr;
+    // small-M banks (pfbm.hip.h)
+    const float2 *dftw_ch = nullptr, *dftw_n = nullptr;
+    int drow = 80;
 };
 
 inline size_t bank_lds_bytes(int span_samples, int nt, int nrows, bool chan)
@@ -109,6 +113,52 @@ inline void launch_noise_bank(const Design &des, const FastPath &fp, const BankB
     p.b2map = b.b2map_noise;
     const size_t lds = bank_lds_bytes(bk.D * (NT - 1) + bk.Q * 100, NT, NT, false);
     L(pfb100_kernel<15, 5, NT, false, false, kBankThreads>, p.ntiles, kBankThreads, lds, p);
+}
+
+// ---- the rates below 100 Msps: pfbm_kernel (M = fs / 1 MHz bins) ----
+template <class Launcher>
+inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const BankBuffers &b, size_t x_len,
+                                 long long w0, long long G, Launcher &&L)
+{
+    const btgpu_design &d = des.d;
+    const PfbBank &bk = fp.channel;
+    const int nch = d.high_channel - d.low_channel + 1;
+    PfbmParams p{};
+    p.x = b.x; p.x_len = (long long)x_len; p.x0 = w0 + d.first_channel_sample;
+    p.M = bk.M; p.D = bk.D; p.Q = bk.Q; p.T = G;
+    p.taps = b.taps_ch; p.dftw = b.dftw_ch; p.nsel = nch;
+    p.rho = b.rho_ch; p.rho_real = bk.rho_real ? 1 : 0;
+    p.krot = b.krot_ch; p.rot_period = bk.rot_period;
+    p.ntiles = (int)((G + kPfbmTT - 1) / kPfbmTT);
+    p.d = b.d; p.drow = b.drow; p.ptile = b.ptile; p.phead = b.phead;
+    p.tiles_per_block = des.outs_per_slot / kPfbmTT; p.tail = des.tail;
+    p.gain = des.demod_gain;
+    p.Z = b.Ydebug; p.zstride = b.ystride;
+    const size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, true);
+    if (bk.real_taps) L(pfbm_kernel<true, true>, p.ntiles, kPfbmThreads, lds, p);
+    else L(pfbm_kernel<false, true>, p.ntiles, kPfbmThreads, lds, p);
+    return p.ntiles;
+}
+
+template <class Launcher>
+inline void launch_noise_bank_m(const Design &des, const FastPath &fp, const BankBuffers &b, size_t x_len,
+                                long long w0, int S, Launcher &&L)
+{
+    const btgpu_design &d = des.d;
+    const NoiseStage &ns = fp.noise;
+    const PfbBank &bk = ns.pfb;
+    const int nch = d.high_channel - d.low_channel + 1;
+    const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+    PfbmParams p{};
+    p.x = b.x; p.x_len = (long long)x_len;
+    p.x0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
+    p.M = bk.M; p.D = bk.D; p.Q = bk.Q; p.T = Tn;
+    p.taps = b.taps_n; p.dftw = b.dftw_n; p.nsel = nch;
+    p.krot = b.krot_n; p.rot_period = bk.rot_period;
+    p.ntiles = (int)((Tn + kPfbmTT - 1) / kPfbmTT);
+    p.Z = b.Z; p.zstride = b.zstride;
+    const size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, false);
+    L(pfbm_kernel<false, false>, p.ntiles, kPfbmThreads, lds, p);
 }
 
 }  // namespace btgpu

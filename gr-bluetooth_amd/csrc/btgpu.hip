@@ -109,10 +109,11 @@ struct btgpu_handle {
     DevBuf d_in, d_in_b, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index, d_winbits;
-    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise;
+    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise, d_dftw_ch, d_dftw_n;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
     LaunchShape shape_s1;
     bool noise_pfb = false;
+    bool pfb_small = false, noise_small = false;   // small-M polyphase banks (rates below 100 Msps)
     bool fuse_noise = false;         // noise stage 1 rides on the channel bank's staged input
     bool overlap_noise = false;     // measured: running the two banks concurrently is slower (both saturate the CUs)
     long long zstride = 0;
@@ -157,7 +158,7 @@ struct btgpu_handle {
         DevBuf *all[] = {&d_in, &d_in_b, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
-                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise,
+                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_dftw_ch, &d_dftw_n,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d.p = nullptr;
@@ -203,6 +204,7 @@ struct btgpu_handle {
         b.binpos_n = (const int *)d_binpos_n.p;
         b.Z = (float2 *)d_Z.p; b.zstride = zstride;
         b.prof = (unsigned long long *)d_prof.p;
+        b.dftw_ch = (const float2 *)d_dftw_ch.p; b.dftw_n = (const float2 *)d_dftw_n.p; b.drow = drow;
         return b;
     }
     // host -> device staging of btgpu_work / btgpu_process_host: two pinned host buffers and two device input
@@ -253,7 +255,17 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     }
 
     // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 block sums P, Pt ----
-    if (use_pfb) {
+    if (use_pfb && pfb_small) {
+        BankBuffers bb = bank_buffers(d_x, d_d);
+        auto L = [&](void (*kern)(PfbmParams), int grid, int threads, size_t lds, const PfbmParams &p) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
+        };
+        const int ntiles = launch_channel_bank_m(des, fp, bb, x_len, w0, G, L);
+        HIPCHK(this, hipEventRecord(ev[1], st));
+        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, st,
+                           (const double *)d_ptile.p, (const double *)d_phead.p, ntiles, ops / kPfbmTT,
+                           des.tail / kPfbmTT, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
+    } else if (use_pfb) {
         constexpr int TT = kBankNT - 1;
         BankBuffers bb = bank_buffers(d_x, d_d);
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
@@ -297,6 +309,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                 hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, ns_st, p);
             };
             launch_noise_bank(des, fp, bb, x_len, w0, S, L);
+        } else if (noise_small) {
+            BankBuffers bb = bank_buffers(d_x, d_d);
+            auto L = [&](void (*kern)(PfbmParams), int grid, int threads, size_t lds, const PfbmParams &p) {
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, ns_st, p);
+            };
+            launch_noise_bank_m(des, fp, bb, x_len, w0, S, L);
         } else {
             // stage 1 as a direct-form bank: B-spline prototype (a few hundred taps at most), hop R
             const LaunchShape &s = shape_s1;
@@ -695,20 +713,37 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     {
         FastPath *fp = &h->fp;
         int frc = make_fast_path(h->des, *fp);
-        const bool pfb_ok = !h->des.segmented && (frc == BTGPU_OK || frc == BTGPU_EUNSUPPORTED) && fp->channel.available && fp->channel.Q == 7 && fp->channel.S == 1 &&
-                            h->des.outs_per_slot % 25 == 0;
-        const bool noise_pfb_ok = fp->noise.available && fp->noise.pfb.available && fp->noise.pfb.Q == 15 && fp->noise.pfb.S == 5;
+        const int nch0 = h->des.d.high_channel - h->des.d.low_channel + 1;
+        // 100 Msps: the 10 x 10 FFT bank (pfb100.hip.h); other even integer rates: the small-M bank (pfbm.hip.h)
+        const bool pfb100_ok = fp->channel.available && fp->channel.M == kPfbM && fp->channel.Q == 7 && fp->channel.S == 1 &&
+                               h->des.outs_per_slot % 25 == 0;
+        const bool pfbm_ok = fp->channel.available && fp->channel.M >= 4 && fp->channel.M < kPfbM &&
+                             h->des.outs_per_slot % kPfbmTT == 0 &&
+                             pfbm_lds_bytes(fp->channel.M, fp->channel.D, fp->channel.Q, nch0, true) <= 96 * 1024;
+        const bool pfb_ok = !h->des.segmented && (frc == BTGPU_OK || frc == BTGPU_EUNSUPPORTED) && (pfb100_ok || pfbm_ok);
+        const bool noise_pfb_ok = fp->noise.available && fp->noise.pfb.available && fp->noise.pfb.M == kPfbM &&
+                                  fp->noise.pfb.Q == 15 && fp->noise.pfb.S == 5;
+        const bool noise_small_ok = fp->noise.available && fp->noise.pfb.available && fp->noise.pfb.M >= 4 && fp->noise.pfb.M < kPfbM &&
+                                    pfbm_lds_bytes(fp->noise.pfb.M, fp->noise.pfb.D, fp->noise.pfb.Q, nch0, false) <= 96 * 1024;
         const bool staged_ok = !h->des.segmented && fp->noise.available &&
-                               (noise_pfb_ok || pick_shape(fp->noise.R, fp->noise.direct.ntp, h->shape_s1));
+                               (noise_pfb_ok || noise_small_ok || pick_shape(fp->noise.R, fp->noise.direct.ntp, h->shape_s1));
         h->noise_pfb = noise_pfb_ok;
+        h->noise_small = noise_small_ok && !getenv("BTGPU_NO_PFBM_NOISE");
         h->fuse_noise = false;
         int ch = cfg->channelizer, sq = cfg->squelch;
+        // BTGPU_AUTO=direct: AUTO resolves to the bit-exact direct forms (tests of the host protocol layer that
+        // compare printed text with the oracle's, character for character)
+        if (getenv("BTGPU_AUTO") && std::strcmp(getenv("BTGPU_AUTO"), "direct") == 0) {
+            if (ch == BTGPU_CHANNELIZER_AUTO) ch = BTGPU_CHANNELIZER_DIRECT;
+            if (sq == BTGPU_SQUELCH_AUTO) sq = BTGPU_SQUELCH_DIRECT;
+        }
         if (ch == BTGPU_CHANNELIZER_AUTO) ch = pfb_ok ? BTGPU_CHANNELIZER_POLYPHASE : BTGPU_CHANNELIZER_DIRECT;
         if (sq == BTGPU_SQUELCH_AUTO) sq = staged_ok ? BTGPU_SQUELCH_STAGED : BTGPU_SQUELCH_DIRECT;
         if ((ch == BTGPU_CHANNELIZER_POLYPHASE && !pfb_ok) || (sq == BTGPU_SQUELCH_STAGED && !staged_ok) ||
             (ch != BTGPU_CHANNELIZER_POLYPHASE && ch != BTGPU_CHANNELIZER_DIRECT) ||
             (sq != BTGPU_SQUELCH_STAGED && sq != BTGPU_SQUELCH_DIRECT)) { delete h; return BTGPU_EUNSUPPORTED; }
         h->use_pfb = ch == BTGPU_CHANNELIZER_POLYPHASE;
+        h->pfb_small = h->use_pfb && !pfb100_ok;
         h->use_staged = sq == BTGPU_SQUELCH_STAGED;
         h->keep_Y = !h->use_pfb || (cfg->flags & BTGPU_FLAG_DEBUG_Y);
         h->margin = h->use_staged ? kNoiseMargin : 0;
@@ -794,7 +829,16 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     if (h->keep_Y) TRY(h->alloc(h->d_Y, (size_t)nch * h->ystride * sizeof(float2)));
     if (!h->use_staged) TRY(h->alloc(h->d_Yn, (size_t)nch * h->ystride_n * sizeof(float2)));
-    if (h->use_pfb) {
+    if (h->use_pfb && h->pfb_small) {
+        const PfbBank &b = h->fp.channel;
+        h->ntiles_max = (int)((G + kPfbmTT - 1) / kPfbmTT);
+        TRY(h->upload(h->d_pfb_taps_ch, b.taps.data(), b.taps.size() * sizeof(float)));
+        TRY(h->upload(h->d_dftw_ch, b.dftw.data(), b.dftw.size() * sizeof(float)));
+        TRY(h->upload(h->d_rho_ch, b.rho.data(), b.rho.size() * sizeof(float)));
+        TRY(h->upload(h->d_krot_ch, b.krot.data(), b.krot.size() * sizeof(float)));
+        TRY(h->alloc(h->d_ptile, (size_t)nch * h->ntiles_max * sizeof(double)));
+        TRY(h->alloc(h->d_phead, (size_t)nch * h->ntiles_max * sizeof(double)));
+    } else if (h->use_pfb) {
         const PfbBank &b = h->fp.channel;
         h->ntiles_max = (int)((G + 24) / 25);
         TRY(h->upload(h->d_pfb_taps_ch, b.taps.data(), b.taps.size() * sizeof(float)));
@@ -829,6 +873,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
                 TRY(h->upload(h->d_b2map_noise, mn.data(), mn.size() * sizeof(uint16_t)));
             }
             TRY(h->upload(h->d_krot_n, ns.pfb.krot.data(), ns.pfb.krot.size() * sizeof(float)));
+        } else if (h->noise_small) {
+            TRY(h->upload(h->d_pfb_taps_n, ns.pfb.taps.data(), ns.pfb.taps.size() * sizeof(float)));
+            TRY(h->upload(h->d_dftw_n, ns.pfb.dftw.data(), ns.pfb.dftw.size() * sizeof(float)));
+            TRY(h->upload(h->d_krot_n, ns.pfb.krot.data(), ns.pfb.krot.size() * sizeof(float)));
         } else {
             TRY(h->upload(h->d_taps_s1, ns.direct.taps.data(), ns.direct.taps.size() * sizeof(float)));
             TRY(h->upload(h->d_rot_s1, ns.direct.rot.data(), ns.direct.rot.size() * sizeof(float)));
@@ -840,7 +888,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_h3, ns.h3.data(), ns.h3.size() * sizeof(float)));
         TRY(h->upload(h->d_w, ns.weights.data(), ns.weights.size() * sizeof(double)));
     }
-    h->drow = h->use_pfb ? 80 : win_drow(nch);            // the polyphase epilogue writes 80-float rows
+    h->drow = (h->use_pfb && !h->pfb_small) ? 80 : win_drow(nch);   // the 100-bin bank's epilogue writes 80-float rows
     if (nch > 80) return fail(BTGPU_EUNSUPPORTED);
     TRY(h->alloc(h->d_P, (size_t)nch * h->nb_max * sizeof(double)));
     TRY(h->alloc(h->d_Pt, (size_t)nch * h->nb_max * sizeof(double)));
@@ -894,6 +942,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

@@ -87,13 +87,15 @@ constexpr int kNoiseMargin = 4096;      // samples before a segment the staged n
 
 struct PfbBank {
     bool available = false;
+    int M = 0;                          // bins: fs / 1 MHz (100: the 10 x 10 FFT kernel; 4..50: the small-M kernel)
     int D = 0;                          // hop (input samples per output instant)
     int L = 0;                          // prototype length
     int Q = 0;                          // taps per polyphase branch, ceil(L / 100)
     int S = 0;                          // 2*D / 100: branch-window slide per two output instants
     bool real_taps = false;
-    std::vector<float> taps;            // [Q*100][2]  a[j] = proto[L-1-j] * exp(-j 2 pi delta j / 100)
-    std::vector<float> twiddle;         // [100][2]    exp(-j 2 pi m1 p2 / 100) at index m1*10 + p2
+    std::vector<float> taps;            // [Q*M][2]  a[j] = proto[L-1-j] * exp(-j 2 pi delta j / M)
+    std::vector<float> twiddle;         // M = 100: [100][2] exp(-j 2 pi m1 p2 / 100) at index m1*10 + p2
+    std::vector<float> dftw;            // M < 100: [M][nch][2] exp(-j 2 pi p m_c / M), the DFT restricted to the channels' bins
     std::vector<int> binpos;            // [nch] position of the channel's bin in the in-place 10x10 FFT output
     std::vector<int> binnat;            // [nch] the bin itself, m in 0..99 (channel epilogue: Y[t][m])
     int rot_period = 0;

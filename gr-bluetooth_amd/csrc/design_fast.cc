@@ -46,9 +46,11 @@ long long gcdll(long long a, long long b)
 bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::vector<double> &foff_hz,
                double fs)
 {
-    const int M = kPfbM;
-    if (std::fabs(fs - 100e6) > 1e-3) return false;
+    // bins of 1 MHz: M = fs / 1 MHz must be an even integer (two output instants per symbol)
+    const int M = (int)std::llround(fs / 1e6);
+    if (std::fabs(fs - 1e6 * M) > 1e-3 || M < 2 || M > kPfbM || M % 2 != 0) return false;
     if ((2 * D) % M != 0) return false;
+    b.M = M;
     const int nch = (int)foff_hz.size();
     const double lowoff = foff_hz[0] / 1e6;
     const double delta = lowoff - std::floor(lowoff);
@@ -95,7 +97,7 @@ bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::v
         const long long m = (long long)std::floor(off - delta + 0.5);
         if (std::fabs(off - (m + delta)) > 1e-9) return false;
         const int mm = (int)(((m % M) + M) % M);
-        b.binpos[c] = 10 * (mm % 10) + mm / 10;
+        b.binpos[c] = M == kPfbM ? 10 * (mm % 10) + mm / 10 : mm;
         b.binnat[c] = mm;
         {
             // one-step rotation: exp(-j 2 pi foff D / fs), exact on the quarter-turn grid
@@ -124,6 +126,16 @@ bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::v
             b.krot[((size_t)c * period + t) * 2 + 0] = c_r * rr - c_i * ri;
             b.krot[((size_t)c * period + t) * 2 + 1] = c_r * ri + c_i * rr;
         }
+    }
+    if (M < kPfbM) {
+        b.dftw.resize((size_t)M * nch * 2);
+        for (int pidx = 0; pidx < M; pidx++)
+            for (int c = 0; c < nch; c++) {
+                float wr, wi;
+                phasor_turns(-(double)((long long)pidx * b.binnat[c] % M) / (double)M, wr, wi);
+                b.dftw[((size_t)pidx * nch + c) * 2 + 0] = wr;
+                b.dftw[((size_t)pidx * nch + c) * 2 + 1] = wi;
+            }
     }
     b.available = true;
     return true;

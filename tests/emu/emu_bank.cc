@@ -95,6 +95,69 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     return 0;
 }
 
+// The small-M banks (pfbm.hip.h): channel bank -> d [G][drow] + block sums, noise bank -> Z.  Same outputs and sizes[]
+// as emu_bank_run, plus sizes[6] = drow.
+int emu_bank_m_run(double fs, double fc, int mode, const float *iq, long long x_len, long long w0, int S,
+                   float *d_out, double *P_out, double *Pt_out, float *Z_out, float *Y_out, long long *sizes)
+{
+    btgpu_config cfg{};
+    cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = 10.0; cfg.mode = mode;
+    static Design des; static FastPath fp;
+    int rc = make_design(cfg, des);
+    if (rc) return rc;
+    rc = make_fast_path(des, fp);
+    if (rc) return rc;
+    if (!fp.channel.available || fp.channel.M >= kPfbM || !fp.noise.available || !fp.noise.pfb.available) return BTGPU_EUNSUPPORTED;
+    const btgpu_design &d = des.d;
+    const int nch = d.high_channel - d.low_channel + 1;
+    const int ops = des.outs_per_slot;
+    const long long G = (long long)ops * (S - 1) + d.ddc_out;
+    const int nb = (int)((G + ops - 1) / ops);
+    const NoiseStage &ns = fp.noise;
+    const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+    const long long zstride = (Tn + 10 + 63) / 64 * 64, ystride = (G + 63) / 64 * 64;
+    const int drow = win_drow(nch);
+    sizes[0] = G; sizes[1] = nb; sizes[2] = nch; sizes[3] = zstride; sizes[4] = ystride; sizes[5] = Tn; sizes[6] = drow;
+    if (!d_out) return 0;
+    const int ntiles_max = (int)((G + kPfbmTT - 1) / kPfbmTT);
+    std::vector<double> ptile((size_t)nch * ntiles_max, 0.0), phead((size_t)nch * ntiles_max, 0.0);
+    std::vector<float4> xbuf((size_t)x_len / 2 + 16);
+    std::memcpy(xbuf.data(), iq, (size_t)x_len * sizeof(float2));
+    BankBuffers b;
+    b.x = (const float2 *)xbuf.data();
+    b.taps_ch = (const float2 *)fp.channel.taps.data(); b.dftw_ch = (const float2 *)fp.channel.dftw.data();
+    b.krot_ch = (const float2 *)fp.channel.krot.data(); b.rho_ch = (const float2 *)fp.channel.rho.data();
+    b.d = d_out; b.drow = drow; b.ptile = ptile.data(); b.phead = phead.data();
+    b.Ydebug = (float2 *)Y_out; b.ystride = ystride;
+    b.taps_n = (const float2 *)ns.pfb.taps.data(); b.dftw_n = (const float2 *)ns.pfb.dftw.data();
+    b.krot_n = (const float2 *)ns.pfb.krot.data();
+    b.Z = (float2 *)Z_out; b.zstride = zstride;
+    auto L = [&](void (*kern)(PfbmParams), int grid, int threads, size_t lds, const PfbmParams &p) {
+        if (lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", lds); std::abort(); }
+        std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
+        emu::launch(dim3((unsigned)grid), dim3((unsigned)threads), [&]() { kern(p); });
+    };
+    const int ntiles = launch_channel_bank_m(des, fp, b, (size_t)x_len, w0, G, L);
+    launch_noise_bank_m(des, fp, b, (size_t)x_len, w0, S, L);
+    const int tpb = ops / kPfbmTT, tail_tiles = des.tail / kPfbmTT;
+    for (int c = 0; c < nch; c++)
+        for (int bi = 0; bi < nb; bi++) {
+            double s = 0.0, h = 0.0;
+            for (int k = 0; k < tpb; k++) {
+                const int t = bi * tpb + k;
+                if (t < ntiles) {
+                    const double v = ptile[(size_t)c * ntiles + t];
+                    s += v;
+                    if (k < tail_tiles) h += v;
+                    else if (k == tail_tiles) h += phead[(size_t)c * ntiles + t];
+                }
+            }
+            P_out[(size_t)c * nb + bi] = s;
+            Pt_out[(size_t)c * nb + bi] = h;
+        }
+    return 0;
+}
+
 // staged-squelch stage 2 constants (host design) for the tests' numpy restatement of noise_stage2_kernel
 int emu_stage2_design(double fs, double fc, int mode, float *h3, double *w, int *ints /* outs, nw, L3, R, pad, Jm */)
 {

@@ -23,6 +23,9 @@ def emu():
     L.emu_bank_run.restype = ctypes.c_int
     L.emu_bank_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, fp, ctypes.c_longlong, ctypes.c_longlong,
                                ctypes.c_int, ctypes.c_int, fp, dp, dp, fp, fp, ctypes.POINTER(ctypes.c_longlong)]
+    L.emu_bank_m_run.restype = ctypes.c_int
+    L.emu_bank_m_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, fp, ctypes.c_longlong, ctypes.c_longlong,
+                                 ctypes.c_int, fp, dp, dp, fp, fp, ctypes.POINTER(ctypes.c_longlong)]
     L.emu_stage2_design.restype = ctypes.c_int
     L.emu_stage2_design.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, fp, dp, ctypes.POINTER(ctypes.c_int)]
     L.emu_b2map.restype = ctypes.c_int
@@ -187,3 +190,65 @@ def test_channel_bank_other_geometries(emu, po, synth, fc, mode):
         assert np.linalg.norm(yk - y * rot) / np.linalg.norm(y) <= 1e-5
         e_gpu = (r["P"][c, k:k + nblk].sum() + (r["Pt"][c, k + nblk] if tail else 0.0)) / o.ddc_out
         assert abs(e_gpu - e_on) / e_on <= 1e-5
+
+
+def _run_m(L, fs, fc, mode, x, w0, S):
+    sizes = (ctypes.c_longlong * 7)()
+    fp = ctypes.POINTER(ctypes.c_float)
+    dp = ctypes.POINTER(ctypes.c_double)
+    xf = np.ascontiguousarray(x.astype(np.complex64)).view(np.float32)
+    rc = L.emu_bank_m_run(fs, fc, mode, xf.ctypes.data_as(fp), len(x), w0, S, None, None, None, None, None, sizes)
+    assert rc == 0
+    G, nb, nch, zstride, ystride, Tn, drow = [int(v) for v in sizes]
+    d = np.full((G + 64, drow), np.nan, np.float32)
+    P = np.zeros((nch, nb)); Pt = np.zeros((nch, nb))
+    Z = np.full((nch, zstride), np.nan + 0j, np.complex64)
+    Y = np.full((nch, ystride), np.nan + 0j, np.complex64)
+    rc = L.emu_bank_m_run(fs, fc, mode, xf.ctypes.data_as(fp), len(x), w0, S, d.ctypes.data_as(fp), P.ctypes.data_as(dp),
+                          Pt.ctypes.data_as(dp), Z.view(np.float32).ctypes.data_as(fp), Y.view(np.float32).ctypes.data_as(fp), sizes)
+    assert rc == 0
+    return dict(d=d, P=P, Pt=Pt, Z=Z, Y=Y, G=G, nb=nb, nch=nch, Tn=Tn)
+
+
+@pytest.mark.parametrize("fs,fc,mode", [(8e6, 2476.5e6, 1), (8e6, 2476.5e6, 0), (20e6, 2441e6, 1), (4e6, 2476e6, 1), (16e6, 2440e6, 1),
+                                        (50e6, 2441e6, 1)])
+def test_small_m_banks_vs_oracle(emu, po, synth, fs, fc, mode):
+    """pfbm_kernel (M = fs / 1 MHz bins): BASELINE configs[1] (8 Msps, eight channels on the half-MHz grid) and the
+    other even rates, multi_sniffer and multi_LAP geometry -- demodulated stream, channel output, window energy and
+    the staged squelch's E_off against the oracle, at the FAST path's tolerances."""
+    S = 8 if mode == 1 else 2
+    laps = (0x24D952, 0x4831DD, 0x9E8B33)
+    iq, _ = synth.make_capture(fs, fc, S, laps=laps, seed=11, snr_db=25, occupancy=0.9)
+    o = po.Oracle(fs, fc, 10.0, mode)
+    H = o.history
+    x = np.concatenate([np.zeros(4096 + H - 1, np.complex64), iq.astype(np.complex64)])
+    r = _run_m(emu, fs, fc, mode, x, 4096, S)
+    assert r["nch"] == o.high_ch - o.low_ch + 1
+    k = S - 1
+    win = o.window(iq, k)
+    nblk, tail = o.ddc_out // 1250, o.ddc_out % 1250
+    ints = (ctypes.c_int * 6)()
+    assert emu.emu_stage2_design(fs, fc, mode, None, None, ints) == 0
+    outs, nw, L3 = ints[0], ints[1], ints[2]
+    h3 = np.zeros(L3, np.float32); w = np.zeros(nw)
+    emu.emu_stage2_design(fs, fc, mode, h3.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ints)
+    for ch in sorted({o.low_ch, (o.low_ch + o.high_ch) // 2, o.high_ch}):
+        c = ch - o.low_ch
+        y, e_on = o.channel_samples(win, ch)
+        dref = o.demod(y)[1:]
+        got = r["d"][1250 * k + 1:1250 * k + o.ddc_out - 1, c]
+        strong = (np.abs(y[1:-1]) > 1e-2 * np.abs(y).max()) & (np.abs(y[:-2]) > 1e-2 * np.abs(y).max())
+        assert np.abs(got - dref)[strong].max() <= 1e-4
+        turns = (2402e6 + ch * 1e6 - fc) * o.decim * 1250 * k / fs
+        rot = np.exp(-2j * np.pi * (turns - np.floor(turns)))
+        yk = r["Y"][c, 1250 * k:1250 * k + o.ddc_out]
+        assert np.linalg.norm(yk - y * rot) / np.linalg.norm(y) <= 1e-5
+        e_gpu = (r["P"][c, k:k + nblk].sum() + (r["Pt"][c, k + nblk] if tail else 0.0)) / o.ddc_out
+        assert abs(e_gpu - e_on) / e_on <= 1e-5
+        if mode == 1:                                           # window k = 7 has capture samples in its squelch slot
+            z = r["Z"][c, k * outs:k * outs + nw + L3 - 1].astype(np.complex128)
+            assert np.isfinite(z).all()
+            yh = np.array([np.dot(h3.astype(np.float64), z[j:j + L3]) for j in range(nw)])
+            q = float(np.dot(w, np.abs(yh) ** 2))
+            ok, snr, e_off = o.check_snr(win, ch, e_on)
+            assert abs(q / o.noise_out - e_off) / e_off <= 1e-5, (ch, q / o.noise_out, e_off)

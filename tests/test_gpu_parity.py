@@ -133,15 +133,18 @@ def test_fast_path_is_default_at_100msps_and_margin_is_reported(pkg):
     assert b.design.channelizer == pkg.CHANNELIZER_POLYPHASE and b.design.squelch == pkg.SQUELCH_STAGED
     assert b.design.left_margin >= 2200
     b.close()
-    b = pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False)             # no 100-bin bank at 8 Msps: direct DDC,
-    assert b.design.channelizer == pkg.CHANNELIZER_DIRECT          # staged squelch (direct-form stage 1)
+    b = pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False)             # 8 Msps: the small-M polyphase bank (8 bins),
+    assert b.design.channelizer == pkg.CHANNELIZER_POLYPHASE       # staged squelch
     assert b.design.squelch == pkg.SQUELCH_STAGED and b.design.left_margin >= 200
     b.close()
-    b = pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False, squelch=pkg.SQUELCH_DIRECT)
-    assert b.design.squelch == pkg.SQUELCH_DIRECT and b.design.left_margin == 0
+    b = pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False, channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT)
+    assert (b.design.channelizer, b.design.squelch, b.design.left_margin) == (pkg.CHANNELIZER_DIRECT, pkg.SQUELCH_DIRECT, 0)
+    b.close()
+    b = pkg.multi_sniffer(5e6, 2470e6, 10.0, False)               # odd samples per symbol: no shared output grid,
+    assert b.design.channelizer == pkg.CHANNELIZER_DIRECT          # direct form only
     b.close()
     with pytest.raises(pkg.BtgpuError):
-        pkg.multi_sniffer(8e6, 2476.5e6, 10.0, False, channelizer=pkg.CHANNELIZER_POLYPHASE)
+        pkg.multi_sniffer(5e6, 2470e6, 10.0, False, channelizer=pkg.CHANNELIZER_POLYPHASE)
 
 
 def test_golden_fixture(pkg):
@@ -390,7 +393,7 @@ def test_fast_path_ragged_pushes_equal_one_shot(pkg, synth):
 def test_work_contract(pkg, po, synth):
     """work(): history()-1 old items + new ones; consumes whole slots only."""
     fs, fc = 8e6, 2476.5e6
-    blk = pkg.multi_sniffer(fs, fc, 10.0, False)
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT)
     H, slot = blk.history(), blk.output_multiple()
     assert (H, slot) == (31601, 5000)
     assert blk.work(np.zeros(H - 1 + slot - 1, np.complex64)) == 0          # not a whole slot yet
@@ -430,7 +433,7 @@ def test_process_device_with_halo_equals_stream(pkg, po, synth):
     fs, fc = 8e6, 2476.5e6
     iq, _ = synth.make_capture(fs, fc, 20, laps=(0x24D952, 0x4831DD), seed=13, snr_db=24, occupancy=0.5)
     want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq, threads=8)
-    blk = pkg.multi_sniffer(fs, fc, 10.0, False)
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT)
     H, slot = blk.history(), blk.output_multiple()
     full = np.concatenate([np.zeros(H - 1, np.complex64), iq])
     got = []
@@ -679,3 +682,48 @@ def test_bench_two_ranks_on_one_device_equal_one_rank(tmp_path):
     if torch.cuda.device_count() < 2:
         bad = subprocess.run(base + ["--gpus", "2", "--slots", "24"], capture_output=True, text=True, env=env, timeout=300)
         assert bad.returncode != 0 and "only" in (bad.stderr + bad.stdout)
+
+
+@pytest.mark.parametrize("fs,fc,nslots", [(8e6, 2476.5e6, 40), (20e6, 2441e6, 24), (4e6, 2476e6, 40), (50e6, 2441e6, 12)])
+def test_fast_path_small_rates_vs_oracle_and_direct(pkg, po, synth, fs, fc, nslots):
+    """BASELINE configs[1] and the other even rates on their default path -- the small-M polyphase bank
+    (pfbm_kernel) + staged squelch -- against the oracle and the bit-exact DIRECT path: channel output rel-L2
+    <= 1e-5, E_on / E_off <= 1e-5, SNR <= 1e-4 dB, records identical on (slot, channel, kind, offset, LAP,
+    ac_errors), nsym within +-8.  multi_LAP geometry too."""
+    laps = (0x24D952, 0x4831DD, 0x9E8B33, 0xABCDEF)
+    iq, _ = synth.make_capture(fs, fc, nslots, laps=laps, seed=int(fs / 1e6) + 100, snr_db=24, occupancy=0.6)
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    want, _ = o.run_stream(iq, threads=16)
+    nch = o.high_ch - o.low_ch + 1
+    out = {}
+    for name, kw in (("direct", dict(channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT)), ("fast", {})):
+        b = pkg.multi_sniffer(fs, fc, 10.0, False, flags=pkg.FLAG_DEBUG_Y, max_batch_slots=nslots, **kw)
+        if name == "fast":
+            assert (b.design.channelizer, b.design.squelch) == (pkg.CHANNELIZER_POLYPHASE, pkg.SQUELCH_STAGED)
+        b.push(iq)
+        out[name] = dict(hits=b.poll(), Y={c: b.debug_fetch(0, c, 0, 1 << 22) for c in (o.low_ch, o.high_ch)},
+                         eon=b.debug_fetch(2, 0, 0, nslots * nch), eoff=b.debug_fetch(3, 0, 0, nslots * nch),
+                         snr=b.debug_fetch(4, 0, 0, nslots * nch))
+        b.close()
+    assert len(want) > 5
+    assert _keys(out["direct"]["hits"]) == _keys(want)
+    fk, wk = _keys(out["fast"]["hits"]), _keys(want)
+    assert [k[:6] for k in fk] == [k[:6] for k in wk]
+    assert max(abs(a[6] - b[6]) for a, b in zip(fk, wk)) <= 8
+    for c in (o.low_ch, o.high_ch):
+        a, r = out["fast"]["Y"][c], out["direct"]["Y"][c]
+        n = min(len(a), len(r))
+        assert np.linalg.norm(a[1:n] - r[1:n]) / np.linalg.norm(r[1:n]) <= 1e-5
+    m = np.isfinite(out["direct"]["snr"]) & (out["direct"]["eoff"] > 0)
+    assert m.sum() > 20
+    for key in ("eon", "eoff"):
+        assert np.max(np.abs(out["fast"][key][m] - out["direct"][key][m]) / out["direct"][key][m]) <= 1e-5
+    assert np.max(np.abs(out["fast"]["snr"][m] - out["direct"]["snr"][m])) <= 1e-4
+    lo = po.Oracle(fs, fc, 10.0, po.MODE_LAP)
+    lwant, _ = lo.run_stream(iq, threads=16)
+    lb = pkg.multi_LAP(fs, fc, 10.0)
+    assert lb.design.channelizer == pkg.CHANNELIZER_POLYPHASE
+    lb.push(iq)
+    lgot = lb.poll()
+    lb.close()
+    assert len(lwant) > 3 and [k[:6] for k in _keys(lgot)] == [k[:6] for k in _keys(lwant)]

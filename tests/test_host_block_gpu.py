@@ -8,6 +8,11 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# These tests compare printed text with the oracle pipeline character for character (they are about the host
+# protocol layer): the blocks' AUTO settings resolve to the bit-exact direct forms here.  The default
+# (polyphase) path through the same blocks is covered by test_btrx_amd_time_partitioned_... and by
+# tests/test_gpu_parity.py.
+os.environ["BTGPU_AUTO"] = "direct"
 BTRX = os.path.join(ROOT, "gr-bluetooth_amd", "host", "btrx_amd")
 
 
@@ -200,10 +205,12 @@ def test_btrx_amd_time_partitioned_over_devices_prints_the_same(synth, tmp_path,
     path = str(tmp_path / "cap.cfile")
     iq.astype(np.complex64).tofile(path)
     base = [BTRX, "-f", "%.1fM" % (fc / 1e6), "-r", rate, "-i", path] + (["-S"] if sniff else [])
-    one = subprocess.run(base, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    env.pop("BTGPU_AUTO", None)                                  # the blocks' default path: polyphase banks, staged squelch
+    one = subprocess.run(base, capture_output=True, text=True, timeout=300, env=env)
     assert one.returncode == 0, one.stderr
     assert len(one.stdout.splitlines()) > 5
     for n in (2, 3):
-        many = subprocess.run(base + ["--gpus", str(n), "--all-on-device0"], capture_output=True, text=True, timeout=300)
+        many = subprocess.run(base + ["--gpus", str(n), "--all-on-device0"], capture_output=True, text=True, timeout=300, env=env)
         assert many.returncode == 0, many.stderr
         assert many.stdout == one.stdout, n
