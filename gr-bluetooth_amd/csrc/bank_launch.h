@@ -125,13 +125,13 @@ inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const Ba
     const int nch = d.high_channel - d.low_channel + 1;
     PfbmParams p{};
     p.x = b.x; p.x_len = (long long)x_len; p.x0 = w0 + d.first_channel_sample;
-    p.M = bk.M; p.D = bk.D; p.Q = bk.Q; p.T = G;
+    p.M = bk.M; p.D = bk.D; p.Q = bk.Q; p.T = G; p.TT = pfbm_tile(bk.M);
     p.taps = b.taps_ch; p.dftw = b.dftw_ch; p.nsel = nch;
     p.rho = b.rho_ch; p.rho_real = bk.rho_real ? 1 : 0;
     p.krot = b.krot_ch; p.rot_period = bk.rot_period;
-    p.ntiles = (int)((G + kPfbmTT - 1) / kPfbmTT);
+    p.ntiles = (int)((G + p.TT - 1) / p.TT);
     p.d = b.d; p.drow = b.drow; p.ptile = b.ptile; p.phead = b.phead;
-    p.tiles_per_block = des.outs_per_slot / kPfbmTT; p.tail = des.tail;
+    p.tiles_per_block = des.outs_per_slot / p.TT; p.tail = des.tail;
     p.gain = des.demod_gain;
     p.Z = b.Ydebug; p.zstride = b.ystride;
     const size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, true);
@@ -152,10 +152,10 @@ inline void launch_noise_bank_m(const Design &des, const FastPath &fp, const Ban
     PfbmParams p{};
     p.x = b.x; p.x_len = (long long)x_len;
     p.x0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
-    p.M = bk.M; p.D = bk.D; p.Q = bk.Q; p.T = Tn;
+    p.M = bk.M; p.D = bk.D; p.Q = bk.Q; p.T = Tn; p.TT = pfbm_tile(bk.M);
     p.taps = b.taps_n; p.dftw = b.dftw_n; p.nsel = nch;
     p.krot = b.krot_n; p.rot_period = bk.rot_period;
-    p.ntiles = (int)((Tn + kPfbmTT - 1) / kPfbmTT);
+    p.ntiles = (int)((Tn + p.TT - 1) / p.TT);
     p.Z = b.Z; p.zstride = b.zstride;
     const size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, false);
     L(pfbm_kernel<false, false>, p.ntiles, kPfbmThreads, lds, p);

@@ -263,8 +263,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         const int ntiles = launch_channel_bank_m(des, fp, bb, x_len, w0, G, L);
         HIPCHK(this, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, st,
-                           (const double *)d_ptile.p, (const double *)d_phead.p, ntiles, ops / kPfbmTT,
-                           des.tail / kPfbmTT, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
+                           (const double *)d_ptile.p, (const double *)d_phead.p, ntiles, ops / pfbm_tile(fp.channel.M),
+                           des.tail / pfbm_tile(fp.channel.M), (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     } else if (use_pfb) {
         constexpr int TT = kBankNT - 1;
         BankBuffers bb = bank_buffers(d_x, d_d);
@@ -718,7 +718,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         const bool pfb100_ok = fp->channel.available && fp->channel.M == kPfbM && fp->channel.Q == 7 && fp->channel.S == 1 &&
                                h->des.outs_per_slot % 25 == 0;
         const bool pfbm_ok = fp->channel.available && fp->channel.M >= 4 && fp->channel.M < kPfbM &&
-                             h->des.outs_per_slot % kPfbmTT == 0 &&
+                             h->des.outs_per_slot % pfbm_tile(fp->channel.M) == 0 &&
                              pfbm_lds_bytes(fp->channel.M, fp->channel.D, fp->channel.Q, nch0, true) <= 96 * 1024;
         const bool pfb_ok = !h->des.segmented && (frc == BTGPU_OK || frc == BTGPU_EUNSUPPORTED) && (pfb100_ok || pfbm_ok);
         const bool noise_pfb_ok = fp->noise.available && fp->noise.pfb.available && fp->noise.pfb.M == kPfbM &&
@@ -831,7 +831,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     if (!h->use_staged) TRY(h->alloc(h->d_Yn, (size_t)nch * h->ystride_n * sizeof(float2)));
     if (h->use_pfb && h->pfb_small) {
         const PfbBank &b = h->fp.channel;
-        h->ntiles_max = (int)((G + kPfbmTT - 1) / kPfbmTT);
+        h->ntiles_max = (int)((G + pfbm_tile(b.M) - 1) / pfbm_tile(b.M));
         TRY(h->upload(h->d_pfb_taps_ch, b.taps.data(), b.taps.size() * sizeof(float)));
         TRY(h->upload(h->d_dftw_ch, b.dftw.data(), b.dftw.size() * sizeof(float)));
         TRY(h->upload(h->d_rho_ch, b.rho.data(), b.rho.size() * sizeof(float)));

@@ -9,7 +9,7 @@
 // -- angles and |Y|^2 tile sums leave in the layouts of the direct path (d[g][drow], ptile / phead for
 // block_sum_kernel).  Noise bank (staged squelch, stage 1): Z[c][t] de-rotated.
 //
-// One workgroup = TT = 50 new output instants (+ 1 halo instant for the demod), 256 lanes:
+// One workgroup = TT new output instants (250 for M <= 10, else 50; + 1 halo instant for the demod), 256 lanes:
 //   0  input span -> LDS (aligned 16-byte loads, unconditional), taps and DFT table -> LDS
 //   A  lane = (instant, branch): Q taps from LDS
 //   B  lane = (channel, run of R instants): M-term DFT row per instant, demod against the previous instant,
@@ -24,12 +24,14 @@
 
 namespace btgpu {
 
-constexpr int kPfbmTT = 50;            // new instants per tile (divides the 1250 outputs of a slot)
 constexpr int kPfbmThreads = 256;
+// new instants per tile: a divisor of the 1250 outputs of a slot, large enough that a tile is worth a workgroup
+// (M * TT branch outputs) and small enough that its rows fit the LDS
+inline int pfbm_tile(int M) { return M <= 10 ? 250 : 50; }
 
 struct PfbmParams {
     const float2 *x; long long x_len; long long x0;
-    int M, D, Q;
+    int M, D, Q, TT;             // TT: new output instants per tile
     long long T;                 // output instants in total
     const float2 *taps;          // [Q*M]
     const float2 *dftw;          // [M][nsel]
@@ -45,17 +47,18 @@ struct PfbmParams {
 
 inline size_t pfbm_lds_bytes(int M, int D, int Q, int nsel, bool chan)
 {
-    const int nt = kPfbmTT + (chan ? 1 : 0);
+    const int tt = pfbm_tile(M), nt = tt + (chan ? 1 : 0);
     const int span = 2 * ((D * (nt - 1) + Q * M + 3) / 2);
     size_t cf = (size_t)span + (size_t)Q * M + (size_t)M * nsel + (size_t)nt * (M + 1);
-    size_t fl = chan ? (size_t)kPfbmTT * nsel + 2 * 256 : 0;
+    size_t fl = chan ? (size_t)tt * nsel + 2 * 256 : 0;
     return cf * sizeof(float2) + fl * sizeof(float) + 64;
 }
 
 template <bool REAL, bool CHAN>
 __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
 {
-    constexpr int TT = kPfbmTT, NT = TT + (CHAN ? 1 : 0), NTH = kPfbmThreads;
+    constexpr int NTH = kPfbmThreads;
+    const int TT = p.TT, NT = TT + (CHAN ? 1 : 0);
     const int M = p.M, D = p.D, Q = p.Q, nsel = p.nsel;
     const int UST = M + 1;                                       // odd pitch for even M: lanes (t, p) of phase A spread over the banks
     HIP_DYNAMIC_SHARED(float4, lds4)

@@ -119,7 +119,8 @@ int emu_bank_m_run(double fs, double fc, int mode, const float *iq, long long x_
     const int drow = win_drow(nch);
     sizes[0] = G; sizes[1] = nb; sizes[2] = nch; sizes[3] = zstride; sizes[4] = ystride; sizes[5] = Tn; sizes[6] = drow;
     if (!d_out) return 0;
-    const int ntiles_max = (int)((G + kPfbmTT - 1) / kPfbmTT);
+    const int TTm = pfbm_tile(fp.channel.M);
+    const int ntiles_max = (int)((G + TTm - 1) / TTm);
     std::vector<double> ptile((size_t)nch * ntiles_max, 0.0), phead((size_t)nch * ntiles_max, 0.0);
     std::vector<float4> xbuf((size_t)x_len / 2 + 16);
     std::memcpy(xbuf.data(), iq, (size_t)x_len * sizeof(float2));
@@ -139,7 +140,7 @@ int emu_bank_m_run(double fs, double fc, int mode, const float *iq, long long x_
     };
     const int ntiles = launch_channel_bank_m(des, fp, b, (size_t)x_len, w0, G, L);
     launch_noise_bank_m(des, fp, b, (size_t)x_len, w0, S, L);
-    const int tpb = ops / kPfbmTT, tail_tiles = des.tail / kPfbmTT;
+    const int tpb = ops / TTm, tail_tiles = des.tail / TTm;
     for (int c = 0; c < nch; c++)
         for (int bi = 0; bi < nb; bi++) {
             double s = 0.0, h = 0.0;

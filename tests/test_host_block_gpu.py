@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # protocol layer): the blocks' AUTO settings resolve to the bit-exact direct forms here.  The default
 # (polyphase) path through the same blocks is covered by test_btrx_amd_time_partitioned_... and by
 # tests/test_gpu_parity.py.
-os.environ["BTGPU_AUTO"] = "direct"
+@pytest.fixture(autouse=True)
+def _bit_exact_auto(monkeypatch):
+    monkeypatch.setenv("BTGPU_AUTO", "direct")
 BTRX = os.path.join(ROOT, "gr-bluetooth_amd", "host", "btrx_amd")
 
 
