@@ -22,6 +22,7 @@ the same capture (tests/paritylib.py).
 """
 import argparse
 import hashlib
+import gc
 import json
 import os
 import socket
@@ -206,17 +207,26 @@ def run_rank(args):
     fence()
     for i in range(args.warmup):
         step(last=(i == args.warmup - 1))
+    # no cyclic-GC pass inside the timed region (a generation-2 sweep of the interpreter heap with torch
+    # loaded costs tens of milliseconds, i.e. more than the whole region at the default K)
+    gc.collect()
+    gc.disable()
     fence()
     tm0 = blk.timing()
     t0 = time.perf_counter()
     got_i, got_s = [], []
+    marks = [t0]
     for i in range(args.steps):
         ints, snr = step(last=(i == args.steps - 1))
         got_i.append(ints); got_s.append(snr)
+        marks.append(time.perf_counter())
     ints = np.concatenate(got_i, axis=0)
     snr = np.concatenate(got_s, axis=0)
+    t_loop = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
+    fence_ms = (time.perf_counter() - t_loop) * 1e3
+    gc.enable()
     kernel_ms, kernel_launches = tdiff(tm0, blk.timing())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
@@ -342,6 +352,8 @@ def run_rank(args):
                        "gather": ("one async all_gather per batch (%s), %d rounds" % (args.backend, gatherer.rounds)) if world > 1 else "none",
                        "channelizer": {1: "direct", 2: "polyphase"}[int(des.channelizer)],
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},
+            "fence_ms": round(fence_ms, 3),
+            "step_enqueue_ms": [round(float(v), 3) for v in np.percentile(np.diff(np.array(marks)) * 1e3, [0, 50, 100])],
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": parity,

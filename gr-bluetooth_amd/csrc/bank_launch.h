@@ -135,7 +135,12 @@ inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const Ba
     p.gain = des.demod_gain;
     p.Z = b.Ydebug; p.zstride = b.ystride;
     const size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, true);
-    if (bk.real_taps) L(pfbm_kernel<true, true>, p.ntiles, kPfbmThreads, lds, p);
+    const bool f8 = bk.natural && bk.M == 8 && nch == 8 && b.drow == 8 && p.TT + 1 <= kPfbmThreads;
+    if (f8 && bk.Q == 7 && !bk.real_taps) L(pfbm_kernel<false, true, 8, 7, true>, p.ntiles, kPfbmThreads, lds, p);          // C8: half-MHz grid
+    else if (f8 && bk.Q == 7) L(pfbm_kernel<true, true, 8, 7, true>, p.ntiles, kPfbmThreads, lds, p);
+    else if (bk.M == 8 && bk.Q == 7 && !bk.real_taps) L(pfbm_kernel<false, true, 8, 7>, p.ntiles, kPfbmThreads, lds, p);
+    else if (bk.M == 20 && bk.Q == 7 && bk.real_taps) L(pfbm_kernel<true, true, 20, 7>, p.ntiles, kPfbmThreads, lds, p);
+    else if (bk.real_taps) L(pfbm_kernel<true, true>, p.ntiles, kPfbmThreads, lds, p);
     else L(pfbm_kernel<false, true>, p.ntiles, kPfbmThreads, lds, p);
     return p.ntiles;
 }
@@ -158,7 +163,9 @@ inline void launch_noise_bank_m(const Design &des, const FastPath &fp, const Ban
     p.ntiles = (int)((Tn + p.TT - 1) / p.TT);
     p.Z = b.Z; p.zstride = b.zstride;
     const size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, false);
-    L(pfbm_kernel<false, false>, p.ntiles, kPfbmThreads, lds, p);
+    if (bk.natural && bk.M == 8 && nch == 8 && bk.Q == 15) L(pfbm_kernel<false, false, 8, 15, true>, p.ntiles, kPfbmThreads, lds, p);
+    else if (bk.M == 8 && bk.Q == 15) L(pfbm_kernel<false, false, 8, 15>, p.ntiles, kPfbmThreads, lds, p);
+    else L(pfbm_kernel<false, false>, p.ntiles, kPfbmThreads, lds, p);
 }
 
 }  // namespace btgpu

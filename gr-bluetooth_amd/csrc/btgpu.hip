@@ -945,6 +945,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfbm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, true, 8, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<true, true, 20, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, false, 8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, true, 8, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<true, true, 8, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, false, 8, 15, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

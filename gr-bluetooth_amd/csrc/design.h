@@ -102,6 +102,7 @@ struct PfbBank {
     std::vector<float> krot;            // [nch][rot_period][2]  C_m * exp(-j 2 pi f D t / fs)
     std::vector<float> rho;             // [nch][2]  exp(-j 2 pi f D / fs): y[t] conj(y[t-1]) = Y[t] conj(Y[t-1]) rho
     bool rho_real = false;              // every rho is +-1 (integer-MHz offsets at D = 50)
+    bool natural = false;               // M = 8 = nch with channel c in bin c (bin of channel 0 folded into the taps)
 };
 
 // Lane -> task table of the second DFT pass over `rows` instants (tasks (row, m1), row-contiguous

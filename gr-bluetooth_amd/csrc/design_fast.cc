@@ -127,6 +127,28 @@ bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::v
             b.krot[((size_t)c * period + t) * 2 + 1] = c_r * ri + c_i * rr;
         }
     }
+    // eight bins, eight consecutive channels (8 Msps): fold the bin of channel 0 into the branch taps,
+    //   a[j] e^{-j 2 pi r j / M} with r = bin(0)  <=>  bin(c) -> bin(c) - r = c,
+    // so that the kernel can run a natural-order radix-2 FFT instead of the M x nch product
+    b.natural = false;
+    if (M == 8 && nch == 8) {
+        bool consecutive = true;
+        for (int c = 0; c < nch; c++) consecutive = consecutive && b.binnat[c] == (b.binnat[0] + c) % M;
+        if (consecutive) {
+            const int r = b.binnat[0];
+            b.real_taps = true;
+            for (int j = 0; j < b.L; j++) {
+                float wr, wi;
+                phasor_turns(-(delta + r) * j / M, wr, wi);
+                const double h = proto[b.L - 1 - j];
+                b.taps[2 * j + 0] = (float)(h * wr);
+                b.taps[2 * j + 1] = (float)(h * wi);
+                if (b.taps[2 * j + 1] != 0.f) b.real_taps = false;
+            }
+            for (int c = 0; c < nch; c++) b.binnat[c] = b.binpos[c] = c;
+            b.natural = true;
+        }
+    }
     if (M < kPfbM) {
         b.dftw.resize((size_t)M * nch * 2);
         for (int pidx = 0; pidx < M; pidx++)

@@ -54,12 +54,36 @@ inline size_t pfbm_lds_bytes(int M, int D, int Q, int nsel, bool chan)
     return cf * sizeof(float2) + fl * sizeof(float) + 64;
 }
 
-template <bool REAL, bool CHAN>
+// MC, QC: M and Q as compile-time constants (0 = take them from the parameters): the common geometries
+// (8 and 20 Msps) get fully unrolled tap and DFT loops with the lane's taps / DFT column in registers
+// natural-order 8-point DFT, Y_k = sum_p u_p e^{-j 2 pi p k / 8}: radix-2 decimation in frequency, in place
+__device__ __forceinline__ void fft8(cf (&u)[8])
+{
+    const float h = 0.70710678118654752f;
+    auto mulmj = [](cf v) { return mk(v.y, -v.x); };                 // * (-j)
+    cf a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = u[i] + u[i + 4]; b[i] = u[i] - u[i + 4]; }
+    b[1] = mk(b[1].x + b[1].y, b[1].y - b[1].x) * mk(h, h);          // * e^{-j pi/4}
+    b[2] = mulmj(b[2]);
+    b[3] = mk(b[3].y - b[3].x, -b[3].x - b[3].y) * mk(h, h);         // * e^{-j 3 pi/4}
+    auto dft4 = [&](cf (&v)[4], int o) {
+        const cf c0 = v[0] + v[2], c1 = v[1] + v[3], d0 = v[0] - v[2], d1 = mulmj(v[1] - v[3]);
+        u[o] = c0 + c1; u[o + 4] = c0 - c1; u[o + 2] = d0 + d1; u[o + 6] = d0 - d1;
+    };
+    dft4(a, 0);
+    dft4(b, 1);
+}
+
+// F8: eight bins = the eight channels in natural order (PfbBank::natural): phase B is one lane per instant
+// with the 8-point FFT above instead of the M x nch product
+template <bool REAL, bool CHAN, int MC = 0, int QC = 0, bool F8 = false>
 __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
 {
+    static_assert(!F8 || MC == 8, "the FFT variant is the 8-bin bank");
     constexpr int NTH = kPfbmThreads;
     const int TT = p.TT, NT = TT + (CHAN ? 1 : 0);
-    const int M = p.M, D = p.D, Q = p.Q, nsel = p.nsel;
+    const int M = MC ? MC : p.M, D = p.D, Q = QC ? QC : p.Q, nsel = p.nsel;
     const int UST = M + 1;                                       // odd pitch for even M: lanes (t, p) of phase A spread over the banks
     HIP_DYNAMIC_SHARED(float4, lds4)
     cf *lds = (cf *)lds4;
@@ -68,7 +92,7 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
     cf *s_taps = xs + 2 * N4;                                    // [Q M]
     cf *s_w = s_taps + Q * M;                                    // [M][nsel]
     cf *U = s_w + M * nsel;                                      // [NT][UST]
-    float *s_d = (float *)(U + NT * UST);                        // [TT][nsel] angles on their way to d (CHAN)
+    float *s_d = (float *)(U + ((NT * UST + 1) & ~1));           // [TT][nsel] angles on their way to d (CHAN), 16-byte aligned
     float *s_part = s_d + TT * nsel;                             // [256][2] run sums (CHAN)
     const int l = threadIdx.x;
     const int tile = blockIdx.x;
@@ -104,20 +128,129 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
     __syncthreads();
 
     // ---- phase A: branch filters, lane = (instant tl, branch pp)
-    for (int i = l; i < NT * M; i += NTH) {
-        const int tl = i / M, pp = i - tl * M;
-        const cf *z = xs + shift + D * tl + pp;
-        const cf *a = s_taps + pp;
-        cf u = mk(0.f, 0.f);
-        for (int q = 0; q < Q; q++) {
-            const cf v = z[q * M], t = a[q * M];
-            if (REAL) u = t.xx * v + u;
-            else { u = t.xx * v + u; u = mk(-t.y, t.y) * v.yx + u; }
+    if (MC && QC && NTH % (MC ? MC : 1) == 0) {
+        // the branch of a lane never changes (M divides the workgroup): its taps stay in registers
+        constexpr int MM = MC ? MC : 1, QQ = QC ? QC : 1;
+        const int pp = l % MM;
+        cf a[QQ];
+#pragma unroll
+        for (int q = 0; q < QQ; q++) a[q] = s_taps[q * MM + pp];
+        for (int tl = l / MM; tl < NT; tl += NTH / MM) {
+            const cf *z = xs + shift + D * tl + pp;
+            cf u = mk(0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < QQ; q++) {
+                const cf v = z[q * MM];
+                if (REAL) u = a[q].xx * v + u;
+                else { u = a[q].xx * v + u; u = mk(-a[q].y, a[q].y) * v.yx + u; }
+            }
+            U[tl * UST + pp] = u;
         }
-        U[tl * UST + pp] = u;
+    } else {
+        for (int i = l; i < NT * M; i += NTH) {
+            const int tl = i / M, pp = i - tl * M;
+            const cf *z = xs + shift + D * tl + pp;
+            const cf *a = s_taps + pp;
+            cf u = mk(0.f, 0.f);
+            for (int q = 0; q < Q; q++) {
+                const cf v = z[q * M], t = a[q * M];
+                if (REAL) u = t.xx * v + u;
+                else { u = t.xx * v + u; u = mk(-t.y, t.y) * v.yx + u; }
+            }
+            U[tl * UST + pp] = u;
+        }
     }
     __syncthreads();
 
+    if (F8 && CHAN) {
+        // ---- phase B, lane = instant: FFT of the lane's own U row (written back in place), then the demod
+        // against the neighbour's row; |Y|^2 through an LDS tile (the dead input span) to the per-channel sums
+        float *s_m = (float *)xs;                                  // [TT][8]
+        cf y[8];
+        if (l < NT) {
+            cf *u = U + l * UST;
+#pragma unroll
+            for (int c = 0; c < 8; c++) y[c] = u[c];
+            fft8(y);
+#pragma unroll
+            for (int c = 0; c < 8; c++) u[c] = y[c];
+        }
+        __syncthreads();
+        if (l >= 1 && l < NT) {
+            const long long t = t0 + l;
+            const bool live = t < p.T;
+            const DemodConst kc = demod_constants(p.gain);
+            const cf *ub = U + (l - 1) * UST;
+            float dd[8], mm[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const cf rho = ((const cf *)p.rho)[c];             // uniform: scalar loads
+                const cf ya = y[c], yb = ub[c];
+                mm[c] = live ? ya.x * ya.x + ya.y * ya.y : 0.f;
+                const cf ybr = cmulf(yb, mk(rho.x, -rho.y));
+                const cf pq = ybr.xx * ya + ybr.yy * mk(ya.y, -ya.x);
+                dd[c] = demod_poly(kc, pq.x, pq.y);
+            }
+            float4 *od = (float4 *)(s_d + (l - 1) * 8), *om = (float4 *)(s_m + (l - 1) * 8);
+            od[0] = make_float4(dd[0], dd[1], dd[2], dd[3]); od[1] = make_float4(dd[4], dd[5], dd[6], dd[7]);
+            om[0] = make_float4(mm[0], mm[1], mm[2], mm[3]); om[1] = make_float4(mm[4], mm[5], mm[6], mm[7]);
+            if (p.Z && live) {                                                              // BTGPU_FLAG_DEBUG_Y
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const cf kr = ((const cf *)p.krot)[(size_t)c * p.rot_period + (int)(t % p.rot_period)];
+                    ((cf *)p.Z)[(size_t)c * p.zstride + t] = cmulf(y[c], kr);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const long long g1 = t0 + 1;
+            const long long rows = p.T - g1 < TT ? p.T - g1 : TT;
+            const int n4 = (int)rows * 2;                          // drow == nsel == 8: the tile is one contiguous piece of d
+            float4 *dst = (float4 *)(p.d + (size_t)g1 * 8);
+            for (int i = l; i < n4; i += NTH) dst[i] = ((const float4 *)s_d)[i];
+        }
+        {
+            // lane = (channel, run of 8 instants)
+            const int c = l & 7, run = l >> 3;
+            const int hr = p.tail % TT;
+            const bool want_head = hr > 0 && tile % p.tiles_per_block == p.tail / TT;
+            float sum = 0.f, head = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int r = run * 8 + k;
+                if (r < TT) {
+                    const float m = s_m[r * 8 + c];
+                    sum += m;
+                    if (want_head && r < hr) head += m;
+                }
+            }
+            s_part[2 * l] = sum; s_part[2 * l + 1] = head;
+        }
+        __syncthreads();
+        if (l < 8) {
+            double sacc = 0.0, hacc = 0.0;
+            for (int r = 0; r < NTH / 8; r++) { sacc += (double)s_part[2 * (r * 8 + l)]; hacc += (double)s_part[2 * (r * 8 + l) + 1]; }
+            p.ptile[(size_t)l * p.ntiles + tile] = sacc;
+            p.phead[(size_t)l * p.ntiles + tile] = hacc;
+        }
+    } else if (F8) {
+        // noise bank, lane = instant: FFT, de-rotate, eight coalesced row stores
+        if (l < NT && t0 + l < p.T) {
+            const long long t = t0 + l;
+            cf y[8];
+            const cf *u = U + l * UST;
+#pragma unroll
+            for (int c = 0; c < 8; c++) y[c] = u[c];
+            fft8(y);
+            const int ph = (int)(((unsigned)(t0 % p.rot_period) + (unsigned)l) % (unsigned)p.rot_period);
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const cf kr = ((const cf *)p.krot)[(size_t)c * p.rot_period + ph];
+                ((cf *)p.Z)[(size_t)c * p.zstride + t] = cmulf(y[c], kr);
+            }
+        }
+    } else
     // ---- phase B: DFT rows + epilogue, lane = (channel c, run of R instants)
     if (CHAN) {
         const int R = nsel * TT <= NTH ? 1 : (nsel * TT + NTH - 1) / NTH;      // instants per lane
@@ -131,11 +264,22 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
             const int tl0 = 1 + run * R;
             const int hr = p.tail % TT;
             const bool want_head = hr > 0 && tile % p.tiles_per_block == p.tail / TT;     // block-uniform
+            constexpr int MW = MC && MC <= 20 ? MC : 1;
+            cf wreg[MW];                                           // this channel's DFT column (small M)
+            if (MC && MC <= 20) {
+#pragma unroll
+                for (int pp = 0; pp < MW; pp++) wreg[pp] = s_w[pp * nsel + c];
+            }
             auto bin = [&](int tl) {
                 const cf *u = U + tl * UST;
-                const cf *w = s_w + c;
                 cf y = mk(0.f, 0.f);
-                for (int pp = 0; pp < M; pp++) y = cmulf(u[pp], w[pp * nsel]) + y;
+                if (MC && MC <= 20) {
+#pragma unroll
+                    for (int pp = 0; pp < MW; pp++) y = cmulf(u[pp], wreg[pp]) + y;
+                } else {
+                    const cf *w = s_w + c;
+                    for (int pp = 0; pp < M; pp++) y = cmulf(u[pp], w[pp * nsel]) + y;
+                }
                 return y;
             };
             cf yb = bin(tl0 - 1);
@@ -176,17 +320,18 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
         }
     } else {
         // noise bank: every (instant, channel) -> Z, de-rotated
-        for (int i = l; i < NT * nsel; i += NTH) {
-            const int c = i / NT, tl = i - c * NT;
-            const long long t = t0 + tl;
-            if (t >= p.T) continue;
-            const cf *u = U + tl * UST;
-            const cf *w = s_w + c;
-            cf y = mk(0.f, 0.f);
-            for (int pp = 0; pp < M; pp++) y = cmulf(u[pp], w[pp * nsel]) + y;
-            const cf kr = ((const cf *)p.krot)[(size_t)c * p.rot_period + (int)(t % p.rot_period)];
-            ((cf *)p.Z)[(size_t)c * p.zstride + t] = cmulf(y, kr);
-        }
+        const unsigned ph0 = (unsigned)(t0 % p.rot_period);
+        for (int c = 0; c < nsel; c++)
+            for (int tl = l; tl < NT; tl += NTH) {
+                const long long t = t0 + tl;
+                if (t >= p.T) continue;
+                const cf *u = U + tl * UST;
+                const cf *w = s_w + c;
+                cf y = mk(0.f, 0.f);
+                for (int pp = 0; pp < M; pp++) y = cmulf(u[pp], w[pp * nsel]) + y;
+                const cf kr = ((const cf *)p.krot)[(size_t)c * p.rot_period + (int)((ph0 + (unsigned)tl) % (unsigned)p.rot_period)];
+                ((cf *)p.Z)[(size_t)c * p.zstride + t] = cmulf(y, kr);
+            }
     }
 }
 
