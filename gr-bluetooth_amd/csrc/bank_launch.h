@@ -21,7 +21,7 @@ struct BankBuffers {                        // device (or emulated) memory
     const float2 *taps_ch = nullptr, *twiddle = nullptr, *krot_ch = nullptr, *rho_ch = nullptr;
     const int *binpos_ch = nullptr, *binnat_ch = nullptr;
     const uint16_t *b2map_fused = nullptr, *b2map_fused_wide = nullptr, *b2map_ch = nullptr, *b2map_noise = nullptr;
-    float *d = nullptr; double *ptile = nullptr, *phead = nullptr;
+    float *d = nullptr; float *dcol = nullptr; double *ptile = nullptr, *phead = nullptr;
     float2 *Ydebug = nullptr; long long ystride = 0;
     const float2 *taps_n = nullptr, *krot_n = nullptr; const int *binpos_n = nullptr;
     float2 *Z = nullptr; long long zstride = 0;
@@ -57,7 +57,7 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
     p.nsel = nch; p.binpos = b.binpos_ch; p.binnat = b.binnat_ch; p.krot = b.krot_ch;
     p.rot_period = bk.rot_period; p.rho = b.rho_ch; p.rho_real = bk.rho_real ? 1 : 0;
     p.ntiles = (int)((G + TT - 1) / TT);
-    p.d = b.d; p.ptile = b.ptile; p.phead = b.phead;
+    p.d = b.d; p.dcol = b.dcol; p.ptile = b.ptile; p.phead = b.phead;
     p.tiles_per_block = ops / TT; p.tail = des.tail; p.nb = nb;
     p.gain = des.demod_gain;
     p.Z = b.Ydebug; p.zstride = b.ystride;

@@ -75,6 +75,7 @@ struct btgpu_handle {
     struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
         DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_winfin, d_symbits, d_hdr;
         DevBuf d_d;                           // demodulated stream of the batch: the tail reads it under the next batch's banks
+        DevBuf d_dcol;                        // 100-bin bank: the same stream tile by tile channel-major [tile][80][25], what finish_kernel reads
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
@@ -115,6 +116,7 @@ struct btgpu_handle {
     bool noise_pfb = false;
     bool pfb_small = false, noise_small = false;   // small-M polyphase banks (rates below 100 Msps)
     bool fuse_noise = false;         // noise stage 1 rides on the channel bank's staged input
+    bool use_dcol = false;          // 100-bin bank: also writes the tile-blocked channel-major copy the tail reads
     bool overlap_noise = false;     // measured: running the two banks concurrently is slower (both saturate the CUs)
     long long zstride = 0;
     int ntiles_max = 0;
@@ -161,10 +163,10 @@ struct btgpu_handle {
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_dftw_ch, &d_dftw_n,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
-        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d.p = nullptr;
+        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d.p = tc[1].d_dcol.p = nullptr;
                       tc[1].d_winfin.p = tc[1].d_symbits.p = tc[1].d_hdr.p = nullptr; }
         for (TailCtx &t : tc) {
-            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d};
+            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -188,9 +190,10 @@ struct btgpu_handle {
         if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
     }
 
-    BankBuffers bank_buffers(const float2 *d_x, const DevBuf &d_d) const
+    BankBuffers bank_buffers(const float2 *d_x, const DevBuf &d_d, const DevBuf *d_dcol = nullptr) const
     {
         BankBuffers b;
+        b.dcol = (use_dcol && d_dcol) ? (float *)d_dcol->p : nullptr;
         b.x = d_x;
         b.taps_ch = (const float2 *)d_pfb_taps_ch.p; b.twiddle = (const float2 *)d_pfb_tw.p;
         b.krot_ch = (const float2 *)d_krot_ch.p; b.rho_ch = (const float2 *)d_rho_ch.p;
@@ -267,7 +270,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            des.tail / pfbm_tile(fp.channel.M), (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     } else if (use_pfb) {
         constexpr int TT = kBankNT - 1;
-        BankBuffers bb = bank_buffers(d_x, d_d);
+        BankBuffers bb = bank_buffers(d_x, d_d, &t.d_dcol);
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
         };
@@ -394,11 +397,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             if (want_syms)
                 hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
-                                   (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)d_symbits.p);
+                                   (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)d_symbits.p,
+                                   (const float *)(use_dcol ? t.d_dcol.p : nullptr));
             else
                 hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
-                                   (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)nullptr);
+                                   (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)nullptr,
+                                   (const float *)(use_dcol ? t.d_dcol.p : nullptr));
             }
             hipLaunchKernelGGL(nsym_patch_kernel, dim3(32), dim3(256), 0, tail_stream, (DeviceHit *)d_hits.p,
                                (const unsigned int *)d_hitcount.p, max_hits, (const int *)d_winlen.p, nch,
@@ -744,6 +749,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             (sq != BTGPU_SQUELCH_STAGED && sq != BTGPU_SQUELCH_DIRECT)) { delete h; return BTGPU_EUNSUPPORTED; }
         h->use_pfb = ch == BTGPU_CHANNELIZER_POLYPHASE;
         h->pfb_small = h->use_pfb && !pfb100_ok;
+        h->use_dcol = h->use_pfb && !h->pfb_small && getenv("BTGPU_NO_DCOL") == nullptr;   // (the knob: A/B timing only)
         h->use_staged = sq == BTGPU_SQUELCH_STAGED;
         h->keep_Y = !h->use_pfb || (cfg->flags & BTGPU_FLAG_DEBUG_Y);
         h->margin = h->use_staged ? kNoiseMargin : 0;
@@ -917,6 +923,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
         TRY(h->alloc(t.d_fin, (size_t)S * nch * sizeof(FinishRec)));
         TRY(h->alloc(t.d_d, (size_t)h->drow * (h->ystride + 64) * sizeof(float)));   // [G][drow], time-major
+        if (h->use_dcol) TRY(h->alloc(t.d_dcol, (size_t)((h->ystride + 64) / (kBankNT - 1) + 2) * 80 * (kBankNT - 1) * sizeof(float)));
         if (h->want_hdrs) TRY(h->alloc(t.d_hdr, (size_t)h->max_hits * sizeof(HeaderRec)));
         if (h->want_syms) {
             const size_t maxfin = (size_t)S * nch;            // one FinishRec per hit window, whatever max_hits is
@@ -933,6 +940,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     if (!h->async) {                      // synchronous mode: one context, used for every batch
         h->tc[1].d_winlen = h->tc[0].d_winlen; h->tc[1].d_hits = h->tc[0].d_hits;
         h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d = h->tc[0].d_d;
+        h->tc[1].d_dcol = h->tc[0].d_dcol;
         h->tc[1].d_winfin = h->tc[0].d_winfin; h->tc[1].d_symbits = h->tc[0].d_symbits; h->tc[1].d_hdr = h->tc[0].d_hdr;
     }
 #undef TRY

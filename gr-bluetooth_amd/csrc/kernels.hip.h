@@ -808,7 +808,8 @@ template <bool SYMS>
 __global__ __launch_bounds__(64) void finish_kernel(
     WindowParams p, const float *__restrict__ d, int drow, long long d_rows,
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
-    const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits)
+    const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits,
+    const float *__restrict__ dcol = nullptr)
 {
     constexpr unsigned int RING = kFinRing, MASK = RING - 1;
     __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
@@ -845,6 +846,18 @@ __global__ __launch_bounds__(64) void finish_kernel(
         if (p.dbg_stop == 9) {                                   // timing experiment (BTGPU_WIN_STOP=9): no stream traffic
 #pragma unroll
             for (int j = 0; j < kFinRows; j++) v[j] = 0.01f * (float)((hi + j) & 7) - 0.03f;
+            return;
+        }
+        if (dcol) {
+            // the 100-bin bank's tile-blocked copy [tile][80][25]: sample q of channel c sits at
+            // q + 25 (79 (q / 25) + c) -- sixteen consecutive samples share one or two cache lines
+#pragma unroll
+            for (int j = 0; j < kFinRows; j++) {
+                const unsigned int idx = hi + j;
+                const unsigned int q = (unsigned int)row0 + (idx < nvalid ? idx : nvalid - 1);
+                const unsigned int tq = (unsigned int)(((unsigned long long)q * 0x51EB851Full) >> 35);   // q / 25 (v_mul_hi_u32)
+                v[j] = dcol[(size_t)(q + 25u * (79u * tq + (unsigned int)c))];
+            }
             return;
         }
 #pragma unroll

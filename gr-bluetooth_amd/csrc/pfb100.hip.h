@@ -63,6 +63,9 @@ struct PfbParams {
     int ntiles;
     // channel epilogue
     float *d;                    // [T][80] time-major (row stride 80 floats)
+    float *dcol;                 // [ntiles][80][TT] the same angles tile by tile, channel-major inside a tile: one lane of
+                                 // finish_kernel follows ONE channel, here its TT instants are 4 TT contiguous bytes
+                                 // (in d they sit 320 bytes apart: a cache line per sample).  null: not written
     double *ptile;               // [nsel][ntiles]
     double *phead;               // [nsel][ntiles]  sum of the first (tail % TT) instants of each tile
     int tiles_per_block, tail, nb;
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
     float *s_part = (float *)U;                              // [NTH / 80][80][2] run sums: the channel rows of U are dead after pass 2
     float *s_d = (float *)U + (NTH / 80) * 80 * 2;           // [TT][80] angles of the tile on their way to d
     static_assert(!CHAN || ((NTH / 80) * 80 * 2) % 4 == 0, "s_d must be 16-byte aligned");
-    static_assert(!CHAN || (NTH / 80) * 80 * 2 + TT * 80 <= 2 * NT * UST, "run sums and the angle tile must fit the dead DFT rows");
+    float *s_dc = s_d + TT * 80;                             // [80][TT] the same tile channel-major (-> dcol)
+    static_assert(!CHAN || (NTH / 80) * 80 * 2 + 2 * TT * 80 <= 2 * NT * UST, "run sums and the angle tiles must fit the dead DFT rows");
     const bool krot_lds = !CHAN && p.rot_period <= 4 && p.nsel <= 80;
     const int l = threadIdx.x;
 
@@ -477,18 +481,23 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
             // LDS tile s_d[TT][80] (lanes = channels: consecutive banks) and leave as 16-byte pieces below,
             // a quarter of the store instructions a lane-per-angle store needs
             float *drow = s_d + (tl0 - 1) * 80 + e_c;
+            float *dcolp = s_dc + e_c * TT + (tl0 - 1);         // lanes = channels: pitch TT = 25 floats, odd -> all banks
             // one output: |Y|^2 into the tile sum, Y[t] conj(Y[t-1]) rho -> angle -> d[t][c]
             auto one_real = [&](int k) {
                 const cf ya = y[k + 1], yb = y[k] * e_rho.xx;                  // rho = +-1
                 sum += ya.x * ya.x + ya.y * ya.y;
                 const cf pp = yb.xx * ya + yb.yy * mk(ya.y, -ya.x);
-                drow[k * 80] = demod_poly(kc, pp.x, pp.y);
+                const float a = demod_poly(kc, pp.x, pp.y);
+                drow[k * 80] = a;
+                dcolp[k] = a;
             };
             auto one_any = [&](int k) {
                 const cf ya = y[k + 1], yb = cmulf(y[k], mk(e_rho.x, -e_rho.y));   // conj(Y[t-1] conj(rho)) = conj(Y[t-1]) rho
                 sum += ya.x * ya.x + ya.y * ya.y;
                 const cf pp = yb.xx * ya + yb.yy * mk(ya.y, -ya.x);
-                drow[k * 80] = demod_poly(kc, pp.x, pp.y);
+                const float a = demod_poly(kc, pp.x, pp.y);
+                drow[k * 80] = a;
+                dcolp[k] = a;
             };
             constexpr int LAST = TT - (CH - 1) * RUN;            // instants of the last run
             const bool whole = t0 + NT <= p.T;                   // block-uniform: every instant of the tile exists
@@ -556,6 +565,12 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
             float4 *dst = (float4 *)(p.d + (size_t)g1 * 80);
             if (!(p.dbg & 2))
                 for (int i = l; i < (int)rows * 20; i += NTH) dst[i] = ((const float4 *)s_d)[i];
+            if (p.dcol && !(p.dbg & 2)) {
+                // the whole tile, instants past the stream included (never read): 80 TT floats = TT * 20 pieces
+                static_assert((80 * TT) % 4 == 0, "tile of dcol in 16-byte pieces");
+                float4 *dc = (float4 *)(p.dcol + (size_t)tile * (80 * TT));
+                for (int i = l; i < TT * 20; i += NTH) dc[i] = ((const float4 *)s_dc)[i];
+            }
         }
         if (l < p.nsel) {
             double sum = 0.0, head = 0.0;

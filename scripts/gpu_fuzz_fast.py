@@ -16,9 +16,10 @@ pkg = load_pkg()
 synth = importlib.import_module("gr_bluetooth_amd.synth")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
-fs, fc = 100e6, 2441e6
+RATES = [(100e6, 2441e6), (8e6, 2476.5e6), (20e6, 2441e6), (100e6, 2441e6)]     # polyphase banks: 100 bins, 8 bins (FFT), 20 bins
 bad = 0
 for case in range(cases):
+    fs, fc = RATES[int(rng.integers(0, len(RATES)))]
     nsl = int(rng.integers(8, 14)); snr_db = float(rng.uniform(12, 30)); occ = float(rng.uniform(0.2, 0.9))
     sq = float(rng.choice([5.0, 10.0, 14.0])); sniff = bool(rng.integers(0, 2)); le = sniff and bool(rng.integers(0, 2))
     laps = tuple(int(x) for x in rng.integers(0, 1 << 24, 6))
@@ -52,6 +53,6 @@ for case in range(cases):
         print('   only oracle:', sorted(ws - gs))
     bad += not ok
     noise_total = globals().get("noise_total", 0) + len(noise_born)
-    print("case %2d sniff %d le %d sq %4.1f snr %4.1f occ %.2f slots %2d hits %3d packet-born identical %s, noise-born differing %d, nsym dev %d" %
-          (case, sniff, le, sq, snr_db, occ, nsl, len(want), core, len(noise_born), dev))
+    print("case %2d fs %3.0fM sniff %d le %d sq %4.1f snr %4.1f occ %.2f slots %2d hits %3d packet-born identical %s, noise-born differing %d, nsym dev %d" %
+          (case, fs / 1e6, sniff, le, sq, snr_db, occ, nsl, len(want), core, len(noise_born), dev))
 print("mismatches on planted bursts:", bad, " offset +-1:", shifted, " noise-born records differing:", noise_total)

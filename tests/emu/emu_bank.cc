@@ -63,6 +63,8 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     b.binpos_ch = fp.channel.binpos.data(); b.binnat_ch = fp.channel.binnat.data();
     b.b2map_fused = mf.data(); b.b2map_fused_wide = mw.data(); b.b2map_ch = mc.data(); b.b2map_noise = mn.data();
     b.d = d_out; b.ptile = ptile.data(); b.phead = phead.data();
+    std::vector<float> dcol((size_t)ntiles_max * 80 * 25, -77.f);
+    b.dcol = dcol.data();
     b.Ydebug = (float2 *)Y_out; b.ystride = ystride;
     b.taps_n = (const float2 *)ns.pfb.taps.data(); b.krot_n = (const float2 *)ns.pfb.krot.data();
     b.binpos_n = ns.pfb.binpos.data();
@@ -75,6 +77,12 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     // fuse: 1 = fused, four waves per tile (the default); 3 = fused, eight waves
     const int ntiles = launch_channel_bank(des, fp, fuse == 1 || fuse == 3, b, (size_t)x_len, w0, S, G, nb, L, fuse == 3);
     if (fuse == 2) launch_noise_bank(des, fp, b, (size_t)x_len, w0, S, L);
+    // the tile-blocked copy finish_kernel reads must hold the very same angles: dcol[tile][c][r] == d[25 tile + r][c]
+    for (long long g = 0; g < G; g++)
+        for (int c = 0; c < nch; c++) {
+            const float a = d_out[(size_t)g * 80 + c], bcol = dcol[((size_t)(g / 25) * 80 + c) * 25 + g % 25];
+            if (std::memcmp(&a, &bcol, sizeof a) != 0) { std::fprintf(stderr, "emu: dcol != d at g %lld c %d\n", g, c); return -100; }
+        }
     // block sums exactly as block_sum_kernel orders them (per block: tiles ascending)
     const int tpb = ops / 25, tail_tiles = des.tail / 25;
     for (int c = 0; c < nch; c++)
