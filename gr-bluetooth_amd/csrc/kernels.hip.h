@@ -431,6 +431,46 @@ __device__ __forceinline__ void search_classic(const uint32_t *mybits, int limit
 // compare against the affine access code AC(0) ^ cols(LAP) with popcount < 7
 // (check_ac, lib/packet_impl.cc:471-510).  Hits are taken greedily with resume at c + 68 and
 // limit = min(len - 68, 625), which is what the reference's while (limit >= 0) loop does.
+// One Mueller & Mueller update (multi_block::mm_cr, lib/multi_block.cc:128-155; clock_recovery_mm_ff [EXT]) after
+// the interpolator produced `out`: the reference's float operations in its order, one rounding each.
+//   mm_val = slice(last) * out - slice(out) * last      slice(x) = x < 0 ? -1 : +1
+// Both products are exact (+-x), so the value is the ONE rounding of their difference: the sign of `last` is
+// XORed into `out` and vice versa (two full-rate bit operations each instead of v_bfi + v_mul), then one subtract.
+// Returns floor(mu) as an integer: the input samples to advance by.
+__device__ __forceinline__ int mm_update(float out, float &last, float &omega, float &mu, const WindowParams &p)
+{
+    const uint32_t ob = __float_as_uint(out), lb = __float_as_uint(last);
+    const float t1 = __uint_as_float(ob ^ (lb & 0x80000000u));      // slice(last) * out
+    const float t2 = __uint_as_float(lb ^ (ob & 0x80000000u));      // slice(out) * last
+    const float mm_val = t1 - t2;
+    last = out;
+    omega = omega + (p.gain_omega * mm_val);
+    {
+        const float xx = omega - p.omega_mid;                        // branchless_clip [EXT], roundings kept
+        const float x1 = fabsf(xx + p.omega_relative_limit) - fabsf(xx - p.omega_relative_limit);
+        omega = fmaf(0.5f, x1, p.omega_mid);                         // 0.5 * x1 is exact
+    }
+    mu = mu + (omega + (p.gain_mu * mm_val));
+    const float fl = floorf(mu);
+    mu = mu - fl;
+    return (int)fl;
+}
+
+// Sliced symbols, one bit each (1 = the sample is not negative), 32 per word, symbol n in bit n & 31.  Inside
+// the recursion a word is collected with ONE instruction per symbol: the sample's sign bit is shifted in from
+// the right (v_alignbit), which leaves the word bit-reversed and inverted until it is flushed.  (The interpolator
+// sum starts from +0 and is never -0, so "sign bit clear" is "x >= 0"; the compare + select + shift + or it
+// replaces cost five instructions, one of them a v_cndmask on vcc.)
+__device__ __forceinline__ uint32_t sym_push(uint32_t acc, float out)
+{
+    return __builtin_amdgcn_alignbit(acc, __float_as_uint(out), 31);     // (acc << 1) | sign(out)
+}
+// the collected word in the stored format; n = symbols in it (1..32)
+__device__ __forceinline__ uint32_t sym_word(uint32_t acc, int n)
+{
+    return (~__brev(acc)) >> (32 - n);
+}
+
 template <class LAY>
 __global__ __launch_bounds__(kWinThreads) void window_kernel(
     WindowParams p, const float *__restrict__ d, long long d_rows, const double *__restrict__ P,
@@ -553,14 +593,16 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         fetch(base + kAdv);
         unsigned int lim = (unsigned int)(base + kWinRows - 8);
         if (lim > ni - 1) lim = ni - 1;                          // while (ii < ni) of the reference
-        const float *col = mytile + c - base * kWinRowStride;
+        // byte offset of this lane's column in row `base` of the tile (24-bit arithmetic: one v_mad_u32_u24 per symbol)
+        const uint32_t colb = (uint32_t)(((int)(mytile - tile) + c - base * kWinRowStride) * 4);
         while (ii <= lim && oo < nmax) {
             // interpolate: sum_q T[imu][7-q] * in[ii+q], q ascending
-            int imu = (int)rintf(mu * 128.0f);
-            imu = imu < 0 ? 0 : (imu > 128 ? 128 : imu);
-            const float4 ta = *(const float4 *)&mmse[imu * kMmseStride + 4];   // T[4..7]
-            const float4 tb = *(const float4 *)&mmse[imu * kMmseStride];       // T[0..3]
-            const float *in = col + ii * kWinRowStride;
+            // mu = x - floor(x) lies in [0, 1] (1.0 when x is a tiny negative number): imu in 0..128, no clamp needed
+            const int imu = (int)rintf(mu * 128.0f);
+            const char *trow = (const char *)mmse + __mul24(imu, kMmseStride * 4);
+            const float4 ta = *(const float4 *)(trow + 16);                    // T[4..7]
+            const float4 tb = *(const float4 *)trow;                           // T[0..3]
+            const float *in = (const float *)((const char *)tile + (__umul24(ii, (uint32_t)(kWinRowStride * 4)) + colb));
             float acc = 0.f;
             acc = fmaf(ta.w, in[0 * kWinRowStride], acc);
             acc = fmaf(ta.z, in[1 * kWinRowStride], acc);
@@ -571,24 +613,10 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             acc = fmaf(tb.y, in[6 * kWinRowStride], acc);
             acc = fmaf(tb.x, in[7 * kWinRowStride], acc);
             const float out = acc;
-            // slice(x) = (x < 0) ? -1 : +1; neither operand can be -0.0 (sums starting from +0)
-            const float s_last = __builtin_copysignf(1.0f, last);
-            const float s_out = __builtin_copysignf(1.0f, out);
-            const float mm_val = fmaf(s_last, out, -(s_out * last));     // both products exact
-            last = out;
-            omega = omega + (p.gain_omega * mm_val);
-            {
-                const float xx = omega - p.omega_mid;
-                const float x1 = fabsf(xx + p.omega_relative_limit) - fabsf(xx - p.omega_relative_limit);
-                omega = fmaf(0.5f, x1, p.omega_mid);                     // 0.5 * x1 is exact
-            }
-            mu = mu + (omega + (p.gain_mu * mm_val));
-            const float fl = floorf(mu);
-            ii += (unsigned int)(int)fl;
-            mu = mu - fl;
+            ii += (unsigned int)mm_update(out, last, omega, mu, p);
             // slicer: one bit per symbol
-            cur |= (out < 0.f ? 0u : 1u) << (oo & 31);
-            if ((oo & 31) == 31) { gbits[(oo >> 5) * kWinThreads] = cur; cur = 0u; }
+            cur = sym_push(cur, out);
+            if ((oo & 31) == 31) gbits[(oo >> 5) * kWinThreads] = sym_word(cur, 32);
             oo++;
         }
         if (oo < nmax && ii < ni) s_live[it & 1] = 1;            // this lane needs another chunk
@@ -596,7 +624,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         if (!s_live[it & 1]) break;                              // uniform
         base += kAdv;
     }
-    if (oo & 31) gbits[(oo >> 5) * kWinThreads] = cur;
+    if (oo & 31) gbits[(oo >> 5) * kWinThreads] = sym_word(cur, oo & 31);
     if (p.dbg_stop == 2) return;
     {
         // every lane reads back the words it wrote itself (all loads in flight together)
@@ -838,7 +866,8 @@ __global__ __launch_bounds__(64) void finish_kernel(
     int oo = r.oo;
     float *my = slab + threadIdx.x * kFinSlab;
     uint32_t *sb = SYMS ? symbits + (size_t)f * kSymWords : nullptr;
-    uint32_t cur = (SYMS && (oo & 31)) ? sb[oo >> 5] : 0u;       // partially filled word left by the window kernel
+    // partially filled word left by the window kernel, back into the collecting format (sym_push)
+    uint32_t cur = (SYMS && (oo & 31)) ? __brev(~sb[oo >> 5]) >> (32 - (oo & 31)) : 0u;
     // rows [hi - RING, hi) are resident, row q in slot q & 31 (slots 0..7 also at 32..39); refills are whole
     // 16-row blocks, so a block is either slots 0..15 (guard copy of its first half) or 16..31
     unsigned int hi = ii & ~(unsigned int)(kFinRows - 1);
@@ -898,23 +927,10 @@ __global__ __launch_bounds__(64) void finish_kernel(
             acc = fmaf(tb.y, in[6], acc);
             acc = fmaf(tb.x, in[7], acc);
             const float out = acc;
-            const float s_last = __builtin_copysignf(1.0f, last);
-            const float s_out = __builtin_copysignf(1.0f, out);
-            const float mm_val = fmaf(s_last, out, -(s_out * last));     // both products exact
-            last = out;
-            omega = omega + (p.gain_omega * mm_val);
-            {
-                const float xx = omega - p.omega_mid;
-                const float x1 = fabsf(xx + p.omega_relative_limit) - fabsf(xx - p.omega_relative_limit);
-                omega = fmaf(0.5f, x1, p.omega_mid);                     // 0.5 * x1 is exact
-            }
-            mu = mu + (omega + (p.gain_mu * mm_val));
-            const float fl = floorf(mu);
-            ii += (unsigned int)(int)fl;
-            mu = mu - fl;
+            ii += (unsigned int)mm_update(out, last, omega, mu, p);
             if (SYMS) {
-                cur |= (out < 0.f ? 0u : 1u) << (oo & 31);
-                if ((oo & 31) == 31) { if ((oo >> 5) < kSymWords) sb[oo >> 5] = cur; cur = 0u; }
+                cur = sym_push(cur, out);
+                if ((oo & 31) == 31 && (oo >> 5) < kSymWords) sb[oo >> 5] = sym_word(cur, 32);
             }
             oo++;
         }
@@ -922,7 +938,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
         // lies below ii and takes rows [hi, hi + 16)
         put(v);
     }
-    if (SYMS && (oo & 31) && (oo >> 5) < kSymWords) sb[oo >> 5] = cur;
+    if (SYMS && (oo & 31) && (oo >> 5) < kSymWords) sb[oo >> 5] = sym_word(cur, oo & 31);
     win_len[r.w] = oo;
   }
 }

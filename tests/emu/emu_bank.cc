@@ -9,8 +9,6 @@
 #include <cstring>
 #include <vector>
 
-static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
-static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 #include "bank_launch.h"
 

@@ -62,6 +62,14 @@ static inline unsigned __brev(unsigned v)
     for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
     return r;
 }
+static inline int __mul24(int a, int b) { return a * b; }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
+{
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31));
+}
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
 static inline void sincospi(double x, double *s, double *c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }   // fibers: one OS thread
