@@ -1,23 +1,30 @@
-"""Randomised differential run of the FAST path (100 Msps polyphase bank + staged squelch, tolerance
-contract) vs the oracle.  Records whose symbols lie inside a planted burst must be identical on
-(slot, channel, kind, LAP, ac_errors), the symbol offset within +-1 (a symbol more or less emitted in
-the noise before the burst), nsym within +-8.  Records born from noise-only symbols
-(false access addresses between bursts) are counted separately: the clock-recovery loop quantises mu
-to 1/128 sample, so a 1e-7 perturbation of the demodulated stream can move a noise symbol by ~0.02
-and flip it."""
+"""Randomised differential run of the FAST path (polyphase banks + staged squelch, tolerance contract)
+vs the oracle, judged by the same classification the tests and bench.py use (tests/paritylib.py):
+PLANTED records (classic hits whose (channel, LAP) is a burst of the capture's ground truth at that slot)
+must agree on (slot, channel, kind, LAP, ac_errors) and offset, nsym within +-8; OTHER records (born from
+noise-only symbols: false access addresses, LE hits in noise) are counted per side.  The clock-recovery
+loop quantises mu to 1/128 sample, so a 1e-7 perturbation of the demodulated stream can move a noise
+symbol by ~0.02 and flip it.  GPU only.
+    python scripts/gpu_fuzz_fast.py [cases] [seed]
+"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import importlib
 import numpy as np
 import pyoracle as po
+import paritylib
 from tests.conftest import load_pkg
 pkg = load_pkg()
 synth = importlib.import_module("gr_bluetooth_amd.synth")
+bdist = importlib.import_module("gr_bluetooth_amd.dist")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 RATES = [(100e6, 2441e6), (8e6, 2476.5e6), (20e6, 2441e6), (100e6, 2441e6)]     # polyphase banks: 100 bins, 8 bins (FFT), 20 bins
-bad = 0
+tot = dict(cases=0, planted=0, planted_differing=0, planted_offset_differs=0, other_gpu=0, other_ref=0, other_only_gpu=0,
+           other_only_ref=0, nsym_dev_max=0, failed=0)
 for case in range(cases):
     fs, fc = RATES[int(rng.integers(0, len(RATES)))]
     nsl = int(rng.integers(8, 14)); snr_db = float(rng.uniform(12, 30)); occ = float(rng.uniform(0.2, 0.9))
@@ -28,31 +35,22 @@ for case in range(cases):
     want, _ = o.run_stream(iq, threads=32)
     blk = pkg.multi_sniffer(fs, fc, sq, False, le=le) if sniff else pkg.multi_LAP(fs, fc, sq)
     assert blk.design.channelizer == pkg.CHANNELIZER_POLYPHASE and blk.design.squelch == pkg.SQUELCH_STAGED
-    blk_history = blk.design.history
     blk.push(iq); got = blk.poll(); blk.close()
-    sps = int(fs / 1e6); slot_len = 625 * sps
-
-    H = blk_history
-
-    def in_burst(key):
-        pos = key[0] * slot_len - (H - 1) + key[3] * sps
-        return any(t["channel"] == key[1] and t["start"] - H <= pos <= t["start"] + t["nbits"] * sps + H for t in truth)
-    gk, wk = [h.key()[:6] for h in got], [h.key()[:6] for h in want]
-    gs, ws = set(gk), set(wk)
-    diff = gs ^ ws
-    noise_born = sorted(d for d in diff if not in_burst(d))
-    # packet-born differences: allowed only as the same record one symbol earlier / later
-    pg = sorted(d for d in gs - ws if in_burst(d)); pw = sorted(d for d in ws - gs if in_burst(d))
-    core = len(pg) == len(pw) and all(a[:3] == b[:3] and a[4:] == b[4:] and abs(a[3] - b[3]) <= 1 for a, b in zip(pg, pw))
-    shifted = globals().get("shifted", 0) + len(pg)
-    both = {h.key()[:6]: h.nsym for h in want}
-    dev = max([abs(h.nsym - both[h.key()[:6]]) for h in got if h.key()[:6] in both], default=0)
-    ok = core and dev <= 8
-    if diff:
-        print('   only GPU   :', sorted(gs - ws))
-        print('   only oracle:', sorted(ws - gs))
-    bad += not ok
-    noise_total = globals().get("noise_total", 0) + len(noise_born)
-    print("case %2d fs %3.0fM sniff %d le %d sq %4.1f snr %4.1f occ %.2f slots %2d hits %3d packet-born identical %s, noise-born differing %d, nsym dev %d" %
-          (case, fs / 1e6, sniff, le, sq, snr_db, occ, nsl, len(want), core, len(noise_born), dev))
-print("mismatches on planted bursts:", bad, " offset +-1:", shifted, " noise-born records differing:", noise_total)
+    gi, _ = bdist.hits_to_arrays(got)
+    wi, _ = bdist.hits_to_arrays(want)
+    d = paritylib.differential(gi, wi, truth, lag=6 if sniff else 1)      # window lag of the record's slot index: 6-slot / 1.1-slot history
+    ok = d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= 8
+    tot["cases"] += 1; tot["failed"] += not ok
+    tot["planted"] += d["planted_ref"]; tot["planted_differing"] += d["planted_only_gpu"] + d["planted_only_ref"]
+    tot["planted_offset_differs"] += d["planted_offset_differs"]
+    tot["other_gpu"] += d["other_gpu"]; tot["other_ref"] += d["other_ref"]
+    tot["other_only_gpu"] += d["other_only_gpu"]; tot["other_only_ref"] += d["other_only_ref"]
+    tot["nsym_dev_max"] = max(tot["nsym_dev_max"], d["planted_nsym_max_abs_dev"])
+    if not ok or d["other_only_gpu"] or d["other_only_ref"]:
+        gs, ws = set(h.key()[:6] for h in got), set(h.key()[:6] for h in want)
+        print("   only GPU   :", sorted(gs - ws))
+        print("   only oracle:", sorted(ws - gs))
+    print("case %3d fs %3.0fM sniff %d le %d sq %4.1f snr %4.1f occ %.2f slots %2d  planted %3d identical %s offset-differs %d nsym-dev %d  other gpu/ref %d/%d one-sided %d/%d" %
+          (case, fs / 1e6, sniff, le, sq, snr_db, occ, nsl, d["planted_ref"], d["planted_identical"], d["planted_offset_differs"],
+           d["planted_nsym_max_abs_dev"], d["other_gpu"], d["other_ref"], d["other_only_gpu"], d["other_only_ref"]))
+print("TOTAL", tot)
