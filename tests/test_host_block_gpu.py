@@ -146,6 +146,34 @@ def test_btrx_amd_hopper_follows_a_hopping_piconet(po, synth, tmp_path):
     assert got == want
 
 
+@pytest.mark.parametrize("path_kind", ["direct", "polyphase"])
+def test_btrx_amd_hopper_full_band_100msps(po, synth, tmp_path, monkeypatch, path_kind):
+    """BASELINE configs[4] on one GPU: the whole 79-channel band at 100 Msps, a master hopping over all
+    channels, btrx_amd -l LAP -p (multi_hopper).  Every hop is visible, so UAP / CLK1-6 fall after nine
+    packets and CLK1-27 after about twenty; text equal to the oracle pipeline -- on the bit-exact DIRECT
+    front end and on the default polyphase front end (the packets' symbols are the same on both)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("toh", os.path.join(ROOT, "tests", "test_oracle_hop.py"))
+    toh = importlib.util.module_from_spec(spec); spec.loader.exec_module(toh)
+    if path_kind == "polyphase":
+        monkeypatch.delenv("BTGPU_AUTO", raising=False)
+    fs, fc = 100e6, 2441e6
+    lap, uap, clk0, nsl = 0x24D952, 0xAF, 0x3A5C7E1, 90
+    iq, truth = synth.make_hopping_capture(fs, fc, nsl, lap, uap, clk0, seed=5, dh1_fraction=0.0)
+    path = str(tmp_path / "hop100.cfile")
+    iq.tofile(path)
+    out = subprocess.run([BTRX, "-f", "2441M", "-r", "100M", "-i", path, "-l", "%06x" % lap, "-p", "-c", "16"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    hits, _ = o.run_stream(iq, threads=min(64, os.cpu_count() or 8))
+    want, hb = toh._hopper_text(po, o, iq, hits, lap, nsl)
+    got = out.stdout.split("\n", 1)[1]
+    assert "We have a winner! UAP = 0xaf" in want
+    assert "Acquired CLK1-27 offset = 0x%07x" % ((clk0 - 6) & 0x7FFFFFF) in want
+    assert got == want
+
+
 def test_btrx_amd_hopper_with_an_aliasing_receiver(po, synth, tmp_path):
     """btrx_amd -l LAP -p --aliased on a 25 Msps capture that folds all 79 channels into 26..50 (odd
     samples per symbol: the segmented DIRECT path): hop reversal on aliased channel numbers, then one
