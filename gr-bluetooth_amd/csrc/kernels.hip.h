@@ -818,14 +818,14 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 }
 
 // Continue the M&M recursion of the windows that reported hits (a few per cent) to the end of their
-// window and store len.  One lane per window; each lane stages its own column of the time-major
-// stream d[g][drow] into a private LDS slab, kFinRows rows at a time, all loads of a chunk in
-// flight together.  A strided column costs a cache line per row, but only the hit windows read it and
-// off the critical path; measured against the alternatives -- a channel-major copy of the whole stream
-// written by the bank kernel (round 1: 0.9 GB of writes and two LDS transposes on the critical path) and a
-// throughput-style gather of the hit columns in front of this kernel (its burst of strided reads slowed the
-// next batch's bank kernel by as much as it saved here) -- this is the cheapest.  No cross-lane data =>
-// no barriers.
+// window and store len.  One lane per window; each lane stages its own channel into a private LDS slab,
+// kFinRows samples at a time, all loads of a refill in flight together.  Source: the 100-bin bank's
+// tile-blocked copy dcol[tile][80][25] (a channel's 25 consecutive instants are 100 contiguous bytes) or,
+// where no such copy exists (small-M and direct-form banks: rows of 4..40 floats), the strided column of the
+// time-major stream d[g][drow].  The strided column of the 80-float rows cost a cache line per sample
+// (2.0 GB of HBM reads per 2304-slot batch for 90 MB of samples, and 0.08 ms on the bank kernel running
+// beside it); a throughput-style gather of the hit columns in front of this kernel was no better (its burst
+// slowed the next batch's bank kernel by as much as it saved here).  No cross-lane data => no barriers.
 constexpr int kFinRows = 16;       // rows per refill
 constexpr int kFinRing = 32;       // rows resident per lane
 constexpr int kFinSlab = kFinRing + 8 + 1;   // + the first eight slots again behind the ring (the 8-tap window never wraps),

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 from tests.conftest import load_pkg
 
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 2304
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 pkg = load_pkg()
 synth = importlib.import_module("gr_bluetooth_amd.synth")
@@ -30,8 +30,8 @@ for _ in range(nb):
     blk.flush()
     blk.poll_arrays()
 c = blk.debug_fetch(9, 0, 0, 1 << 24).astype(np.float64).reshape(-1, 8).sum(axis=0)
-names = ["stage input", "A branch FIR (+noise)", "B1 DFT pass + twiddle", "B2 DFT pass", "C noise store",
-         "epilogue runs", "tile sums", "-"]
+names = ["0 stage input", "A branch FIR (+noise)", "B1 DFT pass + twiddle", "B2 DFT pass -> Y", "C' noise bin loads",
+         "C epilogue (demod, sums) + Z stores + barrier", "copy-out d / dcol + tile sums", "-"]
 tot = c.sum()
 for n, v in zip(names, c):
     print("%-24s %6.2f %%" % (n, 100.0 * v / tot))
