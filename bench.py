@@ -200,6 +200,12 @@ def run_rank(args):
     # Bring the device to its steady power state first: an idle MI355X sits at 500 MHz and needs
     # some tens of milliseconds of load before the clocks settle (measured: the first ~5 batches
     # after idle run ~1.5x slower).  Untimed, like the W warm-up steps that follow.
+    # No cyclic-GC pass inside the timed region (a generation-2 sweep of the interpreter heap with torch
+    # loaded costs tens of milliseconds, i.e. more than the whole region at the default K) -- and none
+    # between the warm-up and the timed region either: the device clocks sag during any idle gap and
+    # take ~10 batches to come back.
+    gc.collect()
+    gc.disable()
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:      # per-rank clock: no collectives in here
         step(last=False, gather=False)
@@ -207,10 +213,6 @@ def run_rank(args):
     fence()
     for i in range(args.warmup):
         step(last=(i == args.warmup - 1))
-    # no cyclic-GC pass inside the timed region (a generation-2 sweep of the interpreter heap with torch
-    # loaded costs tens of milliseconds, i.e. more than the whole region at the default K)
-    gc.collect()
-    gc.disable()
     fence()
     tm0 = blk.timing()
     t0 = time.perf_counter()
@@ -223,6 +225,8 @@ def run_rank(args):
     ints = np.concatenate(got_i, axis=0)
     snr = np.concatenate(got_s, axis=0)
     t_loop = time.perf_counter()
+    if os.environ.get("BENCH_DUMP_STEPS"):
+        print("step_ms", [round(float(v) * 1e3, 2) for v in np.diff(np.array(marks))], file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
     fence_ms = (time.perf_counter() - t_loop) * 1e3
