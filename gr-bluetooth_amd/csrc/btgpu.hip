@@ -847,7 +847,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     } else if (h->use_pfb) {
         const PfbBank &b = h->fp.channel;
         h->ntiles_max = (int)((G + 24) / 25);
-        TRY(h->upload(h->d_pfb_taps_ch, b.taps.data(), b.taps.size() * sizeof(float)));
+        { const std::vector<float> tp = pack_branch_major(b); TRY(h->upload(h->d_pfb_taps_ch, tp.data(), tp.size() * sizeof(float))); }
         TRY(h->upload(h->d_pfb_tw, b.twiddle.data(), b.twiddle.size() * sizeof(float)));
         TRY(h->upload(h->d_binpos_ch, b.binpos.data(), b.binpos.size() * sizeof(int)));
         TRY(h->upload(h->d_binnat_ch, b.binnat.data(), b.binnat.size() * sizeof(int)));
@@ -870,7 +870,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
         h->zstride = (Tn + 10 + 63) / 64 * 64;
         if (h->noise_pfb) {
-            TRY(h->upload(h->d_pfb_taps_n, ns.pfb.taps.data(), ns.pfb.taps.size() * sizeof(float)));
+            { const std::vector<float> tp = pack_branch_major(ns.pfb); TRY(h->upload(h->d_pfb_taps_n, tp.data(), tp.size() * sizeof(float))); }
             if (!h->d_pfb_tw.p) TRY(h->upload(h->d_pfb_tw, ns.pfb.twiddle.data(), ns.pfb.twiddle.size() * sizeof(float)));
             TRY(h->upload(h->d_binpos_n, ns.pfb.binpos.data(), ns.pfb.binpos.size() * sizeof(int)));
             {

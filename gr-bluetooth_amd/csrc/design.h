@@ -112,6 +112,11 @@ struct PfbBank {
 // Entry = row << 4 | m1, 0xffff = idle lane.  `sweeps` * `lanes` entries.
 std::vector<uint16_t> make_dft_pass2_map(int rows, int lanes, int sweeps);
 
+// The 100-bin kernel's tap table: branch-major and padded so that a lane fetches the Q taps of its branch with
+// 16-byte loads.  Real taps: [M][(Q+3)&~3] floats; complex: [M][(Q+1)&~1][2].  (b.taps itself is [Q*M][2],
+// tap-major: what the small-M kernel stages through LDS.)
+std::vector<float> pack_branch_major(const PfbBank &b);
+
 struct NoiseStage {
     bool available = false;
     int R = 0;                          // stage-1 hop = 5 * decimation

@@ -165,6 +165,27 @@ bool build_pfb(PfbBank &b, const std::vector<double> &proto, int D, const std::v
 
 }  // namespace
 
+std::vector<float> pack_branch_major(const PfbBank &b)
+{
+    const int M = b.M, Q = b.Q;
+    std::vector<float> out;
+    if (b.real_taps) {
+        const int QP = (Q + 3) & ~3;
+        out.assign((size_t)M * QP, 0.f);
+        for (int q = 0; q < Q; q++)
+            for (int p = 0; p < M; p++) out[(size_t)p * QP + q] = b.taps[2 * ((size_t)q * M + p)];
+    } else {
+        const int QP = (Q + 1) & ~1;
+        out.assign((size_t)M * QP * 2, 0.f);
+        for (int q = 0; q < Q; q++)
+            for (int p = 0; p < M; p++) {
+                out[((size_t)p * QP + q) * 2 + 0] = b.taps[2 * ((size_t)q * M + p) + 0];
+                out[((size_t)p * QP + q) * 2 + 1] = b.taps[2 * ((size_t)q * M + p) + 1];
+            }
+    }
+    return out;
+}
+
 std::vector<uint16_t> make_dft_pass2_map(int rows, int lanes, int sweeps)
 {
     // residue classes of the tasks

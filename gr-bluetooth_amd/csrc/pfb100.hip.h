@@ -50,7 +50,7 @@ struct PfbParams {
     const float2 *x; long long x_len; long long x0;   // x index of tap 0 for output instant 0
     int D;
     long long T;                 // output instants in total
-    const float2 *taps;          // [Q*100]
+    const float2 *taps;          // branch-major packed: [100][8] floats (real taps, Q = 7) or [100][(Q+1)&~1] complex
     const float2 *twiddle;       // [100]
     int nsel;
     const int *binpos;           // [nsel] position of the channel's bin in the in-place DFT output (noise banks)
@@ -74,7 +74,7 @@ struct PfbParams {
     float2 *Z; long long zstride;   // [nsel][zstride]
     // fused noise stage 1 (FUSEN): the channel tile's staged input also feeds the NU = 5 noise-bank
     // instants whose first tap lies in the tile's 1250 new samples
-    const float2 *n_taps;        // [15*100]
+    const float2 *n_taps;        // [100][16] complex, branch-major
     const int *n_binpos;         // [nsel]
     const float2 *n_krot;        // [nsel][n_period]
     int n_period;
@@ -308,11 +308,43 @@ __global__ __launch_bounds__(NTH, (FUSEN ? 3 * NTH / 256 : 1)) void pfb100_kerne
         // memory returns in order, so the staging wait excludes them
         const cf tw = ((const cf *)p.twiddle)[l < 100 ? l : 99];
         b2task = (uint32_t)p.b2map[l] | ((uint32_t)(NSW == 2 ? p.b2map[NTH + l] : (uint16_t)0xffffu) << 16);
+        // branch taps, branch-major and packed (design.h pack_branch_major): a lane's Q taps are one or two
+        // 16-byte loads per four real / two complex taps instead of Q 8-byte loads a branch stride apart.
+        // (Measured: the 22 per-lane table loads of a fused tile cost 10 % of the kernel by their number, not
+        // their bytes -- the same loads from one address cost the same.)
+        {
+            const int pp = a_on ? a_pp : 0;
+            if (REAL) {
+                constexpr int QP = (Q + 3) & ~3;
+                const float4 *tp = (const float4 *)p.taps + pp * (QP / 4);
 #pragma unroll
-        for (int q = 0; q < Q; q++) a[q] = ((const cf *)p.taps)[q * M + (a_on ? a_pp : 0)];
+                for (int k = 0; k < QP / 4; k++) {
+                    const float4 t = tp[k];
+                    if (4 * k + 0 < Q) a[4 * k + 0] = mk(t.x, 0.f);
+                    if (4 * k + 1 < Q) a[4 * k + 1] = mk(t.y, 0.f);
+                    if (4 * k + 2 < Q) a[4 * k + 2] = mk(t.z, 0.f);
+                    if (4 * k + 3 < Q) a[4 * k + 3] = mk(t.w, 0.f);
+                }
+            } else {
+                constexpr int QP = (Q + 1) & ~1;
+                const float4 *tp = (const float4 *)p.taps + pp * (QP / 2);
+#pragma unroll
+                for (int k = 0; k < QP / 2; k++) {
+                    const float4 t = tp[k];
+                    a[2 * k] = mk(t.x, t.y);
+                    if (2 * k + 1 < Q) a[2 * k + 1] = mk(t.z, t.w);
+                }
+            }
+        }
         if (FUSEN) {
+            constexpr int QP = (NQ + 1) & ~1;
+            const float4 *tp = (const float4 *)p.n_taps + nz_pp * (QP / 2);
 #pragma unroll
-            for (int q = 0; q < NQ; q++) an[q] = ((const cf *)p.n_taps)[q * M + nz_pp];
+            for (int k = 0; k < QP / 2; k++) {
+                const float4 t = tp[k];
+                an[2 * k] = mk(t.x, t.y);
+                if (2 * k + 1 < NQ) an[2 * k + 1] = mk(t.z, t.w);
+            }
             // bin position and de-rotation factor of this lane's noise outputs (phase C')
             const int np = p.n_period;
             const int ph0 = ((nz_u0 % np) + np) % np;             // block-uniform

@@ -56,7 +56,12 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     std::memcpy(xbuf.data(), iq, (size_t)x_len * sizeof(float2));
     BankBuffers b;
     b.x = (const float2 *)xbuf.data();
-    b.taps_ch = (const float2 *)fp.channel.taps.data(); b.twiddle = (const float2 *)fp.channel.twiddle.data();
+    // the 100-bin kernel reads its taps branch-major in 16-byte pieces: keep the packed tables 16-byte aligned
+    const std::vector<float> tch = pack_branch_major(fp.channel), tn = pack_branch_major(ns.pfb);
+    std::vector<float4> tch4((tch.size() + 3) / 4 + 1), tn4((tn.size() + 3) / 4 + 1);
+    std::memcpy(tch4.data(), tch.data(), tch.size() * sizeof(float));
+    std::memcpy(tn4.data(), tn.data(), tn.size() * sizeof(float));
+    b.taps_ch = (const float2 *)tch4.data(); b.twiddle = (const float2 *)fp.channel.twiddle.data();
     b.krot_ch = (const float2 *)fp.channel.krot.data(); b.rho_ch = (const float2 *)fp.channel.rho.data();
     b.binpos_ch = fp.channel.binpos.data(); b.binnat_ch = fp.channel.binnat.data();
     b.b2map_fused = mf.data(); b.b2map_fused_wide = mw.data(); b.b2map_ch = mc.data(); b.b2map_noise = mn.data();
@@ -64,7 +69,7 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     std::vector<float> dcol((size_t)ntiles_max * 80 * 25, -77.f);
     b.dcol = dcol.data();
     b.Ydebug = (float2 *)Y_out; b.ystride = ystride;
-    b.taps_n = (const float2 *)ns.pfb.taps.data(); b.krot_n = (const float2 *)ns.pfb.krot.data();
+    b.taps_n = (const float2 *)tn4.data(); b.krot_n = (const float2 *)ns.pfb.krot.data();
     b.binpos_n = ns.pfb.binpos.data();
     b.Z = (float2 *)Z_out; b.zstride = zstride;
     auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
