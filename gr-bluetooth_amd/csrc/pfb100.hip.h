@@ -689,7 +689,13 @@ __global__ __launch_bounds__(256) void noise_stage2_kernel(
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f *zv = (const v4f *)zs;
-    for (int j = 4 * threadIdx.x; j < nout; j += 4 * blockDim.x) {
+    // only the outputs a slot's quadrature weights touch are formed: nw (182) of every `outs` (250) -- the
+    // squelch averages the reference's noise_out = 850 of the 1250 2-Msps outputs of a slot.  Compact index
+    // jc -> (slot jc / nwp, output jc % nwp) with nwp = nw rounded up to four.
+    const int nwp = (nw + 3) & ~3;
+    for (int jc = 4 * threadIdx.x; jc < ks * nwp; jc += 4 * blockDim.x) {
+        const int sl = jc / nwp, r = jc - sl * nwp;
+        const int j = sl * outs + r;                                 // even: outs is even, r a multiple of four
         v2f y0 = {0.f, 0.f}, y1 = y0, y2 = y0, y3 = y0;              // (re, im) pairs -> v_pk_fma_f32
         v4f q0 = zv[j >> 1], q1 = zv[(j >> 1) + 1];
         for (int m = 0; m < L3 / 2; m++) {                           // taps 2m, 2m+1 (L3 is even)
