@@ -115,6 +115,29 @@ inline void launch_noise_bank(const Design &des, const FastPath &fp, const BankB
     L(pfb100_kernel<15, 5, NT, false, false, kBankThreads>, p.ntiles, kBankThreads, lds, p);
 }
 
+// Parameters of window_kernel / finish_kernel for a batch of S slots (nb energy blocks per channel, d rows ystride
+// apart in the direct-form buffers).  dbg_stop / fin_prio are left 0 / 3.
+inline WindowParams make_window_params(const Design &des, int S, int nb, long long ystride, int max_hits, bool want_syms,
+                                       const uint64_t *btbb_pcol)
+{
+    const btgpu_design &d = des.d;
+    WindowParams p{};
+    p.nch = d.high_channel - d.low_channel + 1; p.S = S; p.outs_per_slot = des.outs_per_slot;
+    p.ddc_out = d.ddc_out; p.noise_out = d.noise_out;
+    p.blocks_per_window = des.blocks_per_window; p.tail = des.tail; p.nb = nb; p.ystride = ystride;
+    p.target_snr = des.cfg.squelch_db;
+    p.gain_mu = des.gain_mu; p.mu0 = des.mu0; p.omega_relative_limit = des.omega_relative_limit;
+    p.omega0 = des.omega0; p.gain_omega = des.gain_omega; p.omega_mid = des.omega_mid;
+    p.mode = des.cfg.mode; p.max_hits = max_hits;
+    p.a0_lo = des.ac.a0_lo; p.a0_hi = des.ac.a0_hi;
+    p.le = (des.cfg.flags & BTGPU_FLAG_LE) ? 1 : 0; p.low_channel = d.low_channel;
+    p.syms = want_syms ? 1 : 0;
+    p.btbb = d.correlator == BTGPU_CORRELATOR_BTBB ? 1 : 0;
+    p.btbb_pcol = btbb_pcol;
+    p.fin_prio = 3;
+    return p;
+}
+
 // ---- the rates below 100 Msps: pfbm_kernel (M = fs / 1 MHz bins) ----
 template <class Launcher>
 inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const BankBuffers &b, size_t x_len,

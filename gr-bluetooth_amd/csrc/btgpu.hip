@@ -351,18 +351,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
 
     // ---- K3: squelch + M&M + slicer + access-code search ----
     {
-        WindowParams p{};
-        p.nch = nch; p.S = S; p.outs_per_slot = ops; p.ddc_out = d.ddc_out; p.noise_out = d.noise_out;
-        p.blocks_per_window = des.blocks_per_window; p.tail = des.tail; p.nb = nb; p.ystride = ystride;
-        p.target_snr = des.cfg.squelch_db;
-        p.gain_mu = des.gain_mu; p.mu0 = des.mu0; p.omega_relative_limit = des.omega_relative_limit;
-        p.omega0 = des.omega0; p.gain_omega = des.gain_omega; p.omega_mid = des.omega_mid;
-        p.mode = des.cfg.mode; p.max_hits = max_hits;
-        p.a0_lo = des.ac.a0_lo; p.a0_hi = des.ac.a0_hi;
-        p.le = (des.cfg.flags & BTGPU_FLAG_LE) ? 1 : 0; p.low_channel = d.low_channel;
-        p.syms = want_syms ? 1 : 0;
-        p.btbb = d.correlator == BTGPU_CORRELATOR_BTBB ? 1 : 0;
-        p.btbb_pcol = (const uint64_t *)d_pcol.p;
+        WindowParams p = make_window_params(des, S, nb, ystride, max_hits, want_syms, (const uint64_t *)d_pcol.p);
         { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
         { static const int fp_ = getenv("BTGPU_FIN_PRIO") ? atoi(getenv("BTGPU_FIN_PRIO")) : 3; p.fin_prio = fp_; }
         auto launch_window = [&](auto lay) {

@@ -22,6 +22,8 @@ extern "C" {
 // Outputs (caller-allocated): d [G][80] float, P/Pt [nch][nb] double (block sums as block_sum_kernel forms them),
 // Z [nch][zstride] complex64 (noise stage 1), Y [nch][ystride] complex64 (de-rotated channel output, optional).
 // sizes[]: G, nb, nch, zstride, ystride, Tn (filled in).  Returns 0 or a negative error.
+static std::vector<float> *g_keep_dcol = nullptr;      // emu_front_run: keep the tile-blocked copy the bank kernel wrote
+
 int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_len, long long w0, int S, int fuse,
                  float *d_out, double *P_out, double *Pt_out, float *Z_out, float *Y_out, long long *sizes)
 {
@@ -86,6 +88,7 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
             const float a = d_out[(size_t)g * 80 + c], bcol = dcol[((size_t)(g / 25) * 80 + c) * 25 + g % 25];
             if (std::memcmp(&a, &bcol, sizeof a) != 0) { std::fprintf(stderr, "emu: dcol != d at g %lld c %d\n", g, c); return -100; }
         }
+    if (g_keep_dcol) *g_keep_dcol = dcol;
     // block sums exactly as block_sum_kernel orders them (per block: tiles ascending)
     const int tpb = ops / 25, tail_tiles = des.tail / 25;
     for (int c = 0; c < nch; c++)
@@ -197,3 +200,100 @@ int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// The whole FAST front end on the CPU: channel bank + noise stage 1 (pfbm_kernel, or the fused 100-bin pfb100_kernel
+// with its tile-blocked copy dcol for the finish kernel), noise stage 2 (restated here
+// in plain loops: the kernel reduces with wave shuffles, which the emulator does not model), window_kernel (squelch,
+// M&M, slicer, access-code / LE search), finish_kernel, nsym_patch_kernel -- the kernels' own source, lanes as
+// fibers.  Records: [n][8] int64 = slot, channel, kind, offset, lap, ac_errors, nsym, 0; snr_out [n].
+// Returns the number of records (<= cap) or a negative error.
+extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double squelch_db, const float *iq, long long x_len, int S,
+                               long long *rec_out, double *snr_out, int cap)
+{
+    btgpu_config cfg{};
+    cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = squelch_db; cfg.mode = mode;
+    cfg.flags = le ? BTGPU_FLAG_LE : 0;
+    static Design des; static FastPath fp;
+    int rc = make_design(cfg, des);
+    if (rc) return rc;
+    rc = make_fast_path(des, fp);
+    if (rc) return rc;
+    long long sizes[8] = {0};
+    const bool big = fp.channel.available && fp.channel.M == kPfbM;        // 100 Msps: the 100-bin bank (fused noise stage 1) + dcol
+    rc = big ? emu_bank_run(fs, fc, mode, iq, x_len, 0, S, 1, nullptr, nullptr, nullptr, nullptr, nullptr, sizes)
+             : emu_bank_m_run(fs, fc, mode, iq, x_len, 0, S, nullptr, nullptr, nullptr, nullptr, nullptr, sizes);
+    if (rc) return rc;
+    const long long G = sizes[0], zstride = sizes[3];
+    const int nb = (int)sizes[1], nch = (int)sizes[2], drow = big ? 80 : (int)sizes[6];
+    std::vector<float4> dbuf(((size_t)(G + 64) * drow + 3) / 4 + 4);          // 16-byte aligned rows
+    float *d = (float *)dbuf.data();
+    std::vector<double> P((size_t)nch * nb), Pt((size_t)nch * nb);
+    std::vector<float> Z((size_t)nch * zstride * 2, 0.f);
+    std::vector<float> dcol;
+    if (big) {
+        g_keep_dcol = &dcol;
+        rc = emu_bank_run(fs, fc, mode, iq, x_len, 0, S, 1, d, P.data(), Pt.data(), Z.data(), nullptr, sizes);
+        g_keep_dcol = nullptr;
+    } else rc = emu_bank_m_run(fs, fc, mode, iq, x_len, 0, S, d, P.data(), Pt.data(), Z.data(), nullptr, sizes);
+    if (rc) return rc;
+
+    // noise stage 2 (noise_stage2_kernel's arithmetic): y^[J] = sum_i h3[i] Z[c][J + i], Qn[c][k] = sum_j w[j] |y^[outs k + j]|^2
+    const NoiseStage &ns = fp.noise;
+    std::vector<double> Qn((size_t)nch * S);
+    for (int c = 0; c < nch; c++)
+        for (int k = 0; k < S; k++) {
+            double acc = 0.0;
+            for (int j = 0; j < ns.nw; j++) {
+                float yr = 0.f, yi = 0.f;
+                const float *z = Z.data() + ((size_t)c * zstride + (size_t)k * ns.outs + j) * 2;
+                for (int i = 0; i < ns.L3; i++) { yr = std::fmaf(ns.h3[i], z[2 * i], yr); yi = std::fmaf(ns.h3[i], z[2 * i + 1], yi); }
+                acc += ns.weights[j] * (double)(yr * yr + yi * yi);
+            }
+            Qn[(size_t)c * S + k] = acc;
+        }
+
+    const int max_hits = 1 << 16;
+    std::vector<uint64_t> pcol(des.ac.btbb_pcol, des.ac.btbb_pcol + 24);
+    WindowParams p = make_window_params(des, S, nb, 0, max_hits, false, pcol.data());
+    const size_t W = (size_t)S * nch;
+    std::vector<double> e_on(W), e_off(W), snr(W);
+    std::vector<int> win_len(W, -1), win_fin(W, -1);
+    std::vector<DeviceHit> hits((size_t)max_hits);
+    std::vector<FinishRec> fin(W);
+    unsigned int counts[2] = {0, 0};
+    std::vector<uint32_t> winbits((size_t)((S + 2) / 3 + 1) * kBitWords * kWinThreads, 0u);
+    auto launch_window = [&](auto lay) {
+        using LAY = decltype(lay);
+        emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() {
+            window_kernel<LAY>(p, d, G, P.data(), Pt.data(), Qn.data(), des.mmse, &des.ac.byte_lo[0][0], &des.ac.byte_hi[0][0],
+                               e_on.data(), e_off.data(), snr.data(), win_len.data(), hits.data(), &counts[0], fin.data(),
+                               &counts[1], &des.le.hdr[0][0], des.le.whiten16, des.le.index_of_channel, win_fin.data(),
+                               (uint32_t *)nullptr, winbits.data());
+        });
+    };
+    if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
+    else if (drow == 40) launch_window(WinLayout<6, 40, 10>{});
+    else if (drow == 20) launch_window(WinLayout<12, 20, 5>{});
+    else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});
+    else launch_window(WinLayout<64, 4, 1>{});
+    {
+        const unsigned nblk = (unsigned)((counts[1] + kFinLanes - 1) / kFinLanes + 1);
+        emu::launch(dim3(nblk), dim3(kFinLanes), [&]() {
+            finish_kernel<false>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), (uint32_t *)nullptr,
+                                 big ? (const float *)dcol.data() : (const float *)nullptr);
+        });
+        emu::launch(dim3(4), dim3(256), [&]() {
+            nsym_patch_kernel(hits.data(), &counts[0], max_hits, win_len.data(), nch, (const int *)nullptr);
+        });
+    }
+    int n = (int)std::min<unsigned>(counts[0], (unsigned)std::min(cap, max_hits));
+    for (int i = 0; i < n; i++) {
+        const DeviceHit &h = hits[i];
+        long long *r = rec_out + (size_t)i * 8;
+        r[0] = h.slot; r[1] = des.d.low_channel + h.channel_idx; r[2] = h.kind; r[3] = h.offset; r[4] = h.lap; r[5] = h.ac_errors;
+        r[6] = h.nsym; r[7] = 0;
+        snr_out[i] = h.snr;
+    }
+    return n;
+}

@@ -252,3 +252,47 @@ def test_small_m_banks_vs_oracle(emu, po, synth, fs, fc, mode):
             q = float(np.dot(w, np.abs(yh) ** 2))
             ok, snr, e_off = o.check_snr(win, ch, e_on)
             assert abs(q / o.noise_out - e_off) / e_off <= 1e-5, (ch, q / o.noise_out, e_off)
+
+
+@pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (8e6, 2476.5e6, False, False), (20e6, 2441e6, True, False),
+                                            (100e6, 2441e6, True, True)])
+def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff, le):
+    """The whole FAST front end on the CPU (8 / 20 Msps small-M banks; 100 Msps: the fused 100-bin bank, 79 channels, the
+    three-slot window layout and the finish kernel on the tile-blocked copy) -- polyphase channel and noise banks, squelch, window_kernel
+    (M&M clock recovery, slicer, access-code / LE search), finish_kernel, nsym patch: the product's kernel source run
+    lane by lane under the emulator (only noise stage 2, a wave-shuffle reduction, is restated in the harness) --
+    against the oracle on a capture with bursts: the tolerance contract of the polyphase path (tests/paritylib.py,
+    DESIGN.md section 5): planted records identical, offsets identical, nsym within +-8."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import paritylib
+    L = emu
+    L.emu_front_m_run.restype = ctypes.c_int
+    L.emu_front_m_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                  ctypes.POINTER(ctypes.c_float), ctypes.c_longlong, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    S = 18 if fs < 100e6 else 12
+    laps = (0x24D952, 0x4831DD, 0x9E8B33)
+    iq, truth = synth.make_capture(fs, fc, S, laps=laps, seed=23, snr_db=22, occupancy=0.8)
+    mode = po.MODE_SNIFFER if sniff else po.MODE_LAP
+    o = po.Oracle(fs, fc, 10.0, mode, le=le)
+    want, _ = o.run_stream(iq, threads=8)
+    H = o.history
+    x = np.concatenate([np.zeros(H - 1, np.complex64), iq.astype(np.complex64)])   # the scheduler's history()-1 zeros in front
+    xf = np.ascontiguousarray(x).view(np.float32)
+    cap = 4096
+    rec = np.zeros((cap, 8), np.int64)
+    snr = np.zeros(cap, np.float64)
+    n = L.emu_front_m_run(fs, fc, mode, int(le), 10.0, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), S,
+                          rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap)
+    assert n >= 0, n
+    got = rec[:n, :7]
+    got = got[np.lexsort((got[:, 3], got[:, 2], got[:, 1], got[:, 0]))]
+    wi = np.array([[h.slot, h.channel, h.kind, h.offset, h.lap, h.ac_errors, h.nsym] for h in want], np.int64).reshape(-1, 7)
+    assert len(wi) > 5
+    d = paritylib.differential(got, wi, truth, lag=6 if sniff else 1)
+    print(d)
+    assert d["planted_ref"] > 3, d
+    assert d["planted_identical"] and d["planted_offset_differs"] == 0, d
+    assert d["planted_nsym_max_abs_dev"] <= 8, d
+    assert d["other_only_gpu"] + d["other_only_ref"] <= 2, d
