@@ -3,6 +3,7 @@
 // (tests/emu), so that the tile / halo / noise-grid arithmetic that is checked on the CPU is the
 // very code that runs in production.
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 
 #include "design.h"
@@ -15,6 +16,31 @@ constexpr int kBankThreads = 256;            // lanes per tile of the non-fused 
 constexpr int kBankThreadsWide = 512;        // fused channel + noise bank: eight waves per tile
 constexpr int kBankNT = 26;                 // channel instants per tile (25 new + 1 halo for the demod)
 constexpr int kNoiseNT = 10;                // instants per tile of the stand-alone noise stage 1
+
+// launch geometry of ddc_direct_kernel: T outputs per workgroup, the taps in chunks of JC through 64 KB of LDS
+struct LaunchShape {
+    int T = 0;        // lanes (= outputs) per workgroup
+    int JC = 0;       // taps per LDS chunk
+    size_t lds = 0;
+};
+
+inline bool pick_shape(int D, int ntp, LaunchShape &s)
+{
+    const size_t budget = 64 * 1024;
+    for (int T : {256, 128, 64}) {
+        size_t fixed = (size_t)(T - 1) * D * sizeof(float2);
+        if (fixed + 64 * sizeof(float2) > budget) continue;
+        long long room = (long long)((budget - fixed) / sizeof(float2));
+        int jc = (int)std::min<long long>(ntp, room / 8 * 8);
+        if (jc < 8) continue;
+        s.T = T;
+        s.JC = jc;
+        s.lds = (size_t)((T - 1) * D + jc) * sizeof(float2);
+        return true;
+    }
+    return false;
+}
+
 
 struct BankBuffers {                        // device (or emulated) memory
     const float2 *x = nullptr;

@@ -37,29 +37,6 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
-struct LaunchShape {
-    int T = 0;        // lanes (= outputs) per workgroup
-    int JC = 0;       // taps per LDS chunk
-    size_t lds = 0;
-};
-
-bool pick_shape(int D, int ntp, LaunchShape &s)
-{
-    const size_t budget = 64 * 1024;
-    for (int T : {256, 128, 64}) {
-        size_t fixed = (size_t)(T - 1) * D * sizeof(float2);
-        if (fixed + 64 * sizeof(float2) > budget) continue;
-        long long room = (long long)((budget - fixed) / sizeof(float2));
-        int jc = (int)std::min<long long>(ntp, room / 8 * 8);
-        if (jc < 8) continue;
-        s.T = T;
-        s.JC = jc;
-        s.lds = (size_t)((T - 1) * D + jc) * sizeof(float2);
-        return true;
-    }
-    return false;
-}
-
 }  // namespace
 
 struct btgpu_handle {

@@ -4,6 +4,7 @@
 namespace emu {
 thread_local dim3 t_idx, b_idx, b_dim, g_dim;
 alignas(64) char dyn_lds[160 * 1024];
+char xchg[1024][16];
 
 namespace {
 constexpr size_t kStack = 256 * 1024;

@@ -201,12 +201,62 @@ int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
 
 }  // extern "C"
 
+
+// window_kernel + finish_kernel + nsym_patch_kernel over the demodulated stream d (time-major, `drow` floats per row;
+// dcol = the 100-bin bank's tile-blocked copy or null), the channel block energies P / Pt and the noise energies Qn
+static int run_detect(const Design &des, int S, int nb, int nch, int drow, long long G, const float *d, const float *dcol_p,
+                      const double *P, const double *Pt, const double *Qn, long long *rec_out, double *snr_out, int cap)
+{
+    const int max_hits = 1 << 16;
+    std::vector<uint64_t> pcol(des.ac.btbb_pcol, des.ac.btbb_pcol + 24);
+    WindowParams p = make_window_params(des, S, nb, 0, max_hits, false, pcol.data());
+    const size_t W = (size_t)S * nch;
+    std::vector<double> e_on(W), e_off(W), snr(W);
+    std::vector<int> win_len(W, -1), win_fin(W, -1);
+    std::vector<DeviceHit> hits((size_t)max_hits);
+    std::vector<FinishRec> fin(W);
+    unsigned int counts[2] = {0, 0};
+    std::vector<uint32_t> winbits((size_t)((S + 2) / 3 + 1) * kBitWords * kWinThreads, 0u);
+    auto launch_window = [&](auto lay) {
+        using LAY = decltype(lay);
+        emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() {
+            window_kernel<LAY>(p, d, G, P, Pt, Qn, des.mmse, &des.ac.byte_lo[0][0], &des.ac.byte_hi[0][0],
+                               e_on.data(), e_off.data(), snr.data(), win_len.data(), hits.data(), &counts[0], fin.data(),
+                               &counts[1], &des.le.hdr[0][0], des.le.whiten16, des.le.index_of_channel, win_fin.data(),
+                               (uint32_t *)nullptr, winbits.data());
+        });
+    };
+    if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
+    else if (drow == 40) launch_window(WinLayout<6, 40, 10>{});
+    else if (drow == 20) launch_window(WinLayout<12, 20, 5>{});
+    else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});
+    else launch_window(WinLayout<64, 4, 1>{});
+    {
+        const unsigned nblk = (unsigned)((counts[1] + kFinLanes - 1) / kFinLanes + 1);
+        emu::launch(dim3(nblk), dim3(kFinLanes), [&]() {
+            finish_kernel<false>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), (uint32_t *)nullptr,
+                                 dcol_p);
+        });
+        emu::launch(dim3(4), dim3(256), [&]() {
+            nsym_patch_kernel(hits.data(), &counts[0], max_hits, win_len.data(), nch, (const int *)nullptr);
+        });
+    }
+    int n = (int)std::min<unsigned>(counts[0], (unsigned)std::min(cap, max_hits));
+    for (int i = 0; i < n; i++) {
+        const DeviceHit &h = hits[i];
+        long long *r = rec_out + (size_t)i * 8;
+        r[0] = h.slot; r[1] = des.d.low_channel + h.channel_idx; r[2] = h.kind; r[3] = h.offset; r[4] = h.lap; r[5] = h.ac_errors;
+        r[6] = h.nsym; r[7] = 0;
+        snr_out[i] = h.snr;
+    }
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The whole FAST front end on the CPU: channel bank + noise stage 1 (pfbm_kernel, or the fused 100-bin pfb100_kernel
-// with its tile-blocked copy dcol for the finish kernel), noise stage 2 (restated here
-// in plain loops: the kernel reduces with wave shuffles, which the emulator does not model), window_kernel (squelch,
-// M&M, slicer, access-code / LE search), finish_kernel, nsym_patch_kernel -- the kernels' own source, lanes as
-// fibers.  Records: [n][8] int64 = slot, channel, kind, offset, lap, ac_errors, nsym, 0; snr_out [n].
+// with its tile-blocked copy dcol for the finish kernel), noise_stage2_kernel, window_kernel (squelch, M&M, slicer,
+// access-code / LE search), finish_kernel, nsym_patch_kernel -- the kernels' own source, lanes as fibers (only the
+// block sums over the tiles' partial energies are formed by the host loops of emu_bank_*_run).  Records: [n][8] int64 = slot, channel, kind, offset, lap, ac_errors, nsym, 0; snr_out [n].
 // Returns the number of records (<= cap) or a negative error.
 extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double squelch_db, const float *iq, long long x_len, int S,
                                long long *rec_out, double *snr_out, int cap)
@@ -238,62 +288,72 @@ extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double sq
     } else rc = emu_bank_m_run(fs, fc, mode, iq, x_len, 0, S, d, P.data(), Pt.data(), Z.data(), nullptr, sizes);
     if (rc) return rc;
 
-    // noise stage 2 (noise_stage2_kernel's arithmetic): y^[J] = sum_i h3[i] Z[c][J + i], Qn[c][k] = sum_j w[j] |y^[outs k + j]|^2
+    // noise stage 2: the kernel itself (its wave-shuffle reduction runs on the emulator's exchange buffer)
     const NoiseStage &ns = fp.noise;
     std::vector<double> Qn((size_t)nch * S);
-    for (int c = 0; c < nch; c++)
-        for (int k = 0; k < S; k++) {
-            double acc = 0.0;
-            for (int j = 0; j < ns.nw; j++) {
-                float yr = 0.f, yi = 0.f;
-                const float *z = Z.data() + ((size_t)c * zstride + (size_t)k * ns.outs + j) * 2;
-                for (int i = 0; i < ns.L3; i++) { yr = std::fmaf(ns.h3[i], z[2 * i], yr); yi = std::fmaf(ns.h3[i], z[2 * i + 1], yi); }
-                acc += ns.weights[j] * (double)(yr * yr + yi * yi);
-            }
-            Qn[(size_t)c * S + k] = acc;
-        }
+    {
+        const int run = ns.outs * (kS2Slots - 1) + ns.nw;
+        const size_t lds2 = (size_t)((run + ns.L3 + 6) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
+        if (lds2 > sizeof emu::dyn_lds) return BTGPU_EUNSUPPORTED;
+        std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
+        emu::launch(dim3((unsigned)((S + kS2Slots - 1) / kS2Slots), (unsigned)nch), dim3(256), [&]() {
+            noise_stage2_kernel((const float2 *)Z.data(), zstride, ns.outs, ns.nw, ns.L3, ns.h3.data(), ns.weights.data(), Qn.data(), S);
+        });
+    }
+    return run_detect(des, S, nb, nch, drow, G, d, big ? dcol.data() : nullptr, P.data(), Pt.data(), Qn.data(), rec_out, snr_out, cap);
+}
 
-    const int max_hits = 1 << 16;
-    std::vector<uint64_t> pcol(des.ac.btbb_pcol, des.ac.btbb_pcol + 24);
-    WindowParams p = make_window_params(des, S, nb, 0, max_hits, false, pcol.data());
-    const size_t W = (size_t)S * nch;
-    std::vector<double> e_on(W), e_off(W), snr(W);
-    std::vector<int> win_len(W, -1), win_fin(W, -1);
-    std::vector<DeviceHit> hits((size_t)max_hits);
-    std::vector<FinishRec> fin(W);
-    unsigned int counts[2] = {0, 0};
-    std::vector<uint32_t> winbits((size_t)((S + 2) / 3 + 1) * kBitWords * kWinThreads, 0u);
-    auto launch_window = [&](auto lay) {
-        using LAY = decltype(lay);
-        emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() {
-            window_kernel<LAY>(p, d, G, P.data(), Pt.data(), Qn.data(), des.mmse, &des.ac.byte_lo[0][0], &des.ac.byte_hi[0][0],
-                               e_on.data(), e_off.data(), snr.data(), win_len.data(), hits.data(), &counts[0], fin.data(),
-                               &counts[1], &des.le.hdr[0][0], des.le.whiten16, des.le.index_of_channel, win_fin.data(),
-                               (uint32_t *)nullptr, winbits.data());
+// ---------------------------------------------------------------------------------------------------
+// The DIRECT (bit-exact) front end on the CPU: ddc_direct_kernel<2> for the channel bank and for the exact noise
+// filter, energy_kernel (wave shuffles emulated), demod_rows_kernel, then window / finish / nsym patch as above --
+// launched with the product's own geometry (pick_shape, shared output grid).  Even samples per symbol only (the
+// segmented form of the odd rates is not wired here).  Records as emu_front_m_run.
+extern "C" int emu_front_direct_run(double fs, double fc, int mode, int le, double squelch_db, const float *iq, long long x_len, int S,
+                                    long long *rec_out, double *snr_out, int cap)
+{
+    btgpu_config cfg{};
+    cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = squelch_db; cfg.mode = mode;
+    cfg.flags = le ? BTGPU_FLAG_LE : 0;
+    static Design des;
+    int rc = make_design(cfg, des);
+    if (rc) return rc;
+    if (des.segmented) return BTGPU_EUNSUPPORTED;
+    const btgpu_design &d = des.d;
+    const int nch = d.high_channel - d.low_channel + 1, ops = des.outs_per_slot, drow = win_drow(nch);
+    const long long G = (long long)ops * (S - 1) + d.ddc_out, Gn = (long long)ops * S;
+    const int nb = (int)((G + ops - 1) / ops);
+    const long long ystride = (G + 63) / 64 * 64, ystride_n = (Gn + 63) / 64 * 64;
+    LaunchShape sc, sn;
+    if (!pick_shape(d.decimation, des.channel.ntp, sc) || !pick_shape(d.decimation, des.noise.ntp, sn)) return BTGPU_EUNSUPPORTED;
+    std::vector<float2> xbuf((size_t)x_len + 8);
+    std::memcpy(xbuf.data(), iq, (size_t)x_len * sizeof(float2));
+    std::vector<double> st(nch), sno(nch);
+    for (int c = 0; c < nch; c++) {
+        st[c] = -des.channel.foff[c] * d.decimation / cfg.sample_rate;
+        sno[c] = -des.noise.foff[c] * d.decimation / cfg.sample_rate;
+    }
+    std::vector<float2> Y((size_t)nch * ystride), Yn((size_t)nch * ystride_n);
+    auto ddc = [&](const LaunchShape &sh, const FilterBank &bank, long long first, const std::vector<double> &step, float2 *out,
+                   long long Gout, long long ys) {
+        if (sh.lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", sh.lds); std::abort(); }
+        emu::launch(dim3((unsigned)((Gout + sh.T - 1) / sh.T), (unsigned)((nch + 1) / 2)), dim3((unsigned)sh.T), [&]() {
+            ddc_direct_kernel<2>(xbuf.data(), x_len, first, d.decimation, bank.ntp, sh.JC, (const float2 *)bank.taps.data(),
+                                 (const float2 *)bank.rot.data(), bank.rot_period, step.data(), out, Gout, ys, nch, 0, 0LL);
         });
     };
-    if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
-    else if (drow == 40) launch_window(WinLayout<6, 40, 10>{});
-    else if (drow == 20) launch_window(WinLayout<12, 20, 5>{});
-    else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});
-    else launch_window(WinLayout<64, 4, 1>{});
-    {
-        const unsigned nblk = (unsigned)((counts[1] + kFinLanes - 1) / kFinLanes + 1);
-        emu::launch(dim3(nblk), dim3(kFinLanes), [&]() {
-            finish_kernel<false>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), (uint32_t *)nullptr,
-                                 big ? (const float *)dcol.data() : (const float *)nullptr);
-        });
-        emu::launch(dim3(4), dim3(256), [&]() {
-            nsym_patch_kernel(hits.data(), &counts[0], max_hits, win_len.data(), nch, (const int *)nullptr);
-        });
-    }
-    int n = (int)std::min<unsigned>(counts[0], (unsigned)std::min(cap, max_hits));
-    for (int i = 0; i < n; i++) {
-        const DeviceHit &h = hits[i];
-        long long *r = rec_out + (size_t)i * 8;
-        r[0] = h.slot; r[1] = des.d.low_channel + h.channel_idx; r[2] = h.kind; r[3] = h.offset; r[4] = h.lap; r[5] = h.ac_errors;
-        r[6] = h.nsym; r[7] = 0;
-        snr_out[i] = h.snr;
-    }
-    return n;
+    ddc(sc, des.channel, d.first_channel_sample, st, Y.data(), G, ystride);
+    ddc(sn, des.noise, d.first_noise_sample, sno, Yn.data(), Gn, ystride_n);
+    std::vector<double> P((size_t)nch * nb), Pt((size_t)nch * nb), Qn((size_t)nch * S);
+    emu::launch(dim3((unsigned)nb, (unsigned)nch), dim3(256), [&]() {
+        energy_kernel(Y.data(), G, ystride, ops, des.tail, P.data(), Pt.data(), nb, nch, ops);
+    });
+    emu::launch(dim3((unsigned)S, (unsigned)nch), dim3(256), [&]() {
+        energy_kernel(Yn.data(), Gn, ystride_n, ops, 0, Qn.data(), (double *)nullptr, S, nch, d.noise_out);
+    });
+    std::vector<float4> dbuf(((size_t)(G + 64) * drow + 3) / 4 + 4);
+    float *dd = (float *)dbuf.data();
+    emu::launch(dim3((unsigned)((G + 63) / 64)), dim3(256), [&]() {
+        demod_rows_kernel(Y.data(), G, ystride, nch, des.atan_tab, des.demod_gain, dd, drow);
+    });
+    return run_detect(des, S, nb, nch, drow, G, dd, nullptr, P.data(), Pt.data(), Qn.data(), rec_out, snr_out, cap);
 }

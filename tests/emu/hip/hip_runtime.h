@@ -73,6 +73,20 @@ static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4
 static inline float __fdiv_rn(float a, float b) { return a / b; }
 static inline void sincospi(double x, double *s, double *c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }   // fibers: one OS thread
-// wave-level exchanges are not emulated: kernels that need them are not run under the emulator
-template <class T> static inline T __shfl_down(T, int, int = 64) { std::fprintf(stderr, "emu: __shfl_down\n"); std::abort(); }
+// __shfl_down through a per-workgroup exchange buffer and two workgroup barriers (write, read): exact for kernels
+// whose shuffles sit in workgroup-uniform control flow or are followed only by the exit of the lanes that skip them
+// (the emulator's barrier ignores exited lanes) -- energy_kernel, block_sum_kernel, noise_stage2_kernel.
+namespace emu { extern char xchg[1024][16]; }
+template <class T> static inline T __shfl_down(T v, int off, int width = 64)
+{
+    static_assert(sizeof(T) <= 16, "exchange slot");
+    const unsigned tid = threadIdx.x;
+    std::memcpy(emu::xchg[tid], &v, sizeof(T));
+    emu::barrier();
+    T r = v;
+    const unsigned lane = tid % (unsigned)width;
+    if (lane + (unsigned)off < (unsigned)width && tid + (unsigned)off < blockDim.x) std::memcpy(&r, emu::xchg[tid + off], sizeof(T));
+    emu::barrier();
+    return r;
+}
 static inline unsigned long long __ballot(int) { std::fprintf(stderr, "emu: __ballot\n"); std::abort(); }

@@ -260,7 +260,7 @@ def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff,
     """The whole FAST front end on the CPU (8 / 20 Msps small-M banks; 100 Msps: the fused 100-bin bank, 79 channels, the
     three-slot window layout and the finish kernel on the tile-blocked copy) -- polyphase channel and noise banks, squelch, window_kernel
     (M&M clock recovery, slicer, access-code / LE search), finish_kernel, nsym patch: the product's kernel source run
-    lane by lane under the emulator (only noise stage 2, a wave-shuffle reduction, is restated in the harness) --
+    lane by lane under the emulator (noise stage 2 included: its wave-shuffle reduction runs on the emulator's exchange buffer) --
     against the oracle on a capture with bursts: the tolerance contract of the polyphase path (tests/paritylib.py,
     DESIGN.md section 5): planted records identical, offsets identical, nsym within +-8."""
     import sys
@@ -296,3 +296,39 @@ def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff,
     assert d["planted_identical"] and d["planted_offset_differs"] == 0, d
     assert d["planted_nsym_max_abs_dev"] <= 8, d
     assert d["other_only_gpu"] + d["other_only_ref"] <= 2, d
+
+
+@pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (4e6, 2476e6, False, False)])
+def test_emulated_direct_front_end_is_bit_exact(emu, po, synth, fs, fc, sniff, le):
+    """The DIRECT path's kernels run on the CPU under the emulator -- direct-form channel and noise banks (the
+    reference's exact filters), block energies, demodulation, window / finish / nsym patch -- and the hit records equal
+    the oracle's in EVERY field (slot, channel, kind, offset, LAP / AA, errors, nsym) and the SNRs to 1e-9 dB: the
+    bit-exact contract the -m gpu tests assert on the device, checked here on the kernels' own source."""
+    L = emu
+    L.emu_front_direct_run.restype = ctypes.c_int
+    L.emu_front_direct_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.POINTER(ctypes.c_float), ctypes.c_longlong, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    S = 12
+    laps = (0x24D952, 0x4831DD, 0x9E8B33)
+    iq, truth = synth.make_capture(fs, fc, S, laps=laps, seed=29, snr_db=20, occupancy=0.8)
+    mode = po.MODE_SNIFFER if sniff else po.MODE_LAP
+    o = po.Oracle(fs, fc, 10.0, mode, le=le)
+    want, _ = o.run_stream(iq, threads=8)
+    x = np.concatenate([np.zeros(o.history - 1, np.complex64), iq.astype(np.complex64)])
+    xf = np.ascontiguousarray(x).view(np.float32)
+    cap = 4096
+    rec = np.zeros((cap, 8), np.int64)
+    snr = np.zeros(cap, np.float64)
+    n = L.emu_front_direct_run(fs, fc, mode, int(le), 10.0, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), S,
+                               rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap)
+    assert n >= 0, n
+    order = np.lexsort((rec[:n, 3], rec[:n, 2], rec[:n, 1], rec[:n, 0]))
+    got, gs = rec[:n, :7][order], snr[:n][order]
+    wi = np.array([[h.slot, h.channel, h.kind, h.offset, h.lap, h.ac_errors, h.nsym] for h in want], np.int64).reshape(-1, 7)
+    ws = np.array([h.snr for h in want])
+    wo = np.lexsort((wi[:, 3], wi[:, 2], wi[:, 1], wi[:, 0]))
+    wi, ws = wi[wo], ws[wo]
+    assert len(wi) > 5
+    assert got.shape == wi.shape and (got == wi).all(), (got[:10], wi[:10])
+    assert np.max(np.abs(gs - ws)) < 1e-9
