@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <vector>
 
@@ -356,4 +357,33 @@ extern "C" int emu_front_direct_run(double fs, double fc, int mode, int le, doub
         demod_rows_kernel(Y.data(), G, ystride, nch, des.atan_tab, des.demod_gain, dd, drow);
     });
     return run_detect(des, S, nb, nch, drow, G, dd, nullptr, P.data(), Pt.data(), Qn.data(), rec_out, snr_out, cap);
+}
+
+// scan_symbols_kernel (the window kernel's access-code search, search_classic) over a captured symbol stream, as
+// btgpu_debug_scan_symbols launches it; every qualifying offset.  out: [n][3] = absolute offset, LAP, errors, sorted.
+extern "C" long emu_scan_symbols(const uint8_t *symbols, long long n, long long *out, long cap)
+{
+    btgpu_config cfg{};
+    cfg.sample_rate = 8e6; cfg.center_freq = 2476.5e6; cfg.squelch_db = 10.0; cfg.mode = BTGPU_MODE_SNIFFER;
+    static Design des;
+    int rc = make_design(cfg, des);
+    if (rc) return rc;
+    const size_t nwords = (size_t)(n + 31) / 32;
+    std::vector<uint32_t> words(nwords + 1, 0u);
+    for (long long i = 0; i < n; i++) if (symbols[i] & 1) words[(size_t)i >> 5] |= 1u << (i & 31);
+    const unsigned long long chunks = ((unsigned long long)n + 624) / 625;
+    const int max_hits = 1 << 20;
+    std::vector<DeviceHit> hits((size_t)max_hits);
+    unsigned int count = 0;
+    emu::launch(dim3((unsigned)((chunks + kWinThreads - 1) / kWinThreads)), dim3(kWinThreads), [&]() {
+        scan_symbols_kernel(words.data(), (unsigned long long)n, 1, des.ac.a0_lo, des.ac.a0_hi, &des.ac.byte_lo[0][0], &des.ac.byte_hi[0][0],
+                            hits.data(), &count, max_hits);
+    });
+    if ((int)count > max_hits) return BTGPU_EOVERFLOW;
+    std::vector<std::array<long long, 3>> all(count);
+    for (unsigned int i = 0; i < count; i++) all[i] = {(long long)hits[i].slot * 625 + hits[i].offset, (long long)hits[i].lap, (long long)hits[i].ac_errors};
+    std::sort(all.begin(), all.end());
+    long m = 0;
+    for (const auto &a : all) if (m < cap) { out[3 * m] = a[0]; out[3 * m + 1] = a[1]; out[3 * m + 2] = a[2]; m++; }
+    return (long)count;
 }

@@ -332,3 +332,29 @@ def test_emulated_direct_front_end_is_bit_exact(emu, po, synth, fs, fc, sniff, l
     assert len(wi) > 5
     assert got.shape == wi.shape and (got == wi).all(), (got[:10], wi[:10])
     assert np.max(np.abs(gs - ws)) < 1e-9
+
+
+def test_emulated_correlator_on_the_reference_symbol_capture(emu, po):
+    """The device correlator's source (scan_symbols_kernel -> search_classic, the window kernel's phase 2) run under the
+    emulator over the reference's own fixture, the 3 997 342 captured symbols of samples/channel37.dem: every
+    qualifying offset equals the oracle's classic_packet::sniff_ac answers, and with the stream policy (a hit moves the
+    scan on by 68 symbols) the 33 hits / 3 LAPs the compiled reference produced (tests/golden/channel37_hits.json)."""
+    import json
+    G = os.path.join(ROOT, "tests", "golden")
+    gold = json.load(open(os.path.join(G, "channel37_hits.json")))
+    dem = np.ascontiguousarray(np.unpackbits(np.load(os.path.join(G, "channel37.bits.npy")))[:gold["n_symbols"]].astype(np.uint8))
+    L = emu
+    L.emu_scan_symbols.restype = ctypes.c_long
+    L.emu_scan_symbols.argtypes = [ctypes.POINTER(ctypes.c_uint8), ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong), ctypes.c_long]
+    cap = 1 << 16
+    out = np.zeros((cap, 3), np.int64)
+    n = L.emu_scan_symbols(dem.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), len(dem), out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), cap)
+    assert 0 < n <= cap
+    every = out[:n]
+    assert [int(o) for o in every[:, 0]] == po.qualifying_offsets(dem)
+    stream, nxt = [], 0
+    for o, lap, e in every:
+        if o < nxt:
+            continue
+        stream.append([int(o), "%06x" % int(lap), int(e)]); nxt = int(o) + 68
+    assert stream == gold["hits"] and len(stream) == 33
