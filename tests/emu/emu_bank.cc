@@ -206,11 +206,15 @@ int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
 // window_kernel + finish_kernel + nsym_patch_kernel over the demodulated stream d (time-major, `drow` floats per row;
 // dcol = the 100-bin bank's tile-blocked copy or null), the channel block energies P / Pt and the noise energies Qn
 static int run_detect(const Design &des, int S, int nb, int nch, int drow, long long G, const float *d, const float *dcol_p,
-                      const double *P, const double *Pt, const double *Qn, long long *rec_out, double *snr_out, int cap)
+                      const double *P, const double *Pt, const double *Qn, long long *rec_out, double *snr_out, int cap,
+                      uint32_t *sym_out = nullptr, uint8_t *hdr_out = nullptr)
 {
+    // sym_out [cap][kSymWords]: packed symbols of each record's window (BTGPU_FLAG_SYMBOLS); hdr_out [cap][132]: the
+    // header sweep (64 UAPs, 64 types, fec13_ok as 4 bytes) of header_sweep_kernel (BTGPU_FLAG_HEADERS)
+    const bool want_syms = sym_out != nullptr;
     const int max_hits = 1 << 16;
     std::vector<uint64_t> pcol(des.ac.btbb_pcol, des.ac.btbb_pcol + 24);
-    WindowParams p = make_window_params(des, S, nb, 0, max_hits, false, pcol.data());
+    WindowParams p = make_window_params(des, S, nb, 0, max_hits, want_syms, pcol.data());
     const size_t W = (size_t)S * nch;
     std::vector<double> e_on(W), e_off(W), snr(W);
     std::vector<int> win_len(W, -1), win_fin(W, -1);
@@ -218,13 +222,14 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     std::vector<FinishRec> fin(W);
     unsigned int counts[2] = {0, 0};
     std::vector<uint32_t> winbits((size_t)((S + 2) / 3 + 1) * kBitWords * kWinThreads, 0u);
+    std::vector<uint32_t> symbits(want_syms ? W * kSymWords : 1, 0u);
     auto launch_window = [&](auto lay) {
         using LAY = decltype(lay);
         emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() {
             window_kernel<LAY>(p, d, G, P, Pt, Qn, des.mmse, &des.ac.byte_lo[0][0], &des.ac.byte_hi[0][0],
                                e_on.data(), e_off.data(), snr.data(), win_len.data(), hits.data(), &counts[0], fin.data(),
                                &counts[1], &des.le.hdr[0][0], des.le.whiten16, des.le.index_of_channel, win_fin.data(),
-                               (uint32_t *)nullptr, winbits.data());
+                               want_syms ? symbits.data() : (uint32_t *)nullptr, winbits.data());
         });
     };
     if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
@@ -235,20 +240,32 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     {
         const unsigned nblk = (unsigned)((counts[1] + kFinLanes - 1) / kFinLanes + 1);
         emu::launch(dim3(nblk), dim3(kFinLanes), [&]() {
-            finish_kernel<false>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), (uint32_t *)nullptr,
-                                 dcol_p);
+            if (want_syms) finish_kernel<true>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), symbits.data(), dcol_p);
+            else finish_kernel<false>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), (uint32_t *)nullptr, dcol_p);
         });
         emu::launch(dim3(4), dim3(256), [&]() {
-            nsym_patch_kernel(hits.data(), &counts[0], max_hits, win_len.data(), nch, (const int *)nullptr);
+            nsym_patch_kernel(hits.data(), &counts[0], max_hits, win_len.data(), nch, want_syms ? win_fin.data() : (const int *)nullptr);
         });
     }
     int n = (int)std::min<unsigned>(counts[0], (unsigned)std::min(cap, max_hits));
+    std::vector<HeaderRec> hdr((size_t)std::max(n, 1));
+    if (hdr_out && want_syms && n > 0) {
+        emu::launch(dim3((unsigned)std::min(n, 64)), dim3(64), [&]() {
+            header_sweep_kernel(hits.data(), &counts[0], n, symbits.data(), des.wh.first18,
+                                des.d.correlator == BTGPU_CORRELATOR_BTBB ? 68 : 72, hdr.data());
+        });
+    }
     for (int i = 0; i < n; i++) {
         const DeviceHit &h = hits[i];
         long long *r = rec_out + (size_t)i * 8;
         r[0] = h.slot; r[1] = des.d.low_channel + h.channel_idx; r[2] = h.kind; r[3] = h.offset; r[4] = h.lap; r[5] = h.ac_errors;
         r[6] = h.nsym; r[7] = 0;
         snr_out[i] = h.snr;
+        if (sym_out) std::memcpy(sym_out + (size_t)i * kSymWords, h.sym >= 0 ? symbits.data() + (size_t)h.sym * kSymWords : symbits.data(), kSymWords * 4);
+        if (hdr_out) {
+            std::memcpy(hdr_out + (size_t)i * 132, hdr[i].uap, 64); std::memcpy(hdr_out + (size_t)i * 132 + 64, hdr[i].type, 64);
+            std::memcpy(hdr_out + (size_t)i * 132 + 128, &hdr[i].fec13_ok, 4);
+        }
     }
     return n;
 }
@@ -309,6 +326,7 @@ extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double sq
 // filter, energy_kernel (wave shuffles emulated), demod_rows_kernel, then window / finish / nsym patch as above --
 // launched with the product's own geometry (pick_shape, shared output grid).  Even samples per symbol only (the
 // segmented form of the odd rates is not wired here).  Records as emu_front_m_run.
+static uint32_t *g_sym_out = nullptr; static uint8_t *g_hdr_out = nullptr;     // set by emu_front_direct_headers_run
 extern "C" int emu_front_direct_run(double fs, double fc, int mode, int le, double squelch_db, const float *iq, long long x_len, int S,
                                     long long *rec_out, double *snr_out, int cap)
 {
@@ -356,7 +374,17 @@ extern "C" int emu_front_direct_run(double fs, double fc, int mode, int le, doub
     emu::launch(dim3((unsigned)((G + 63) / 64)), dim3(256), [&]() {
         demod_rows_kernel(Y.data(), G, ystride, nch, des.atan_tab, des.demod_gain, dd, drow);
     });
-    return run_detect(des, S, nb, nch, drow, G, dd, nullptr, P.data(), Pt.data(), Qn.data(), rec_out, snr_out, cap);
+    return run_detect(des, S, nb, nch, drow, G, dd, nullptr, P.data(), Pt.data(), Qn.data(), rec_out, snr_out, cap, g_sym_out, g_hdr_out);
+}
+
+// the same with the packed symbols of every record's window and the GPU header sweep (BTGPU_FLAG_HEADERS)
+extern "C" int emu_front_direct_headers_run(double fs, double fc, int mode, int le, double squelch_db, const float *iq, long long x_len,
+                                            int S, long long *rec_out, double *snr_out, int cap, uint32_t *sym_out, uint8_t *hdr_out)
+{
+    g_sym_out = sym_out; g_hdr_out = hdr_out;
+    const int n = emu_front_direct_run(fs, fc, mode, le, squelch_db, iq, x_len, S, rec_out, snr_out, cap);
+    g_sym_out = nullptr; g_hdr_out = nullptr;
+    return n;
 }
 
 // scan_symbols_kernel (the window kernel's access-code search, search_classic) over a captured symbol stream, as

@@ -89,4 +89,13 @@ template <class T> static inline T __shfl_down(T v, int off, int width = 64)
     emu::barrier();
     return r;
 }
-static inline unsigned long long __ballot(int) { std::fprintf(stderr, "emu: __ballot\n"); std::abort(); }
+static inline unsigned long long __ballot(int pred)
+{
+    const unsigned tid = threadIdx.x, w0 = tid & ~63u;
+    emu::xchg[tid][0] = pred ? 1 : 0;
+    emu::barrier();
+    unsigned long long m = 0;
+    for (unsigned i = 0; i < 64 && w0 + i < blockDim.x; i++) if (emu::xchg[w0 + i][0]) m |= 1ull << i;
+    emu::barrier();
+    return m;
+}

@@ -358,3 +358,44 @@ def test_emulated_correlator_on_the_reference_symbol_capture(emu, po):
             continue
         stream.append([int(o), "%06x" % int(lap), int(e)]); nxt = int(o) + 68
     assert stream == gold["hits"] and len(stream) == 33
+
+
+def test_emulated_header_sweep_equals_try_clock(emu, po, synth):
+    """BTGPU_FLAG_SYMBOLS / _HEADERS on the CPU: the emulated DIRECT front end exports the packed symbols of every hit
+    window (window_kernel + finish_kernel<SYMS>), header_sweep_kernel (wave ballots emulated) sweeps the 64 CLK1-6
+    candidates -- equal to classic_packet::try_clock of the oracle (UAP from the HEC, packet type, FEC-1/3 verdict) on
+    the symbols the hit hands over (lib/packet_impl.cc:1046-1063)."""
+    L = emu
+    L.emu_front_direct_headers_run.restype = ctypes.c_int
+    L.emu_front_direct_headers_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                               ctypes.POINTER(ctypes.c_float), ctypes.c_longlong, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)]
+    fs, fc, S = 8e6, 2476.5e6, 14
+    iq, _ = synth.make_capture(fs, fc, S, laps=(0x24D952, 0x4831DD), seed=71, snr_db=24, occupancy=0.6)
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    x = np.concatenate([np.zeros(o.history - 1, np.complex64), iq.astype(np.complex64)])
+    xf = np.ascontiguousarray(x).view(np.float32)
+    cap, KW = 1024, 120
+    rec = np.zeros((cap, 8), np.int64); snr = np.zeros(cap)
+    sym = np.zeros((cap, KW), np.uint32); hdr = np.zeros((cap, 132), np.uint8)
+    n = L.emu_front_direct_headers_run(fs, fc, po.MODE_SNIFFER, 0, 10.0, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), S,
+                                       rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                       cap, sym.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), hdr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    assert n > 3
+    checked = 0
+    for i in range(n):
+        slot, ch, kind, off, lap, err, nsym = [int(v) for v in rec[i, :7]]
+        if kind != 0:
+            continue
+        bits = np.unpackbits(sym[i].view(np.uint8), bitorder="little")
+        s = bits[off: off + min(nsym, KW * 32 - off)]
+        assert len(s) >= 126
+        want = [po.try_clock(s, c) for c in range(64)]
+        ok = want[0][2]
+        assert bool(int(hdr[i, 128:132].view(np.int32)[0])) == ok
+        if ok:
+            assert [int(v) for v in hdr[i, :64]] == [w[0] for w in want]
+            assert [int(v) for v in hdr[i, 64:128]] == [w[1] for w in want]
+            checked += 1
+    assert checked > 3
