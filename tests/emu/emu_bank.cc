@@ -1,8 +1,8 @@
-// Host emulation of the polyphase bank kernels (TEST INFRASTRUCTURE; see hip/hip_runtime.h):
-// runs pfb100_kernel -- the same source hipcc compiles for gfx950, launched through the same
-// bank_launch.h the runtime uses -- thread by thread on the CPU and hands the demodulated stream,
-// the tile energy sums and the noise stage-1 output back to the Python tests, which compare them
-// with the oracle.
+// Host emulation of the HIP kernels (TEST INFRASTRUCTURE; see hip/hip_runtime.h): the same source hipcc compiles
+// for gfx950 -- polyphase banks (pfb100.hip.h, pfbm.hip.h), direct-form banks, energy / demod kernels, noise stage 2,
+// window / finish / nsym-patch kernels, the symbol-stream correlator and the header sweep (kernels.hip.h) -- launched
+// through the same bank_launch.h the runtime uses, run lane by lane on the CPU (fibers, real barriers, wave shuffles
+// and ballots through an exchange buffer), results handed to the Python tests, which compare them with the oracle.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,8 +1,9 @@
-"""The polyphase bank kernels (gr-bluetooth_amd/csrc/pfb100.hip.h), compiled for the HOST and run thread
-by thread under tests/emu (fibers for lanes, real barriers): index arithmetic, tile / halo / noise-grid
-geometry, LDS layouts and the lane -> task tables are checked here, where no GPU exists, against the
-oracle -- the same checks the -m gpu tests repeat on the device through the C ABI.  The kernel source and
-its launch code (bank_launch.h) are the product's own; only <hip/hip_runtime.h> is replaced."""
+"""The HIP kernels (gr-bluetooth_amd/csrc/*.hip.h), compiled for the HOST and run thread by thread under tests/emu
+(fibers for lanes, real barriers, wave shuffles / ballots through an exchange buffer): index arithmetic, tile / halo /
+noise-grid geometry, LDS layouts, lane -> task tables -- and whole front ends (banks -> squelch -> clock recovery ->
+correlator -> records, DIRECT bit-exact and polyphase) -- are checked here, where no GPU exists, against the oracle:
+the same checks the -m gpu tests repeat on the device through the C ABI.  The kernel source and its launch code
+(bank_launch.h) are the product's own; only <hip/hip_runtime.h> is replaced."""
 import ctypes
 import os
 import subprocess
