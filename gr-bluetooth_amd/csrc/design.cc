@@ -308,6 +308,7 @@ int make_design(const btgpu_config &cfg, Design &o)
     if (d.ddc_out < 2 * kMmseTaps || d.noise_out < 1) return BTGPU_EINVAL;
 
     // the shared output grid needs whole outputs per slot
+    o.segmented = false;                                         // (a Design may be reused for another configuration)
     if (d.samples_per_slot % d.decimation != 0) {
         // consecutive windows sit on different decimation phases (odd samples per symbol >= 5): no
         // shared output grid; every window is filtered on its own, like the reference does

@@ -31,6 +31,7 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     btgpu_config cfg{};
     cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = 10.0; cfg.mode = mode;
     static Design des; static FastPath fp;
+    des = Design();                                  // a fresh design, like a new handle
     int rc = make_design(cfg, des);
     if (rc) return rc;
     rc = make_fast_path(des, fp);
@@ -118,6 +119,7 @@ int emu_bank_m_run(double fs, double fc, int mode, const float *iq, long long x_
     btgpu_config cfg{};
     cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = 10.0; cfg.mode = mode;
     static Design des; static FastPath fp;
+    des = Design();                                  // a fresh design, like a new handle
     int rc = make_design(cfg, des);
     if (rc) return rc;
     rc = make_fast_path(des, fp);
@@ -180,6 +182,7 @@ int emu_stage2_design(double fs, double fc, int mode, float *h3, double *w, int 
     btgpu_config cfg{};
     cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = 10.0; cfg.mode = mode;
     static Design des; static FastPath fp;
+    des = Design();                                  // a fresh design, like a new handle
     int rc = make_design(cfg, des);
     if (rc) return rc;
     rc = make_fast_path(des, fp);
@@ -283,6 +286,7 @@ extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double sq
     cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = squelch_db; cfg.mode = mode;
     cfg.flags = le ? BTGPU_FLAG_LE : 0;
     static Design des; static FastPath fp;
+    des = Design();                                  // a fresh design, like a new handle
     int rc = make_design(cfg, des);
     if (rc) return rc;
     rc = make_fast_path(des, fp);
@@ -324,8 +328,8 @@ extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double sq
 // ---------------------------------------------------------------------------------------------------
 // The DIRECT (bit-exact) front end on the CPU: ddc_direct_kernel<2> for the channel bank and for the exact noise
 // filter, energy_kernel (wave shuffles emulated), demod_rows_kernel, then window / finish / nsym patch as above --
-// launched with the product's own geometry (pick_shape, shared output grid).  Even samples per symbol only (the
-// segmented form of the odd rates is not wired here).  Records as emu_front_m_run.
+// launched with the product's own geometry (pick_shape; shared output grid, or one segment per window at the odd
+// rates).  Records as emu_front_m_run.
 static uint32_t *g_sym_out = nullptr; static uint8_t *g_hdr_out = nullptr;     // set by emu_front_direct_headers_run
 extern "C" int emu_front_direct_run(double fs, double fc, int mode, int le, double squelch_db, const float *iq, long long x_len, int S,
                                     long long *rec_out, double *snr_out, int cap)
@@ -334,12 +338,16 @@ extern "C" int emu_front_direct_run(double fs, double fc, int mode, int le, doub
     cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = squelch_db; cfg.mode = mode;
     cfg.flags = le ? BTGPU_FLAG_LE : 0;
     static Design des;
+    des = Design();                                  // a fresh design, like a new handle
     int rc = make_design(cfg, des);
     if (rc) return rc;
-    if (des.segmented) return BTGPU_EUNSUPPORTED;
     const btgpu_design &d = des.d;
     const int nch = d.high_channel - d.low_channel + 1, ops = des.outs_per_slot, drow = win_drow(nch);
-    const long long G = (long long)ops * (S - 1) + d.ddc_out, Gn = (long long)ops * S;
+    // odd samples per symbol: every window on its own decimation grid (one segment of outputs per window)
+    const int ops_n = des.segmented ? d.noise_out : ops;
+    const int seg_ch = des.segmented ? d.ddc_out : 0, seg_n = des.segmented ? d.noise_out : 0;
+    const long long seg_stride = d.samples_per_slot;
+    const long long G = (long long)ops * (S - 1) + d.ddc_out, Gn = (long long)ops_n * S;
     const int nb = (int)((G + ops - 1) / ops);
     const long long ystride = (G + 63) / 64 * 64, ystride_n = (Gn + 63) / 64 * 64;
     LaunchShape sc, sn;
@@ -353,21 +361,22 @@ extern "C" int emu_front_direct_run(double fs, double fc, int mode, int le, doub
     }
     std::vector<float2> Y((size_t)nch * ystride), Yn((size_t)nch * ystride_n);
     auto ddc = [&](const LaunchShape &sh, const FilterBank &bank, long long first, const std::vector<double> &step, float2 *out,
-                   long long Gout, long long ys) {
+                   long long Gout, long long ys, int seg) {
         if (sh.lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", sh.lds); std::abort(); }
-        emu::launch(dim3((unsigned)((Gout + sh.T - 1) / sh.T), (unsigned)((nch + 1) / 2)), dim3((unsigned)sh.T), [&]() {
+        const unsigned gx = seg ? (unsigned)(((seg + sh.T - 1) / sh.T) * S) : (unsigned)((Gout + sh.T - 1) / sh.T);
+        emu::launch(dim3(gx, (unsigned)((nch + 1) / 2)), dim3((unsigned)sh.T), [&]() {
             ddc_direct_kernel<2>(xbuf.data(), x_len, first, d.decimation, bank.ntp, sh.JC, (const float2 *)bank.taps.data(),
-                                 (const float2 *)bank.rot.data(), bank.rot_period, step.data(), out, Gout, ys, nch, 0, 0LL);
+                                 (const float2 *)bank.rot.data(), bank.rot_period, step.data(), out, Gout, ys, nch, seg, seg_stride);
         });
     };
-    ddc(sc, des.channel, d.first_channel_sample, st, Y.data(), G, ystride);
-    ddc(sn, des.noise, d.first_noise_sample, sno, Yn.data(), Gn, ystride_n);
+    ddc(sc, des.channel, d.first_channel_sample, st, Y.data(), G, ystride, seg_ch);
+    ddc(sn, des.noise, d.first_noise_sample, sno, Yn.data(), Gn, ystride_n, seg_n);
     std::vector<double> P((size_t)nch * nb), Pt((size_t)nch * nb), Qn((size_t)nch * S);
     emu::launch(dim3((unsigned)nb, (unsigned)nch), dim3(256), [&]() {
         energy_kernel(Y.data(), G, ystride, ops, des.tail, P.data(), Pt.data(), nb, nch, ops);
     });
     emu::launch(dim3((unsigned)S, (unsigned)nch), dim3(256), [&]() {
-        energy_kernel(Yn.data(), Gn, ystride_n, ops, 0, Qn.data(), (double *)nullptr, S, nch, d.noise_out);
+        energy_kernel(Yn.data(), Gn, ystride_n, ops_n, 0, Qn.data(), (double *)nullptr, S, nch, d.noise_out);
     });
     std::vector<float4> dbuf(((size_t)(G + 64) * drow + 3) / 4 + 4);
     float *dd = (float *)dbuf.data();
@@ -394,6 +403,7 @@ extern "C" long emu_scan_symbols(const uint8_t *symbols, long long n, long long 
     btgpu_config cfg{};
     cfg.sample_rate = 8e6; cfg.center_freq = 2476.5e6; cfg.squelch_db = 10.0; cfg.mode = BTGPU_MODE_SNIFFER;
     static Design des;
+    des = Design();                                  // a fresh design, like a new handle
     int rc = make_design(cfg, des);
     if (rc) return rc;
     const size_t nwords = (size_t)(n + 31) / 32;

@@ -299,12 +299,14 @@ def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff,
     assert d["other_only_gpu"] + d["other_only_ref"] <= 2, d
 
 
-@pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (4e6, 2476e6, False, False)])
+@pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (4e6, 2476e6, False, False), (5e6, 2470e6, True, False),
+                                            (2e6, 2476e6, True, True)])
 def test_emulated_direct_front_end_is_bit_exact(emu, po, synth, fs, fc, sniff, le):
     """The DIRECT path's kernels run on the CPU under the emulator -- direct-form channel and noise banks (the
     reference's exact filters), block energies, demodulation, window / finish / nsym patch -- and the hit records equal
     the oracle's in EVERY field (slot, channel, kind, offset, LAP / AA, errors, nsym) and the SNRs to 1e-9 dB: the
-    bit-exact contract the -m gpu tests assert on the device, checked here on the kernels' own source."""
+    bit-exact contract the -m gpu tests assert on the device, checked here on the kernels' own source.  5 Msps: an odd
+    number of samples per symbol, i.e. the segmented form (one output segment per window, rotator restarted)."""
     L = emu
     L.emu_front_direct_run.restype = ctypes.c_int
     L.emu_front_direct_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
