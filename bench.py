@@ -323,6 +323,12 @@ def run_rank(args):
             dt = time.perf_counter() - t1
             cpu = {"value": round(cs * slot / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
                    "sample": "first %d slots (%d samples) of the same capture, oracle/bt_oracle.c single thread" % (cs, cs * slot)}
+            if P > 128:
+                # keep the all-core leg near a minute on hosts with fewer cores than the 256 of the GPU boxes
+                t1 = time.perf_counter()
+                o.run_stream(host[:2 * 128 * slot], max_hits=1 << 20, threads=ncores)
+                rate = 128 * slot / (time.perf_counter() - t1)
+                P = int(max(128, min(P, 80.0 * rate / slot)))
             if P:
                 # all host cores over the first P slots: the full-size differential AND the all-core rate
                 t1 = time.perf_counter()
