@@ -256,7 +256,7 @@ def test_small_m_banks_vs_oracle(emu, po, synth, fs, fc, mode):
 
 
 @pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (8e6, 2476.5e6, False, False), (20e6, 2441e6, True, False),
-                                            (100e6, 2441e6, True, True)])
+                                            (50e6, 2441e6, True, False), (100e6, 2441e6, True, True)])
 def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff, le):
     """The whole FAST front end on the CPU (8 / 20 Msps small-M banks; 100 Msps: the fused 100-bin bank, 79 channels, the
     three-slot window layout and the finish kernel on the tile-blocked copy) -- polyphase channel and noise banks, squelch, window_kernel
@@ -272,7 +272,7 @@ def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff,
     L.emu_front_m_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                   ctypes.POINTER(ctypes.c_float), ctypes.c_longlong, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
-    S = 18 if fs < 100e6 else 12
+    S = 18 if fs < 50e6 else 12
     laps = (0x24D952, 0x4831DD, 0x9E8B33)
     iq, truth = synth.make_capture(fs, fc, S, laps=laps, seed=23, snr_db=22, occupancy=0.8)
     mode = po.MODE_SNIFFER if sniff else po.MODE_LAP
@@ -402,3 +402,29 @@ def test_emulated_header_sweep_equals_try_clock(emu, po, synth):
             assert [int(v) for v in hdr[i, 64:128]] == [w[1] for w in want]
             checked += 1
     assert checked > 3
+
+
+@pytest.mark.parametrize("fs,fc,S", [(8e6, 2476.5e6, 1), (8e6, 2476.5e6, 2), (100e6, 2441e6, 1)])
+def test_emulated_front_end_tiny_batches_and_silence(emu, fs, fc, S):
+    """Edge cases of the batch geometry: one and two slots (fewer windows than a window-kernel workgroup holds, partial
+    tiles at the end of the stream) and an all-zero stream (0 / 0 energies: SNR is NaN, no window passes the squelch):
+    the kernels run to completion under the emulator (LDS poisoned with NaNs, so an uninitialised read would surface)
+    and report no records."""
+    L = emu
+    L.emu_front_m_run.restype = ctypes.c_int
+    L.emu_front_m_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                  ctypes.POINTER(ctypes.c_float), ctypes.c_longlong, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    sps = int(fs / 1e6)
+    H = {8: 31601, 100: 395001}[sps]                               # history() of the sniffer (SURVEY A.1)
+    for kind in ("zeros", "noise"):
+        rng = np.random.default_rng(3)
+        n = H - 1 + S * 625 * sps
+        x = (0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        if kind == "zeros":
+            x[:] = 0
+        xf = np.ascontiguousarray(x).view(np.float32)
+        rec = np.zeros((256, 8), np.int64); snr = np.zeros(256)
+        r = L.emu_front_m_run(fs, fc, 1, 1, 10.0, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), S,
+                              rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 256)
+        assert r == 0, (kind, r)
