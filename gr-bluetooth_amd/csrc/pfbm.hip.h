@@ -45,6 +45,14 @@ struct PfbmParams {
     float2 *Z; long long zstride;
 };
 
+// phase B of the channel bank, lane = (run, channel): instants per run such that nsel * ceil(TT / R) <= 256 lanes
+__host__ __device__ inline int pfbm_run(int nsel, int TT)
+{
+    int R = nsel * TT <= kPfbmThreads ? 1 : (nsel * TT + kPfbmThreads - 1) / kPfbmThreads;
+    while (nsel * ((TT + R - 1) / R) > kPfbmThreads) R++;
+    return R;
+}
+
 inline size_t pfbm_lds_bytes(int M, int D, int Q, int nsel, bool chan)
 {
     const int tt = pfbm_tile(M), nt = tt + (chan ? 1 : 0);
@@ -253,7 +261,9 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
     } else
     // ---- phase B: DFT rows + epilogue, lane = (channel c, run of R instants)
     if (CHAN) {
-        const int R = nsel * TT <= NTH ? 1 : (nsel * TT + NTH - 1) / NTH;      // instants per lane
+        // instants per lane: the smallest R whose nrun = ceil(TT / R) runs of all nsel channels fit the workgroup
+        // (ceil(nsel TT / NTH) alone does not guarantee it: nsel = 29, TT = 50 gives R = 6, nrun = 9, 261 lanes)
+        const int R = pfbm_run(nsel, TT);
         const int nrun = (TT + R - 1) / R;
         const int run = l / nsel, c = l - run * nsel;
         const bool on = run < nrun;

@@ -212,11 +212,13 @@ def _run_m(L, fs, fc, mode, x, w0, S):
 
 
 @pytest.mark.parametrize("fs,fc,mode", [(8e6, 2476.5e6, 1), (8e6, 2476.5e6, 0), (20e6, 2441e6, 1), (4e6, 2476e6, 1), (16e6, 2440e6, 1),
-                                        (50e6, 2441e6, 1)])
+                                        (50e6, 2441e6, 1), (30e6, 2441e6, 1), (50e6, 2476.5e6, 1), (40e6, 2441e6, 0)])
 def test_small_m_banks_vs_oracle(emu, po, synth, fs, fc, mode):
     """pfbm_kernel (M = fs / 1 MHz bins): BASELINE configs[1] (8 Msps, eight channels on the half-MHz grid) and the
     other even rates, multi_sniffer and multi_LAP geometry -- demodulated stream, channel output, window energy and
-    the staged squelch's E_off against the oracle, at the FAST path's tolerances."""
+    the staged squelch's E_off against the oracle, at the FAST path's tolerances.  30 Msps / 2441 MHz (29 channels),
+    50 Msps / 2476.5 MHz (29) and 40 Msps / 2441 MHz (39) are the geometries where ceil(nsel TT / 256) instants per
+    lane left the last run's highest channels without a lane: the highest channel is among those checked."""
     S = 8 if mode == 1 else 2
     laps = (0x24D952, 0x4831DD, 0x9E8B33)
     iq, _ = synth.make_capture(fs, fc, S, laps=laps, seed=11, snr_db=25, occupancy=0.9)
