@@ -153,7 +153,7 @@ def run_rank(args):
 
     blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
                             channelizer=args.channelizer, squelch=args.squelch_mode,
-                            flags=(0 if args.sync else pkg.FLAG_ASYNC) | (pkg.FLAG_HEADERS if args.headers else 0))
+                            flags=(0 if args.sync else pkg.FLAG_ASYNC) | (pkg.FLAG_HEADERS if args.headers else 0) | pkg.FLAG_TIMING)
     des = blk.design
     H, slot = des.history, des.samples_per_slot
     nch = des.high_channel - des.low_channel + 1

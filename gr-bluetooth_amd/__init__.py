@@ -30,7 +30,7 @@ MODE_LAP, MODE_SNIFFER = 0, 1
 CHANNELIZER_AUTO, CHANNELIZER_DIRECT, CHANNELIZER_POLYPHASE = 0, 1, 2
 SQUELCH_AUTO, SQUELCH_DIRECT, SQUELCH_STAGED = 0, 1, 2
 CORRELATOR_AUTO, CORRELATOR_INTREE, CORRELATOR_BTBB = 0, 1, 2   # multi_LAP default: BTBB (libbtbb, as the reference)
-FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS, FLAG_HEADERS = 1, 2, 4, 8, 16
+FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS, FLAG_HEADERS, FLAG_TIMING, FLAG_NO_NSYM = 1, 2, 4, 8, 16, 32, 64
 KIND_AC, KIND_AA = 0, 1
 
 
@@ -78,7 +78,7 @@ EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_stre
            "btgpu_last_error", "btgpu_work", "btgpu_push", "btgpu_process_device", "btgpu_poll",
            "btgpu_poll_symbols", "btgpu_poll_headers", "btgpu_hopseq_create", "btgpu_hopseq_destroy",
            "btgpu_hopseq_init_candidates", "btgpu_hopseq_winnow", "btgpu_hopseq_candidates", "btgpu_hopseq_lookup",
-           "btgpu_hopseq_fetch", "btgpu_pending", "btgpu_flush", "btgpu_last_timing", "btgpu_debug_fetch",
+           "btgpu_hopseq_fetch", "btgpu_pending", "btgpu_flush", "btgpu_device", "btgpu_device_count", "btgpu_last_timing", "btgpu_debug_fetch",
            "btgpu_debug_scan_symbols", "btgpu_debug_lut", "btgpu_process_host"]
 
 

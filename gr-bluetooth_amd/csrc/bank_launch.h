@@ -161,6 +161,7 @@ inline WindowParams make_window_params(const Design &des, int S, int nb, long lo
     p.btbb = d.correlator == BTGPU_CORRELATOR_BTBB ? 1 : 0;
     p.btbb_pcol = btbb_pcol;
     p.fin_prio = 3;
+    p.want_len = 1;
     return p;
 }
 

@@ -48,27 +48,40 @@ struct btgpu_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     int drow = 80;                               // row stride (floats) of the time-major demodulated stream
-    hipStream_t tail_stream = nullptr;
-    struct TailCtx {                 // per in-flight batch: everything the tail (finish + harvest) touches
+    // Three streams form the pipeline of a batch: `stream` (or the caller's) carries the FRONT -- the banks, which
+    // read the input and write only per-context buffers; `post_stream` the POST stage -- tile sums -> block sums,
+    // squelch stage 2, window kernel; `tail_stream` the TAIL -- finish / nsym / header sweep / record copies.  The
+    // banks of batch n+1 therefore start the moment the banks of batch n end, with post(n) and tail(n) running beside
+    // them on the CUs' spare issue slots (round 2: only the tail overlapped, 0.54 ms of a 2.05 ms step waited in line).
+    hipStream_t post_stream = nullptr, tail_stream = nullptr;
+    static constexpr int kCtx = 3;       // in-flight batches (BTGPU_FLAG_ASYNC): front(n+2) | post(n+1) | tail(n)
+    struct TailCtx {                 // per in-flight batch: everything the front writes and the post / tail stages read
         DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_winfin, d_symbits, d_hdr;
-        DevBuf d_d;                           // demodulated stream of the batch: the tail reads it under the next batch's banks
+        DevBuf d_d;                           // demodulated stream of the batch
         DevBuf d_dcol;                        // 100-bin bank: the same stream tile by tile channel-major [tile][80][25], what finish_kernel reads
+        DevBuf d_ptile, d_phead;              // polyphase banks: |Y|^2 tile sums (-> block_sum_kernel on the post stream)
+        DevBuf d_Z;                           // staged squelch: stage-1 output (-> noise_stage2_kernel on the post stream)
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
         DeviceHit *h_hits = nullptr;          // pinned: first kEagerHits records, copied by the tail stream
-        hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t evn[3] = {nullptr, nullptr, nullptr};      // noise branch: start, after stage 1, after stage 2
-        hipEvent_t detect_done = nullptr, tail_done = nullptr;
+        // timing events (recorded only with BTGPU_FLAG_TIMING): front 0 start, 1 channel bank, 2 demod / energy (direct
+        // form), 3 noise stage 1 / direct noise bank, 4 direct noise energy; post 5 start, 6 block sums, 7 squelch
+        // stage 2, 8 window; tail 9 start, 10 end
+        hipEvent_t ev[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr;
         int S = 0;
         uint64_t abs_first_slot = 0;
         bool pending = false;
-    } tc[2];
-    int cur = 0;
+    } tc[kCtx];
+    int cur = 0, nctx = 1;
+    int last_ctx = 0;                // context of the most recent batch (debug fetch)
     bool async = false;
+    bool timing_on = false;          // BTGPU_FLAG_TIMING: bracket the kernels with events (btgpu_last_timing)
+    bool no_nsym = false;            // BTGPU_FLAG_NO_NSYM: skip the M&M continuation that produces hit.nsym
+    bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
     hipStream_t copy_stream = nullptr;
-    hipStream_t noise_stream = nullptr;          // the squelch banks run beside the channel bank
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t spill_stream = nullptr;          // harvest: records beyond the eager copies (never behind an input copy)
     static constexpr unsigned kEagerHits = 65536;
     static constexpr unsigned kEagerFin = 8192;
     bool want_syms = false, want_hdrs = false;
@@ -87,14 +100,13 @@ struct btgpu_handle {
     DevBuf d_in, d_in_b, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index, d_winbits;
-    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_ptile, d_phead, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise, d_dftw_ch, d_dftw_n;
-    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_Z, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
+    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise, d_dftw_ch, d_dftw_n;
+    DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
     LaunchShape shape_s1;
     bool noise_pfb = false;
     bool pfb_small = false, noise_small = false;   // small-M polyphase banks (rates below 100 Msps)
     bool fuse_noise = false;         // noise stage 1 rides on the channel bank's staged input
     bool use_dcol = false;          // 100-bin bank: also writes the tile-blocked channel-major copy the tail reads
-    bool overlap_noise = false;     // measured: running the two banks concurrently is slower (both saturate the CUs)
     long long zstride = 0;
     int ntiles_max = 0;
     LaunchShape shape_ch, shape_n;
@@ -137,20 +149,17 @@ struct btgpu_handle {
         DevBuf *all[] = {&d_in, &d_in_b, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
-                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_ptile, &d_phead, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_dftw_ch, &d_dftw_n,
-                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_Z, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
+                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_dftw_ch, &d_dftw_n,
+                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
-        if (!async) { tc[1].d_winlen.p = tc[1].d_hits.p = tc[1].d_hitcount.p = tc[1].d_fin.p = tc[1].d_d.p = tc[1].d_dcol.p = nullptr;
-                      tc[1].d_winfin.p = tc[1].d_symbits.p = tc[1].d_hdr.p = nullptr; }
         for (TailCtx &t : tc) {
-            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol};
+            DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol,
+                            &t.d_ptile, &t.d_phead, &t.d_Z};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
             for (auto &e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-            for (auto &e : t.evn) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-            if (t.detect_done) { (void)hipEventDestroy(t.detect_done); t.detect_done = nullptr; }
-            if (t.tail_done) { (void)hipEventDestroy(t.tail_done); t.tail_done = nullptr; }
+            for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
             if (t.h_count) { (void)hipHostFree(t.h_count); t.h_count = nullptr; }
             if (t.h_hits) { (void)hipHostFree(t.h_hits); t.h_hits = nullptr; }
         }
@@ -159,18 +168,15 @@ struct btgpu_handle {
             if (ev_copied[k]) { (void)hipEventDestroy(ev_copied[k]); ev_copied[k] = nullptr; }
             if (ev_consumed[k]) { (void)hipEventDestroy(ev_consumed[k]); ev_consumed[k] = nullptr; }
         }
-        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
-        if (tail_stream) { (void)hipStreamDestroy(tail_stream); tail_stream = nullptr; }
-        if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
-        if (noise_stream) { (void)hipStreamDestroy(noise_stream); noise_stream = nullptr; }
-        if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
-        if (ev_join) { (void)hipEventDestroy(ev_join); ev_join = nullptr; }
+        for (hipStream_t *st : {&stream, &post_stream, &tail_stream, &copy_stream, &spill_stream})
+            if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     }
 
-    BankBuffers bank_buffers(const float2 *d_x, const DevBuf &d_d, const DevBuf *d_dcol = nullptr) const
+    BankBuffers bank_buffers(const float2 *d_x, const TailCtx &t, bool with_dcol = false) const
     {
         BankBuffers b;
-        b.dcol = (use_dcol && d_dcol) ? (float *)d_dcol->p : nullptr;
+        const DevBuf &d_d = t.d_d, &d_ptile = t.d_ptile, &d_phead = t.d_phead, &d_Z = t.d_Z;
+        b.dcol = (use_dcol && with_dcol) ? (float *)t.d_dcol.p : nullptr;
         b.x = d_x;
         b.taps_ch = (const float2 *)d_pfb_taps_ch.p; b.twiddle = (const float2 *)d_pfb_tw.p;
         b.krot_ch = (const float2 *)d_krot_ch.p; b.rho_ch = (const float2 *)d_rho_ch.p;
@@ -218,46 +224,43 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     last_S = S;
     last_G = G;
     TailCtx &t = tc[cur];
+    TailCtx &prev = tc[(cur + nctx - 1) % nctx];                 // the batch enqueued before this one
     int carried = BTGPU_OK;                                      // overflow of the batch harvested here
     if (t.pending) { int hrc = harvest(t); if (hrc == BTGPU_EOVERFLOW) carried = hrc; else if (hrc != BTGPU_OK) return hrc; }
     hipEvent_t *ev = t.ev;
     DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin, &d_d = t.d_d;
     DevBuf &d_winfin = t.d_winfin, &d_symbits = t.d_symbits;
     t.S = S; t.abs_first_slot = abs_first_slot;
+    auto mark = [&](int k, hipStream_t s_) -> hipError_t { return timing_on ? hipEventRecord(ev[k], s_) : hipSuccess; };
 
+    // =========================== FRONT (stream `st`): the banks ===========================
+    // Where the front also writes buffers the post stage of the previous batch still reads (direct forms: Y, P, Q
+    // exist once), it waits for that post stage; the polyphase + staged configuration writes per-context buffers only.
+    if (!pipelined && nctx > 1 && prev.detect_done && &prev != &t) HIPCHK(this, hipStreamWaitEvent(st, prev.detect_done, 0));
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
-    HIPCHK(this, hipEventRecord(ev[0], st));
-    // fork: the noise bank only needs the input, it runs on its own stream beside the channel bank
-    hipStream_t ns_st = overlap_noise ? noise_stream : st;
-    if (overlap_noise) {
-        HIPCHK(this, hipEventRecord(ev_fork, st));
-        HIPCHK(this, hipStreamWaitEvent(noise_stream, ev_fork, 0));
-    }
+    HIPCHK(this, mark(0, st));
+    int ntiles = 0, tiles_per_block = 1, tail_tiles = 0;
 
-    // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 block sums P, Pt ----
+    // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 tile sums (polyphase) or block sums P, Pt (direct) ----
     if (use_pfb && pfb_small) {
-        BankBuffers bb = bank_buffers(d_x, d_d);
+        BankBuffers bb = bank_buffers(d_x, t);
         auto L = [&](void (*kern)(PfbmParams), int grid, int threads, size_t lds, const PfbmParams &p) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
         };
-        const int ntiles = launch_channel_bank_m(des, fp, bb, x_len, w0, G, L);
-        HIPCHK(this, hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, st,
-                           (const double *)d_ptile.p, (const double *)d_phead.p, ntiles, ops / pfbm_tile(fp.channel.M),
-                           des.tail / pfbm_tile(fp.channel.M), (double *)d_P.p, (double *)d_Pt.p, nb, nch);
+        ntiles = launch_channel_bank_m(des, fp, bb, x_len, w0, G, L);
+        tiles_per_block = ops / pfbm_tile(fp.channel.M); tail_tiles = des.tail / pfbm_tile(fp.channel.M);
+        HIPCHK(this, mark(1, st));
     } else if (use_pfb) {
         constexpr int TT = kBankNT - 1;
-        BankBuffers bb = bank_buffers(d_x, d_d, &t.d_dcol);
+        BankBuffers bb = bank_buffers(d_x, t, true);
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
         };
         // four waves per tile measured faster than eight (BTGPU_BANK_THREADS=512 keeps the wide variant reachable)
         static const bool wide = getenv("BTGPU_BANK_THREADS") && atoi(getenv("BTGPU_BANK_THREADS")) == 512;
-        const int ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, wide);
-        HIPCHK(this, hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, st,
-                           (const double *)d_ptile.p, (const double *)d_phead.p, ntiles, ops / TT,
-                           des.tail / TT, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
+        ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, wide);
+        tiles_per_block = ops / TT; tail_tiles = des.tail / TT;
+        HIPCHK(this, mark(1, st));
     } else {
         const LaunchShape &s = shape_ch;
         const unsigned gx = seg_ch ? (unsigned)(((seg_ch + s.T - 1) / s.T) * S) : (unsigned)((G + s.T - 1) / s.T);
@@ -266,74 +269,87 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            w0 + (long long)d.first_channel_sample, d.decimation, des.channel.ntp, s.JC,
                            (const float2 *)d_taps_ch.p, (const float2 *)d_rot_ch.p, des.channel.rot_period,
                            (const double *)d_rotstep_ch.p, (float2 *)d_Y.p, G, ystride, nch, seg_ch, seg_stride);
-        HIPCHK(this, hipEventRecord(ev[1], st));
+        HIPCHK(this, mark(1, st));
         dim3 g2((unsigned)nb, (unsigned)nch);
         hipLaunchKernelGGL(energy_kernel, g2, dim3(256), 0, st, (const float2 *)d_Y.p, G,
                            ystride, ops, des.tail, (double *)d_P.p, (double *)d_Pt.p, nb, nch, ops);
         hipLaunchKernelGGL(demod_rows_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, st, (const float2 *)d_Y.p, G,
                            ystride, nch, (const float *)d_atan.p, des.demod_gain, (float *)d_d.p, drow);
     }
-    HIPCHK(this, hipEventRecord(ev[2], st));
+    HIPCHK(this, mark(2, st));
 
-    // ---- noise bank -> Qn[c][k] = noise_out * E_off ----
-    HIPCHK(this, hipEventRecord(t.evn[0], ns_st));
+    // ---- noise bank: stage 1 of the staged squelch (unless fused into the channel bank) or the direct form ----
+    const NoiseStage &ns = fp.noise;
     if (use_staged) {
-        const NoiseStage &ns = fp.noise;
         const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
         const long long xs0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
         if (fuse_noise) {
             // stage 1 already ran inside the channel-bank kernel
         } else if (noise_pfb) {
-            BankBuffers bb = bank_buffers(d_x, d_d);
+            BankBuffers bb = bank_buffers(d_x, t);
             auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
-                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, ns_st, p);
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
             };
             launch_noise_bank(des, fp, bb, x_len, w0, S, L);
         } else if (noise_small) {
-            BankBuffers bb = bank_buffers(d_x, d_d);
+            BankBuffers bb = bank_buffers(d_x, t);
             auto L = [&](void (*kern)(PfbmParams), int grid, int threads, size_t lds, const PfbmParams &p) {
-                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, ns_st, p);
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
             };
             launch_noise_bank_m(des, fp, bb, x_len, w0, S, L);
         } else {
             // stage 1 as a direct-form bank: B-spline prototype (a few hundred taps at most), hop R
             const LaunchShape &s = shape_s1;
             dim3 grid((unsigned)((Tn + s.T - 1) / s.T), (unsigned)((nch + 1) / 2));
-            hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, ns_st, d_x, (long long)x_len, xs0, ns.R,
+            hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len, xs0, ns.R,
                                ns.direct.ntp, s.JC, (const float2 *)d_taps_s1.p, (const float2 *)d_rot_s1.p,
-                               ns.direct.rot_period, (const double *)d_rotstep_s1.p, (float2 *)d_Z.p, Tn, zstride, nch, 0, 0LL);
+                               ns.direct.rot_period, (const double *)d_rotstep_s1.p, (float2 *)t.d_Z.p, Tn, zstride, nch, 0, 0LL);
         }
-        HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
-        const int run = ns.outs * (kS2Slots - 1) + ns.nw;
-        const size_t lds2 = (size_t)((run + ns.L3 + 6) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
-        hipLaunchKernelGGL(noise_stage2_kernel, dim3((S + kS2Slots - 1) / kS2Slots, nch), dim3(256), lds2, ns_st,
-                           (const float2 *)d_Z.p, zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p,
-                           (const double *)d_w.p, (double *)d_Q.p, S);
+        HIPCHK(this, mark(3, st));
+        HIPCHK(this, mark(4, st));
     } else {
         const LaunchShape &s = shape_n;
         const unsigned gx = seg_n ? (unsigned)(((seg_n + s.T - 1) / s.T) * S) : (unsigned)((Gn + s.T - 1) / s.T);
         dim3 grid(gx, (unsigned)((nch + 1) / 2));
-        hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, ns_st, d_x, (long long)x_len,
+        hipLaunchKernelGGL(ddc_direct_kernel<2>, grid, dim3(s.T), s.lds, st, d_x, (long long)x_len,
                            w0 + (long long)d.first_noise_sample, d.decimation, des.noise.ntp, s.JC,
                            (const float2 *)d_taps_n.p, (const float2 *)d_rot_n.p, des.noise.rot_period,
                            (const double *)d_rotstep_n.p, (float2 *)d_Yn.p, Gn, ystride_n, nch, seg_n, seg_stride);
-        HIPCHK(this, hipEventRecord(t.evn[1], ns_st));
+        HIPCHK(this, mark(3, st));
         dim3 g2((unsigned)S, (unsigned)nch);
-        hipLaunchKernelGGL(energy_kernel, g2, dim3(256), 0, ns_st, (const float2 *)d_Yn.p, Gn,
+        hipLaunchKernelGGL(energy_kernel, g2, dim3(256), 0, st, (const float2 *)d_Yn.p, Gn,
                            ystride_n, ops_n, 0, (double *)d_Q.p, (double *)nullptr, S, nch, d.noise_out);
+        HIPCHK(this, mark(4, st));
     }
-    HIPCHK(this, hipEventRecord(t.evn[2], ns_st));
-    if (overlap_noise) HIPCHK(this, hipStreamWaitEvent(st, t.evn[2], 0));      // join before the window kernel
-    HIPCHK(this, hipEventRecord(ev[4], st));
+    HIPCHK(this, hipEventRecord(t.front_done, st));
+
+    // =========================== POST (post_stream): sums, squelch stage 2, window kernel ===========================
+    hipStream_t ps = post_stream;
+    HIPCHK(this, hipStreamWaitEvent(ps, t.front_done, 0));
+    HIPCHK(this, mark(5, ps));
+    if (use_pfb)
+        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, ps,
+                           (const double *)t.d_ptile.p, (const double *)t.d_phead.p, ntiles, tiles_per_block,
+                           tail_tiles, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
+    HIPCHK(this, mark(6, ps));
+    if (use_staged) {
+        const int run = ns.outs * (kS2Slots - 1) + ns.nw;
+        const size_t lds2 = (size_t)((run + ns.L3 + 6) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
+        hipLaunchKernelGGL(noise_stage2_kernel, dim3((S + kS2Slots - 1) / kS2Slots, nch), dim3(256), lds2, ps,
+                           (const float2 *)t.d_Z.p, zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p,
+                           (const double *)d_w.p, (double *)d_Q.p, S);
+    }
+    HIPCHK(this, mark(7, ps));
 
     // ---- K3: squelch + M&M + slicer + access-code search ----
     {
         WindowParams p = make_window_params(des, S, nb, ystride, max_hits, want_syms, (const uint64_t *)d_pcol.p);
         { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
         { static const int fp_ = getenv("BTGPU_FIN_PRIO") ? atoi(getenv("BTGPU_FIN_PRIO")) : 3; p.fin_prio = fp_; }
+        p.want_len = no_nsym ? 0 : 1;
         auto launch_window = [&](auto lay) {
             using LAY = decltype(lay);
-            hipLaunchKernelGGL(window_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, st, p,
+            hipLaunchKernelGGL(window_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, ps, p,
                                (const float *)d_d.p, G,
                                (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
                                (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
@@ -349,17 +365,18 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         else if (drow == 20) launch_window(WinLayout<12, 20, 5>{});
         else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});
         else launch_window(WinLayout<64, 4, 1>{});
-        HIPCHK(this, hipEventRecord(ev[5], st));
-        // ---- tail: finish + nsym on the tail stream, overlapping the next batch's banks ----
-        HIPCHK(this, hipEventRecord(t.detect_done, st));
+        HIPCHK(this, mark(8, ps));
+        // =========================== TAIL (tail_stream): finish + nsym + record copies ===========================
+        HIPCHK(this, hipEventRecord(t.detect_done, ps));
         HIPCHK(this, hipStreamWaitEvent(tail_stream, t.detect_done, 0));
+        HIPCHK(this, mark(9, tail_stream));
         {
             // windows with hits: at most one FinishRec per window; lanes beyond fin_count exit
             // (the kernel strides over the records: the grid only bounds the waves in flight)
             const long long cap = (long long)S * nch;
             const unsigned nblk = (unsigned)std::min<long long>((cap + kFinLanes - 1) / kFinLanes, 4096);
             static const bool tail_off = getenv("BTGPU_TAIL_OFF") != nullptr;   // timing experiments only: records lose nsym
-            if (!tail_off) {
+            if (!tail_off && (!no_nsym || want_syms)) {
             if (want_syms)
                 hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
@@ -387,17 +404,18 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                 HIPCHK(this, hipMemcpyAsync(t.h_sym, d_symbits.p, (size_t)kEagerFin * kSymWords * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, tail_stream));
             // records travel to pinned host memory on the tail stream too: harvesting a batch is
-            // then pure host work and never waits on the other stream
+            // then pure host work and never waits on the other streams
             HIPCHK(this, hipMemcpyAsync(t.h_count, d_hitcount.p, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
             const size_t eager = std::min<size_t>((size_t)max_hits, (size_t)kEagerHits);
             HIPCHK(this, hipMemcpyAsync(t.h_hits, d_hits.p, eager * sizeof(DeviceHit), hipMemcpyDeviceToHost, tail_stream));
         }
     }
-    HIPCHK(this, hipEventRecord(ev[6], tail_stream));
+    HIPCHK(this, mark(10, tail_stream));
     HIPCHK(this, hipEventRecord(t.tail_done, tail_stream));
     HIPCHK(this, hipGetLastError());
     t.pending = true;
-    cur ^= 1;
+    last_ctx = cur;
+    cur = (cur + 1) % nctx;
     if (!async) { const int hrc = harvest(t); return hrc != BTGPU_OK ? hrc : carried; }
     return carried;
 }
@@ -444,15 +462,20 @@ int btgpu_handle::harvest(TailCtx &t)
     const btgpu_design &d = des.d;
     HIPCHK(this, hipEventSynchronize(t.tail_done));
     t.pending = false;
-    float ms = 0;
-    hipEvent_t a[6] = {t.ev[0], t.ev[1], t.evn[0], t.evn[1], t.ev[4], t.ev[5]};
-    hipEvent_t e[6] = {t.ev[1], t.ev[2], t.evn[1], t.evn[2], t.ev[5], t.ev[6]};
-    for (int i = 0; i < 6; i++) {
-        HIPCHK(this, hipEventElapsedTime(&ms, a[i], e[i]));
-        timing.kernel_ms[i] += ms;
-        timing.kernel_launches[i] += 1;
+    if (timing_on) {
+        // BTGPU_K_*: channel bank | demod + energy (direct) or tile sums -> block sums (polyphase) | noise stage 1 or
+        // direct noise bank | squelch stage 2 or direct noise energy | window | tail
+        float ms = 0;
+        const bool blk = use_pfb;
+        hipEvent_t a[6] = {t.ev[0], blk ? t.ev[5] : t.ev[1], t.ev[2], use_staged ? t.ev[6] : t.ev[3], t.ev[7], t.ev[9]};
+        hipEvent_t e[6] = {t.ev[1], blk ? t.ev[6] : t.ev[2], t.ev[3], use_staged ? t.ev[7] : t.ev[4], t.ev[8], t.ev[10]};
+        for (int i = 0; i < 6; i++) {
+            HIPCHK(this, hipEventElapsedTime(&ms, a[i], e[i]));
+            timing.kernel_ms[i] += ms;
+            timing.kernel_launches[i] += 1;
+        }
+        HIPCHK(this, hipEventElapsedTime(&ms, t.ev[0], t.ev[10])); timing.total_ms += ms;
     }
-    HIPCHK(this, hipEventElapsedTime(&ms, t.ev[0], t.ev[6])); timing.total_ms += ms;
     timing.batches += 1;
     timing.slots += (uint64_t)t.S;
     timing.samples += (uint64_t)t.S * (uint64_t)d.samples_per_slot;
@@ -465,8 +488,8 @@ int btgpu_handle::harvest(TailCtx &t)
         if (count > kEagerHits) {             // rare: more records than the eager copy carries
             hh.resize(count);
             HIPCHK(this, hipMemcpyAsync(hh.data() + kEagerHits, (const DeviceHit *)t.d_hits.p + kEagerHits,
-                                     sizeof(DeviceHit) * (count - kEagerHits), hipMemcpyDeviceToHost, copy_stream));
-            HIPCHK(this, hipStreamSynchronize(copy_stream));
+                                     sizeof(DeviceHit) * (count - kEagerHits), hipMemcpyDeviceToHost, spill_stream));
+            HIPCHK(this, hipStreamSynchronize(spill_stream));
         }
         size_t q0 = queue.size();
         size_t hi = 0;
@@ -489,8 +512,8 @@ int btgpu_handle::harvest(TailCtx &t)
                     if ((unsigned)x.sym < kEagerFin) std::memcpy(bits.data(), t.h_sym + (size_t)x.sym * kSymWords, kSymWords * sizeof(uint32_t));
                     else {
                         HIPCHK(this, hipMemcpyAsync(bits.data(), (const uint32_t *)t.d_symbits.p + (size_t)x.sym * kSymWords,
-                                                 kSymWords * sizeof(uint32_t), hipMemcpyDeviceToHost, copy_stream));
-                        HIPCHK(this, hipStreamSynchronize(copy_stream));
+                                                 kSymWords * sizeof(uint32_t), hipMemcpyDeviceToHost, spill_stream));
+                        HIPCHK(this, hipStreamSynchronize(spill_stream));
                     }
                 }
                 qbits.push_back(std::move(bits));
@@ -501,8 +524,8 @@ int btgpu_handle::harvest(TailCtx &t)
                 HeaderRec r;
                 if (hit_index < kEagerFin) r = t.h_hdr[hit_index];
                 else {
-                    HIPCHK(this, hipMemcpyAsync(&r, (const HeaderRec *)t.d_hdr.p + hit_index, sizeof r, hipMemcpyDeviceToHost, copy_stream));
-                    HIPCHK(this, hipStreamSynchronize(copy_stream));
+                    HIPCHK(this, hipMemcpyAsync(&r, (const HeaderRec *)t.d_hdr.p + hit_index, sizeof r, hipMemcpyDeviceToHost, spill_stream));
+                    HIPCHK(this, hipStreamSynchronize(spill_stream));
                 }
                 std::memcpy(hd.uap, r.uap, 64); std::memcpy(hd.type, r.type, 64); hd.fec13_ok = r.fec13_ok;
                 qhdr.push_back(hd);
@@ -540,8 +563,8 @@ int btgpu_handle::harvest(TailCtx &t)
 int btgpu_handle::harvest_all(bool block)
 {
     int rc_all = BTGPU_OK;
-    for (int i = 0; i < 2; i++) {
-        TailCtx &t = tc[(cur + i) & 1];             // tc[cur] is the older one
+    for (int i = 0; i < nctx; i++) {
+        TailCtx &t = tc[(cur + i) % nctx];          // tc[cur] is the oldest one
         if (!t.pending) continue;
         if (!block && hipEventQuery(t.tail_done) != hipSuccess) break;
         int rc = harvest(t);
@@ -779,16 +802,28 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
-    if (hipStreamCreateWithFlags(&h->noise_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
-    if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
-    if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
+    if (hipStreamCreateWithFlags(&h->spill_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
+    {
+        // the post stage of batch n (latency-bound: tile sums, squelch stage 2, window kernel) shares the device with the
+        // banks of batch n+1: high priority, so that its workgroups are placed as bank tiles retire instead of queueing
+        // behind all of them (BTGPU_POST_PRIO=0: normal priority, A/B timing only)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const bool post_hi = !(getenv("BTGPU_POST_PRIO") && atoi(getenv("BTGPU_POST_PRIO")) == 0);
+        if (hipStreamCreateWithPriority(&h->post_stream, hipStreamNonBlocking, post_hi ? hi : lo) != hipSuccess) return fail(BTGPU_EDEVICE);
+    }
     for (auto &t : h->tc) {
         for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
-        for (auto &e : t.evn) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
-        if (hipEventCreateWithFlags(&t.detect_done, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
-        if (hipEventCreateWithFlags(&t.tail_done, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
+        for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done})
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     h->async = (cfg->flags & BTGPU_FLAG_ASYNC) != 0;
+    h->nctx = h->async ? btgpu_handle::kCtx : 1;
+    if (getenv("BTGPU_CTX")) h->nctx = std::max(1, std::min((int)btgpu_handle::kCtx, atoi(getenv("BTGPU_CTX"))));   // A/B timing only
+    h->timing_on = (cfg->flags & BTGPU_FLAG_TIMING) != 0 || getenv("BTGPU_TIMING") != nullptr;
+    h->no_nsym = (cfg->flags & BTGPU_FLAG_NO_NSYM) != 0;
+    // front(n+1) beside post(n): only where the front writes nothing but per-context buffers (BTGPU_PIPE=0: off, A/B)
+    h->pipelined = h->use_pfb && h->use_staged && !(getenv("BTGPU_PIPE") && atoi(getenv("BTGPU_PIPE")) == 0);
     h->want_hdrs = (cfg->flags & BTGPU_FLAG_HEADERS) != 0;
     h->want_syms = (cfg->flags & BTGPU_FLAG_SYMBOLS) != 0 || h->want_hdrs;
 
@@ -817,8 +852,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->upload(h->d_dftw_ch, b.dftw.data(), b.dftw.size() * sizeof(float)));
         TRY(h->upload(h->d_rho_ch, b.rho.data(), b.rho.size() * sizeof(float)));
         TRY(h->upload(h->d_krot_ch, b.krot.data(), b.krot.size() * sizeof(float)));
-        TRY(h->alloc(h->d_ptile, (size_t)nch * h->ntiles_max * sizeof(double)));
-        TRY(h->alloc(h->d_phead, (size_t)nch * h->ntiles_max * sizeof(double)));
     } else if (h->use_pfb) {
         const PfbBank &b = h->fp.channel;
         h->ntiles_max = (int)((G + 24) / 25);
@@ -837,8 +870,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             TRY(h->upload(h->d_b2map_ch, mc.data(), mc.size() * sizeof(uint16_t)));
         }
         TRY(h->upload(h->d_krot_ch, b.krot.data(), b.krot.size() * sizeof(float)));
-        TRY(h->alloc(h->d_ptile, (size_t)nch * h->ntiles_max * sizeof(double)));
-        TRY(h->alloc(h->d_phead, (size_t)nch * h->ntiles_max * sizeof(double)));
     }
     if (h->use_staged) {
         const NoiseStage &ns = h->fp.noise;
@@ -865,7 +896,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             for (int c = 0; c < nch; c++) st[c] = -ns.direct.foff[c] * ns.R / cfg->sample_rate;
             TRY(h->upload(h->d_rotstep_s1, st.data(), st.size() * sizeof(double)));
         }
-        TRY(h->alloc(h->d_Z, (size_t)nch * h->zstride * sizeof(float2)));
         TRY(h->upload(h->d_h3, ns.h3.data(), ns.h3.size() * sizeof(float)));
         TRY(h->upload(h->d_w, ns.weights.data(), ns.weights.size() * sizeof(double)));
     }
@@ -891,8 +921,13 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_eoff, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_snr, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_winbits, (size_t)((S + 2) / 3) * kBitWords * kWinThreads * sizeof(uint32_t)));   // most workgroups: 3 slots each
-    for (int i = 0; i < (h->async ? 2 : 1); i++) {
+    for (int i = 0; i < h->nctx; i++) {
         auto &t = h->tc[i];
+        if (h->use_pfb) {
+            TRY(h->alloc(t.d_ptile, (size_t)nch * h->ntiles_max * sizeof(double)));
+            TRY(h->alloc(t.d_phead, (size_t)nch * h->ntiles_max * sizeof(double)));
+        }
+        if (h->use_staged) TRY(h->alloc(t.d_Z, (size_t)nch * h->zstride * sizeof(float2)));
         TRY(h->alloc(t.d_winlen, (size_t)S * nch * sizeof(int)));
         TRY(h->alloc(t.d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
         TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
@@ -906,17 +941,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             TRY(h->alloc(t.d_symbits, std::max<size_t>(maxfin, btgpu_handle::kEagerFin) * kSymWords * sizeof(uint32_t)));
         }
     }
-    for (auto &t : h->tc) {
+    for (int i = 0; i < h->nctx; i++) {
+        auto &t = h->tc[i];
         if (h->want_hdrs && hipHostMalloc((void **)&t.h_hdr, (size_t)btgpu_handle::kEagerFin * sizeof(HeaderRec), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)btgpu_handle::kEagerFin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_count, 2 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_hits, (size_t)btgpu_handle::kEagerHits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
-    }
-    if (!h->async) {                      // synchronous mode: one context, used for every batch
-        h->tc[1].d_winlen = h->tc[0].d_winlen; h->tc[1].d_hits = h->tc[0].d_hits;
-        h->tc[1].d_hitcount = h->tc[0].d_hitcount; h->tc[1].d_fin = h->tc[0].d_fin; h->tc[1].d_d = h->tc[0].d_d;
-        h->tc[1].d_dcol = h->tc[0].d_dcol;
-        h->tc[1].d_winfin = h->tc[0].d_winfin; h->tc[1].d_symbits = h->tc[0].d_symbits; h->tc[1].d_hdr = h->tc[0].d_hdr;
     }
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
@@ -939,7 +969,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))
-        fprintf(stderr, "btgpu_create: d=%p,%p Z=%p ptile=%p\n", h->tc[0].d_d.p, h->tc[1].d_d.p, h->d_Z.p, h->d_ptile.p);
+        fprintf(stderr, "btgpu_create: %d contexts, d=%p Z=%p ptile=%p\n", h->nctx, h->tc[0].d_d.p, h->tc[0].d_Z.p, h->tc[0].d_ptile.p);
 
     h->carry.assign((size_t)(d.history - 1) * 2, 0.f);   // GNU Radio pre-fills history()-1 zeros [EXT]
     *out = h;
@@ -963,6 +993,13 @@ int btgpu_get_design(const btgpu_handle *h, btgpu_design *out)
 }
 
 int btgpu_history(const btgpu_handle *h) { return h ? h->des.d.history : BTGPU_EINVAL; }
+int btgpu_device(const btgpu_handle *h) { return h ? h->device : BTGPU_EINVAL; }
+int btgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BTGPU_ENODEVICE;
+    return n;
+}
 const char *btgpu_last_error(const btgpu_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
 int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, size_t left_margin,
@@ -1073,7 +1110,7 @@ int btgpu_flush(btgpu_handle *h)
     // on", the caller's next device-wide synchronise (torch.cuda.synchronize / hipDeviceSynchronize) took
     // 23-32 ms in one run out of four on an idle device -- after these per-stream waits it takes 20 us
     // (0 long ones in 24 runs, one of 6 ms in the 12 before).
-    for (hipStream_t st : {h->stream, h->tail_stream, h->copy_stream, h->noise_stream}) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {h->stream, h->post_stream, h->tail_stream, h->copy_stream, h->spill_stream}) (void)hipStreamSynchronize(st);
     return rc;
 }
 
@@ -1158,12 +1195,12 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
             if (first >= avail) return 0;
             count = std::min(count, avail - first);
             if (hipSetDevice(h->device) != hipSuccess) return BTGPU_EDEVICE;
-            if (hipMemcpy2D(out, sizeof(float), (const float *)h->tc[h->cur ^ 1].d_d.p + first * h->drow + c, (size_t)h->drow * sizeof(float),
+            if (hipMemcpy2D(out, sizeof(float), (const float *)h->tc[h->last_ctx].d_d.p + first * h->drow + c, (size_t)h->drow * sizeof(float),
                             sizeof(float), count, hipMemcpyDeviceToHost) != hipSuccess) return BTGPU_EDEVICE;
             return (long)count;
         }
-        case 7: src = h->tc[h->cur ^ 1].d_winlen.p; elem = sizeof(int); avail = (size_t)h->last_S * nch; break;
-        case 8: src = h->tc[h->cur ^ 1].d_fin.p; elem = sizeof(FinishRec); avail = (size_t)h->last_S * nch; break;
+        case 7: src = h->tc[h->last_ctx].d_winlen.p; elem = sizeof(int); avail = (size_t)h->last_S * nch; break;
+        case 8: src = h->tc[h->last_ctx].d_fin.p; elem = sizeof(FinishRec); avail = (size_t)h->last_S * nch; break;
         case 9: if (!h->d_prof.p) return BTGPU_EINVAL; src = h->d_prof.p; elem = sizeof(unsigned long long); avail = (size_t)(h->ntiles_max + 64) * 8; break;
         case 2: src = h->d_eon.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 3: src = h->d_eoff.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;

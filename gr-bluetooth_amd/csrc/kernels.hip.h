@@ -302,6 +302,7 @@ struct WindowParams {
     int btbb;                   // multi_LAP: libbtbb-style search (BTGPU_CORRELATOR_BTBB)
     const uint64_t *btbb_pcol;  // [24] parity column of each LAP bit (device memory)
     int fin_prio;               // wave priority of finish_kernel (0..3)
+    int want_len;               // 0 (BTGPU_FLAG_NO_NSYM): windows that outlast the detection span are not continued, nsym = -1
     int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
 };
 
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     if (nhits > 0) {
         const bool ended = ii >= ni || oo >= demod_n;                  // the window ended inside phase 1
         if (ended) win_len[w] = oo;
-        if (!ended || p.syms) {
+        if ((!ended && p.want_len) || p.syms) {
             // the handlers need len = symbols in the whole window (and, with BTGPU_FLAG_SYMBOLS, the
             // symbols): hand the M&M state to finish_kernel (dense waves of hit windows)
             const unsigned int f = atomicAdd(fin_count, 1u);
@@ -953,7 +954,8 @@ __global__ void nsym_patch_kernel(DeviceHit *__restrict__ hits, const unsigned i
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     {
         const size_t w = (size_t)hits[i].slot * nch + hits[i].channel_idx;
-        hits[i].nsym = win_len[w] - hits[i].sub - hits[i].offset;
+        const int len = win_len[w];
+        hits[i].nsym = len < 0 ? -1 : len - hits[i].sub - hits[i].offset;     // len < 0: BTGPU_FLAG_NO_NSYM, window not continued
         if (win_fin) hits[i].sym = win_fin[w];
     }
 }

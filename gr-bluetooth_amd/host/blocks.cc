@@ -28,7 +28,9 @@ multi_block::multi_block(double sample_rate, double center_freq, double squelch_
     // and hands the sliced symbols of every hit, with the GPU's sweep of its packet header over the
     // 64 clock candidates, to its packet handlers
     // multi_hopper (lib/multi_hopper_impl.cc:52-56) has the sniffer's symbol history but no LE pass
-    const int flags = mode == BTGPU_MODE_SNIFFER ? ((hopper ? 0 : BTGPU_FLAG_LE) | BTGPU_FLAG_HEADERS) : 0;
+    // multi_LAP prints the LAP of a hit and nothing that depends on the rest of the window
+    // (lib/multi_LAP_impl.cc:93-110): no clock-recovery continuation for hit.nsym
+    const int flags = mode == BTGPU_MODE_SNIFFER ? ((hopper ? 0 : BTGPU_FLAG_LE) | BTGPU_FLAG_HEADERS) : BTGPU_FLAG_NO_NSYM;
     d_headers = (flags & BTGPU_FLAG_HEADERS) != 0;
     d_sample_rate = sample_rate;
     d_center_freq = center_freq;
@@ -46,6 +48,7 @@ multi_block::multi_block(double sample_rate, double center_freq, double squelch_
     if (rc != BTGPU_OK)      // no CPU fallback: fail loudly
         throw std::runtime_error(std::string("gr::bluetooth: btgpu_create failed: ") + btgpu_strerror(rc));
     btgpu_get_design(d_gpu, &d_design);
+    d_device = btgpu_device(d_gpu);                 // the ordinal cfg.device = -1 resolved to
     // reference: lib/multi_block.cc:116-119
     printf("history set to %d samples: channel=%d, noise=%d\n", d_design.history,
            d_design.ntaps_channel + d_design.decimation * 8, d_design.ntaps_noise);
@@ -105,11 +108,16 @@ long multi_block::run_partitioned(const gr_complex *items, size_t n_new, int ngp
     if (total == 0) return 0;
     const uint64_t first_abs = d_cumulative_count / slot;              // slot index of the first new slot
     // one handle per range: range 0 on this block's own handle, the others on handles of their own devices
+    // the block's own handle sits on d_device (resolved at construction); range r goes to device (d_device + r) % ndev
+    const int ndev = btgpu_device_count();
+    if (!all_on_device0 && (ndev < ngpus))
+        throw std::runtime_error("gr::bluetooth: run_partitioned over " + std::to_string(ngpus) + " devices, " +
+                                 std::to_string(ndev < 0 ? 0 : ndev) + " visible");
     std::vector<btgpu_handle *> g((size_t)ngpus, nullptr);
     g[0] = d_gpu;
     for (int r = 1; r < ngpus; r++) {
         btgpu_config cfg = d_cfg;
-        cfg.device = all_on_device0 ? d_cfg.device : r;
+        cfg.device = all_on_device0 ? d_device : (d_device + r) % ndev;
         int rc = btgpu_create(&cfg, &g[(size_t)r]);
         if (rc != BTGPU_OK) {
             for (int q = 1; q < r; q++) btgpu_destroy(g[(size_t)q]);

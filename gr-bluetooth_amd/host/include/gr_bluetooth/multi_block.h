@@ -39,6 +39,7 @@ protected:
 
     void drain(btgpu_handle *g);          // records of `g` -> handle_hit, in order
     btgpu_config d_cfg{};                 // what d_gpu was created with (run_partitioned clones it per device)
+    int d_device = 0;                     // HIP ordinal d_gpu lives on
 
 public:
     // Time-partitioned run over `ngpus` devices of this node (no GNU Radio counterpart: a flowgraph hands a

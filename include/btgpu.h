@@ -69,6 +69,13 @@ extern "C" {
                                            stream order) or after btgpu_flush.  The tail of batch
                                            n (finish_kernel, record copy) overlaps batch n+1.    */
 
+#define BTGPU_FLAG_TIMING    0x20       /* bracket the kernels of every batch with HIP events for btgpu_last_timing
+                                           (off by default: eleven event records per batch are not free)     */
+#define BTGPU_FLAG_NO_NSYM   0x40       /* LAP-list consumers (multi_LAP prints the LAP only, lib/multi_LAP_impl.cc:93-110):
+                                           skip the clock-recovery continuation over the rest of a hit window that
+                                           only produces hit.nsym; nsym is then -1 unless the window ended inside
+                                           the 693-symbol detection span.  Ignored with BTGPU_FLAG_SYMBOLS / HEADERS */
+
 #define BTGPU_KIND_AC 0
 #define BTGPU_KIND_AA 1
 
@@ -117,11 +124,13 @@ typedef struct btgpu_hit {
     double   snr_db;      /* 10 log10(E_on / E_off) of the (slot, channel) window           */
 } btgpu_hit;
 
-/* Per-kernel GPU time, cumulative since btgpu_create (callers take differences), measured with
- * HIP events recorded on the streams the kernels are launched on; a batch is accounted when
- * its records are harvested. */
+/* Per-kernel GPU time (needs BTGPU_FLAG_TIMING; zeros otherwise), cumulative since btgpu_create (callers take
+ * differences), measured with HIP events recorded on the streams the kernels are launched on; a batch is
+ * accounted when its records are harvested.  With BTGPU_FLAG_ASYNC up to three batches are in flight (banks of
+ * batch n+2, post stage of n+1, tail of n on three streams): a kernel's time then includes what it loses to
+ * the kernels running beside it. */
 #define BTGPU_K_DDC_CHANNEL   0   /* channel bank (direct DDC or polyphase channelizer) */
-#define BTGPU_K_DEMOD_ENERGY  1   /* quadrature demod + |Y|^2 block sums (0 when fused)  */
+#define BTGPU_K_DEMOD_ENERGY  1   /* direct form: quadrature demod + |Y|^2 block sums; polyphase: tile sums -> block sums */
 #define BTGPU_K_DDC_NOISE     2   /* noise bank                                          */
 #define BTGPU_K_NOISE_ENERGY  3   /* noise |Y|^2 per-slot sums                           */
 #define BTGPU_K_WINDOW        4   /* squelch + M&M + slicer + access-code search         */
@@ -148,6 +157,8 @@ int  btgpu_create(const btgpu_config *cfg, btgpu_handle **out);
 void btgpu_destroy(btgpu_handle *h);
 int  btgpu_get_design(const btgpu_handle *h, btgpu_design *out);
 int  btgpu_history(const btgpu_handle *h);
+int  btgpu_device(const btgpu_handle *h);     /* HIP ordinal the handle lives on (what device = -1 resolved to) */
+int  btgpu_device_count(void);                /* visible gfx950-capable HIP devices, or BTGPU_ENODEVICE          */
 const char *btgpu_last_error(const btgpu_handle *h);
 
 /* ---- work() ----

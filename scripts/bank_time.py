@@ -1,5 +1,6 @@
 """Average duration of the bank kernel on the C79 workload, no result checks (kernel experiments).
     python scripts/bank_time.py [slots] [batches]"""
+import os as _os; _os.environ.setdefault("BTGPU_TIMING", "1")   # btgpu_last_timing is opt-in
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import importlib

@@ -1,4 +1,5 @@
 """Fast path (polyphase channel bank + staged squelch) vs direct path vs oracle at C79."""
+import os as _os; _os.environ.setdefault("BTGPU_TIMING", "1")   # btgpu_last_timing is opt-in
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

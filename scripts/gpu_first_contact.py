@@ -1,4 +1,5 @@
 """First-contact GPU check: C8 sniffer on a synthetic capture, hits and intermediates vs the oracle."""
+import os as _os; _os.environ.setdefault("BTGPU_TIMING", "1")   # btgpu_last_timing is opt-in
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

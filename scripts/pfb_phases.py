@@ -4,6 +4,7 @@ Runs the C79 bench workload synchronously for a few batches with the in-kernel c
 enabled and prints the share of wave-cycles per phase.  GPU only.
     python scripts/pfb_phases.py [slots] [batches]
 """
+import os as _os; _os.environ.setdefault("BTGPU_TIMING", "1")   # btgpu_last_timing is opt-in
 import os, sys
 os.environ["BTGPU_PFB_PROF"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
