@@ -4,16 +4,21 @@
 // very code that runs in production.
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "design.h"
 #include "pfb100.hip.h"
+#include "pfb100f.hip.h"
 #include "pfbm.hip.h"
 
 namespace btgpu {
 
 constexpr int kBankThreads = 256;            // lanes per tile of the non-fused banks
 constexpr int kBankThreadsWide = 512;        // fused channel + noise bank: eight waves per tile
+constexpr int kBankThreadsF = 320;           // pfb100f_kernel: five waves per run of tiles (every DFT pass in one sweep)
+// which kernel runs the fused C79 bank (launch_channel_bank)
+enum BankVariant { kBankLegacy = 0, kBankLegacyWide = 1, kBankRun256 = 2, kBankRun320 = 3 };
 constexpr int kBankNT = 26;                 // channel instants per tile (25 new + 1 halo for the demod)
 constexpr int kNoiseNT = 10;                // instants per tile of the stand-alone noise stage 1
 
@@ -46,7 +51,7 @@ struct BankBuffers {                        // device (or emulated) memory
     const float2 *x = nullptr;
     const float2 *taps_ch = nullptr, *twiddle = nullptr, *krot_ch = nullptr, *rho_ch = nullptr;
     const int *binpos_ch = nullptr, *binnat_ch = nullptr;
-    const uint16_t *b2map_fused = nullptr, *b2map_fused_wide = nullptr, *b2map_ch = nullptr, *b2map_noise = nullptr;
+    const uint16_t *b2map_fused = nullptr, *b2map_fused_wide = nullptr, *b2map_ch = nullptr, *b2map_noise = nullptr, *b2map_f320 = nullptr;
     float *d = nullptr; float *dcol = nullptr; double *ptile = nullptr, *phead = nullptr;
     float2 *Ydebug = nullptr; long long ystride = 0;
     const float2 *taps_n = nullptr, *krot_n = nullptr; const int *binpos_n = nullptr;
@@ -57,20 +62,21 @@ struct BankBuffers {                        // device (or emulated) memory
     int drow = 80;
 };
 
-inline size_t bank_lds_bytes(int span_samples, int nt, int nrows, bool chan)
+inline size_t bank_lds_bytes(int span_samples, int nt, int nrows, bool chan, bool own_twiddles = false)
 {
     const int span = 2 * ((span_samples + 3) / 2);
     const int ysz = chan ? nt * kPfbYst : 0;
     const int asz = kPfbRegion(span, ysz);
-    return (size_t)(asz + nrows * kPfbUst) * sizeof(float2) + (chan ? 0 : (80 * 4) * sizeof(float2) + 80 * sizeof(int));
+    return (size_t)(asz + nrows * kPfbUst + (own_twiddles ? 100 : 0)) * sizeof(float2) + (chan ? 0 : (80 * 4) * sizeof(float2) + 80 * sizeof(int));
 }
 
 // Channel bank (+ fused noise stage 1).  L(kernel, grid, threads, lds_bytes, params) performs the launch.
 // Returns the number of channel tiles.
 template <class Launcher>
 inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_noise, const BankBuffers &b,
-                               size_t x_len, long long w0, int S, long long G, int nb, Launcher &&L, bool wide = false)
+                               size_t x_len, long long w0, int S, long long G, int nb, Launcher &&L, int variant = kBankLegacy)
 {
+    const bool wide = variant == kBankLegacyWide;
     const btgpu_design &d = des.d;
     const PfbBank &bk = fp.channel;
     const int nch = d.high_channel - d.low_channel + 1;
@@ -86,6 +92,7 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
     p.d = b.d; p.dcol = b.dcol; p.ptile = b.ptile; p.phead = b.phead;
     p.tiles_per_block = ops / TT; p.tail = des.tail; p.nb = nb;
     p.gain = des.demod_gain;
+    p.kc = demod_constants(p.gain);
     p.Z = b.Ydebug; p.zstride = b.ystride;
     p.prof = b.prof;
     { static const int dbg = getenv("BTGPU_PFB_DBG") ? atoi(getenv("BTGPU_PFB_DBG")) : 0; p.dbg = dbg; }
@@ -101,7 +108,23 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
         p.b2map = wide ? b.b2map_fused_wide : b.b2map_fused;
         const size_t lds = bank_lds_bytes((250 - 1) + 250 * 4 + 15 * 100, NT, NT + 5, true);
         const int grid = p.ntiles + p.pre_tiles;
-        if (wide) {
+        // the run kernels share the march of the staged input between the two banks: the squelch grid must sit on
+        // the channel grid (design_fast.cc aligns it for this geometry)
+        const bool run_ok = p.n_off == 0 && (variant == kBankRun256 || variant == kBankRun320);
+        if (!run_ok && (variant == kBankRun256 || variant == kBankRun320) && getenv("BTGPU_VERBOSE"))
+            fprintf(stderr, "launch_channel_bank: squelch grid off the channel grid (n_off %d): round-2 kernel\n", p.n_off);
+        if (run_ok) {
+            const size_t lds = bank_lds_bytes((250 - 1) + 250 * 4 + 15 * 100, NT, NT + 5, true, true);
+            const int nruns = (grid + kBankKT - 1) / kBankKT;
+            if (variant == kBankRun320) {
+                p.b2map = b.b2map_f320;
+                if (bk.real_taps) L(pfb100f_kernel<kBankThreadsF, true, kBankKT>, nruns, kBankThreadsF, lds, p);
+                else L(pfb100f_kernel<kBankThreadsF, false, kBankKT>, nruns, kBankThreadsF, lds, p);
+            } else {
+                if (bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT>, nruns, kBankThreads, lds, p);
+                else L(pfb100f_kernel<kBankThreads, false, kBankKT>, nruns, kBankThreads, lds, p);
+            }
+        } else if (wide) {
             if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreadsWide, true>, grid, kBankThreadsWide, lds, p);
             else L(pfb100_kernel<7, 1, NT, false, true, kBankThreadsWide, true>, grid, kBankThreadsWide, lds, p);
         } else {

@@ -100,7 +100,7 @@ struct btgpu_handle {
     DevBuf d_in, d_in_b, d_taps_ch, d_taps_n, d_rot_ch, d_rot_n, d_rotstep_ch, d_rotstep_n;
     DevBuf d_Y, d_Yn, d_P, d_Pt, d_Q, d_mmse, d_atan, d_aclo, d_achi;
     DevBuf d_eon, d_eoff, d_snr, d_le_hdr, d_le_whiten, d_le_index, d_winbits;
-    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise, d_dftw_ch, d_dftw_n;
+    DevBuf d_pfb_taps_ch, d_pfb_tw, d_binpos_ch, d_binnat_ch, d_rho_ch, d_krot_ch, d_b2map_fused, d_b2map_fused_wide, d_b2map_ch, d_b2map_noise, d_b2map_f320, d_dftw_ch, d_dftw_n;
     DevBuf d_pfb_taps_n, d_binpos_n, d_krot_n, d_h3, d_w, d_taps_s1, d_rot_s1, d_rotstep_s1, d_prof, d_pcol, d_wh18;
     LaunchShape shape_s1;
     bool noise_pfb = false;
@@ -149,7 +149,7 @@ struct btgpu_handle {
         DevBuf *all[] = {&d_in, &d_in_b, &d_taps_ch, &d_taps_n, &d_rot_ch, &d_rot_n, &d_rotstep_ch, &d_rotstep_n,
                          &d_Y, &d_Yn, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
-                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_dftw_ch, &d_dftw_n,
+                         &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_b2map_f320, &d_dftw_ch, &d_dftw_n,
                          &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (TailCtx &t : tc) {
@@ -183,7 +183,7 @@ struct btgpu_handle {
         b.binpos_ch = (const int *)d_binpos_ch.p; b.binnat_ch = (const int *)d_binnat_ch.p;
         b.b2map_fused = (const uint16_t *)d_b2map_fused.p; b.b2map_fused_wide = (const uint16_t *)d_b2map_fused_wide.p;
         b.b2map_ch = (const uint16_t *)d_b2map_ch.p;
-        b.b2map_noise = (const uint16_t *)d_b2map_noise.p;
+        b.b2map_noise = (const uint16_t *)d_b2map_noise.p; b.b2map_f320 = (const uint16_t *)d_b2map_f320.p;
         b.d = (float *)d_d.p; b.ptile = (double *)d_ptile.p; b.phead = (double *)d_phead.p;
         b.Ydebug = (keep_Y && use_pfb) ? (float2 *)d_Y.p : nullptr; b.ystride = ystride;
         b.taps_n = (const float2 *)d_pfb_taps_n.p; b.krot_n = (const float2 *)d_krot_n.p;
@@ -224,7 +224,6 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     last_S = S;
     last_G = G;
     TailCtx &t = tc[cur];
-    TailCtx &prev = tc[(cur + nctx - 1) % nctx];                 // the batch enqueued before this one
     int carried = BTGPU_OK;                                      // overflow of the batch harvested here
     if (t.pending) { int hrc = harvest(t); if (hrc == BTGPU_EOVERFLOW) carried = hrc; else if (hrc != BTGPU_OK) return hrc; }
     hipEvent_t *ev = t.ev;
@@ -234,9 +233,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     auto mark = [&](int k, hipStream_t s_) -> hipError_t { return timing_on ? hipEventRecord(ev[k], s_) : hipSuccess; };
 
     // =========================== FRONT (stream `st`): the banks ===========================
-    // Where the front also writes buffers the post stage of the previous batch still reads (direct forms: Y, P, Q
-    // exist once), it waits for that post stage; the polyphase + staged configuration writes per-context buffers only.
-    if (!pipelined && nctx > 1 && prev.detect_done && &prev != &t) HIPCHK(this, hipStreamWaitEvent(st, prev.detect_done, 0));
+    // (The post stage runs behind it on the same stream unless BTGPU_PIPE=1, see btgpu_create.)
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
     HIPCHK(this, mark(0, st));
     int ntiles = 0, tiles_per_block = 1, tail_tiles = 0;
@@ -256,9 +253,15 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
         };
-        // four waves per tile measured faster than eight (BTGPU_BANK_THREADS=512 keeps the wide variant reachable)
-        static const bool wide = getenv("BTGPU_BANK_THREADS") && atoi(getenv("BTGPU_BANK_THREADS")) == 512;
-        ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, wide);
+        // BTGPU_BANK: run320 (default) | run256 -- pfb100f_kernel, runs of tiles per workgroup; legacy | wide -- the
+        // round-2 kernel with four / eight waves per tile (A/B timing)
+        static const int variant = [] {
+            const char *e = getenv("BTGPU_BANK");
+            if (!e) return (int)kBankRun320;
+            const std::string v(e);
+            return v == "legacy" ? (int)kBankLegacy : v == "wide" ? (int)kBankLegacyWide : v == "run256" ? (int)kBankRun256 : (int)kBankRun320;
+        }();
+        ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, variant);
         tiles_per_block = ops / TT; tail_tiles = des.tail / TT;
         HIPCHK(this, mark(1, st));
     } else {
@@ -324,8 +327,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     HIPCHK(this, hipEventRecord(t.front_done, st));
 
     // =========================== POST (post_stream): sums, squelch stage 2, window kernel ===========================
-    hipStream_t ps = post_stream;
-    HIPCHK(this, hipStreamWaitEvent(ps, t.front_done, 0));
+    hipStream_t ps = pipelined ? post_stream : st;
+    if (pipelined) HIPCHK(this, hipStreamWaitEvent(ps, t.front_done, 0));
     HIPCHK(this, mark(5, ps));
     if (use_pfb)
         hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, ps,
@@ -804,13 +807,11 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
     if (hipStreamCreateWithFlags(&h->spill_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
     {
-        // the post stage of batch n (latency-bound: tile sums, squelch stage 2, window kernel) shares the device with the
-        // banks of batch n+1: high priority, so that its workgroups are placed as bank tiles retire instead of queueing
-        // behind all of them (BTGPU_POST_PRIO=0: normal priority, A/B timing only)
+        // stream of the post stage in the BTGPU_PIPE=1 experiment (BTGPU_POST_PRIO: its priority)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const bool post_hi = !(getenv("BTGPU_POST_PRIO") && atoi(getenv("BTGPU_POST_PRIO")) == 0);
-        if (hipStreamCreateWithPriority(&h->post_stream, hipStreamNonBlocking, post_hi ? hi : lo) != hipSuccess) return fail(BTGPU_EDEVICE);
+        const int pp = getenv("BTGPU_POST_PRIO") ? atoi(getenv("BTGPU_POST_PRIO")) : 0;       // 1 high, 0 normal, -1 low
+        if (hipStreamCreateWithPriority(&h->post_stream, hipStreamNonBlocking, pp > 0 ? hi : pp < 0 ? lo : 0) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     for (auto &t : h->tc) {
         for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
@@ -822,8 +823,13 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     if (getenv("BTGPU_CTX")) h->nctx = std::max(1, std::min((int)btgpu_handle::kCtx, atoi(getenv("BTGPU_CTX"))));   // A/B timing only
     h->timing_on = (cfg->flags & BTGPU_FLAG_TIMING) != 0 || getenv("BTGPU_TIMING") != nullptr;
     h->no_nsym = (cfg->flags & BTGPU_FLAG_NO_NSYM) != 0;
-    // front(n+1) beside post(n): only where the front writes nothing but per-context buffers (BTGPU_PIPE=0: off, A/B)
-    h->pipelined = h->use_pfb && h->use_staged && !(getenv("BTGPU_PIPE") && atoi(getenv("BTGPU_PIPE")) == 0);
+    // front(n+1) beside post(n) (BTGPU_PIPE=1; possible only where the front writes nothing but per-context buffers).
+    // OFF by default -- measured (profiles/r03_a_*): with today's kernels the overlap LOSES.  Every one of them is
+    // occupancy-bound by LDS (bank tile 49.8 KB, window workgroup 51 KB, squelch stage 2 24 KB per workgroup of four
+    // waves): a resident window workgroup displaces a bank tile for its whole 0.3-0.6 ms life, so the bank kernel
+    // went 1.5 -> 2.7 ms while the post stage went 0.54 -> 1.0 ms: 3.0 ms per step against 2.1 ms in line.  Only
+    // the tail (finish_kernel: 12 KB, a few dozen waves) fits beside three bank tiles and keeps overlapping.
+    h->pipelined = h->use_pfb && h->use_staged && getenv("BTGPU_PIPE") && atoi(getenv("BTGPU_PIPE")) == 1;
     h->want_hdrs = (cfg->flags & BTGPU_FLAG_HEADERS) != 0;
     h->want_syms = (cfg->flags & BTGPU_FLAG_SYMBOLS) != 0 || h->want_hdrs;
 
@@ -864,7 +870,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             const std::vector<uint16_t> mf = make_dft_pass2_map(kBankNT + 5, kBankThreads, 2);
             const std::vector<uint16_t> mc = make_dft_pass2_map(kBankNT, kBankThreads, 2);
             const std::vector<uint16_t> mw = make_dft_pass2_map(kBankNT + 5, kBankThreadsWide, 1);
-            if (mf.empty() || mc.empty() || mw.empty()) return fail(BTGPU_EUNSUPPORTED);
+            const std::vector<uint16_t> m5 = make_dft_pass2_map(kBankNT + 5, kBankThreadsF, 1);
+            if (mf.empty() || mc.empty() || mw.empty() || m5.empty()) return fail(BTGPU_EUNSUPPORTED);
+            TRY(h->upload(h->d_b2map_f320, m5.data(), m5.size() * sizeof(uint16_t)));
             TRY(h->upload(h->d_b2map_fused_wide, mw.data(), mw.size() * sizeof(uint16_t)));
             TRY(h->upload(h->d_b2map_fused, mf.data(), mf.size() * sizeof(uint16_t)));
             TRY(h->upload(h->d_b2map_ch, mc.data(), mc.size() * sizeof(uint16_t)));
@@ -967,6 +975,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreadsF, true, kBankKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreadsF, false, kBankKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, kBankKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, false, kBankKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))
         fprintf(stderr, "btgpu_create: %d contexts, d=%p Z=%p ptile=%p\n", h->nctx, h->tc[0].d_d.p, h->tc[0].d_Z.p, h->tc[0].d_ptile.p);

@@ -281,6 +281,20 @@ int make_fast_path(const Design &des, FastPath &fp)
     const int nh = d.ntaps_noise;
     if (clen < nh) return BTGPU_OK;
     ns.pad = (clen - nh) / 2;
+    ns.Jm = 6;
+    if (ns.R == 250 && d.decimation == 50) {
+        // 100 Msps: put the stage-1 grid on the channel bank's tile grid, so that the fused kernel (pfb100f.hip.h)
+        // marches its staged input once for both banks: stage-1 instant u starts at
+        // first_noise_sample - pad - Jm R + R u, the channel tiles at first_channel_sample - D + 1250 tile; the
+        // pad nearest the centred one that makes their difference a multiple of R (any pad in [0, clen - nh] places
+        // the reference filter inside the composite, the fit below adapts)
+        const long long base = (long long)d.first_channel_sample - d.decimation - d.first_noise_sample + (long long)ns.Jm * ns.R;
+        const int want = (int)((((-base) % ns.R) + ns.R) % ns.R);            // pad mod R
+        int best = -1;
+        for (int c = want; c <= clen - nh; c += ns.R)
+            if (best < 0 || std::abs(c - (clen - nh) / 2) < std::abs(best - (clen - nh) / 2)) best = c;
+        if (best >= 0) ns.pad = best;
+    }
     std::vector<double> tgt(clen, 0.0);
     for (int i = 0; i < nh; i++) tgt[ns.pad + i] = des.h_noise[i];
     // normal equations (Toeplitz autocorrelation of the prototype at lags of R)
@@ -312,7 +326,6 @@ int make_fast_path(const Design &des, FastPath &fp)
     }
     // quadrature weights: sum_{i=0}^{noise_out-1} f[i] from samples f[U*J], U = R / decim = 5
     const int U = ns.R / d.decimation;
-    ns.Jm = 6;
     const int half = ns.Jm * U;
     std::vector<double> phi(2 * half + 1);
     {

@@ -46,6 +46,27 @@ constexpr int kPfbYst = 113;     // LDS pitch (complex) of the bin rows Y (= 1 m
 // size (complex) of the LDS region shared by the input span, the pass-1 twiddles behind it and the bin rows
 constexpr int kPfbRegion(int span, int ysz) { return (((span + 100 > ysz ? span + 100 : ysz)) + 1) & ~1; }
 
+// Quadrature demodulation of the tolerance path: gain * atan2(pi, pr) of (pr, pi), the product
+// a conj(b) already rotated by rho.  gr::fast_atan2f [EXT] is a 256-interval table with linear
+// interpolation (1.3e-6 rad off the true arctangent); here an odd degree-13 minimax polynomial
+// (3.4e-7 rad in float) stands in for it, and the octant / quadrant unfolding works on sign bits:
+//   A = atan(min/max) in [0, pi/4],  q = pi/4 - A
+//   first quadrant   a1 = pi/4 - q sgn(|pr| - |pi|)       (x-dominant: A, y-dominant: pi/2 - A)
+//   left half plane  a2 = pi/2 + (a1 - pi/2) sgn(pr)       (pr < 0: pi - a1)
+//   lower half plane a2 sgn(pi)
+// with every constant and coefficient pre-multiplied by the gain.  (0, 0) gives 0 like the
+// reference; zeros are made positive first so that their sign bits decide like ">= 0" does.
+struct DemodConst { float c[7]; float q4, q2; };
+__host__ __device__ __forceinline__ DemodConst demod_constants(float gain)
+{
+    DemodConst k;
+    k.c[0] = gain * 9.9999611154e-01f; k.c[1] = gain * -3.3317368021e-01f; k.c[2] = gain * 1.9807815191e-01f;
+    k.c[3] = gain * -1.3233340512e-01f; k.c[4] = gain * 7.9623641276e-02f; k.c[5] = gain * -3.3604192045e-02f;
+    k.c[6] = gain * 6.8117834093e-03f;
+    k.q4 = gain * 0.78539816339744831f;
+    k.q2 = 2.0f * k.q4;                                           // exactly twice q4: (0, 0) comes out as 0
+    return k;
+}
 struct PfbParams {
     const float2 *x; long long x_len; long long x0;   // x index of tap 0 for output instant 0
     int D;
@@ -70,6 +91,7 @@ struct PfbParams {
     double *phead;               // [nsel][ntiles]  sum of the first (tail % TT) instants of each tile
     int tiles_per_block, tail, nb;
     float gain;
+    DemodConst kc;               // demod_constants(gain), formed on the host (pfb100f_kernel: kernel arguments = scalar registers)
     // noise epilogue / debug copy of the de-rotated channel output
     float2 *Z; long long zstride;   // [nsel][zstride]
     // fused noise stage 1 (FUSEN): the channel tile's staged input also feeds the NU = 5 noise-bank
@@ -134,27 +156,6 @@ __device__ __forceinline__ void dft10(cf *v)
     v[4] = E[4] + o4; v[9] = E[4] - o4;
 }
 
-// Quadrature demodulation of the tolerance path: gain * atan2(pi, pr) of (pr, pi), the product
-// a conj(b) already rotated by rho.  gr::fast_atan2f [EXT] is a 256-interval table with linear
-// interpolation (1.3e-6 rad off the true arctangent); here an odd degree-13 minimax polynomial
-// (3.4e-7 rad in float) stands in for it, and the octant / quadrant unfolding works on sign bits:
-//   A = atan(min/max) in [0, pi/4],  q = pi/4 - A
-//   first quadrant   a1 = pi/4 - q sgn(|pr| - |pi|)       (x-dominant: A, y-dominant: pi/2 - A)
-//   left half plane  a2 = pi/2 + (a1 - pi/2) sgn(pr)       (pr < 0: pi - a1)
-//   lower half plane a2 sgn(pi)
-// with every constant and coefficient pre-multiplied by the gain.  (0, 0) gives 0 like the
-// reference; zeros are made positive first so that their sign bits decide like ">= 0" does.
-struct DemodConst { float c[7]; float q4, q2; };
-__device__ __forceinline__ DemodConst demod_constants(float gain)
-{
-    DemodConst k;
-    k.c[0] = gain * 9.9999611154e-01f; k.c[1] = gain * -3.3317368021e-01f; k.c[2] = gain * 1.9807815191e-01f;
-    k.c[3] = gain * -1.3233340512e-01f; k.c[4] = gain * 7.9623641276e-02f; k.c[5] = gain * -3.3604192045e-02f;
-    k.c[6] = gain * 6.8117834093e-03f;
-    k.q4 = gain * 0.78539816339744831f;
-    k.q2 = 2.0f * k.q4;                                           // exactly twice q4: (0, 0) comes out as 0
-    return k;
-}
 __device__ __forceinline__ float demod_poly(const DemodConst &k, float pr, float pi)
 {
     const uint32_t SIGN = 0x80000000u;

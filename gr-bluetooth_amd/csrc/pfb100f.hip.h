@@ -1,0 +1,404 @@
+// pfb100f.hip.h -- the C79 hot kernel: 100-bin polyphase channelizer + squelch stage 1 + quadrature demod,
+// one workgroup = a RUN of KT consecutive tiles of 25 output instants (round 3).
+//
+// Same algebra and the same LDS layouts as pfb100_kernel<7,1,26,REAL,true,NTH,true> (pfb100.hip.h, which stays
+// the kernel of the non-fused banks): what the reference computes per channel with freq_xlating_fir_filter_ccf
+// [EXT] (lib/multi_block.cc:204 channel filter, :275 noise filter) and multi_block::demod (:158-168), for all 79
+// channels at once.  What changed, and why (measured on the round-2 kernel, profiles/r02_d_*):
+//
+//  * 23 % of a tile's life was the wait for its input span (and for ~30 per-lane table loads behind it), with only
+//    three tiles per CU to hide it.  Here a workgroup walks KT tiles: branch taps, lane roles and twiddles are
+//    fetched ONCE, and the input of tile n+1 is loaded into registers right after the first barrier of tile n --
+//    a whole tile of arithmetic lies between the loads and their first use.
+//  * Phase A read the staged input 3.3 times (channel branches once with a register window, the five noise
+//    instants of the tile 15 taps each straight from LDS: 7500 of the 10 750 eight-byte reads per tile).  The
+//    host now places the squelch stage-1 grid ON the channel grid (design_fast.cc: n_off = 0), so that noise
+//    instant i, branch p, tap q needs the sample the channel lane (p, r = i mod 2) holds at march step
+//    q + (5 i - r) / 2: one march of 25 (r = 0) / 22 (r = 1) reads per lane serves 13 channel instants and 3 / 2
+//    noise instants.
+//  * The 310 ten-point DFTs of a pass took two sweeps of 256 lanes, the second with 54 lanes.  NTH = 320 (five
+//    waves) takes each pass in one sweep and gives the epilogue four runs of <= 7 instants per channel instead of
+//    three of <= 9.  (NTH = 256 is kept for A/B.)
+//  * The copy-out of tile n shares a barrier interval with the staging of tile n+1: five barriers per tile
+//    instead of six.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pfb100.hip.h"
+
+#pragma clang fp contract(fast)
+
+namespace btgpu {
+
+constexpr int kBankKT = 5;                   // tiles per workgroup (a divisor of the 50 tiles of a slot is not required)
+
+// One march of the staged input for branch pp and instant parity R (wave-uniform): channel instants 2 tau + R,
+// tau = 0..12, out of a 7-deep register window; noise instants i = R, R + 2, .. from the same samples:
+//   noise_i[pp] = sum_q an[q] z[q + s_i],  s_i = (5 i - R) / 2        (n_off = 0: the two grids coincide)
+// Multiply-accumulates of the branch filters, written with scalar FMAs on purpose: a packed v_pk_fma_f32 issues at
+// half rate on this chip (scripts/ubench/valu_rates.hip), so two packed FMAs cost what four scalar ones do -- but the
+// packed form needs the tap as (re, re) and (-im, im) register pairs, which this compiler materialises instead of
+// using op_sel: 60 extra registers for the 15 squelch taps, and with them the next tile's prefetched input in scratch.
+__device__ __forceinline__ cf cmac(cf acc, cf tap, cf z)          // acc + tap * z
+{
+    acc.x = fmaf(tap.x, z.x, acc.x); acc.x = fmaf(-tap.y, z.y, acc.x);
+    acc.y = fmaf(tap.x, z.y, acc.y); acc.y = fmaf(tap.y, z.x, acc.y);
+    return acc;
+}
+__device__ __forceinline__ cf rmac(cf acc, float tap, cf z)       // acc + tap * z, real tap
+{
+    acc.x = fmaf(tap, z.x, acc.x); acc.y = fmaf(tap, z.y, acc.y);
+    return acc;
+}
+// Channel taps of a lane: seven real taps (REAL) or seven complex ones
+template <bool REAL> struct ChanTaps { float re[7]; float im[REAL ? 1 : 7]; };
+template <bool REAL>
+__device__ __forceinline__ cf chan_mac(const ChanTaps<REAL> &t, int q, cf w, cf u)
+{
+    if (REAL) return rmac(u, t.re[q], w);
+    return cmac(u, mk(t.re[q], t.im[q]), w);
+}
+
+// An ordering-only dependence (no instruction is emitted): `x` cannot be formed before `dep` exists.  Used to keep the
+// LDS reads of the march a fixed number of steps ahead of the arithmetic -- left alone, the scheduler issues all 25 reads
+// of the unrolled march up front (50 registers), and the register allocator answers by evicting the next tile's
+// prefetched input to scratch memory, which puts a full memory round trip back on every tile's critical path.
+// BTGPU_OPAQUE(x): the value of x is unknown to the optimiser from here on (no instruction either).  The lane index goes
+// through it at the top of every tile: everything derived from it -- LDS and HBM addresses of every phase -- is then
+// recomputed per tile (a few dozen integer operations) instead of being hoisted out of the tile loop, where ~40 such
+// invariants stayed live through all phases and pushed the prefetched input out of the register file.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BTGPU_AFTER(x, dep) asm volatile("" : "+v"(x) : "v"(dep))
+#define BTGPU_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define BTGPU_OPAQUE(x) ((void)0)
+#define BTGPU_AFTER(x, dep) ((void)(dep))                        /* host emulation of the kernels (tests/emu) */
+#endif
+
+template <int R, bool REAL>
+__device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &a, const cf (&an)[15], cf *U, int pp)
+{
+    constexpr int M = 100, Q = 7, NT = 26, NQ = 15, UST = kPfbUst;
+    constexpr int NI = R == 0 ? 3 : 2;                           // noise instants of this parity: 0,2,4 / 1,3
+    constexpr int NN = R == 0 ? 25 : 22;                         // march steps: max(12 + 7, s_last + 15)
+    constexpr int LA = 4;                                        // LDS reads in flight ahead of the arithmetic
+    // Sample-major: a sample is read once and feeds, at once, every sum it belongs to -- up to seven channel instants
+    // (tap n - tau of instant tau) and up to three squelch instants (tap n - s_i).  No register window; the live state is
+    // the (at most) seven + three accumulators, and neighbouring sums are independent work for the VALU.
+    cf acc[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) acc[k] = mk(0.f, 0.f);
+    cf u[NT / 2];
+    cf zq[LA];
+    int zo = 0;                                                  // always 0: the handle the ordering dependence is hung on
+    auto rd = [&](int n) { return z[n * M + zo]; };
+#pragma unroll
+    for (int k = 0; k < LA; k++) zq[k] = rd(k);
+#pragma unroll
+    for (int n = 0; n < NN; n++) {
+        const cf zn = zq[n % LA];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = R + 2 * k, s = (5 * i - R) / 2, q = n - s;
+            if (q >= 0 && q < NQ) acc[k] = cmac(acc[k], an[q], zn);
+        }
+        float last = zn.x;
+#pragma unroll
+        for (int tau = 0; tau < NT / 2; tau++) {
+            const int q = n - tau;
+            if (q == 0) u[tau] = mk(0.f, 0.f);
+            if (q >= 0 && q < Q) { u[tau] = chan_mac<REAL>(a, q, zn, u[tau]); last = u[tau].y; }
+            if (q == Q - 1) U[(2 * tau + R) * UST + pp] = u[tau];
+        }
+        if (n + LA < NN) {
+            BTGPU_AFTER(zo, last);                               // read n + LA only once step n has been worked off
+            zq[n % LA] = rd(n + LA);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NI; k++) U[(NT + R + 2 * k) * UST + pp] = acc[k];
+}
+
+template <int NTH, bool REAL, int KT>
+__global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbParams p)
+{
+    static_assert(NTH == 256 || NTH == 320, "lane roles are laid out for four or five waves");
+    constexpr int M = 100, Q = 7, DH = 50, NT = 26, TT = NT - 1, NQ = 15, NR = 250, NU = 5;
+    constexpr int NROWS = NT + NU, UST = kPfbUst, YST = kPfbYst;
+    constexpr int SPAN = (NR - 1) + NR * (NU - 1) + NQ * M;      // 2749 samples: the noise instants reach furthest
+    constexpr int N4 = (SPAN + 3) / 2, span = 2 * N4;            // 16-byte pieces staged (aligned start: + 1 sample)
+    constexpr int ASZ = kPfbRegion(span, NT * YST);
+    constexpr int PER = (N4 + NTH - 1) / NTH;
+    constexpr int NSW = NTH == 256 ? 2 : 1;                      // sweeps of a DFT pass
+    constexpr int NTASK = NROWS * 10;
+    static_assert(NSW * NTH >= NTASK, "a DFT pass must fit its sweeps");
+    constexpr int CH = NTH / 80, RUN = (TT + CH - 1) / CH;
+    constexpr int NZT = (80 * NU + NTH - 1) / NTH;
+    HIP_DYNAMIC_SHARED(float4, lds4)
+    cf *lds = (cf *)lds4;
+    cf *xs = lds;                                                // [span]        input span of the tile
+    cf *Y = lds;                                                 // [NT][YST]     bin rows (the span is dead after phase A)
+    cf *U = lds + ASZ;                                           // [NROWS][UST]  DFT rows
+    cf *s_tw = U + NROWS * UST;                                  // [100]         pass-1 twiddles (stored once per workgroup)
+    float *s_part = (float *)U;                                  // [CH][80][2]   run sums (the channel rows of U are dead after pass 2)
+    float *s_d = (float *)U + CH * 80 * 2;                       // [TT][80]      angles on their way to d
+    float *s_dc = s_d + TT * 80;                                 // [80][TT]      the same tile channel-major (-> dcol)
+    static_assert((CH * 80 * 2) % 4 == 0 && CH * 80 * 2 + 2 * TT * 80 <= 2 * NT * UST, "epilogue tiles must fit the dead DFT rows");
+    const int l0 = threadIdx.x;
+
+    // ---- the run of tiles of this workgroup (XCD-aware: neighbouring runs share their halo in one L2) ----
+    const int ntl = p.ntiles + p.pre_tiles;                      // pre-tiles own squelch instants only
+    const int nruns = (ntl + KT - 1) / KT;
+    const int tu0 = xcd_remap(blockIdx.x, nruns) * KT;
+    const int tu1 = tu0 + KT < ntl ? tu0 + KT : ntl;
+
+    // ---- what a lane FETCHES for its roles, once per workgroup (what it can compute is recomputed per tile) ----
+    ChanTaps<REAL> a;
+    cf an[NQ];
+    {
+        const int app = l0 & 127;
+        const int pp = (app < M && l0 < 256) ? app : 0;
+        if (REAL) {
+            const float4 *tp = (const float4 *)p.taps + pp * 2;                  // [100][8] floats
+            const float4 t0 = tp[0], t1 = tp[1];
+            a.re[0] = t0.x; a.re[1] = t0.y; a.re[2] = t0.z; a.re[3] = t0.w; a.re[4] = t1.x; a.re[5] = t1.y; a.re[6] = t1.z;
+        } else {
+            const float4 *tp = (const float4 *)p.taps + pp * 4;                  // [100][8] complex
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float4 t = tp[k];
+                a.re[2 * k] = t.x; a.im[REAL ? 0 : 2 * k] = t.y;
+                if (2 * k + 1 < Q) { a.re[2 * k + 1] = t.z; a.im[REAL ? 0 : 2 * k + 1] = t.w; }
+            }
+        }
+        const float4 *np = (const float4 *)p.n_taps + pp * 8;                    // [100][16] complex
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 t = np[k];
+            an[2 * k] = mk(t.x, t.y);
+            if (2 * k + 1 < NQ) an[2 * k + 1] = mk(t.z, t.w);
+        }
+    }
+    if (l0 < 100) s_tw[l0] = ((const cf *)p.twiddle)[l0];        // visible after the first barrier of the first tile
+    uint32_t b2task = (uint32_t)p.b2map[l0];
+    if (NSW == 2) b2task |= (uint32_t)p.b2map[NTH + l0] << 16; else b2task |= 0xffff0000u;
+    int e_pos; cf e_rho;
+    {
+        const int ec = l0 % 80, ecc = ec < p.nsel ? ec : p.nsel - 1;
+        e_pos = p.binnat[ecc];
+        e_rho = ((const cf *)p.rho)[ecc];
+    }
+    int nz_pos[NZT];                                             // bin position of this lane's squelch outputs
+#pragma unroll
+    for (int j = 0; j < NZT; j++) {
+        const int i = l0 + j * NTH < p.nsel * NU ? l0 + j * NTH : p.nsel * NU - 1;
+        nz_pos[j] = p.n_binpos[i / NU];
+    }
+    const DemodConst &kc = p.kc;                                 // kernel arguments: scalar registers
+
+    auto span_start = [&](int tile) -> long long { return (p.x0 + (long long)DH * ((long long)tile * TT - 1)) & ~1LL; };
+    auto interior = [&](int tile) -> bool {                      // block-uniform
+        const long long a0 = span_start(tile);
+        return a0 >= 0 && a0 + 2LL * N4 <= p.x_len;
+    };
+    // Input span of a tile.  Interior tiles (all but a handful at the two ends of the stream): one straight run of
+    // aligned 16-byte loads into registers, issued a whole tile ahead of their use.  Tiles that touch a stream edge
+    // are staged in place when their turn comes, element by element with clamped addresses (zeros outside).
+    // (named registers, not an array: an array that lives across the tile loop stays in scratch memory)
+    static_assert(PER <= 6, "explicit prefetch registers below");
+    float4 v0, v1, v2, v3, v4, v5;
+    v0 = v1 = v2 = v3 = v4 = v5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_span = [&](int tile, int l) {
+        const float4 *xb = (const float4 *)(p.x + span_start(tile));
+        auto at = [&](int j) { return xb[l + j * NTH < N4 ? l + j * NTH : N4 - 1]; };
+        v0 = at(0); if (PER > 1) v1 = at(1); if (PER > 2) v2 = at(2); if (PER > 3) v3 = at(3);
+        if (PER > 4) v4 = at(4); if (PER > 5) v5 = at(5);
+    };
+    auto stage_edge = [&](int tile, int l) {
+        const long long a0 = span_start(tile);
+#pragma unroll 1
+        for (int i = l; i < N4; i += NTH) {
+            const long long s0 = a0 + 2LL * i, s1 = s0 + 1;
+            const bool in0 = s0 >= 0 && s0 < p.x_len, in1 = s1 >= 0 && s1 < p.x_len;
+            const float2 q0 = p.x[in0 ? s0 : 0], q1 = p.x[in1 ? s1 : 0];
+            ((float4 *)xs)[i] = make_float4(in0 ? q0.x : 0.f, in0 ? q0.y : 0.f, in1 ? q1.x : 0.f, in1 ? q1.y : 0.f);
+        }
+    };
+    // angle tiles + tile sums of a finished tile -> HBM (reads the epilogue's LDS tiles: call between its barrier
+    // and the next barrier, before phase A of the following tile writes the DFT rows again)
+    auto copy_out = [&](int tile, int l) {
+        const long long g1 = (long long)tile * TT;                               // first owned instant
+        const long long rows = p.T - g1 < TT ? p.T - g1 : TT;                    // ... inside the stream
+        float4 *dst = (float4 *)(p.d + (size_t)g1 * 80);
+        for (int i = l; i < (int)rows * 20; i += NTH) dst[i] = ((const float4 *)s_d)[i];
+        if (p.dcol) {
+            float4 *dc = (float4 *)(p.dcol + (size_t)tile * (80 * TT));
+            for (int i = l; i < TT * 20; i += NTH) dc[i] = ((const float4 *)s_dc)[i];
+        }
+        if (l < p.nsel) {
+            double sum = 0.0, head = 0.0;
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                sum += (double)s_part[(k * 80 + l) * 2];
+                head += (double)s_part[(k * 80 + l) * 2 + 1];
+            }
+            p.ptile[(size_t)l * p.ntiles + tile] = sum;
+            p.phead[(size_t)l * p.ntiles + tile] = head;         // first (tail % TT) instants of this tile
+        }
+    };
+
+    const int shift = (int)((p.x0 - DH) & 1LL);                  // the span starts at an even sample: same for every tile (DH TT is even)
+    const int np = p.n_period;
+    if (interior(tu0 - p.pre_tiles)) load_span(tu0 - p.pre_tiles, l0);
+    for (int tu = tu0; tu < tu1; tu++) {
+        const int tile = tu - p.pre_tiles;
+        const long long t0 = (long long)tile * TT - 1;           // global instant of local row 0 (the halo instant)
+        const int nz_u0 = p.n_u0 + NU * tile;                    // first squelch instant owned by this tile
+        int l = l0;
+        BTGPU_OPAQUE(l);                                         // (see the macro: keeps per-phase addresses out of the loop-invariant set)
+        const int a_pp = l & 127, a_r = (l >> 7) & 1;
+        const bool a_on = a_pp < M && l < 256;
+        const int e_chunk = l / 80, e_c = l - 80 * e_chunk;
+        const bool e_on = e_chunk < CH && e_c < p.nsel;
+        // ---- input span + twiddles -> LDS; the previous tile's results leave in the same barrier interval ----
+        if (tu > tu0 && tile - 1 >= 0) copy_out(tile - 1, l);
+        if (interior(tile)) {
+            auto put = [&](int j, const float4 &q) { const int i = l + j * NTH; if (i < N4) ((float4 *)xs)[i] = q; };
+            put(0, v0); if (PER > 1) put(1, v1); if (PER > 2) put(2, v2); if (PER > 3) put(3, v3);
+            if (PER > 4) put(4, v4); if (PER > 5) put(5, v5);
+        } else stage_edge(tile, l);
+        __syncthreads();
+        // the next tile's input: in flight under this tile's arithmetic
+        if (tu + 1 < tu1 && interior(tile + 1)) load_span(tile + 1, l);
+        // de-rotation factors of this lane's squelch outputs (consumed at the end of the tile)
+        cf nz_rot[NZT];
+        {
+            const int ph0 = ((nz_u0 % np) + np) % np;            // block-uniform
+#pragma unroll
+            for (int j = 0; j < NZT; j++) {
+                const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
+                int ph = ph0 + i % NU;
+                ph = ph >= np ? ph - np : ph;
+                nz_rot[j] = ((const cf *)p.n_krot)[(size_t)(i / NU) * np + ph];
+            }
+        }
+
+        // ---- phase A: branch filters of the channel bank and of squelch stage 1, one march of the span ----
+        if (a_on) {
+            const cf *z = xs + shift + DH * a_r + a_pp;
+            // (pre-tiles, tile < 0: their channel rows are garbage nobody reads -- no branch inside the march)
+            if (a_r == 0) march_branch<0, REAL>(z, a, an, U, a_pp);      // wave-uniform
+            else march_branch<1, REAL>(z, a, an, U, a_pp);
+        }
+        __syncthreads();
+
+        // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100}, in place ----
+#pragma unroll
+        for (int sw = 0; sw < NSW; sw++) {
+            const int bi = l + sw * NTH;
+            if (bi < NTASK) {
+                const int brow = bi / 10, bp2 = bi - 10 * brow;
+                cf *col = U + brow * UST + bp2;
+                const cf *twp = s_tw + bp2;
+                cf x[10];
+#pragma unroll
+                for (int k = 0; k < 10; k++) x[k] = col[10 * k];
+                dft10(x);
+                col[0] = x[0];
+#pragma unroll
+                for (int k = 1; k < 10; k++) col[10 * k] = cmulf(x[k], twp[10 * k]);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B2: DFT over p2.  Channel rows: bin m = m1 + 10 m2 -> Y[row][m]; squelch rows stay in place ----
+#pragma unroll
+        for (int sw = 0; sw < NSW; sw++) {
+            const uint32_t task = sw == 0 ? (b2task & 0xffffu) : (b2task >> 16);
+            if (task != 0xffffu) {
+                const int row = (int)(task >> 4), m1 = (int)(task & 15u);
+                cf2 *src = (cf2 *)(U + row * UST + 10 * m1);
+                cf x[10];
+#pragma unroll
+                for (int k = 0; k < 5; k++) { const cf2 t = src[k]; x[2 * k] = t.xy; x[2 * k + 1] = t.zw; }
+                dft10(x);
+                if (row < NT) {
+                    cf *dst = Y + row * YST + m1;
+#pragma unroll
+                    for (int k = 0; k < 10; k++) dst[10 * k] = x[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { cf2 t; t.xy = x[2 * k]; t.zw = x[2 * k + 1]; src[k] = t; }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase C: squelch stage-1 bins (fetched now, stored after the channel epilogue) ----
+        cf nz_val[NZT];
+#pragma unroll
+        for (int j = 0; j < NZT; j++) {
+            const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
+            nz_val[j] = U[(NT + i % NU) * UST + nz_pos[j]];
+        }
+        // channel epilogue (run sums and angle tiles go to the channel rows of U, dead since pass 2; the squelch rows
+        // read above lie behind them), lane (run, c): <= RUN consecutive instants, the previous instant's bin in registers
+        if (tile >= 0 && e_on) {
+            const int tl0 = 1 + e_chunk * RUN;
+            const cf *yc = Y + e_pos;
+            // instants of this run that exist: inside the tile and inside the stream
+            const long long left = p.T - (t0 + tl0);
+            int nval = NT - tl0 < RUN ? NT - tl0 : RUN;
+            nval = left < nval ? (int)(left < 0 ? 0 : left) : nval;
+            // head sum (first tail % TT instants of the tile): only the tile that holds the end of a window's last
+            // partial block is ever asked for it (block_sum_kernel)
+            const int hr = (p.tail % TT > 0 && tile % p.tiles_per_block == p.tail / TT) ? p.tail % TT : 0;   // block-uniform
+            float sum = 0.f, head = 0.f;
+            float *drow = s_d + (tl0 - 1) * 80 + e_c;
+            float *dcolp = s_dc + e_c * TT + (tl0 - 1);
+            // one instant per step, the bins read two steps ahead; fenced like the march (the unrolled run is
+            // independent work the scheduler would otherwise overlap at the price of a hundred registers)
+            cf yb = yc[(tl0 - 1) * YST], ya = yc[tl0 * YST];
+#pragma unroll
+            for (int k = 0; k < RUN; k++) {
+                const int rn = tl0 + k + 1 < NT ? tl0 + k + 1 : NT - 1;
+                const cf yn = yc[rn * YST];
+                if (k < nval) {
+                    const cf ybr = p.rho_real ? yb * e_rho.xx : cmulf(yb, mk(e_rho.x, -e_rho.y));   // conj(Y[t-1]) rho, conjugated
+                    const float m = ya.x * ya.x + ya.y * ya.y;
+                    sum += m;
+                    if (tl0 + k - 1 < hr) head += m;
+                    const cf pq = ybr.xx * ya + ybr.yy * mk(ya.y, -ya.x);                       // Y[t] conj(Y[t-1]) rho
+                    const float ang = demod_poly(kc, pq.x, pq.y);
+                    drow[k * 80] = ang;
+                    dcolp[k] = ang;
+                }
+                yb = ya; ya = yn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            s_part[(e_chunk * 80 + e_c) * 2 + 0] = sum;
+            s_part[(e_chunk * 80 + e_c) * 2 + 1] = head;
+            if (p.Z) {                                           // BTGPU_FLAG_DEBUG_Y: the de-rotated channel output
+                const int period = p.rot_period;
+                int ph = (int)((t0 + tl0) % period);
+                for (int k = 0; k < nval; k++) {
+                    const cf kr = ((const cf *)p.krot)[e_c * period + ph];
+                    ((cf *)p.Z)[(size_t)e_c * p.zstride + (t0 + tl0 + k)] = cmulf(yc[(tl0 + k) * YST], kr);
+                    ph = ph + 1 == period ? 0 : ph + 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NZT; j++) {
+            const int i = l + j * NTH;
+            const int u = nz_u0 + i % NU;
+            if (i < p.nsel * NU && u >= 0 && u < p.n_T)
+                ((cf *)p.n_Z)[(size_t)(i / NU) * p.n_zstride + u] = cmulf(nz_val[j], nz_rot[j]);
+        }
+        __syncthreads();                                         // angle tiles complete; Y (= the span region) is dead
+    }
+    if (tu1 - 1 - p.pre_tiles >= 0) copy_out(tu1 - 1 - p.pre_tiles, l0);
+}
+
+}  // namespace btgpu

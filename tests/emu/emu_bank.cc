@@ -52,7 +52,8 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     const std::vector<uint16_t> mc = make_dft_pass2_map(kBankNT, kBankThreads, 2);
     const std::vector<uint16_t> mn = make_dft_pass2_map(kNoiseNT, kBankThreads, 2);
     const std::vector<uint16_t> mw = make_dft_pass2_map(kBankNT + 5, kBankThreadsWide, 1);
-    if (mf.empty() || mc.empty() || mn.empty() || mw.empty()) return BTGPU_EUNSUPPORTED;
+    const std::vector<uint16_t> m5 = make_dft_pass2_map(kBankNT + 5, kBankThreadsF, 1);
+    if (mf.empty() || mc.empty() || mn.empty() || mw.empty() || m5.empty()) return BTGPU_EUNSUPPORTED;
     const int ntiles_max = (int)((G + 24) / 25);
     std::vector<double> ptile((size_t)nch * ntiles_max, 0.0), phead((size_t)nch * ntiles_max, 0.0);
     // x must be readable as float4 at even sample offsets: keep a 16-byte aligned copy with slack
@@ -68,7 +69,7 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     b.taps_ch = (const float2 *)tch4.data(); b.twiddle = (const float2 *)fp.channel.twiddle.data();
     b.krot_ch = (const float2 *)fp.channel.krot.data(); b.rho_ch = (const float2 *)fp.channel.rho.data();
     b.binpos_ch = fp.channel.binpos.data(); b.binnat_ch = fp.channel.binnat.data();
-    b.b2map_fused = mf.data(); b.b2map_fused_wide = mw.data(); b.b2map_ch = mc.data(); b.b2map_noise = mn.data();
+    b.b2map_fused = mf.data(); b.b2map_fused_wide = mw.data(); b.b2map_ch = mc.data(); b.b2map_noise = mn.data(); b.b2map_f320 = m5.data();
     b.d = d_out; b.ptile = ptile.data(); b.phead = phead.data();
     std::vector<float> dcol((size_t)ntiles_max * 80 * 25, -77.f);
     b.dcol = dcol.data();
@@ -81,8 +82,10 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);      // NaN pattern: reads of unwritten LDS show up
         emu::launch(dim3((unsigned)grid), dim3((unsigned)threads), [&]() { kern(p); });
     };
-    // fuse: 1 = fused, four waves per tile (the default); 3 = fused, eight waves
-    const int ntiles = launch_channel_bank(des, fp, fuse == 1 || fuse == 3, b, (size_t)x_len, w0, S, G, nb, L, fuse == 3);
+    // fuse: 1 = fused, runs of tiles, five waves (the default); 4 = the same with four waves; 5 = the round-2 kernel, four
+    // waves per tile; 3 = the round-2 kernel, eight waves
+    const int variant = fuse == 3 ? kBankLegacyWide : fuse == 5 ? kBankLegacy : fuse == 4 ? kBankRun256 : kBankRun320;
+    const int ntiles = launch_channel_bank(des, fp, fuse == 1 || fuse >= 3, b, (size_t)x_len, w0, S, G, nb, L, variant);
     if (fuse == 2) launch_noise_bank(des, fp, b, (size_t)x_len, w0, S, L);
     // the tile-blocked copy finish_kernel reads must hold the very same angles: dcol[tile][c][r] == d[25 tile + r][c]
     for (long long g = 0; g < G; g++)

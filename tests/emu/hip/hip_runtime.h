@@ -48,6 +48,7 @@ static inline void __syncthreads() { emu::barrier(); }
 static inline unsigned long long clock64() { return 0ULL; }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
