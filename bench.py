@@ -21,6 +21,7 @@ one step against the CPU oracle run on all host cores over the first --parity-sl
 the same capture (tests/paritylib.py).
 """
 import argparse
+import collections
 import hashlib
 import gc
 import json
@@ -67,6 +68,10 @@ def parse_args(argv=None):
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
     ap.add_argument("--headers", action="store_true", help="also export hit symbols and run the GPU header sweep (BTGPU_FLAG_HEADERS), as the C++ multi_sniffer block does")
+    ap.add_argument("--le", action="store_true", help="also run the le_packet::sniff_aa pass (BTGPU_FLAG_LE), as the C++ multi_sniffer block does")
+    ap.add_argument("--no-block-config", action="store_true", help="skip the second timed region in the drop-in block's configuration (LE | HEADERS)")
+    ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP events (BTGPU_FLAG_TIMING off): kernel traces without event records; roofline then has no kernel time")
+    ap.add_argument("--force-gather", action="store_true", help="N = 1: still push the records through the HitGatherer collective (single-rank process group; first contact of the RCCL path on one GPU)")
     ap.add_argument("--sync", action="store_true", help="harvest every batch before the next one is enqueued (no tail overlap)")
     ap.add_argument("--channelizer", type=int, default=0)
     ap.add_argument("--squelch-mode", type=int, default=0, help="0 auto, 1 direct, 2 staged")
@@ -130,11 +135,15 @@ def run_rank(args):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     coll_device = device if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if world > 1 or args.force_gather:
+        if world == 1:                              # a one-rank group: the collective path end to end on one GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     pkg = load_pkg()
     import importlib
@@ -151,9 +160,13 @@ def run_rank(args):
     gen = dict(laps=laps, seed=args.seed, snr_db=args.snr, occupancy=args.occupancy, cfo_hz=args.cfo_hz,
                max_payload_bits=args.max_payload_bits)
 
-    blk = pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
-                            channelizer=args.channelizer, squelch=args.squelch_mode,
-                            flags=(0 if args.sync else pkg.FLAG_ASYNC) | (pkg.FLAG_HEADERS if args.headers else 0) | pkg.FLAG_TIMING)
+    base_flags = (0 if args.sync else pkg.FLAG_ASYNC) | (0 if args.no_timing else pkg.FLAG_TIMING)
+
+    def make_block(extra):
+        return pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
+                                 channelizer=args.channelizer, squelch=args.squelch_mode, flags=base_flags | extra)
+    head_flags = (pkg.FLAG_HEADERS if args.headers else 0) | (pkg.FLAG_LE if args.le else 0)
+    blk = make_block(head_flags)
     des = blk.design
     H, slot = des.history, des.samples_per_slot
     nch = des.high_channel - des.low_channel + 1
@@ -166,19 +179,21 @@ def run_rank(args):
     n_complex = seg.shape[0]
     assert n_complex >= n_need and a0 == first * slot - (H - 1) - margin   # (the generator runs to the end of the last slot)
     torch.cuda.synchronize()
-    gatherer = bdist.HitGatherer(cap=8192, device=coll_device)
+    gatherer = bdist.HitGatherer(cap=8192, device=coll_device, force=args.force_gather)
+    gathering = world > 1 or args.force_gather
 
-    def step(last=False, gather=True):
+    def step(last=False, gather=True, blk=None):
         """One pass of the hot path over the rank's batch.  In the (default) pipelined mode the
         records of a batch are harvested while the next batch runs; the last step of a timed
         region flushes, so every record of every step is on the host inside the timed region.
         N > 1: the records this rank has ready are posted to one asynchronous all_gather; what
         comes back here is the previous post (collected while this batch computes)."""
+        blk = blk or head_blk
         blk.process_device(seg.data_ptr(), n_complex, first, S, left_margin=margin)
         if last:
             blk.flush()
         ints, snr = bdist.struct_to_arrays(blk.poll_arrays())
-        if world == 1 or not gather:
+        if not gathering or not gather:
             return ints, snr
         got = gatherer.collect() if gatherer.pending is not None else (ints[:0], snr[:0])
         gatherer.post(ints, snr)
@@ -186,6 +201,8 @@ def run_rank(args):
             more = gatherer.collect(drain=True)
             got = (np.concatenate([got[0], more[0]], axis=0), np.concatenate([got[1], more[1]], axis=0))
         return got
+
+    head_blk = blk
 
     def tdiff(a, b):
         return np.array(list(b.kernel_ms)) - np.array(list(a.kernel_ms)), \
@@ -204,43 +221,73 @@ def run_rank(args):
     # loaded costs tens of milliseconds, i.e. more than the whole region at the default K) -- and none
     # between the warm-up and the timed region either: the device clocks sag during any idle gap and
     # take ~10 batches to come back.
-    gc.collect()
-    gc.disable()
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:      # per-rank clock: no collectives in here
-        step(last=False, gather=False)
-    step(last=True, gather=False)
-    fence()
-    for i in range(args.warmup):
-        step(last=(i == args.warmup - 1))
-    fence()
-    tm0 = blk.timing()
-    t0 = time.perf_counter()
-    got_i, got_s = [], []
-    marks = [t0]
-    for i in range(args.steps):
-        ints, snr = step(last=(i == args.steps - 1))
-        got_i.append(ints); got_s.append(snr)
-        marks.append(time.perf_counter())
-    ints = np.concatenate(got_i, axis=0)
-    snr = np.concatenate(got_s, axis=0)
-    t_loop = time.perf_counter()
-    if os.environ.get("BENCH_DUMP_STEPS"):
-        print("step_ms", [round(float(v) * 1e3, 2) for v in np.diff(np.array(marks))], file=sys.stderr)
-    fence()
-    elapsed = time.perf_counter() - t0
-    fence_ms = (time.perf_counter() - t_loop) * 1e3
-    gc.enable()
-    kernel_ms, kernel_launches = tdiff(tm0, blk.timing())
+    def timed_region(b, gather=True):
+        """prewarm + W warm-up steps + K timed steps on block `b`; returns (elapsed s, ints, snr, marks, fence ms, kernel ms,
+        kernel launches)."""
+        gc.collect()
+        gc.disable()
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_ms * 1e-3:      # per-rank clock: no collectives in here
+            step(last=False, gather=False, blk=b)
+        step(last=True, gather=False, blk=b)
+        fence()
+        for i in range(args.warmup):
+            step(last=(i == args.warmup - 1), gather=gather, blk=b)
+        fence()
+        tm0 = b.timing()
+        t0 = time.perf_counter()
+        got_i, got_s = [], []
+        marks = [t0]
+        for i in range(args.steps):
+            ints, snr = step(last=(i == args.steps - 1), gather=gather, blk=b)
+            got_i.append(ints); got_s.append(snr)
+            marks.append(time.perf_counter())
+        ints = np.concatenate(got_i, axis=0)
+        snr = np.concatenate(got_s, axis=0)
+        t_loop = time.perf_counter()
+        if os.environ.get("BENCH_DUMP_STEPS"):
+            print("step_ms", [round(float(v) * 1e3, 2) for v in np.diff(np.array(marks))], file=sys.stderr)
+        fence()
+        elapsed = time.perf_counter() - t0
+        fence_ms = (time.perf_counter() - t_loop) * 1e3
+        gc.enable()
+        kms, kl = tdiff(tm0, b.timing())
+        return elapsed, ints, snr, marks, fence_ms, kms, kl
+
+    elapsed, ints, snr, marks, fence_ms, kernel_ms, kernel_launches = timed_region(blk)
+    rank_elapsed = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # every step processes the same resident batch: keep one copy of the (identical) record set
-    if args.steps > 1 and len(ints):
-        ints_u, idx = np.unique(ints, axis=0, return_index=True)
-        assert len(ints_u) * args.steps == len(ints), "steps produced different record sets"
-        ints, snr = bdist.sort_hits(ints_u, snr[idx])
+        t = torch.zeros(world, dtype=torch.float64, device=coll_device)
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                 # every rank's own time: a slow rank is visible in the line
+        rank_elapsed = [float(v) for v in t.cpu()]
+        elapsed = max(rank_elapsed)
+    def one_copy(ints, snr):
+        # every step processes the same resident batch: keep one copy of the (identical) record set
+        if args.steps > 1 and len(ints):
+            ints_u, idx = np.unique(ints, axis=0, return_index=True)
+            assert len(ints_u) * args.steps == len(ints), "steps produced different record sets"
+            return bdist.sort_hits(ints_u, snr[idx])
+        return ints, snr
+    ints, snr = one_copy(ints, snr)
+
+    # ---- the drop-in block's configuration (N = 1): gr::bluetooth::multi_sniffer always runs the LE pass after the
+    # classic one and hands the symbols of every hit to its packet handlers (lib/multi_sniffer_impl.cc:107-149), so
+    # host/blocks.cc creates its handle with BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS: the same K steps in that configuration
+    block_cfg = None
+    if world == 1 and not args.no_block_config and not (args.le and args.headers):
+        blk.close()
+        blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS)
+        b_el, b_ints, b_snr, _m, _f, b_kms, b_kl = timed_region(blk, gather=False)
+        b_ints, b_snr = one_copy(b_ints, b_snr)
+        block_cfg = {"flags": "BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS (what host/blocks.cc sets for multi_sniffer)",
+                     "value": round(float(S) * slot * args.steps / b_el / 1e6, 3), "unit": "Msamples/s",
+                     "ms_per_step": round(b_el / args.steps * 1e3, 3), "hits": int(len(b_ints)),
+                     "hits_ac": int((b_ints[:, 2] == 0).sum()) if len(b_ints) else 0,
+                     "hits_aa": int((b_ints[:, 2] == 1).sum()) if len(b_ints) else 0,
+                     "kernel_avg_ms": {pkg.KERNEL_NAMES[i]: round(float(b_kms[i] / b_kl[i]), 4) if b_kl[i] else 0.0
+                                       for i in range(len(pkg.KERNEL_NAMES))},
+                     "ac_records_equal_headline": bool(np.array_equal(b_ints[b_ints[:, 2] == 0], ints[ints[:, 2] == 0])) if not args.le else None}
 
     total_samples = float(world) * S * slot * args.steps
     value = total_samples / elapsed / 1e6
@@ -287,6 +334,18 @@ def run_rank(args):
             roof["fp32_tflops"] = round(fl / (avg[dom] * 1e-3) / 1e12, 3)
             roof["fp32_frac"] = round(roof["fp32_tflops"] / FP32_PEAK_TFLOPS, 4)
         roof["build_id"] = build_id()
+        if not args.pmc_json:
+            # self-carrying evidence: a PMC summary under profiles/ is used iff it was collected on THIS build of
+            # libbtgpu.so with this batch size (scripts/pmc_hbm_json.py stamps both); anything else leaves traffic null
+            import glob
+            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm.json")), reverse=True):
+                try:
+                    pj = json.load(open(cand))
+                except (OSError, ValueError):
+                    continue
+                if pj.get("build_id") == roof["build_id"] and pj.get("slots") == S:
+                    args.pmc_json = cand
+                    break
         if args.pmc_json:
             # HBM bytes of the dominant kernel from rocprofv3 PMC passes of the SAME build and batch size
             # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; scripts/collect_profiles.sh stamps the build id)
@@ -302,12 +361,19 @@ def run_rank(args):
 
         # ---- cpu_baseline + parity: the oracle (a port, NOT the upstream binary) ----
         cpu = None
-        parity = {"truth_detected": found, "truth_expected": expected, "hits": int(len(ints)),
+        parity = {"note": "truth_detected / truth_expected is the recall of the synthetic ground truth; the misses are the "
+                          "reference algorithm's -- zero-threshold slicer, no carrier-offset removal (lib/multi_block.cc:171-178): "
+                          "bursts beyond about +-40 kHz of offset are lost by the CPU oracle and the GPU alike "
+                          "(tests/test_gpu_parity.py::test_cfo_sweep_gpu_equals_oracle, DESIGN.md section 5)",
+                  "truth_detected": found, "truth_expected": expected, "hits": int(len(ints)),
                   "records_sha256": hashlib.sha256(np.ascontiguousarray(ints, dtype=np.int64).tobytes()).hexdigest()[:16]}
         if not args.no_cpu:
             import pyoracle as po
             import paritylib
-            o = po.Oracle(fs, fc, args.squelch, po.MODE_SNIFFER)
+            # with the block configuration measured, the oracle runs its LE pass too (one run serves both differentials:
+            # the LE pass only adds access-address records, lib/multi_sniffer_impl.cc:129-149)
+            le_on = bool(args.le or block_cfg is not None)
+            o = po.Oracle(fs, fc, args.squelch, po.MODE_SNIFFER, le=le_on)
             ncores = os.cpu_count() or 1
             P = max(2, min(S, args.parity_slots)) if args.parity_slots > 0 else 0
             nhost = max(P, min(S, 64))
@@ -336,11 +402,20 @@ def run_rank(args):
                 dt2 = time.perf_counter() - t1
                 cpu["all_cores"] = {"value": round(P * slot / dt2 / 1e6, 4), "cores": ncores, "slots": P,
                                     "seconds": round(dt2, 2)}
-                oi, _ = bdist.sort_hits(*bdist.hits_to_arrays(ohits))
+                oi_all, _ = bdist.sort_hits(*bdist.hits_to_arrays(ohits))
+                oi = oi_all if args.le else oi_all[oi_all[:, 2] == 0]      # headline without --le: classic records only
                 gi = ints[ints[:, 0] < P]
                 tr = [t for t in truth if t["slot"] < P]
                 parity["oracle_slots"] = P
                 parity["differential"] = paritylib.differential(gi, oi, tr)
+                if block_cfg is not None:
+                    bi = b_ints[b_ints[:, 0] < P]
+                    block_cfg["differential"] = paritylib.differential(bi, oi_all, tr)
+                    ga = collections.Counter(tuple(int(v) for v in r[[0, 1, 3, 4]]) for r in bi if r[2] == 1)
+                    ra = collections.Counter(tuple(int(v) for v in r[[0, 1, 3, 4]]) for r in oi_all if r[2] == 1)
+                    block_cfg["aa_records"] = {"gpu": int(sum(ga.values())), "ref": int(sum(ra.values())),
+                                               "common": int(sum((ga & ra).values())),
+                                               "note": "access-address records of a classic-only capture are born from noise symbols"}
                 parity["lap_list_equal_ref"] = ("planted records identical" if parity["differential"]["planted_identical"]
                                                 else "PLANTED RECORDS DIFFER") + \
                     "; %d / %d other records on one side only" % (
@@ -359,9 +434,12 @@ def run_rank(args):
                        "occupancy": args.occupancy, "cfo_hz": args.cfo_hz, "max_payload_bits": args.max_payload_bits,
                        "mode": "multi_sniffer",
                        "partition": "time x%d, halo %d + margin %d samples" % (world, H - 1, margin),
-                       "gather": ("one async all_gather per batch (%s), %d rounds" % (args.backend, gatherer.rounds)) if world > 1 else "none",
+                       "gather": ("one async all_gather_into_tensor per batch (%s, own stream), %d rounds" % (args.backend, gatherer.rounds)) if gathering else "none",
+                       "flags": "ASYNC%s%s%s" % ("|LE" if args.le else "", "|HEADERS" if args.headers else "", "" if args.no_timing else "|TIMING"),
                        "channelizer": {1: "direct", 2: "polyphase"}[int(des.channelizer)],
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},
+            "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed],
+            "block_config": block_cfg,
             "fence_ms": round(fence_ms, 3),
             "step_enqueue_ms": [round(float(v), 3) for v in np.percentile(np.diff(np.array(marks)) * 1e3, [0, 50, 100])],
             "roofline": roof,
@@ -369,7 +447,7 @@ def run_rank(args):
             "parity": parity,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_gather:
         dist.barrier()
         dist.destroy_process_group()
     blk.close()

@@ -18,7 +18,9 @@ constexpr int kBankThreads = 256;            // lanes per tile of the non-fused 
 constexpr int kBankThreadsWide = 512;        // fused channel + noise bank: eight waves per tile
 constexpr int kBankThreadsF = 320;           // pfb100f_kernel: five waves per run of tiles (every DFT pass in one sweep)
 // which kernel runs the fused C79 bank (launch_channel_bank)
-enum BankVariant { kBankLegacy = 0, kBankLegacyWide = 1, kBankRun256 = 2, kBankRun320 = 3 };
+enum BankVariant { kBankLegacy = 0, kBankLegacyWide = 1, kBankRun256 = 2, kBankRun320 = 3,
+                   kBankRun256b = 4, kBankRun256c = 5, kBankRun256d = 6,        // run256 with OPT 1 / 3 / 7 (pfb100f.hip.h)
+                   kBankRun256e = 7 };                                          // OPT 3, runs of ten tiles
 constexpr int kBankNT = 26;                 // channel instants per tile (25 new + 1 halo for the demod)
 constexpr int kNoiseNT = 10;                // instants per tile of the stand-alone noise stage 1
 
@@ -110,8 +112,8 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
         const int grid = p.ntiles + p.pre_tiles;
         // the run kernels share the march of the staged input between the two banks: the squelch grid must sit on
         // the channel grid (design_fast.cc aligns it for this geometry)
-        const bool run_ok = p.n_off == 0 && (variant == kBankRun256 || variant == kBankRun320);
-        if (!run_ok && (variant == kBankRun256 || variant == kBankRun320) && getenv("BTGPU_VERBOSE"))
+        const bool run_ok = p.n_off == 0 && variant >= kBankRun256;
+        if (!run_ok && variant >= kBankRun256 && getenv("BTGPU_VERBOSE"))
             fprintf(stderr, "launch_channel_bank: squelch grid off the channel grid (n_off %d): round-2 kernel\n", p.n_off);
         if (run_ok) {
             const size_t lds = bank_lds_bytes((250 - 1) + 250 * 4 + 15 * 100, NT, NT + 5, true, true);
@@ -120,7 +122,11 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
                 p.b2map = b.b2map_f320;
                 if (bk.real_taps) L(pfb100f_kernel<kBankThreadsF, true, kBankKT>, nruns, kBankThreadsF, lds, p);
                 else L(pfb100f_kernel<kBankThreadsF, false, kBankKT>, nruns, kBankThreadsF, lds, p);
-            } else {
+            } else if (variant == kBankRun256b && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 1>, nruns, kBankThreads, lds, p);
+            else if (variant == kBankRun256c && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 3>, nruns, kBankThreads, lds, p);
+            else if (variant == kBankRun256d && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 7>, nruns, kBankThreads, lds, p);
+            else if (variant == kBankRun256e && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 3>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);
+            else {
                 if (bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT>, nruns, kBankThreads, lds, p);
                 else L(pfb100f_kernel<kBankThreads, false, kBankKT>, nruns, kBankThreads, lds, p);
             }

@@ -253,13 +253,15 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
         };
-        // BTGPU_BANK: run320 (default) | run256 -- pfb100f_kernel, runs of tiles per workgroup; legacy | wide -- the
-        // round-2 kernel with four / eight waves per tile (A/B timing)
+        // BTGPU_BANK: run256 (default) | run320 -- pfb100f_kernel, runs of tiles per workgroup, four / five waves;
+        // legacy | wide -- the round-2 kernel with four / eight waves per tile (A/B timing)
         static const int variant = [] {
             const char *e = getenv("BTGPU_BANK");
-            if (!e) return (int)kBankRun320;
+            if (!e) return (int)kBankRun256;
             const std::string v(e);
-            return v == "legacy" ? (int)kBankLegacy : v == "wide" ? (int)kBankLegacyWide : v == "run256" ? (int)kBankRun256 : (int)kBankRun320;
+            return v == "legacy" ? (int)kBankLegacy : v == "wide" ? (int)kBankLegacyWide : v == "run320" ? (int)kBankRun320 :
+                   v == "run256b" ? (int)kBankRun256b : v == "run256c" ? (int)kBankRun256c : v == "run256d" ? (int)kBankRun256d :
+                   v == "run256e" ? (int)kBankRun256e : (int)kBankRun256;
         }();
         ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, variant);
         tiles_per_block = ops / TT; tail_tiles = des.tail / TT;
@@ -714,14 +716,22 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         // 100 Msps: the 10 x 10 FFT bank (pfb100.hip.h); other even integer rates: the small-M bank (pfbm.hip.h)
         const bool pfb100_ok = fp->channel.available && fp->channel.M == kPfbM && fp->channel.Q == 7 && fp->channel.S == 1 &&
                                h->des.outs_per_slot % 25 == 0;
+        // dynamic LDS a workgroup may ask for on the device the handle will live on (gfx950: 160 KB; the banks need up to 96)
+        size_t lds_cap = 64 * 1024;
+        {
+            int dq = cfg->device, mx = 0;
+            if (dq < 0 && hipGetDevice(&dq) != hipSuccess) dq = 0;
+            if (hipDeviceGetAttribute(&mx, hipDeviceAttributeMaxSharedMemoryPerBlock, dq) == hipSuccess && mx > 0) lds_cap = (size_t)mx;
+            if (lds_cap > 96 * 1024) lds_cap = 96 * 1024;          // what hipFuncSetAttribute is asked for below
+        }
         const bool pfbm_ok = fp->channel.available && fp->channel.M >= 4 && fp->channel.M < kPfbM &&
                              h->des.outs_per_slot % pfbm_tile(fp->channel.M) == 0 &&
-                             pfbm_lds_bytes(fp->channel.M, fp->channel.D, fp->channel.Q, nch0, true) <= 96 * 1024;
+                             pfbm_lds_bytes(fp->channel.M, fp->channel.D, fp->channel.Q, nch0, true) <= lds_cap;
         const bool pfb_ok = !h->des.segmented && (frc == BTGPU_OK || frc == BTGPU_EUNSUPPORTED) && (pfb100_ok || pfbm_ok);
         const bool noise_pfb_ok = fp->noise.available && fp->noise.pfb.available && fp->noise.pfb.M == kPfbM &&
                                   fp->noise.pfb.Q == 15 && fp->noise.pfb.S == 5;
         const bool noise_small_ok = fp->noise.available && fp->noise.pfb.available && fp->noise.pfb.M >= 4 && fp->noise.pfb.M < kPfbM &&
-                                    pfbm_lds_bytes(fp->noise.pfb.M, fp->noise.pfb.D, fp->noise.pfb.Q, nch0, false) <= 96 * 1024;
+                                    pfbm_lds_bytes(fp->noise.pfb.M, fp->noise.pfb.D, fp->noise.pfb.Q, nch0, false) <= lds_cap;
         const bool staged_ok = !h->des.segmented && fp->noise.available &&
                                (noise_pfb_ok || noise_small_ok || pick_shape(fp->noise.R, fp->noise.direct.ntp, h->shape_s1));
         h->noise_pfb = noise_pfb_ok;
@@ -979,6 +989,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreadsF, false, kBankKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, kBankKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, false, kBankKT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, kBankKT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, kBankKT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))
         fprintf(stderr, "btgpu_create: %d contexts, d=%p Z=%p ptile=%p\n", h->nctx, h->tc[0].d_d.p, h->tc[0].d_Z.p, h->tc[0].d_ptile.p);

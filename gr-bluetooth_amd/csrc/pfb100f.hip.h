@@ -76,13 +76,13 @@ __device__ __forceinline__ cf chan_mac(const ChanTaps<REAL> &t, int q, cf w, cf 
 #define BTGPU_AFTER(x, dep) ((void)(dep))                        /* host emulation of the kernels (tests/emu) */
 #endif
 
-template <int R, bool REAL>
+template <int R, bool REAL, int OPT>
 __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &a, const cf (&an)[15], cf *U, int pp)
 {
     constexpr int M = 100, Q = 7, NT = 26, NQ = 15, UST = kPfbUst;
     constexpr int NI = R == 0 ? 3 : 2;                           // noise instants of this parity: 0,2,4 / 1,3
     constexpr int NN = R == 0 ? 25 : 22;                         // march steps: max(12 + 7, s_last + 15)
-    constexpr int LA = 4;                                        // LDS reads in flight ahead of the arithmetic
+    constexpr int LA = (OPT & 2) ? 8 : 4;                        // LDS reads in flight ahead of the arithmetic
     // Sample-major: a sample is read once and feeds, at once, every sum it belongs to -- up to seven channel instants
     // (tap n - tau of instant tau) and up to three squelch instants (tap n - s_i).  No register window; the live state is
     // the (at most) seven + three accumulators, and neighbouring sums are independent work for the VALU.
@@ -108,7 +108,11 @@ __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &
         for (int tau = 0; tau < NT / 2; tau++) {
             const int q = n - tau;
             if (q == 0) u[tau] = mk(0.f, 0.f);
-            if (q >= 0 && q < Q) { u[tau] = chan_mac<REAL>(a, q, zn, u[tau]); last = u[tau].y; }
+            if (q >= 0 && q < Q) {
+                if (REAL && (OPT & 4)) u[tau] = a.re[q] * zn + u[tau];       // packed form (A/B of the issue rates)
+                else u[tau] = chan_mac<REAL>(a, q, zn, u[tau]);
+                last = u[tau].y;
+            }
             if (q == Q - 1) U[(2 * tau + R) * UST + pp] = u[tau];
         }
         if (n + LA < NN) {
@@ -120,7 +124,8 @@ __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &
     for (int k = 0; k < NI; k++) U[(NT + R + 2 * k) * UST + pp] = acc[k];
 }
 
-template <int NTH, bool REAL, int KT>
+// OPT (experiments, A/B on the device): 1 = epilogue not fenced, 2 = march reads 8 steps ahead, 4 = packed channel MACs
+template <int NTH, bool REAL, int KT, int OPT = 0>
 __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbParams p)
 {
     static_assert(NTH == 256 || NTH == 320, "lane roles are laid out for four or five waves");
@@ -248,6 +253,16 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         }
     };
 
+    // optional per-phase cycle sums, per wave (BTGPU_PFB_PROF diagnostics; scripts/pfb_phases.py): slot k of wave w of this
+    // workgroup = cycles from the previous mark to mark k, barrier waits included
+    unsigned long long tprev = p.prof ? clock64() : 0ULL;
+    auto mark = [&](int k) {
+        if (p.prof) {
+            const unsigned long long now = clock64();
+            if ((l0 & 63) == 0) p.prof[((size_t)blockIdx.x * (NTH / 64) + (l0 >> 6)) * 8 + k] += now - tprev;
+            tprev = now;
+        }
+    };
     const int shift = (int)((p.x0 - DH) & 1LL);                  // the span starts at an even sample: same for every tile (DH TT is even)
     const int np = p.n_period;
     if (interior(tu0 - p.pre_tiles)) load_span(tu0 - p.pre_tiles, l0);
@@ -269,6 +284,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
             if (PER > 4) put(4, v4); if (PER > 5) put(5, v5);
         } else stage_edge(tile, l);
         __syncthreads();
+        mark(0);
         // the next tile's input: in flight under this tile's arithmetic
         if (tu + 1 < tu1 && interior(tile + 1)) load_span(tile + 1, l);
         // de-rotation factors of this lane's squelch outputs (consumed at the end of the tile)
@@ -288,10 +304,11 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         if (a_on) {
             const cf *z = xs + shift + DH * a_r + a_pp;
             // (pre-tiles, tile < 0: their channel rows are garbage nobody reads -- no branch inside the march)
-            if (a_r == 0) march_branch<0, REAL>(z, a, an, U, a_pp);      // wave-uniform
-            else march_branch<1, REAL>(z, a, an, U, a_pp);
+            if (a_r == 0) march_branch<0, REAL, OPT>(z, a, an, U, a_pp);      // wave-uniform
+            else march_branch<1, REAL, OPT>(z, a, an, U, a_pp);
         }
         __syncthreads();
+        mark(1);
 
         // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100}, in place ----
 #pragma unroll
@@ -311,6 +328,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
             }
         }
         __syncthreads();
+        mark(2);
 
         // ---- phase B2: DFT over p2.  Channel rows: bin m = m1 + 10 m2 -> Y[row][m]; squelch rows stay in place ----
 #pragma unroll
@@ -334,6 +352,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
             }
         }
         __syncthreads();
+        mark(3);
 
         // ---- phase C: squelch stage-1 bins (fetched now, stored after the channel epilogue) ----
         cf nz_val[NZT];
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                     dcolp[k] = ang;
                 }
                 yb = ya; ya = yn;
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(OPT & 1)) __builtin_amdgcn_sched_barrier(0);
             }
             s_part[(e_chunk * 80 + e_c) * 2 + 0] = sum;
             s_part[(e_chunk * 80 + e_c) * 2 + 1] = head;
@@ -396,7 +415,8 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
             if (i < p.nsel * NU && u >= 0 && u < p.n_T)
                 ((cf *)p.n_Z)[(size_t)(i / NU) * p.n_zstride + u] = cmulf(nz_val[j], nz_rot[j]);
         }
-        __syncthreads();                                         // angle tiles complete; Y (= the span region) is dead
+        __syncthreads();
+        mark(4);                                         // angle tiles complete; Y (= the span region) is dead
     }
     if (tu1 - 1 - p.pre_tiles >= 0) copy_out(tu1 - 1 - p.pre_tiles, l0);
 }

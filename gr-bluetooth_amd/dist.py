@@ -58,60 +58,43 @@ def sort_hits(ints, snr):
     return ints[order], snr[order]
 
 
-def gather_hits(ints, snr, group=None, device="cpu"):
-    """Gather every rank's hit records; every rank returns the globally sorted (ints, snr).
-
-    Uses two all_gathers (counts, then records padded to the maximum count): fixed-size,
-    latency-bound traffic of tens of bytes per detected packet."""
-    import torch
-    import torch.distributed as dist
-
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return sort_hits(ints, snr)
-    world = dist.get_world_size(group)
-    n = torch.tensor([len(ints)], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    m = max(max(counts), 1)
-    nf = len(HIT_INT_FIELDS)
-    pad_i = torch.zeros((m, nf), dtype=torch.int64, device=device)
-    pad_s = torch.zeros((m,), dtype=torch.float64, device=device)
-    if len(ints):
-        pad_i[:len(ints)] = torch.from_numpy(np.ascontiguousarray(ints)).to(device)
-        pad_s[:len(ints)] = torch.from_numpy(np.ascontiguousarray(snr)).to(device)
-    all_i = [torch.zeros_like(pad_i) for _ in range(world)]
-    all_s = [torch.zeros_like(pad_s) for _ in range(world)]
-    dist.all_gather(all_i, pad_i, group=group)
-    dist.all_gather(all_s, pad_s, group=group)
-    gi = np.concatenate([all_i[r][:counts[r]].cpu().numpy() for r in range(world)], axis=0)
-    gs = np.concatenate([all_s[r][:counts[r]].cpu().numpy() for r in range(world)], axis=0)
-    return sort_hits(gi, gs)
-
-
 class HitGatherer:
     """One collective per batch: every rank contributes a fixed-size int64 block
     [1 + cap, 8] -- row 0 = (number of records this round, number still to come), rows 1.. =
-    the seven integer fields and the bits of snr_db -- to one asynchronous all_gather.  Nothing
-    about sizes crosses the host beforehand (no counts exchange, no .item()); post() returns at
-    once and collect() of the PREVIOUS post is called while the next batch computes.  More than
-    `cap` records in a batch (rare) spill into extra rounds that every rank agrees on from the
-    headers it received."""
+    the seven integer fields and the bits of snr_db -- to one asynchronous all_gather into ONE
+    stacked receive buffer [world, 1 + cap, 8].  Nothing about sizes crosses the host beforehand (no
+    counts exchange, no .item()); post() returns at once and collect() of the PREVIOUS post is
+    called while the next batch computes.  More than `cap` records in a batch (rare) spill into
+    extra rounds that every rank agrees on from the headers it received.
 
-    def __init__(self, cap=8192, device="cpu", group=None):
+    With a device (backend nccl = RCCL) the whole exchange lives on a stream of its own: the block is
+    packed into a pinned host buffer, copied to the device, gathered, and the stacked result comes
+    back with a single device-to-host copy -- the compute streams of the handle are never touched.
+    force=True runs the collective even in a one-rank group (the single-GPU first-contact test of
+    the RCCL path)."""
+
+    def __init__(self, cap=8192, device="cpu", group=None, force=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.cap, self.device = int(cap), device
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        self.world = dist.get_world_size(group) if self.on else 1
-        self.pending = None                 # (work handle, receive buffers)
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.on = inited and (self.world > 1 or force)
+        self.pending = None                 # (work handle, stacked receive buffer)
         self.backlog_i = np.zeros((0, len(HIT_INT_FIELDS)), np.int64)
         self.backlog_s = np.zeros((0,), np.float64)
         self.rounds = 0
+        self.on_device = str(device) != "cpu"
+        self.stream = None
+        if self.on and self.on_device:
+            self.stream = torch.cuda.Stream(device=device)
+            self.h_send = torch.zeros((1 + self.cap, 8), dtype=torch.int64).pin_memory()
+            self.h_recv = torch.zeros((self.world * (1 + self.cap), 8), dtype=torch.int64).pin_memory()
+            self.d_send = torch.zeros((1 + self.cap, 8), dtype=torch.int64, device=device)
+            self.d_recv = torch.zeros((self.world * (1 + self.cap), 8), dtype=torch.int64, device=device)
 
     def _pack(self):
-        torch = self.torch
         n = min(len(self.backlog_i), self.cap)
         blockh = np.zeros((1 + self.cap, 8), np.int64)
         blockh[0, 0] = n
@@ -120,28 +103,36 @@ class HitGatherer:
             blockh[1:1 + n, :7] = self.backlog_i[:n]
             blockh[1:1 + n, 7] = self.backlog_s[:n].view(np.int64)
         self.backlog_i, self.backlog_s = self.backlog_i[n:], self.backlog_s[n:]
-        t = torch.from_numpy(blockh)
-        if str(self.device) != "cpu":
-            t = t.pin_memory().to(self.device, non_blocking=True)
-        return t
+        return blockh
 
     def post(self, ints, snr):
         """Queue this rank's new records and start the gather of one round."""
+        torch = self.torch
         if len(ints):
             self.backlog_i = np.concatenate([self.backlog_i, np.ascontiguousarray(ints, dtype=np.int64)], axis=0)
             self.backlog_s = np.concatenate([self.backlog_s, np.ascontiguousarray(snr, dtype=np.float64)], axis=0)
         if not self.on:
             return
         assert self.pending is None, "collect() the previous round first"
-        send = self._pack()
-        recv = [self.torch.empty_like(send) for _ in range(self.world)]
-        work = self.dist.all_gather(recv, send, group=self.group, async_op=True)
-        self.pending = (work, recv, send)
+        blockh = self._pack()
+        if self.on_device:
+            self.stream.synchronize()                    # the previous round's copies are done with the pinned buffers
+            self.h_send.numpy()[...] = blockh
+            with torch.cuda.stream(self.stream):
+                self.d_send.copy_(self.h_send, non_blocking=True)
+                work = self.dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group, async_op=True)
+            self.pending = (work, self.d_recv)
+        else:
+            send = torch.from_numpy(blockh)
+            recv = torch.empty((self.world * (1 + self.cap), 8), dtype=torch.int64)      # the blocks of all ranks, concatenated
+            work = self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+            self.pending = (work, recv, send)
         self.rounds += 1
 
     def collect(self, drain=False):
         """Records of the posted round from every rank, sorted (slot, channel, kind, offset).  With
         drain=True keeps going (synchronously) until no rank has records left."""
+        torch = self.torch
         if not self.on:
             i, s = self.backlog_i, self.backlog_s
             self.backlog_i, self.backlog_s = i[:0], s[:0]
@@ -150,12 +141,20 @@ class HitGatherer:
         while True:
             if self.pending is None:
                 self.post(self.backlog_i[:0], self.backlog_s[:0])
-            work, recv, _send = self.pending
-            work.wait()
+            work, recv = self.pending[0], self.pending[1]
+            if self.on_device:
+                with torch.cuda.stream(self.stream):
+                    work.wait()                          # orders the gather stream behind the collective
+                    self.h_recv.copy_(recv, non_blocking=True)       # ONE copy of the stacked blocks
+                self.stream.synchronize()
+                blocks = self.h_recv.numpy().reshape(self.world, 1 + self.cap, 8)
+            else:
+                work.wait()
+                blocks = recv.numpy().reshape(self.world, 1 + self.cap, 8)
             self.pending = None
             more = False
             for r in range(self.world):
-                blk = recv[r].cpu().numpy()
+                blk = blocks[r]
                 n = int(blk[0, 0])
                 more = more or blk[0, 1] > 0
                 if n:

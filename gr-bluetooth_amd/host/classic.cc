@@ -619,54 +619,69 @@ int basic_rate_piconet::hop(uint32_t clock)
     return ch;
 }
 
-bool basic_rate_piconet::uap_from_header(classic_packet &pkt, std::string &out)
+// UAP / CLK1-6 discovery (what lib/piconet_impl.cc:433-517 does, on this class's own state).
+// State: bit k of d_clk6_alive = "if the FIRST packet was sent at CLK1-6 = k, every header seen so far checks out";
+// d_clk6_uap[k] = the UAP that hypothesis implies.  A packet seen `elapsed` slots after the first one is tested
+// under hypothesis k with clock (k + elapsed) mod 64: try_clock() gives the UAP that makes the HEC come out, and
+// the hypothesis survives if that is the UAP it already implied and crc_check() does not refute it.
+bool basic_rate_piconet::remember_hop(uint32_t clkn, int channel, std::string &out)
 {
-    const uint32_t clkn = pkt.clkn();
-    int starting = 0, remaining = 0, first_clock = 0;
-    if (!d_got_first_packet) d_first_pkt_time = clkn;
     if (d_packets_observed >= 1000) {              // MAX_PATTERN_LENGTH
         out += "Oops. More hops than we can remember.\n";
         reset(out);
         return false;
     }
     d_pattern_indices[d_packets_observed] = (int)(clkn - d_first_pkt_time);
-    d_pattern_channels[d_packets_observed] = (uint8_t)pkt.channel();
+    d_pattern_channels[d_packets_observed] = (uint8_t)channel;
     d_packets_observed++;
     d_total_packets_observed++;
-    // every possible clock value of the first packet
-    for (int count = 0; count < 64; count++) {
-        if (!(d_clock6_candidates[count] > -1 || !d_got_first_packet)) continue;
-        const int clock = (int)(((uint32_t)count + clkn - d_first_pkt_time) % 64);
-        starting++;
+    return true;
+}
+
+void basic_rate_piconet::lock_clk6(int k, uint8_t uap)
+{
+    d_clk_offset = (uint32_t)((k - (int)(d_first_pkt_time & 0x3f)) & 0x3f);
+    d_uap = uap;
+    d_have_clk6 = d_have_uap = true;
+}
+
+bool basic_rate_piconet::uap_from_header(classic_packet &pkt, std::string &out)
+{
+    const uint32_t clkn = pkt.clkn();
+    const bool first = !d_got_first_packet;
+    if (first) d_first_pkt_time = clkn;
+    if (!remember_hop(clkn, pkt.channel(), out)) return false;
+    const uint32_t elapsed = clkn - d_first_pkt_time;
+    const uint64_t tried = first ? ~0ull : d_clk6_alive;      // the first packet opens all 64 hypotheses
+    if (first) d_clk6_alive = ~0ull;
+    for (uint64_t todo = tried; todo; todo &= todo - 1) {
+        const int k = __builtin_ctzll(todo);
+        const int clock = (int)(((uint32_t)k + elapsed) & 63u);
         const uint8_t uap = pkt.try_clock(clock);
-        int verdict = -1;
-        if (!d_got_first_packet || uap == d_clock6_candidates[count]) verdict = pkt.crc_check(clock);
-        if (verdict == -1 || verdict == 0) {
-            d_clock6_candidates[count] = -1;
-        } else if (verdict == 1) {
-            d_clock6_candidates[count] = uap;
-            first_clock = count;
-            remaining++;
-        } else {
+        // crc_check: 0 refuted, 1 possible, > 1 payload CRC correct (proof); an inconsistent UAP refutes without looking
+        const int verdict = (first || uap == d_clk6_uap[k]) ? pkt.crc_check(clock) : 0;
+        if (verdict >= 2) {
+            // (the reference returns here before it marks the first packet as seen: kept, see
+            // tests/test_host_block_gpu.py::test_hopper_block_crc_success_quirk)
             appendf(out, "Correct CRC! UAP = 0x%x found after %d total packets.\n", uap, d_total_packets_observed);
-            d_clk_offset = (uint32_t)((count - (int)(d_first_pkt_time & 0x3f)) & 0x3f);
-            d_uap = uap;
-            d_have_clk6 = d_have_uap = true;
+            lock_clk6(k, uap);
             d_total_packets_observed = 0;
             return true;
         }
+        if (verdict == 1) d_clk6_uap[k] = uap;
+        else d_clk6_alive &= ~(1ull << k);
     }
     d_got_first_packet = true;
-    appendf(out, "reduced from %d to %d CLK1-6 candidates\n", starting, remaining);
-    if (remaining == 1) {
-        d_clk_offset = (uint32_t)((first_clock - (int)(d_first_pkt_time & 0x3f)) & 0x3f);
-        d_uap = (uint8_t)d_clock6_candidates[first_clock];
-        d_have_clk6 = d_have_uap = true;
+    const int before = __builtin_popcountll(tried), left = __builtin_popcountll(d_clk6_alive);
+    appendf(out, "reduced from %d to %d CLK1-6 candidates\n", before, left);
+    if (left == 1) {
+        const int k = __builtin_ctzll(d_clk6_alive);
+        lock_clk6(k, d_clk6_uap[k]);
         appendf(out, "We have a winner! UAP = 0x%x found after %d total packets.\n", d_uap, d_total_packets_observed);
         d_total_packets_observed = 0;
         return true;
     }
-    if (remaining == 0) reset(out);
+    if (left == 0) reset(out);
     return false;
 }
 

@@ -146,7 +146,10 @@ private:
     bool d_got_first_packet = false;
     int d_packets_observed = 0, d_total_packets_observed = 0;
     uint32_t d_first_pkt_time = 0;
-    int d_clock6_candidates[64] = {0};
+    uint64_t d_clk6_alive = ~0ull;        // CLK1-6 hypotheses of the first packet that still fit (bit k)
+    uint8_t d_clk6_uap[64] = {0};         // the UAP each hypothesis implies
+    bool remember_hop(uint32_t clkn, int channel, std::string &out);
+    void lock_clk6(int k, uint8_t uap);
     uint32_t d_clk_offset = 0;
     uint8_t d_uap = 0;
     uint16_t d_nap = 0;

@@ -304,7 +304,7 @@ def add_burst(iq, bits, start, sample_rate, center_freq, channel, rng, cfo_hz=10
 
 def make_capture(sample_rate, center_freq, n_slots, laps=(0x24D952,), seed=1, snr_db=25.0,
                  occupancy=0.3, cfo_hz=10e3, max_payload_bits=240, extra_slots=0.0,
-                 channels=None, noise=True, amplitude=1.0):
+                 channels=None, noise=True, amplitude=1.0, cfo_offset_hz=0.0):
     """Return (iq complex64 [n_slots*slot], truth list of dicts).
 
     snr_db is signal power over the noise power in 1 MHz.  Each piconet (LAP)
@@ -337,7 +337,8 @@ def make_capture(sample_rate, center_freq, n_slots, laps=(0x24D952,), seed=1, sn
             bits = packet_bits(lap, rng, nb)
             start = k * slot + int(rng.integers(5 * sps, 15 * sps))
             bb = gfsk_baseband(bits, sps) * amplitude
-            f = (BASE_FREQUENCY + ch * 1e6 - center_freq) + float(rng.uniform(-cfo_hz, cfo_hz))
+            # carrier offset of the burst: cfo_offset_hz (the same for every burst: CFO sweeps) + uniform +-cfo_hz
+            f = (BASE_FREQUENCY + ch * 1e6 - center_freq) + float(rng.uniform(-cfo_hz, cfo_hz)) + float(cfo_offset_hz)
             ph0 = rng.uniform(0, 2 * np.pi)
             m = np.arange(len(bb))
             bb = bb * np.exp(1j * (2 * np.pi * f / sample_rate * m + ph0))

@@ -30,11 +30,25 @@ for _ in range(nb):
     blk.process_device(seg.data_ptr(), seg.shape[0], 0, S, left_margin=des.left_margin)
     blk.flush()
     blk.poll_arrays()
-c = blk.debug_fetch(9, 0, 0, 1 << 24).astype(np.float64).reshape(-1, 8).sum(axis=0)
-names = ["0 stage input", "A branch FIR (+noise)", "B1 DFT pass + twiddle", "B2 DFT pass -> Y", "C' noise bin loads",
-         "C epilogue (demod, sums) + Z stores + barrier", "copy-out d / dcol + tile sums", "-"]
-tot = c.sum()
-for n, v in zip(names, c):
-    print("%-24s %6.2f %%" % (n, 100.0 * v / tot))
+raw = blk.debug_fetch(9, 0, 0, 1 << 24).astype(np.float64).reshape(-1, 8)
+variant = os.environ.get("BTGPU_BANK", "run256")
+if variant in ("legacy", "wide"):
+    c = raw.sum(axis=0)
+    names = ["0 stage input", "A branch FIR (+noise)", "B1 DFT pass + twiddle", "B2 DFT pass -> Y", "C' noise bin loads",
+             "C epilogue (demod, sums) + Z stores + barrier", "copy-out d / dcol + tile sums", "-"]
+    tot = c.sum()
+    for n, v in zip(names, c):
+        print("%-24s %6.2f %%" % (n, 100.0 * v / tot))
+else:
+    # pfb100f_kernel: [workgroup][wave][8]; marks 0..4 = cycles up to the barrier that ends: copy-out + staging | A | B1 | B2 | C
+    nw = 5 if variant == "run320" else 4
+    used = raw[: (len(raw) // nw) * nw].reshape(-1, nw, 8)
+    used = used[used[:, 0, :].sum(axis=1) > 0]
+    names = ["copy-out(n-1) + stage + barrier", "A march + barrier", "B1 + barrier", "B2 + barrier", "C epilogue + Z + barrier"]
+    tot = used[:, :, :5].sum(axis=(0, 2))
+    print("cycles per tile and wave (mean over %d workgroups x %d tiles):" % (len(used), 5 * nb))
+    for k, n in enumerate(names):
+        print("%-34s " % n + " ".join("w%d %7.0f (%4.1f %%)" % (w, used[:, w, k].sum() / len(used) / 5 / nb, 100 * used[:, w, k].sum() / tot[w]) for w in range(nw)))
+    print("tile life (cycles), per wave:", [round(float(t) / len(used) / 5 / nb) for t in tot])
 tm = blk.timing()
 print("ddc_channel avg ms %.4f (with marks enabled)" % (tm.kernel_ms[0] / max(tm.kernel_launches[0], 1)))

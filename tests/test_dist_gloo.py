@@ -54,7 +54,6 @@ def _worker(rank, world, port, tmp):
         for h in o.work(seg[k * slot: k * slot + H], first + k):
             hits.append(h)
     ints, snr = bd.hits_to_arrays(hits)
-    gi, gs = bd.gather_hits(ints, snr, device="cpu")
     # the bench's path: one fixed-size asynchronous all_gather per batch, here with a tiny capacity so
     # that records spill into further rounds, posted in two batches
     g = bd.HitGatherer(cap=3, device="cpu")
@@ -63,8 +62,13 @@ def _worker(rank, world, port, tmp):
     a_i, a_s = g.collect()
     g.post(ints[half:], snr[half:])
     b_i, b_s = g.collect(drain=True)
-    hi, hs = bd.sort_hits(np.concatenate([a_i, b_i], axis=0), np.concatenate([a_s, b_s], axis=0))
-    assert g.rounds >= 3 and np.array_equal(hi, gi) and np.array_equal(hs, gs)
+    gi, gs = bd.sort_hits(np.concatenate([a_i, b_i], axis=0), np.concatenate([a_s, b_s], axis=0))
+    assert g.rounds >= 3
+    # ... and in one round with room for everything: the same records
+    g2 = bd.HitGatherer(cap=4096, device="cpu")
+    g2.post(ints, snr)
+    hi, hs = g2.collect(drain=True)
+    assert g2.rounds == 1 and np.array_equal(hi, gi) and np.array_equal(hs, gs)
     if rank == 0:
         np.save(os.path.join(tmp, "gathered.npy"), gi)
     dist.barrier()

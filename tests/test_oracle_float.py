@@ -182,3 +182,23 @@ def test_edge_cases_empty_short_and_zero(po):
     hits, done = o.run_stream(np.zeros(0, np.complex64)); assert (hits, done) == ([], 0)
     hits, done = o.run_stream(np.zeros(4999, np.complex64)); assert (hits, done) == ([], 0)
     hits, done = o.run_stream(np.zeros(3 * 5000 + 17, np.complex64)); assert (hits, done) == ([], 3)   # NaN snr never passes
+
+
+def test_oracle_detection_falls_with_carrier_offset(po, synth):
+    """The reference slices at zero and removes no carrier offset (multi_block::slicer / demod,
+    lib/multi_block.cc:158-178): its detection probability falls with the burst's offset from the channel centre
+    and is gone at 75 kHz.  (This is why a capture with offsets uniform in +-75 kHz, SURVEY 8(d), is recalled
+    at ~56 % by the oracle and by the GPU alike; the GPU side of the statement is
+    tests/test_gpu_parity.py::test_cfo_sweep_gpu_equals_oracle.)"""
+    import os
+    fs, fc, S = 8e6, 2476.5e6, 40
+    o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    rec = {}
+    for cfo in (0.0, 40e3, 75e3):
+        iq, truth = synth.make_capture(fs, fc, S, laps=(0x24D952, 0x4831DD, 0x9E8B33, 0xABCDEF), seed=77, snr_db=25,
+                                       occupancy=0.6, cfo_hz=0.0, cfo_offset_hz=cfo)
+        hits, _ = o.run_stream(iq, max_hits=1 << 16, threads=min(os.cpu_count() or 1, 16))
+        seen = {(h.slot, h.channel, h.lap) for h in hits if h.kind == 0}
+        exp = [t for t in truth if t["slot"] + 7 < S]
+        rec[cfo] = sum(any((t["slot"] + 6 + d, t["channel"], t["lap"]) in seen for d in (-1, 0, 1)) for t in exp) / len(exp)
+    assert rec[0.0] >= 0.9 and rec[75e3] <= 0.05 and rec[75e3] < rec[40e3] < rec[0.0], rec
