@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--le", action="store_true", help="also run the le_packet::sniff_aa pass (BTGPU_FLAG_LE), as the C++ multi_sniffer block does")
     ap.add_argument("--no-block-config", action="store_true", help="skip the second timed region in the drop-in block's configuration (LE | HEADERS)")
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP events (BTGPU_FLAG_TIMING off): kernel traces without event records; roofline then has no kernel time")
+    ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per record-gather round (one fixed-size all_gather every that "
+                    "many batches and at the flush; measured on one GPU, scripts/gather_cost.py: a round per 2 ms batch costs 5-30 %% "
+                    "of the step depending on how RCCL's kernel lands beside the bank kernel, one per 8 batches nothing)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: still push the records through the HitGatherer collective (single-rank process group; first contact of the RCCL path on one GPU)")
     ap.add_argument("--sync", action="store_true", help="harvest every batch before the next one is enqueued (no tail overlap)")
     ap.add_argument("--channelizer", type=int, default=0)
@@ -195,6 +198,11 @@ def run_rank(args):
         ints, snr = bdist.struct_to_arrays(blk.poll_arrays())
         if not gathering or not gather:
             return ints, snr
+        # one round every --gather-every batches (every rank counts the same batches) and at the flush
+        step.count = getattr(step, "count", 0) + 1
+        if not last and step.count % max(1, args.gather_every):
+            gatherer.hold(ints, snr)
+            return ints[:0], snr[:0]
         got = gatherer.collect() if gatherer.pending is not None else (ints[:0], snr[:0])
         gatherer.post(ints, snr)
         if last:
@@ -434,7 +442,7 @@ def run_rank(args):
                        "occupancy": args.occupancy, "cfo_hz": args.cfo_hz, "max_payload_bits": args.max_payload_bits,
                        "mode": "multi_sniffer",
                        "partition": "time x%d, halo %d + margin %d samples" % (world, H - 1, margin),
-                       "gather": ("one async all_gather_into_tensor per batch (%s, own stream), %d rounds" % (args.backend, gatherer.rounds)) if gathering else "none",
+                       "gather": ("one async all_gather_into_tensor per %d batches (%s, own stream), %d rounds" % (args.gather_every, args.backend, gatherer.rounds)) if gathering else "none",
                        "flags": "ASYNC%s%s%s" % ("|LE" if args.le else "", "|HEADERS" if args.headers else "", "" if args.no_timing else "|TIMING"),
                        "channelizer": {1: "direct", 2: "polyphase"}[int(des.channelizer)],
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},

@@ -155,8 +155,14 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     // ---- the run of tiles of this workgroup (XCD-aware: neighbouring runs share their halo in one L2) ----
     const int ntl = p.ntiles + p.pre_tiles;                      // pre-tiles own squelch instants only
     const int nruns = (ntl + KT - 1) / KT;
-    const int tu0 = xcd_remap(blockIdx.x, nruns) * KT;
-    const int tu1 = tu0 + KT < ntl ? tu0 + KT : ntl;
+    // Tile k of this workgroup is tu0 + k nruns: at any moment the resident workgroups work on (about) CONSECUTIVE tiles,
+    // like one-tile workgroups would -- so the filter-length overlap of neighbouring input spans is read by neighbours at
+    // the same time (L2 hit) and the partial cache lines of Z that neighbouring tiles share are merged in the L2.  With a
+    // workgroup walking consecutive tiles instead, both reuses lie a whole tile time apart, which the L2 (4 MB per XCD)
+    // does not bridge under this kernel's streaming: measured 1.7-2.1 GB fetched for 1.15 GB of input and 3.2 GB written
+    // for 2.4 (profiles/r03_e_pmc_hbm.json, r03_f).  The XCD remap keeps each XCD on one contiguous stretch per step.
+    const int tu0 = xcd_remap(blockIdx.x, nruns);
+    const int tstep = nruns;
 
     // ---- what a lane FETCHES for its roles, once per workgroup (what it can compute is recomputed per tile) ----
     ChanTaps<REAL> a;
@@ -235,11 +241,14 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     auto copy_out = [&](int tile, int l) {
         const long long g1 = (long long)tile * TT;                               // first owned instant
         const long long rows = p.T - g1 < TT ? p.T - g1 : TT;                    // ... inside the stream
-        float4 *dst = (float4 *)(p.d + (size_t)g1 * 80);
-        for (int i = l; i < (int)rows * 20; i += NTH) dst[i] = ((const float4 *)s_d)[i];
+        // streaming stores (non-temporal): 16 KB per tile that nobody reads before the next kernel -- kept out of the L2
+        // they would otherwise flush the input overlap of the next tile and the half-written lines of Z out of
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 *dst = (f4 *)(p.d + (size_t)g1 * 80);
+        for (int i = l; i < (int)rows * 20; i += NTH) __builtin_nontemporal_store(((const f4 *)s_d)[i], dst + i);
         if (p.dcol) {
-            float4 *dc = (float4 *)(p.dcol + (size_t)tile * (80 * TT));
-            for (int i = l; i < TT * 20; i += NTH) dc[i] = ((const float4 *)s_dc)[i];
+            f4 *dc = (f4 *)(p.dcol + (size_t)tile * (80 * TT));
+            for (int i = l; i < TT * 20; i += NTH) __builtin_nontemporal_store(((const f4 *)s_dc)[i], dc + i);
         }
         if (l < p.nsel) {
             double sum = 0.0, head = 0.0;
@@ -266,7 +275,8 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     const int shift = (int)((p.x0 - DH) & 1LL);                  // the span starts at an even sample: same for every tile (DH TT is even)
     const int np = p.n_period;
     if (interior(tu0 - p.pre_tiles)) load_span(tu0 - p.pre_tiles, l0);
-    for (int tu = tu0; tu < tu1; tu++) {
+    int prev_tile = -1;                                          // the tile whose results are waiting in LDS (copy-out)
+    for (int tu = tu0; tu < ntl; tu += tstep) {
         const int tile = tu - p.pre_tiles;
         const long long t0 = (long long)tile * TT - 1;           // global instant of local row 0 (the halo instant)
         const int nz_u0 = p.n_u0 + NU * tile;                    // first squelch instant owned by this tile
@@ -277,7 +287,8 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         const int e_chunk = l / 80, e_c = l - 80 * e_chunk;
         const bool e_on = e_chunk < CH && e_c < p.nsel;
         // ---- input span + twiddles -> LDS; the previous tile's results leave in the same barrier interval ----
-        if (tu > tu0 && tile - 1 >= 0) copy_out(tile - 1, l);
+        if (prev_tile >= 0) copy_out(prev_tile, l);
+        prev_tile = tile;
         if (interior(tile)) {
             auto put = [&](int j, const float4 &q) { const int i = l + j * NTH; if (i < N4) ((float4 *)xs)[i] = q; };
             put(0, v0); if (PER > 1) put(1, v1); if (PER > 2) put(2, v2); if (PER > 3) put(3, v3);
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         __syncthreads();
         mark(0);
         // the next tile's input: in flight under this tile's arithmetic
-        if (tu + 1 < tu1 && interior(tile + 1)) load_span(tile + 1, l);
+        if (tu + tstep < ntl && interior(tile + tstep)) load_span(tile + tstep, l);
         // de-rotation factors of this lane's squelch outputs (consumed at the end of the tile)
         cf nz_rot[NZT];
         {
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         __syncthreads();
         mark(4);                                         // angle tiles complete; Y (= the span region) is dead
     }
-    if (tu1 - 1 - p.pre_tiles >= 0) copy_out(tu1 - 1 - p.pre_tiles, l0);
+    if (prev_tile >= 0) copy_out(prev_tile, l0);
 }
 
 }  // namespace btgpu

@@ -59,7 +59,8 @@ def sort_hits(ints, snr):
 
 
 class HitGatherer:
-    """One collective per batch: every rank contributes a fixed-size int64 block
+    """One collective per round (a round = one batch, or every few batches: the caller's cadence -- all ranks must use the
+    same one): every rank contributes a fixed-size int64 block
     [1 + cap, 8] -- row 0 = (number of records this round, number still to come), rows 1.. =
     the seven integer fields and the bits of snr_db -- to one asynchronous all_gather into ONE
     stacked receive buffer [world, 1 + cap, 8].  Nothing about sizes crosses the host beforehand (no
@@ -87,6 +88,7 @@ class HitGatherer:
         self.rounds = 0
         self.on_device = str(device) != "cpu"
         self.stream = None
+        self.done = None
         if self.on and self.on_device:
             self.stream = torch.cuda.Stream(device=device)
             self.h_send = torch.zeros((1 + self.cap, 8), dtype=torch.int64).pin_memory()
@@ -105,22 +107,34 @@ class HitGatherer:
         self.backlog_i, self.backlog_s = self.backlog_i[n:], self.backlog_s[n:]
         return blockh
 
-    def post(self, ints, snr):
-        """Queue this rank's new records and start the gather of one round."""
-        torch = self.torch
+    def hold(self, ints, snr):
+        """Queue this rank's new records for the next round (no collective)."""
         if len(ints):
             self.backlog_i = np.concatenate([self.backlog_i, np.ascontiguousarray(ints, dtype=np.int64)], axis=0)
             self.backlog_s = np.concatenate([self.backlog_s, np.ascontiguousarray(snr, dtype=np.float64)], axis=0)
+
+    def post(self, ints, snr):
+        """Queue this rank's new records and start the gather of one round."""
+        torch = self.torch
+        self.hold(ints, snr)
         if not self.on:
             return
         assert self.pending is None, "collect() the previous round first"
         blockh = self._pack()
         if self.on_device:
-            self.stream.synchronize()                    # the previous round's copies are done with the pinned buffers
+            # the whole round is enqueued here, on the gatherer's stream: pack -> device, the collective, the stacked blocks
+            # back to pinned memory, one event.  collect() then only waits for that event -- a whole batch later, when
+            # it has long fired -- instead of enqueueing a copy and waiting for it on the spot.
+            if self.done is not None:
+                self.done.synchronize()                  # (the previous round is through with the pinned buffers)
             self.h_send.numpy()[...] = blockh
             with torch.cuda.stream(self.stream):
                 self.d_send.copy_(self.h_send, non_blocking=True)
                 work = self.dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group, async_op=True)
+                work.wait()                              # orders this stream behind the collective (no host wait)
+                self.h_recv.copy_(self.d_recv, non_blocking=True)    # ONE copy of the stacked blocks
+                self.done = torch.cuda.Event()
+                self.done.record(self.stream)
             self.pending = (work, self.d_recv)
         else:
             send = torch.from_numpy(blockh)
@@ -143,10 +157,7 @@ class HitGatherer:
                 self.post(self.backlog_i[:0], self.backlog_s[:0])
             work, recv = self.pending[0], self.pending[1]
             if self.on_device:
-                with torch.cuda.stream(self.stream):
-                    work.wait()                          # orders the gather stream behind the collective
-                    self.h_recv.copy_(recv, non_blocking=True)       # ONE copy of the stacked blocks
-                self.stream.synchronize()
+                self.done.synchronize()
                 blocks = self.h_recv.numpy().reshape(self.world, 1 + self.cap, 8)
             else:
                 work.wait()

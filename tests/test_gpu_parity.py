@@ -675,7 +675,7 @@ def test_bench_two_ranks_on_one_device_equal_one_rank(tmp_path):
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert (j1["n_gpus"], j2["n_gpus"]) == (1, 2)
-    assert j2["config"]["gather"].startswith("one async all_gather_into_tensor per batch")
+    assert j2["config"]["gather"].startswith("one async all_gather_into_tensor per 8 batches")
     assert j1["parity"]["hits"] > 40
     assert j1["parity"]["hits"] == j2["parity"]["hits"]
     assert j1["parity"]["records_sha256"] == j2["parity"]["records_sha256"]
@@ -775,14 +775,14 @@ def test_no_nsym_flag_skips_the_continuation(pkg, synth):
     """BTGPU_FLAG_NO_NSYM (what the C++ multi_LAP block sets: it prints the LAP and nothing that depends on the rest of
     the window, lib/multi_LAP_impl.cc:93-110): the same records on (slot, channel, kind, offset, LAP, ac_errors); nsym is
     the default path's value where the window ended inside the detection span, else -1 -- and finish_kernel never ran."""
-    fs, fc, S = 100e6, 2441e6, 12
-    iq, _ = synth.make_capture(fs, fc, S, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=5, snr_db=24, occupancy=0.7)
+    fs, fc, S = 100e6, 2441e6, 16
+    iq, _ = synth.make_capture(fs, fc, S, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=5, snr_db=24, occupancy=0.7, cfo_hz=5e3)
     for mk in (lambda **kw: pkg.multi_sniffer(fs, fc, 10.0, False, **kw), lambda **kw: pkg.multi_LAP(fs, fc, 10.0, **kw)):
         a = mk(flags=pkg.FLAG_TIMING)
         a.push(iq); full = _keys(a.poll()); ta = a.timing(); a.close()
         b = mk(flags=pkg.FLAG_NO_NSYM | pkg.FLAG_TIMING)
         b.push(iq); lean = _keys(b.poll()); tb = b.timing(); b.close()
-        assert len(full) > 10 and [k[:6] for k in lean] == [k[:6] for k in full]
+        assert len(full) >= 8 and [k[:6] for k in lean] == [k[:6] for k in full]
         assert all(l[6] in (-1, f[6]) for l, f in zip(lean, full))
         assert any(l[6] == -1 for l in lean) or all(f[6] < 700 for f in full)
         assert tb.kernel_ms[pkg.KERNEL_NAMES.index("finish")] <= ta.kernel_ms[pkg.KERNEL_NAMES.index("finish")]
@@ -798,7 +798,7 @@ def test_rccl_gather_path_single_rank(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu",
-            "--prewarm-ms", "5", "--occupancy", "0.5", "--slots", "96", "--no-block-config"]
+            "--prewarm-ms", "5", "--occupancy", "0.5", "--slots", "96", "--no-block-config", "--gather-every", "1"]
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -810,7 +810,7 @@ def test_rccl_gather_path_single_rank(tmp_path):
     j0 = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
     j1 = json.loads([l for l in forced.stdout.splitlines() if l.startswith("{")][-1])
     assert j0["config"]["gather"] == "none"
-    assert j1["config"]["gather"].startswith("one async all_gather_into_tensor per batch (nccl, own stream)")
+    assert j1["config"]["gather"].startswith("one async all_gather_into_tensor per 1 batches (nccl, own stream)")
     assert int(j1["config"]["gather"].split(",")[-1].split()[0]) >= 4          # one round per step at least
     assert j0["parity"]["hits"] > 80
     assert j1["parity"]["hits"] == j0["parity"]["hits"]
