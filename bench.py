@@ -71,9 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--le", action="store_true", help="also run the le_packet::sniff_aa pass (BTGPU_FLAG_LE), as the C++ multi_sniffer block does")
     ap.add_argument("--no-block-config", action="store_true", help="skip the second timed region in the drop-in block's configuration (LE | HEADERS)")
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP events (BTGPU_FLAG_TIMING off): kernel traces without event records; roofline then has no kernel time")
-    ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per record-gather round (one fixed-size all_gather every that "
+    ap.add_argument("--gather-every", type=int, default=4, help="N > 1: batches per record-gather round (one fixed-size all_gather every that "
                     "many batches and at the flush; measured on one GPU, scripts/gather_cost.py: a round per 2 ms batch costs 5-30 %% "
-                    "of the step depending on how RCCL's kernel lands beside the bank kernel, one per 8 batches nothing)")
+                    "of the step depending on how RCCL's kernel lands beside the bank kernel, one per several batches nothing; the block "
+                    "holds 4096 records per batch of the cadence, more spill into extra rounds)")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: still push the records through the HitGatherer collective (single-rank process group; first contact of the RCCL path on one GPU)")
     ap.add_argument("--sync", action="store_true", help="harvest every batch before the next one is enqueued (no tail overlap)")
     ap.add_argument("--channelizer", type=int, default=0)
@@ -182,7 +183,7 @@ def run_rank(args):
     n_complex = seg.shape[0]
     assert n_complex >= n_need and a0 == first * slot - (H - 1) - margin   # (the generator runs to the end of the last slot)
     torch.cuda.synchronize()
-    gatherer = bdist.HitGatherer(cap=8192, device=coll_device, force=args.force_gather)
+    gatherer = bdist.HitGatherer(cap=4096 * max(1, args.gather_every), device=coll_device, force=args.force_gather)
     gathering = world > 1 or args.force_gather
 
     def step(last=False, gather=True, blk=None):

@@ -20,7 +20,8 @@ constexpr int kBankThreadsF = 320;           // pfb100f_kernel: five waves per r
 // which kernel runs the fused C79 bank (launch_channel_bank)
 enum BankVariant { kBankLegacy = 0, kBankLegacyWide = 1, kBankRun256 = 2, kBankRun320 = 3,
                    kBankRun256b = 4, kBankRun256c = 5, kBankRun256d = 6,        // run256 with OPT 1 / 3 / 7 (pfb100f.hip.h)
-                   kBankRun256e = 7 };                                          // OPT 3, runs of ten tiles
+                   kBankRun256e = 7,                                            // OPT 3, runs of ten tiles
+                   kBankRun256a = 8 };                                          // OPT 0, five tiles (the first form)
 constexpr int kBankNT = 26;                 // channel instants per tile (25 new + 1 halo for the demod)
 constexpr int kNoiseNT = 10;                // instants per tile of the stand-alone noise stage 1
 
@@ -126,9 +127,13 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
             else if (variant == kBankRun256c && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 3>, nruns, kBankThreads, lds, p);
             else if (variant == kBankRun256d && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 7>, nruns, kBankThreads, lds, p);
             else if (variant == kBankRun256e && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 3>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);
+            else if (variant == kBankRun256a && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 0>, nruns, kBankThreads, lds, p);
             else {
-                if (bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT>, nruns, kBankThreads, lds, p);
-                else L(pfb100f_kernel<kBankThreads, false, kBankKT>, nruns, kBankThreads, lds, p);
+                // default: ten tiles per workgroup, epilogue left to the scheduler, march reads eight steps ahead, packed
+                // channel MACs (A/B on the device, profiles/r03_h_bank_times.txt: 1.355 against 1.380 ms for OPT 0 / five tiles)
+                const int nr10 = (grid + 2 * kBankKT - 1) / (2 * kBankKT);
+                if (bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, nr10, kBankThreads, lds, p);
+                else L(pfb100f_kernel<kBankThreads, false, 2 * kBankKT, 3>, nr10, kBankThreads, lds, p);
             }
         } else if (wide) {
             if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreadsWide, true>, grid, kBankThreadsWide, lds, p);

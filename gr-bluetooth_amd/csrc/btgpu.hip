@@ -261,7 +261,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             const std::string v(e);
             return v == "legacy" ? (int)kBankLegacy : v == "wide" ? (int)kBankLegacyWide : v == "run320" ? (int)kBankRun320 :
                    v == "run256b" ? (int)kBankRun256b : v == "run256c" ? (int)kBankRun256c : v == "run256d" ? (int)kBankRun256d :
-                   v == "run256e" ? (int)kBankRun256e : (int)kBankRun256;
+                   v == "run256e" ? (int)kBankRun256e : v == "run256a" ? (int)kBankRun256a : (int)kBankRun256;
         }();
         ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, variant);
         tiles_per_block = ops / TT; tail_tiles = des.tail / TT;
@@ -332,8 +332,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     hipStream_t ps = pipelined ? post_stream : st;
     if (pipelined) HIPCHK(this, hipStreamWaitEvent(ps, t.front_done, 0));
     HIPCHK(this, mark(5, ps));
+    // (tile sums -> block sums stay in line: run on a side stream beside squelch stage 2 they saved their 0.05 ms and cost
+    // 0.4 ms per step in cross-stream dependencies -- 71.6 -> 59.5 Gsamples/s, profiles/r03_h)
+    hipStream_t bs = ps;
     if (use_pfb)
-        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, ps,
+        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, bs,
                            (const double *)t.d_ptile.p, (const double *)t.d_phead.p, ntiles, tiles_per_block,
                            tail_tiles, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     HIPCHK(this, mark(6, ps));
@@ -993,6 +996,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, kBankKT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, false, 2 * kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))
         fprintf(stderr, "btgpu_create: %d contexts, d=%p Z=%p ptile=%p\n", h->nctx, h->tc[0].d_d.p, h->tc[0].d_Z.p, h->tc[0].d_ptile.p);

@@ -82,10 +82,11 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);      // NaN pattern: reads of unwritten LDS show up
         emu::launch(dim3((unsigned)grid), dim3((unsigned)threads), [&]() { kern(p); });
     };
-    // fuse: 1 = fused, runs of tiles, five waves (the default); 4 = the same with four waves; 5 = the round-2 kernel, four
-    // waves per tile; 3 = the round-2 kernel, eight waves
-    const int variant = fuse == 3 ? kBankLegacyWide : fuse == 5 ? kBankLegacy : fuse == 4 ? kBankRun256 : fuse == 6 ? kBankRun256d :
-                        fuse == 7 ? kBankRun256e : kBankRun320;
+    // fuse: 1 = fused, the product's default (pfb100f_kernel, four waves, ten tiles per workgroup); 4 / 6 / 7 / 8 = its other
+    // forms (five tiles and fenced epilogue / packed channel MACs / ten tiles / five waves); 5 = the round-2 kernel,
+    // four waves per tile; 3 = the round-2 kernel, eight waves
+    const int variant = fuse == 3 ? kBankLegacyWide : fuse == 5 ? kBankLegacy : fuse == 4 ? kBankRun256a : fuse == 6 ? kBankRun256d :
+                        fuse == 7 ? kBankRun256e : fuse == 8 ? kBankRun320 : kBankRun256;
     const int ntiles = launch_channel_bank(des, fp, fuse == 1 || fuse >= 3, b, (size_t)x_len, w0, S, G, nb, L, variant);
     if (fuse == 2) launch_noise_bank(des, fp, b, (size_t)x_len, w0, S, L);
     // the tile-blocked copy finish_kernel reads must hold the very same angles: dcol[tile][c][r] == d[25 tile + r][c]

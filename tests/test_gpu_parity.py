@@ -675,7 +675,7 @@ def test_bench_two_ranks_on_one_device_equal_one_rank(tmp_path):
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert (j1["n_gpus"], j2["n_gpus"]) == (1, 2)
-    assert j2["config"]["gather"].startswith("one async all_gather_into_tensor per 8 batches")
+    assert j2["config"]["gather"].startswith("one async all_gather_into_tensor per 4 batches")
     assert j1["parity"]["hits"] > 40
     assert j1["parity"]["hits"] == j2["parity"]["hits"]
     assert j1["parity"]["records_sha256"] == j2["parity"]["records_sha256"]
