@@ -70,6 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--headers", action="store_true", help="also export hit symbols and run the GPU header sweep (BTGPU_FLAG_HEADERS), as the C++ multi_sniffer block does")
     ap.add_argument("--le", action="store_true", help="also run the le_packet::sniff_aa pass (BTGPU_FLAG_LE), as the C++ multi_sniffer block does")
     ap.add_argument("--no-block-config", action="store_true", help="skip the second timed region in the drop-in block's configuration (LE | HEADERS)")
+    ap.add_argument("--full-timing", action="store_true", help="HIP events around every kernel in the headline region too (kernel_avg_ms of all kernels)")
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP events (BTGPU_FLAG_TIMING off): kernel traces without event records; roofline then has no kernel time")
     ap.add_argument("--gather-every", type=int, default=4, help="N > 1: batches per record-gather round (one fixed-size all_gather every that "
                     "many batches and at the flush; measured on one GPU, scripts/gather_cost.py: a round per 2 ms batch costs 5-30 %% "
@@ -164,11 +165,16 @@ def run_rank(args):
     gen = dict(laps=laps, seed=args.seed, snr_db=args.snr, occupancy=args.occupancy, cfo_hz=args.cfo_hz,
                max_payload_bits=args.max_payload_bits)
 
-    base_flags = (0 if args.sync else pkg.FLAG_ASYNC) | (0 if args.no_timing else pkg.FLAG_TIMING)
+    base_flags = 0 if args.sync else pkg.FLAG_ASYNC
+    # HIP events in the timed region: around the channel-bank kernel only (the roofline's kernel; two records per batch) in
+    # the headline region, around every kernel (--full-timing, and always in the block_config region: eleven records per
+    # batch, measured at 2-3 % of the step)
+    head_timing = 0 if args.no_timing else (pkg.FLAG_TIMING if args.full_timing else pkg.FLAG_TIMING_BANK)
 
-    def make_block(extra):
+    def make_block(extra, timing=None):
         return pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
-                                 channelizer=args.channelizer, squelch=args.squelch_mode, flags=base_flags | extra)
+                                 channelizer=args.channelizer, squelch=args.squelch_mode,
+                                 flags=base_flags | extra | (head_timing if timing is None else timing))
     head_flags = (pkg.FLAG_HEADERS if args.headers else 0) | (pkg.FLAG_LE if args.le else 0)
     blk = make_block(head_flags)
     des = blk.design
@@ -286,7 +292,7 @@ def run_rank(args):
     block_cfg = None
     if world == 1 and not args.no_block_config and not (args.le and args.headers):
         blk.close()
-        blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS)
+        blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS, timing=0 if args.no_timing else pkg.FLAG_TIMING)
         b_el, b_ints, b_snr, _m, _f, b_kms, b_kl = timed_region(blk, gather=False)
         b_ints, b_snr = one_copy(b_ints, b_snr)
         block_cfg = {"flags": "BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS (what host/blocks.cc sets for multi_sniffer)",
@@ -324,7 +330,7 @@ def run_rank(args):
         # the dominant kernel is looked for on the critical path: in pipelined mode the tail
         # (finish_kernel) of batch n runs on its own stream underneath batch n+1
         crit = [i for i in range(NK) if not (names[i] == "finish" and not args.sync)]
-        dom = max(crit, key=lambda i: avg[i])
+        dom = max(crit, key=lambda i: avg[i])                  # (light timing: only ddc_channel is non-zero -- it is the dominant one)
         bytes_per_launch = 8.0 * S * slot                      # 8 B per complex input sample, read once
         ach = bytes_per_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         # algorithmic FMA per input sample of the direct-form banks
@@ -335,7 +341,8 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": round(avg[dom], 4),
                 "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(NK)},
-                "note": "ddc_channel = channel bank (+ noise stage 1 when fused); ddc_noise = 0 then"}
+                "note": "ddc_channel = channel bank (+ noise stage 1 when fused); ddc_noise = 0 then; without --full-timing only "
+                        "ddc_channel is bracketed in the headline region (block_config.kernel_avg_ms has every kernel)"}
         direct = (names[dom] == "ddc_channel" and int(des.channelizer) == 1) or \
                  (names[dom] == "ddc_noise" and int(des.squelch) == 1)
         if direct:                                  # direct-form banks are ALU-bound: report the fp32 rate too
@@ -444,7 +451,7 @@ def run_rank(args):
                        "mode": "multi_sniffer",
                        "partition": "time x%d, halo %d + margin %d samples" % (world, H - 1, margin),
                        "gather": ("one async all_gather_into_tensor per %d batches (%s, own stream), %d rounds" % (args.gather_every, args.backend, gatherer.rounds)) if gathering else "none",
-                       "flags": "ASYNC%s%s%s" % ("|LE" if args.le else "", "|HEADERS" if args.headers else "", "" if args.no_timing else "|TIMING"),
+                       "flags": "ASYNC%s%s%s" % ("|LE" if args.le else "", "|HEADERS" if args.headers else "", "" if args.no_timing else ("|TIMING" if args.full_timing else "|TIMING_BANK")),
                        "channelizer": {1: "direct", 2: "polyphase"}[int(des.channelizer)],
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},
             "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed],

@@ -77,7 +77,8 @@ struct btgpu_handle {
     int cur = 0, nctx = 1;
     int last_ctx = 0;                // context of the most recent batch (debug fetch)
     bool async = false;
-    bool timing_on = false;          // BTGPU_FLAG_TIMING: bracket the kernels with events (btgpu_last_timing)
+    bool timing_on = false;          // BTGPU_FLAG_TIMING / _BANK: bracket the kernels with events (btgpu_last_timing)
+    bool timing_full = false;        // every kernel (BTGPU_FLAG_TIMING), not just the channel bank
     bool no_nsym = false;            // BTGPU_FLAG_NO_NSYM: skip the M&M continuation that produces hit.nsym
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
     hipStream_t copy_stream = nullptr;
@@ -230,7 +231,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     DevBuf &d_winlen = t.d_winlen, &d_hits = t.d_hits, &d_hitcount = t.d_hitcount, &d_fin = t.d_fin, &d_d = t.d_d;
     DevBuf &d_winfin = t.d_winfin, &d_symbits = t.d_symbits;
     t.S = S; t.abs_first_slot = abs_first_slot;
-    auto mark = [&](int k, hipStream_t s_) -> hipError_t { return timing_on ? hipEventRecord(ev[k], s_) : hipSuccess; };
+    // BTGPU_FLAG_TIMING: every mark; BTGPU_FLAG_TIMING_BANK alone: only the two around the channel bank
+    auto mark = [&](int k, hipStream_t s_) -> hipError_t { return (timing_on && (timing_full || k <= 1)) ? hipEventRecord(ev[k], s_) : hipSuccess; };
 
     // =========================== FRONT (stream `st`): the banks ===========================
     // (The post stage runs behind it on the same stream unless BTGPU_PIPE=1, see btgpu_create.)
@@ -332,20 +334,27 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     hipStream_t ps = pipelined ? post_stream : st;
     if (pipelined) HIPCHK(this, hipStreamWaitEvent(ps, t.front_done, 0));
     HIPCHK(this, mark(5, ps));
-    // (tile sums -> block sums stay in line: run on a side stream beside squelch stage 2 they saved their 0.05 ms and cost
-    // 0.4 ms per step in cross-stream dependencies -- 71.6 -> 59.5 Gsamples/s, profiles/r03_h)
-    hipStream_t bs = ps;
-    if (use_pfb)
-        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, bs,
+    // tile sums -> block sums: as extra rows of the squelch stage-2 launch where both exist (a kernel of its own costs 0.05 ms
+    // of launch ramp and tail for microseconds of work; on a side stream it saved those and cost 0.4 ms per step in
+    // cross-stream dependencies -- 71.6 -> 59.5 Gsamples/s, profiles/r03_h_*)
+    const bool fused_sums = use_pfb && use_staged;
+    if (use_pfb && !fused_sums)
+        hipLaunchKernelGGL(block_sum_kernel, dim3((nb * nch + 3) / 4), dim3(256), 0, ps,
                            (const double *)t.d_ptile.p, (const double *)t.d_phead.p, ntiles, tiles_per_block,
                            tail_tiles, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     HIPCHK(this, mark(6, ps));
     if (use_staged) {
         const int run = ns.outs * (kS2Slots - 1) + ns.nw;
         const size_t lds2 = (size_t)((run + ns.L3 + 6) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
-        hipLaunchKernelGGL(noise_stage2_kernel, dim3((S + kS2Slots - 1) / kS2Slots, nch), dim3(256), lds2, ps,
+        BlockSumArgs bsa;
+        if (fused_sums) {
+            bsa.ptile = (const double *)t.d_ptile.p; bsa.phead = (const double *)t.d_phead.p; bsa.ntiles = ntiles;
+            bsa.tiles_per_block = tiles_per_block; bsa.tail_tiles = tail_tiles; bsa.P = (double *)d_P.p; bsa.Pt = (double *)d_Pt.p;
+            bsa.nb = nb; bsa.nch = nch; bsa.rows = kS2SumRows;
+        }
+        hipLaunchKernelGGL(noise_stage2_kernel, dim3((S + kS2Slots - 1) / kS2Slots, nch + bsa.rows), dim3(256), lds2, ps,
                            (const float2 *)t.d_Z.p, zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p,
-                           (const double *)d_w.p, (double *)d_Q.p, S);
+                           (const double *)d_w.p, (double *)d_Q.p, S, bsa);
     }
     HIPCHK(this, mark(7, ps));
 
@@ -477,12 +486,12 @@ int btgpu_handle::harvest(TailCtx &t)
         const bool blk = use_pfb;
         hipEvent_t a[6] = {t.ev[0], blk ? t.ev[5] : t.ev[1], t.ev[2], use_staged ? t.ev[6] : t.ev[3], t.ev[7], t.ev[9]};
         hipEvent_t e[6] = {t.ev[1], blk ? t.ev[6] : t.ev[2], t.ev[3], use_staged ? t.ev[7] : t.ev[4], t.ev[8], t.ev[10]};
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < (timing_full ? 6 : 1); i++) {
             HIPCHK(this, hipEventElapsedTime(&ms, a[i], e[i]));
             timing.kernel_ms[i] += ms;
             timing.kernel_launches[i] += 1;
         }
-        HIPCHK(this, hipEventElapsedTime(&ms, t.ev[0], t.ev[10])); timing.total_ms += ms;
+        if (timing_full) { HIPCHK(this, hipEventElapsedTime(&ms, t.ev[0], t.ev[10])); timing.total_ms += ms; }
     }
     timing.batches += 1;
     timing.slots += (uint64_t)t.S;
@@ -834,7 +843,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     h->async = (cfg->flags & BTGPU_FLAG_ASYNC) != 0;
     h->nctx = h->async ? btgpu_handle::kCtx : 1;
     if (getenv("BTGPU_CTX")) h->nctx = std::max(1, std::min((int)btgpu_handle::kCtx, atoi(getenv("BTGPU_CTX"))));   // A/B timing only
-    h->timing_on = (cfg->flags & BTGPU_FLAG_TIMING) != 0 || getenv("BTGPU_TIMING") != nullptr;
+    h->timing_full = (cfg->flags & BTGPU_FLAG_TIMING) != 0 || getenv("BTGPU_TIMING") != nullptr;
+    h->timing_on = h->timing_full || (cfg->flags & BTGPU_FLAG_TIMING_BANK) != 0;
     h->no_nsym = (cfg->flags & BTGPU_FLAG_NO_NSYM) != 0;
     // front(n+1) beside post(n) (BTGPU_PIPE=1; possible only where the front writes nothing but per-context buffers).
     // OFF by default -- measured (profiles/r03_a_*): with today's kernels the overlap LOSES.  Every one of them is

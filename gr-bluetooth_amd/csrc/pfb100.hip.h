@@ -655,11 +655,46 @@ __global__ __launch_bounds__(256) void block_sum_kernel(const double *__restrict
 // forms slot s's weighted sum in double.
 // ------------------------------------------------------------------------------------
 constexpr int kS2Slots = 8;
+// The tile sums -> block sums reduction (block_sum_kernel) rides along as `rows` extra rows of workgroups (blockIdx.y >= the
+// channel count): 0.05 ms of launch ramp and tail for a few microseconds of work when it runs as a kernel of its own.
+struct BlockSumArgs {
+    const double *ptile = nullptr, *phead = nullptr;
+    int ntiles = 0, tiles_per_block = 0, tail_tiles = 0;
+    double *P = nullptr, *Pt = nullptr;
+    int nb = 0, nch = 0;
+    int rows = 0;                    // extra grid rows that do this work (0: none)
+};
+constexpr int kS2SumRows = 8;
 __global__ __launch_bounds__(256) void noise_stage2_kernel(
     const float2 *__restrict__ Z, long long zstride, int outs, int nw, int L3,
-    const float *__restrict__ h3, const double *__restrict__ w, double *__restrict__ Qn, int S)
+    const float *__restrict__ h3, const double *__restrict__ w, double *__restrict__ Qn, int S, BlockSumArgs bs)
 {
     HIP_DYNAMIC_SHARED(float4, lds4)
+    if (bs.rows > 0 && (int)blockIdx.y >= (int)gridDim.y - bs.rows) {
+        // one wave per (channel, block), fixed shuffle tree: the arithmetic of block_sum_kernel, strided over the pairs
+        const int row = (int)blockIdx.y - ((int)gridDim.y - bs.rows);
+        const int nwaves = bs.rows * (int)gridDim.x * (int)(blockDim.x >> 6);
+        const int lane = threadIdx.x & 63;
+        for (int i = (row * (int)gridDim.x + (int)blockIdx.x) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); i < bs.nb * bs.nch; i += nwaves) {
+            const int c = i / bs.nb, b = i % bs.nb;
+            double s = 0.0, h = 0.0;
+            for (int k = lane; k < bs.tiles_per_block; k += 64) {
+                const int t = b * bs.tiles_per_block + k;
+                if (t < bs.ntiles) {
+                    const double v = bs.ptile[(size_t)c * bs.ntiles + t];
+                    s += v;
+                    if (k < bs.tail_tiles) h += v;
+                    else if (k == bs.tail_tiles) h += bs.phead[(size_t)c * bs.ntiles + t];
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); h += __shfl_down(h, off, 64); }
+            if (lane == 0) {
+                bs.P[(size_t)c * bs.nb + b] = s;
+                bs.Pt[(size_t)c * bs.nb + b] = h;
+            }
+        }
+        return;
+    }
     const int k0 = blockIdx.x * kS2Slots, c = blockIdx.y;
     const int ks = (S - k0) < kS2Slots ? (S - k0) : kS2Slots;        // slots in this run
     const int nout = outs * (ks - 1) + nw;                            // y^ needed

@@ -71,6 +71,8 @@ extern "C" {
 
 #define BTGPU_FLAG_TIMING    0x20       /* bracket the kernels of every batch with HIP events for btgpu_last_timing
                                            (off by default: eleven event records per batch are not free)     */
+#define BTGPU_FLAG_TIMING_BANK 0x80      /* the light form: events only around the channel-bank kernel (BTGPU_K_DDC_CHANNEL);
+                                           what bench.py's timed region uses for its roofline figure                */
 #define BTGPU_FLAG_NO_NSYM   0x40       /* LAP-list consumers (multi_LAP prints the LAP only, lib/multi_LAP_impl.cc:93-110):
                                            skip the clock-recovery continuation over the rest of a hit window that
                                            only produces hit.nsym; nsym is then -1 unless the window ended inside

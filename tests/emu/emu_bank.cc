@@ -324,7 +324,7 @@ extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double sq
         if (lds2 > sizeof emu::dyn_lds) return BTGPU_EUNSUPPORTED;
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
         emu::launch(dim3((unsigned)((S + kS2Slots - 1) / kS2Slots), (unsigned)nch), dim3(256), [&]() {
-            noise_stage2_kernel((const float2 *)Z.data(), zstride, ns.outs, ns.nw, ns.L3, ns.h3.data(), ns.weights.data(), Qn.data(), S);
+            noise_stage2_kernel((const float2 *)Z.data(), zstride, ns.outs, ns.nw, ns.L3, ns.h3.data(), ns.weights.data(), Qn.data(), S, BlockSumArgs{});
         });
     }
     return run_detect(des, S, nb, nch, drow, G, d, big ? dcol.data() : nullptr, P.data(), Pt.data(), Qn.data(), rec_out, snr_out, cap);
