@@ -275,7 +275,20 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     const int shift = (int)((p.x0 - DH) & 1LL);                  // the span starts at an even sample: same for every tile (DH TT is even)
     const int np = p.n_period;
     if (interior(tu0 - p.pre_tiles)) load_span(tu0 - p.pre_tiles, l0);
-    int prev_tile = -1;                                          // the tile whose results are waiting in LDS (copy-out)
+    int prev_tile = -1, prev_u0 = 0;                             // the tile whose results are waiting (LDS tiles, squelch outputs in registers)
+    bool prev_any = false;
+    static_assert(NZT <= 2, "two named register pairs carry the squelch outputs");
+    cf zv0 = mk(0.f, 0.f), zv1 = zv0, zr0 = zv0, zr1 = zv0;      // squelch bins of this lane and their de-rotation factors
+    auto flush_prev = [&](int ptile, int pu0, int l) {
+#pragma unroll
+        for (int j = 0; j < NZT; j++) {
+            const int i = l + j * NTH;
+            const int u = pu0 + i % NU;
+            if (i < p.nsel * NU && u >= 0 && u < p.n_T)
+                ((cf *)p.n_Z)[(size_t)(i / NU) * p.n_zstride + u] = cmulf(j == 0 ? zv0 : zv1, j == 0 ? zr0 : zr1);
+        }
+        if (ptile >= 0) copy_out(ptile, l);
+    };
     for (int tu = tu0; tu < ntl; tu += tstep) {
         const int tile = tu - p.pre_tiles;
         const long long t0 = (long long)tile * TT - 1;           // global instant of local row 0 (the halo instant)
@@ -286,20 +299,23 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         const bool a_on = a_pp < M && l < 256;
         const int e_chunk = l / 80, e_c = l - 80 * e_chunk;
         const bool e_on = e_chunk < CH && e_c < p.nsel;
-        // ---- input span + twiddles -> LDS; the previous tile's results leave in the same barrier interval ----
-        if (prev_tile >= 0) copy_out(prev_tile, l);
-        prev_tile = tile;
+        // ---- input span -> LDS, FIRST: the only vector-memory operations outstanding at this point are the prefetch loads
+        // issued a whole tile ago (and the two de-rotation factors behind them).  The previous tile's stores -- squelch
+        // outputs, angle tiles, tile sums -- are issued only now, behind the staging, in the same barrier interval: issued
+        // in front of it (as the epilogue's last act, round-3 first form) they sat between the loads and their s_waitcnt,
+        // and every tile waited for freshly issued HBM writes to retire.
         if (interior(tile)) {
             auto put = [&](int j, const float4 &q) { const int i = l + j * NTH; if (i < N4) ((float4 *)xs)[i] = q; };
             put(0, v0); if (PER > 1) put(1, v1); if (PER > 2) put(2, v2); if (PER > 3) put(3, v3);
             if (PER > 4) put(4, v4); if (PER > 5) put(5, v5);
         } else stage_edge(tile, l);
+        if (prev_any) flush_prev(prev_tile, prev_u0, l);
+        prev_tile = tile; prev_any = true;
         __syncthreads();
         mark(0);
         // the next tile's input: in flight under this tile's arithmetic
         if (tu + tstep < ntl && interior(tile + tstep)) load_span(tile + tstep, l);
-        // de-rotation factors of this lane's squelch outputs (consumed at the end of the tile)
-        cf nz_rot[NZT];
+        // de-rotation factors of this lane's squelch outputs (consumed when the outputs leave, at the top of the next tile)
         {
             const int ph0 = ((nz_u0 % np) + np) % np;            // block-uniform
 #pragma unroll
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                 const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
                 int ph = ph0 + i % NU;
                 ph = ph >= np ? ph - np : ph;
-                nz_rot[j] = ((const cf *)p.n_krot)[(size_t)(i / NU) * np + ph];
+                (j == 0 ? zr0 : zr1) = ((const cf *)p.n_krot)[(size_t)(i / NU) * np + ph];
             }
         }
 
@@ -366,12 +382,12 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         mark(3);
 
         // ---- phase C: squelch stage-1 bins (fetched now, stored after the channel epilogue) ----
-        cf nz_val[NZT];
 #pragma unroll
         for (int j = 0; j < NZT; j++) {
             const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
-            nz_val[j] = U[(NT + i % NU) * UST + nz_pos[j]];
+            (j == 0 ? zv0 : zv1) = U[(NT + i % NU) * UST + nz_pos[j]];
         }
+        prev_u0 = nz_u0;
         // channel epilogue (run sums and angle tiles go to the channel rows of U, dead since pass 2; the squelch rows
         // read above lie behind them), lane (run, c): <= RUN consecutive instants, the previous instant's bin in registers
         if (tile >= 0 && e_on) {
@@ -419,17 +435,10 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < NZT; j++) {
-            const int i = l + j * NTH;
-            const int u = nz_u0 + i % NU;
-            if (i < p.nsel * NU && u >= 0 && u < p.n_T)
-                ((cf *)p.n_Z)[(size_t)(i / NU) * p.n_zstride + u] = cmulf(nz_val[j], nz_rot[j]);
-        }
         __syncthreads();
         mark(4);                                         // angle tiles complete; Y (= the span region) is dead
     }
-    if (prev_tile >= 0) copy_out(prev_tile, l0);
+    if (prev_any) flush_prev(prev_tile, prev_u0, l0);
 }
 
 }  // namespace btgpu
