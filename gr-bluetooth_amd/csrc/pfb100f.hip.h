@@ -244,11 +244,19 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         // streaming stores (non-temporal): 16 KB per tile that nobody reads before the next kernel -- kept out of the L2
         // they would otherwise flush the input overlap of the next tile and the half-written lines of Z out of
         typedef float f4 __attribute__((ext_vector_type(4)));
+        // TT * 20 = 500 pieces of 16 bytes per layout, two per lane: the four LDS reads first, then the four stores (a loop
+        // with a run-time trip count would pay an LDS round trip in front of every store)
+        static_assert(TT * 20 <= 2 * NTH, "two pieces per lane");
+        const int n_d = (int)rows * 20, i1 = l + NTH;
+        const f4 a0 = ((const f4 *)s_d)[l], a1 = ((const f4 *)s_d)[i1 < TT * 20 ? i1 : l];
+        const f4 b0 = ((const f4 *)s_dc)[l], b1 = ((const f4 *)s_dc)[i1 < TT * 20 ? i1 : l];
         f4 *dst = (f4 *)(p.d + (size_t)g1 * 80);
-        for (int i = l; i < (int)rows * 20; i += NTH) __builtin_nontemporal_store(((const f4 *)s_d)[i], dst + i);
+        if (l < n_d) __builtin_nontemporal_store(a0, dst + l);
+        if (i1 < n_d) __builtin_nontemporal_store(a1, dst + i1);
         if (p.dcol) {
             f4 *dc = (f4 *)(p.dcol + (size_t)tile * (80 * TT));
-            for (int i = l; i < TT * 20; i += NTH) __builtin_nontemporal_store(((const f4 *)s_dc)[i], dc + i);
+            if (l < TT * 20) __builtin_nontemporal_store(b0, dc + l);
+            if (i1 < TT * 20) __builtin_nontemporal_store(b1, dc + i1);
         }
         if (l < p.nsel) {
             double sum = 0.0, head = 0.0;
