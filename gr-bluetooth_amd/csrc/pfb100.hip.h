@@ -655,8 +655,8 @@ __global__ __launch_bounds__(256) void block_sum_kernel(const double *__restrict
 // forms slot s's weighted sum in double.
 // ------------------------------------------------------------------------------------
 constexpr int kS2Slots = 8;
-// The tile sums -> block sums reduction (block_sum_kernel) rides along as `rows` extra rows of workgroups (blockIdx.y >= the
-// channel count): 0.05 ms of launch ramp and tail for a few microseconds of work when it runs as a kernel of its own.
+// The tile sums -> block sums reduction (block_sum_kernel) rides along as `rows` extra rows of workgroups (blockIdx.y < rows,
+// the channels follow): 0.05 ms of launch ramp and tail for a few microseconds of work when it runs as a kernel of its own.
 struct BlockSumArgs {
     const double *ptile = nullptr, *phead = nullptr;
     int ntiles = 0, tiles_per_block = 0, tail_tiles = 0;
@@ -670,9 +670,11 @@ __global__ __launch_bounds__(256) void noise_stage2_kernel(
     const float *__restrict__ h3, const double *__restrict__ w, double *__restrict__ Qn, int S, BlockSumArgs bs)
 {
     HIP_DYNAMIC_SHARED(float4, lds4)
-    if (bs.rows > 0 && (int)blockIdx.y >= (int)gridDim.y - bs.rows) {
+    if ((int)blockIdx.y < bs.rows) {
+        // (the FIRST rows of the grid: dispatched first, they run beside the stage-2 workgroups -- as the last rows they
+        // were a tail of their own and the launch took as long as the two kernels it replaced)
         // one wave per (channel, block), fixed shuffle tree: the arithmetic of block_sum_kernel, strided over the pairs
-        const int row = (int)blockIdx.y - ((int)gridDim.y - bs.rows);
+        const int row = (int)blockIdx.y;
         const int nwaves = bs.rows * (int)gridDim.x * (int)(blockDim.x >> 6);
         const int lane = threadIdx.x & 63;
         for (int i = (row * (int)gridDim.x + (int)blockIdx.x) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); i < bs.nb * bs.nch; i += nwaves) {
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(256) void noise_stage2_kernel(
         }
         return;
     }
-    const int k0 = blockIdx.x * kS2Slots, c = blockIdx.y;
+    const int k0 = blockIdx.x * kS2Slots, c = (int)blockIdx.y - bs.rows;
     const int ks = (S - k0) < kS2Slots ? (S - k0) : kS2Slots;        // slots in this run
     const int nout = outs * (ks - 1) + nw;                            // y^ needed
     const int need = nout + L3 - 1;                                   // stage-1 samples needed
