@@ -508,6 +508,22 @@ int btgpu_handle::harvest(TailCtx &t)
                                      sizeof(DeviceHit) * (count - kEagerHits), hipMemcpyDeviceToHost, spill_stream));
             HIPCHK(this, hipStreamSynchronize(spill_stream));
         }
+        // what the eager copies do not carry (more than kEagerFin hit windows / records in one batch: dense captures
+        // at the small rates) comes over in ONE bulk copy each -- not record by record with a synchronise apiece
+        std::vector<uint32_t> sym_spill;
+        std::vector<HeaderRec> hdr_spill;
+        const unsigned nfin = t.h_count[1];
+        if (want_syms && nfin > kEagerFin) {
+            sym_spill.resize((size_t)(nfin - kEagerFin) * kSymWords);
+            HIPCHK(this, hipMemcpyAsync(sym_spill.data(), (const uint32_t *)t.d_symbits.p + (size_t)kEagerFin * kSymWords,
+                                     sym_spill.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, spill_stream));
+        }
+        if (want_hdrs && count > kEagerFin) {
+            hdr_spill.resize(count - kEagerFin);
+            HIPCHK(this, hipMemcpyAsync(hdr_spill.data(), (const HeaderRec *)t.d_hdr.p + kEagerFin,
+                                     hdr_spill.size() * sizeof(HeaderRec), hipMemcpyDeviceToHost, spill_stream));
+        }
+        if (!sym_spill.empty() || !hdr_spill.empty()) HIPCHK(this, hipStreamSynchronize(spill_stream));
         size_t q0 = queue.size();
         size_t hi = 0;
         for (const DeviceHit &x : hh) {
@@ -527,11 +543,8 @@ int btgpu_handle::harvest(TailCtx &t)
                 if (x.sym >= 0) {
                     bits.resize(kSymWords);
                     if ((unsigned)x.sym < kEagerFin) std::memcpy(bits.data(), t.h_sym + (size_t)x.sym * kSymWords, kSymWords * sizeof(uint32_t));
-                    else {
-                        HIPCHK(this, hipMemcpyAsync(bits.data(), (const uint32_t *)t.d_symbits.p + (size_t)x.sym * kSymWords,
-                                                 kSymWords * sizeof(uint32_t), hipMemcpyDeviceToHost, spill_stream));
-                        HIPCHK(this, hipStreamSynchronize(spill_stream));
-                    }
+                    else if ((size_t)((unsigned)x.sym - kEagerFin + 1) * kSymWords <= sym_spill.size())
+                        std::memcpy(bits.data(), sym_spill.data() + (size_t)((unsigned)x.sym - kEagerFin) * kSymWords, kSymWords * sizeof(uint32_t));
                 }
                 qbits.push_back(std::move(bits));
             }
@@ -540,10 +553,7 @@ int btgpu_handle::harvest(TailCtx &t)
                 std::memset(&hd, 0, sizeof hd);
                 HeaderRec r;
                 if (hit_index < kEagerFin) r = t.h_hdr[hit_index];
-                else {
-                    HIPCHK(this, hipMemcpyAsync(&r, (const HeaderRec *)t.d_hdr.p + hit_index, sizeof r, hipMemcpyDeviceToHost, spill_stream));
-                    HIPCHK(this, hipStreamSynchronize(spill_stream));
-                }
+                else r = hdr_spill[hit_index - kEagerFin];
                 std::memcpy(hd.uap, r.uap, 64); std::memcpy(hd.type, r.type, 64); hd.fec13_ok = r.fec13_ok;
                 qhdr.push_back(hd);
             }
