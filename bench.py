@@ -9,16 +9,18 @@ is already resident in HBM.  Workload = BASELINE.json configs[2]: multi_sniffer,
 
 N > 1 (`--gpus N`): the stream is time-partitioned, rank r owns slots [r S, (r+1) S) plus a left
 halo of history()-1 (+ left_margin) samples, and the hit records travel to every rank with ONE
-asynchronous fixed-size all_gather per batch (RCCL over xGMI; gr-bluetooth_amd/dist.py
-HitGatherer) that overlaps the next batch -- weak scaling, per-rank slots fixed.  Started under
+asynchronous fixed-size all_gather_into_tensor per round -- every --gather-every batches and at the
+flush (RCCL over xGMI; gr-bluetooth_amd/dist.py HitGatherer, on a stream of its own) -- weak
+scaling, per-rank slots fixed.  Started under
 torchrun (WORLD_SIZE / RANK / LOCAL_RANK in the environment) each process is one rank; started
 plainly with --gpus N > 1 this script spawns its own N ranks, one device each, and FAILS if it
 cannot see N devices.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`,
-`cpu_baseline` and `parity` objects added.  `parity` (N = 1) is a differential of the records of
-one step against the CPU oracle run on all host cores over the first --parity-slots slots of
-the same capture (tests/paritylib.py).
+`cpu_baseline`, `parity` and (N = 1) `block_config` objects added.  `parity` is a differential of the
+records of one step against the CPU oracle run on all host cores over the first --parity-slots slots
+of the same capture (tests/paritylib.py); `block_config` = the same K steps with the flags the drop-in
+C++ block sets (LE pass, symbols, header sweep), with its own differential.
 """
 import argparse
 import collections

@@ -66,7 +66,8 @@ def _worker(rank, world, port, tmp):
     assert g.rounds >= 3
     # ... and in one round with room for everything: the same records
     g2 = bd.HitGatherer(cap=4096, device="cpu")
-    g2.post(ints, snr)
+    g2.hold(ints[:half], snr[:half])                                 # (a cadence of several batches: held, then posted together)
+    g2.post(ints[half:], snr[half:])
     hi, hs = g2.collect(drain=True)
     assert g2.rounds == 1 and np.array_equal(hi, gi) and np.array_equal(hs, gs)
     if rank == 0:
