@@ -1,5 +1,5 @@
 // pfb100f.hip.h -- the C79 hot kernel: 100-bin polyphase channelizer + squelch stage 1 + quadrature demod,
-// one workgroup = a RUN of KT consecutive tiles of 25 output instants (round 3).
+// one workgroup = a RUN of KT tiles of 25 output instants, taken with stride `nruns` (round 3).
 //
 // Same algebra and the same LDS layouts as pfb100_kernel<7,1,26,REAL,true,NTH,true> (pfb100.hip.h, which stays
 // the kernel of the non-fused banks): what the reference computes per channel with freq_xlating_fir_filter_ccf
@@ -8,19 +8,23 @@
 //
 //  * 23 % of a tile's life was the wait for its input span (and for ~30 per-lane table loads behind it), with only
 //    three tiles per CU to hide it.  Here a workgroup walks KT tiles: branch taps, lane roles and twiddles are
-//    fetched ONCE, and the input of tile n+1 is loaded into registers right after the first barrier of tile n --
-//    a whole tile of arithmetic lies between the loads and their first use.
+//    fetched ONCE, and the input of the next tile is loaded into registers right after the first barrier of the
+//    current one -- a whole tile of arithmetic lies between the loads and their first use.  Tile k of workgroup b
+//    is b + k * nruns (not b * KT + k): neighbouring tiles stay concurrent, so the input overlap of two tiles and
+//    the two halves of a shared Z line still meet in L2 (the consecutive order re-fetched 2.06 GB and wrote
+//    3.2 GB per launch; the strided one is back at 1.16 / 2.44 GB, profiles/r03_j_pmc_hbm.json).
 //  * Phase A read the staged input 3.3 times (channel branches once with a register window, the five noise
 //    instants of the tile 15 taps each straight from LDS: 7500 of the 10 750 eight-byte reads per tile).  The
 //    host now places the squelch stage-1 grid ON the channel grid (design_fast.cc: n_off = 0), so that noise
 //    instant i, branch p, tap q needs the sample the channel lane (p, r = i mod 2) holds at march step
 //    q + (5 i - r) / 2: one march of 25 (r = 0) / 22 (r = 1) reads per lane serves 13 channel instants and 3 / 2
 //    noise instants.
-//  * The 310 ten-point DFTs of a pass took two sweeps of 256 lanes, the second with 54 lanes.  NTH = 320 (five
-//    waves) takes each pass in one sweep and gives the epilogue four runs of <= 7 instants per channel instead of
-//    three of <= 9.  (NTH = 256 is kept for A/B.)
-//  * The copy-out of tile n shares a barrier interval with the staging of tile n+1: five barriers per tile
-//    instead of six.
+//  * The global stores of tile n (Z, d, dcol, tile sums) are issued behind the staging of tile n+1, so that the
+//    wait for the prefetched input never sits behind fresh stores; d / dcol / Z go out non-temporal.
+//  * NTH = 256 with three workgroups per CU (<= 168 VGPRs) is the default.  NTH = 320 (one sweep per DFT pass
+//    instead of two) is kept as BTGPU_BANK=run320 for A/B: it still spills and is slower (profiles/r03_h_*).
+//  * The lane index is laundered once per tile (BTGPU_OPAQUE): without it LICM hoists every per-phase address out
+//    of the tile loop and the kernel spills ~80 registers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,7 +35,7 @@
 
 namespace btgpu {
 
-constexpr int kBankKT = 5;                   // tiles per workgroup (a divisor of the 50 tiles of a slot is not required)
+constexpr int kBankKT = 5;                   // tiles per workgroup of the KT-5 variants (the default launches KT = 10)
 
 // One march of the staged input for branch pp and instant parity R (wave-uniform): channel instants 2 tau + R,
 // tau = 0..12, out of a 7-deep register window; noise instants i = R, R + 2, .. from the same samples:
