@@ -113,7 +113,10 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
         const int grid = p.ntiles + p.pre_tiles;
         // the run kernels share the march of the staged input between the two banks: the squelch grid must sit on
         // the channel grid (design_fast.cc aligns it for this geometry)
-        const bool run_ok = p.n_off == 0 && variant >= kBankRun256;
+        // (the run kernels address the squelch plane and the tile sums with 32-bit byte offsets from a uniform base)
+        const bool fits32 = (unsigned long long)p.nsel * (unsigned long long)p.n_zstride * 8ull < (1ull << 32) &&
+                            (unsigned long long)p.nsel * (unsigned long long)p.ntiles * 8ull < (1ull << 32);
+        const bool run_ok = p.n_off == 0 && fits32 && variant >= kBankRun256;
         if (!run_ok && variant >= kBankRun256 && getenv("BTGPU_VERBOSE"))
             fprintf(stderr, "launch_channel_bank: squelch grid off the channel grid (n_off %d): round-2 kernel\n", p.n_off);
         if (run_ok) {
@@ -125,14 +128,16 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
                 else L(pfb100f_kernel<kBankThreadsF, false, kBankKT>, nruns, kBankThreadsF, lds, p);
             } else if (variant == kBankRun256b && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 1>, nruns, kBankThreads, lds, p);
             else if (variant == kBankRun256c && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 3>, nruns, kBankThreads, lds, p);
-            else if (variant == kBankRun256d && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 7>, nruns, kBankThreads, lds, p);
-            else if (variant == kBankRun256e && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 3>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);
+            else if (variant == kBankRun256d && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // the default without the lean epilogue
+            else if (variant == kBankRun256e && bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 15>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // the default without the paired instants
             else if (variant == kBankRun256a && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 0>, nruns, kBankThreads, lds, p);
             else {
                 // default: ten tiles per workgroup, epilogue left to the scheduler, march reads eight steps ahead, packed
                 // channel MACs (A/B on the device, profiles/r03_h_bank_times.txt: 1.355 against 1.380 ms for OPT 0 / five tiles)
                 const int nr10 = (grid + 2 * kBankKT - 1) / (2 * kBankKT);
-                if (bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, nr10, kBankThreads, lds, p);
+                // + the lean epilogue where the per-step rotation of every channel is +-1 (100 Msps: always)
+                if (bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 31>, nr10, kBankThreads, lds, p);
+                else if (bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, nr10, kBankThreads, lds, p);
                 else L(pfb100f_kernel<kBankThreads, false, 2 * kBankKT, 3>, nr10, kBankThreads, lds, p);
             }
         } else if (wide) {

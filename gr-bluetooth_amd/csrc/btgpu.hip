@@ -252,8 +252,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     } else if (use_pfb) {
         constexpr int TT = kBankNT - 1;
         BankBuffers bb = bank_buffers(d_x, t, true);
+        // BTGPU_BANK_LDS_PAD (diagnostics): extra dynamic LDS per workgroup, i.e. fewer resident tiles per CU (occupancy sweeps)
+        static const size_t lds_pad = [] { const char *e = getenv("BTGPU_BANK_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
+            if (lds_pad) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad));
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds + lds_pad, st, p);
         };
         // BTGPU_BANK: run256 (default) | run320 -- pfb100f_kernel, runs of tiles per workgroup, four / five waves;
         // legacy | wide -- the round-2 kernel with four / eight waves per tile (A/B timing)
@@ -344,8 +347,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            tail_tiles, (double *)d_P.p, (double *)d_Pt.p, nb, nch);
     HIPCHK(this, mark(6, ps));
     if (use_staged) {
-        const int run = ns.outs * (kS2Slots - 1) + ns.nw;
-        const size_t lds2 = (size_t)((run + ns.L3 + 6) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
+        const size_t lds2 = s2_lds_bytes(ns.outs, ns.nw, ns.L3);
         BlockSumArgs bsa;
         if (fused_sums) {
             bsa.ptile = (const double *)t.d_ptile.p; bsa.phead = (const double *)t.d_phead.p; bsa.ntiles = ntiles;
@@ -377,7 +379,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                (uint32_t *)d_symbits.p, (uint32_t *)d_winbits.p);
         };
         // layout by channel count (kernels.hip.h): as many slots per workgroup as fill its 256 lanes
-        if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
+        // (BTGPU_WIN_ROWS=29: 29 rows per chunk = 39.8 KB of LDS, four workgroups per CU instead of three, for A/B -- no faster)
+        static const bool win29 = [] { const char *e = getenv("BTGPU_WIN_ROWS"); return e && atoi(e) == 29; }();
+        if (drow == 80 && win29) launch_window(WinLayout<3, 96, 20, kWinRowsSmall>{});
+        else if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
         else if (drow == 40) launch_window(WinLayout<6, 40, 10>{});
         else if (drow == 20) launch_window(WinLayout<12, 20, 5>{});
         else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});

@@ -313,7 +313,9 @@ __device__ __forceinline__ int popc5min(uint32_t v, uint32_t a, uint32_t b)
 }
 
 constexpr int kWinThreads = 256;     // lane = (slot, channel), slots per workgroup * channels <= 256
-constexpr int kWinRows = 38;         // demod rows staged per chunk and slot
+constexpr int kWinRows = 38;         // demod rows staged per chunk and slot (default of a layout)
+constexpr int kWinRowsSmall = 29;    // the smallest C79 tile that still holds phase 2's tables: 39.8 KB, four workgroups per CU --
+                                     // measured no faster than 38 rows / three (profiles/r03_m_*): the kernel is bound by VALU issue, not occupancy
 // Window-kernel layouts, by channel count.  NSL slots per workgroup, rows of NCP4 float4 (the used
 // columns of the 80-float rows of d) at an LDS row stride of RS floats.
 //   <3, 96, 20>  41..80 channels (C79): 3 x 79 lanes fill four waves to 93 %, one wave per SIMD (2 x 79 in
@@ -328,10 +330,11 @@ constexpr int kWinRows = 38;         // demod rows staged per chunk and slot
 // row stride (floats) of the time-major stream d for a capture of nch channels = 4 * NCP4 of its layout
 inline int win_drow(int nch) { return nch > 40 ? 80 : nch > 20 ? 40 : nch > 8 ? 20 : nch > 4 ? 8 : 4; }
 
-template <int NSL, int RS, int NCP4>
+template <int NSL, int RS, int NCP4, int ROWS = kWinRows>
 struct WinLayout {
     static constexpr int kSlots = NSL, kRowStride = RS, kVecPerRow = NCP4;
-    static constexpr int kTileFloats = kWinRows * RS + (RS % 32 == 0 ? 16 : 8);
+    static constexpr int kRows = ROWS;                       // demod rows staged per chunk and slot
+    static constexpr int kTileFloats = ROWS * RS + (RS % 32 == 0 ? 16 : 8);
 };
 constexpr int kMmseStride = 12;      // floats per interpolator row in LDS: 16-byte slot 3 imu mod 16 instead of
                                      // 2 imu mod 16 (eight classes for the sixteen lanes of a 16-byte read group)
@@ -352,10 +355,10 @@ constexpr int kSymbolsShortAcDev = 68;   // SYMBOLS_PER_BASIC_RATE_SHORTENED_ACC
 // search on by `step` symbols (68: the loop of lib/multi_sniffer_impl.cc:107-127; 1: every
 // qualifying offset); first_only stops at the first one (multi_LAP).  Shared by window_kernel's
 // phase 2 and scan_symbols_kernel, which runs it on captured symbol streams.
-template <class Emit>
+template <class Emit, class AcHi>
 __device__ __forceinline__ void search_classic(const uint32_t *mybits, int limit, int step, bool first_only,
                                                uint64_t a0_lo, uint32_t a0_hi, const uint64_t *ac_lo,
-                                               const uint32_t *ac_hi, int &resume, int &nhits, Emit emit)
+                                               const AcHi *ac_hi, int &resume, int &nhits, Emit emit)
 {
     uint32_t r0 = mybits[0], r1 = mybits[kWinThreads], r2 = mybits[2 * kWinThreads], r3;
     for (int b = 0; b * 32 < limit; b++) {
@@ -398,7 +401,7 @@ __device__ __forceinline__ void search_classic(const uint32_t *mybits, int limit
             const uint32_t whi = x2 & 0xf;
             const uint32_t lap = (uint32_t)(wlo >> 38) & 0xffffff;
             const uint64_t elo = a0_lo ^ ac_lo[lap & 0xff] ^ ac_lo[256 + ((lap >> 8) & 0xff)] ^ ac_lo[512 + (lap >> 16)];
-            const uint32_t ehi = a0_hi ^ ac_hi[lap & 0xff] ^ ac_hi[256 + ((lap >> 8) & 0xff)] ^ ac_hi[512 + (lap >> 16)];
+            const uint32_t ehi = a0_hi ^ (uint32_t)ac_hi[lap & 0xff] ^ (uint32_t)ac_hi[256 + ((lap >> 8) & 0xff)] ^ (uint32_t)ac_hi[512 + (lap >> 16)];
             const int err = __popcll(elo ^ wlo) + __popc((ehi ^ whi) & 0xf);
             if (err < 7) {
                 emit(cpos, lap, err);
@@ -487,22 +490,23 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 {
     constexpr int kWinSlots = LAY::kSlots, kWinRowStride = LAY::kRowStride, kTileFloats = LAY::kTileFloats;
     constexpr int kVecPerRow = LAY::kVecPerRow;
-    __shared__ uint8_t le_hdr[4 * 256];
+    constexpr int kRows = LAY::kRows;
     __shared__ __attribute__((aligned(16))) float mmse[129 * kMmseStride];
     // slot s's rows start 16 s floats into their bank row: the wave that holds the last lanes of one
     // slot and the first of the next then still reads 32 different banks
     __shared__ __attribute__((aligned(16))) float tile[kWinSlots * kTileFloats];
-    // After phase 1 the demod rows are dead and the same LDS holds the sliced symbols of every lane
-    // and the access-code tables of phase 2: the footprint stays under 40 KB, four workgroups per CU,
-    // which keeps every window of a 2048-slot batch resident at once (the M&M recursion is a chain
-    // of dependent operations -- only other waves hide its latency).
-    static_assert(kWinSlots * kTileFloats * 4 >= kBitWords * kWinThreads * 4 + 3 * 256 * 12, "phase-2 tables must fit the dead tile");
+    // After phase 1 the demod rows are dead and the same LDS holds the sliced symbols of every lane, the
+    // access-code tables of phase 2 (the 4 high bits of the 68 as bytes) and the LE header table.  With
+    // 29 rows per chunk (BTGPU_WIN_ROWS=29, C79 layout) the footprint is 39.8 KB, four workgroups per CU
+    // instead of three -- and the kernel takes the same 0.31 ms: 130 M vector instructions, many of
+    // them half-rate compares / selects / conversions, fill its SIMDs' issue slots at either occupancy.
+    static_assert(kWinSlots * kTileFloats * 4 >= kBitWords * kWinThreads * 4 + 3 * 256 * 9 + 1024, "phase-2 tables must fit the dead tile");
     uint32_t *bits = (uint32_t *)tile;                                        // [kBitWords][kWinThreads]
     uint64_t *ac_lo = (uint64_t *)(tile + kBitWords * kWinThreads);           // [3][256]
-    uint32_t *ac_hi = (uint32_t *)(ac_lo + 3 * 256);                          // [3][256]
+    uint8_t *ac_hi = (uint8_t *)(ac_lo + 3 * 256);                            // [3][256]  (bits 64..67 of a column)
+    uint8_t *le_hdr = ac_hi + 3 * 256;                                        // [4][256]  (loaded with the tables, phase 2)
     __shared__ int s_live[2];
     for (int i = threadIdx.x; i < 129 * 8; i += blockDim.x) mmse[(i >> 3) * kMmseStride + (i & 7)] = mmse_g[i];
-    if (p.le) for (int i = threadIdx.x; i < 1024; i += blockDim.x) le_hdr[i] = le_hdr_g[i];
 
     const int nch = p.nch;
     const int sl = (int)threadIdx.x / nch;                       // slot of this lane inside the workgroup
@@ -541,13 +545,13 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const float *mytile = tile + (sl < kWinSlots ? sl : 0) * kTileFloats;
 
     // Chunk schedule.  A lane leaves a chunk with its input index just past the chunk's last usable
-    // row (index + 8 rows must be staged), so the next chunk always starts kWinRows - 7 rows further:
+    // row (index + 8 rows must be staged), so the next chunk always starts kRows - 7 rows further:
     // the schedule is static and the rows of chunk n + 1 are fetched into registers before the
     // recursion over chunk n starts -- the HBM round trip hides under the dependent arithmetic.
     // Every load is unconditional (clamped address): a load under a lane-dependent branch would be
     // waited for at the end of that branch, nine round trips per chunk.
-    constexpr int kAdv = kWinRows - 7;
-    constexpr int kVec = kWinRows * kVecPerRow;                  // float4 per chunk and slot (the used part of the 80-float rows)
+    constexpr int kAdv = kRows - 7;
+    constexpr int kVec = kRows * kVecPerRow;                  // float4 per chunk and slot (the used part of the 80-float rows)
     constexpr int kTot = kVec * kWinSlots;
     constexpr int kPer = (kTot + kWinThreads - 1) / kWinThreads;
     float4 v[kPer];
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         if (threadIdx.x == 0) s_live[it & 1] = 0;
         __syncthreads();
         fetch(base + kAdv);
-        unsigned int lim = (unsigned int)(base + kWinRows - 8);
+        unsigned int lim = (unsigned int)(base + kRows - 8);
         if (lim > ni - 1) lim = ni - 1;                          // while (ii < ni) of the reference
         // byte offset of this lane's column in row `base` of the tile (24-bit arithmetic: one v_mad_u32_u24 per symbol)
         const uint32_t colb = (uint32_t)(((int)(mytile - tile) + c - base * kWinRowStride) * 4);
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 #pragma unroll
         for (int j = 0; j < kBitWords; j++) wv[j] = gbits[(j < nw ? j : 0) * kWinThreads];
         uint64_t tl[4]; uint32_t th[4];
+        const uint32_t lh = p.le ? ((const uint32_t *)le_hdr_g)[threadIdx.x] : 0u;     // 1024 bytes: one word per lane
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int i = (int)threadIdx.x + j * kWinThreads;
@@ -644,8 +649,9 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int i = (int)threadIdx.x + j * kWinThreads;
-            if (i < 768) { ac_lo[i] = tl[j]; ac_hi[i] = th[j]; }
+            if (i < 768) { ac_lo[i] = tl[j]; ac_hi[i] = (uint8_t)th[j]; }
         }
+        if (p.le) ((uint32_t *)le_hdr)[threadIdx.x] = lh;
     }
     __syncthreads();
     if (nmax == 0) return;

@@ -176,6 +176,56 @@ __device__ __forceinline__ float demod_poly(const DemodConst &k, float pr, float
     return __uint_as_float(__float_as_uint(a2) ^ (__float_as_uint(pi) & SIGN));
 }
 
+// The same angle for arguments that are never -0 (the caller forms them with an FMA onto +0): no canonicalising
+// additions; c5 = k.c[5] in a vector register (an FMA takes one scalar operand).
+__device__ __forceinline__ float demod_poly_pz(const DemodConst &k, float c5, float pr, float pi)
+{
+    const uint32_t SIGN = 0x80000000u;
+    const float ax = fabsf(pr), ay = fabsf(pi);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
+    const float z = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = z * z;
+    float P = k.c[6];
+    P = P * s + c5; P = P * s + k.c[4]; P = P * s + k.c[3];
+    P = P * s + k.c[2]; P = P * s + k.c[1]; P = P * s + k.c[0];
+    const float q = k.q4 - z * P;                                 // gain (pi/4 - atan z) >= 0
+    const float dd = ax - ay;                                     // >= 0: x-dominant
+    const uint32_t t1 = __float_as_uint(q) ^ (__float_as_uint(dd) & SIGN);
+    const float w = -k.q4 - __uint_as_float(t1);                  // gain (a1 - pi/2) <= 0
+    const uint32_t t2 = __float_as_uint(w) ^ (__float_as_uint(pr) & SIGN);
+    const float a2 = k.q2 + __uint_as_float(t2);
+    return __uint_as_float(__float_as_uint(a2) ^ (__float_as_uint(pi) & SIGN));
+}
+
+// Two of those angles, written in lockstep: each is a chain of ~20 dependent instructions, and the compiler's scheduler
+// keeps two independent calls one behind the other -- a wave then waits out every link of both chains.
+__device__ __forceinline__ void demod_poly_pz2(const DemodConst &k, float c5, float pr0, float pi0, float pr1, float pi1,
+                                               float &a0, float &a1)
+{
+    const uint32_t SIGN = 0x80000000u;
+    const float ax0 = fabsf(pr0), ay0 = fabsf(pi0), ax1 = fabsf(pr1), ay1 = fabsf(pi1);
+    const float mx0 = fmaxf(fmaxf(ax0, ay0), 1e-37f), mx1 = fmaxf(fmaxf(ax1, ay1), 1e-37f);
+    const float mn0 = fminf(ax0, ay0), mn1 = fminf(ax1, ay1);
+    const float r0 = __builtin_amdgcn_rcpf(mx0), r1 = __builtin_amdgcn_rcpf(mx1);
+    const float z0 = mn0 * r0, z1 = mn1 * r1;
+    const float s0 = z0 * z0, s1 = z1 * z1;
+    float P0 = k.c[6], P1 = k.c[6];
+    P0 = P0 * s0 + c5; P1 = P1 * s1 + c5;
+    P0 = P0 * s0 + k.c[4]; P1 = P1 * s1 + k.c[4];
+    P0 = P0 * s0 + k.c[3]; P1 = P1 * s1 + k.c[3];
+    P0 = P0 * s0 + k.c[2]; P1 = P1 * s1 + k.c[2];
+    P0 = P0 * s0 + k.c[1]; P1 = P1 * s1 + k.c[1];
+    P0 = P0 * s0 + k.c[0]; P1 = P1 * s1 + k.c[0];
+    const float q0 = k.q4 - z0 * P0, q1 = k.q4 - z1 * P1;
+    const float dd0 = ax0 - ay0, dd1 = ax1 - ay1;
+    const uint32_t t10 = __float_as_uint(q0) ^ (__float_as_uint(dd0) & SIGN), t11 = __float_as_uint(q1) ^ (__float_as_uint(dd1) & SIGN);
+    const float w0 = -k.q4 - __uint_as_float(t10), w1 = -k.q4 - __uint_as_float(t11);
+    const uint32_t t20 = __float_as_uint(w0) ^ (__float_as_uint(pr0) & SIGN), t21 = __float_as_uint(w1) ^ (__float_as_uint(pr1) & SIGN);
+    const float b0 = k.q2 + __uint_as_float(t20), b1 = k.q2 + __uint_as_float(t21);
+    a0 = __uint_as_float(__float_as_uint(b0) ^ (__float_as_uint(pi0) & SIGN));
+    a1 = __uint_as_float(__float_as_uint(b1) ^ (__float_as_uint(pi1) & SIGN));
+}
+
 // XCD-aware tile order: consecutive tiles (which share the filter-length halo of their input
 // span) run on the same XCD so the overlap is an L2 hit.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int b, int n)
@@ -650,9 +700,9 @@ __global__ __launch_bounds__(256) void block_sum_kernel(const double *__restrict
 // Noise stage 2: y^[J] = sum_i h3[i] Z[c][J + i]; E_off * noise_out = sum_J w[J - outs k] |y^[J]|^2
 // over slot k's nw stage-2 outputs (quadrature weights incl. the band-limited edge correction;
 // neighbouring slots share 2 Jm outputs).  One workgroup = one channel, KS consecutive slots:
-// the stage-1 samples of the run are staged once, every y^ is computed once (two adjacent
-// outputs per lane, 16-byte LDS reads, wave-uniform taps), |y^|^2 goes to LDS and lane s<KS
-// forms slot s's weighted sum in double.
+// the stage-1 samples of the run are staged once, every y^ is computed once (six adjacent
+// outputs per lane, conflict-free 16-byte LDS reads, wave-uniform taps), |y^|^2 goes to LDS and 32 lanes
+// per slot form its weighted sum in double.
 // ------------------------------------------------------------------------------------
 constexpr int kS2Slots = 8;
 // The tile sums -> block sums reduction (block_sum_kernel) rides along as `rows` extra rows of workgroups (blockIdx.y < rows,
@@ -664,7 +714,14 @@ struct BlockSumArgs {
     int nb = 0, nch = 0;
     int rows = 0;                    // extra grid rows that do this work (0: none)
 };
-constexpr int kS2SumRows = 8;
+constexpr int kS2SumRows = 16;
+// LDS of noise_stage2_kernel: the stage-1 samples of a run of slots (+ the taps' reach + the read-ahead of the last lane,
+// even) and one float per output
+__host__ __device__ constexpr int s2_samples(int outs, int nw, int L3) { return (outs * (kS2Slots - 1) + nw + L3 + 8 + 1) & ~1; }
+__host__ __device__ constexpr size_t s2_lds_bytes(int outs, int nw, int L3)
+{
+    return (size_t)s2_samples(outs, nw, L3) * sizeof(float2) + (size_t)(outs * (kS2Slots - 1) + nw + 4) * sizeof(float);
+}
 __global__ __launch_bounds__(256) void noise_stage2_kernel(
     const float2 *__restrict__ Z, long long zstride, int outs, int nw, int L3,
     const float *__restrict__ h3, const double *__restrict__ w, double *__restrict__ Qn, int S, BlockSumArgs bs)
@@ -673,24 +730,32 @@ __global__ __launch_bounds__(256) void noise_stage2_kernel(
     if ((int)blockIdx.y < bs.rows) {
         // (the FIRST rows of the grid: dispatched first, they run beside the stage-2 workgroups -- as the last rows they
         // were a tail of their own and the launch took as long as the two kernels it replaced)
-        // one wave per (channel, block), fixed shuffle tree: the arithmetic of block_sum_kernel, strided over the pairs
+        // the arithmetic of block_sum_kernel (one wave per (channel, block), lane k = tile k of the block, fixed shuffle
+        // tree), strided over the pairs -- with 16 lanes per pair where a block has at most 16 tiles (100 Msps: 10), four
+        // pairs per wave and pass: the tree's upper levels only add the zeros of the idle lanes, so the sums are the same
+        // bit for bit, and a wave makes a quarter of the passes (each one a dependent load from HBM: with one pair per
+        // wave these rows, ~100 passes per wave, outlasted the stage-2 workgroups of the launch)
         const int row = (int)blockIdx.y;
+        const int g = bs.tiles_per_block <= 16 ? 16 : 64, per = 64 / g;
         const int nwaves = bs.rows * (int)gridDim.x * (int)(blockDim.x >> 6);
-        const int lane = threadIdx.x & 63;
-        for (int i = (row * (int)gridDim.x + (int)blockIdx.x) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); i < bs.nb * bs.nch; i += nwaves) {
-            const int c = i / bs.nb, b = i % bs.nb;
+        const int lane = threadIdx.x & 63, k = lane % g, sub = lane / g;
+        const int wave = (row * (int)gridDim.x + (int)blockIdx.x) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+        for (int i0 = wave * per; i0 < bs.nb * bs.nch; i0 += nwaves * per) {
+            const int i = i0 + sub;
+            const bool on = i < bs.nb * bs.nch;
+            const int c = on ? i / bs.nb : 0, b = on ? i % bs.nb : 0;
             double s = 0.0, h = 0.0;
-            for (int k = lane; k < bs.tiles_per_block; k += 64) {
-                const int t = b * bs.tiles_per_block + k;
-                if (t < bs.ntiles) {
+            for (int kk = k; kk < bs.tiles_per_block; kk += g) {
+                const int t = b * bs.tiles_per_block + kk;
+                if (on && t < bs.ntiles) {
                     const double v = bs.ptile[(size_t)c * bs.ntiles + t];
                     s += v;
-                    if (k < bs.tail_tiles) h += v;
-                    else if (k == bs.tail_tiles) h += bs.phead[(size_t)c * bs.ntiles + t];
+                    if (kk < bs.tail_tiles) h += v;
+                    else if (kk == bs.tail_tiles) h += bs.phead[(size_t)c * bs.ntiles + t];
                 }
             }
-            for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); h += __shfl_down(h, off, 64); }
-            if (lane == 0) {
+            for (int off = g / 2; off > 0; off >>= 1) { s += __shfl_down(s, off, g); h += __shfl_down(h, off, g); }
+            if (k == 0 && on) {
                 bs.P[(size_t)c * bs.nb + b] = s;
                 bs.Pt[(size_t)c * bs.nb + b] = h;
             }
@@ -701,14 +766,14 @@ __global__ __launch_bounds__(256) void noise_stage2_kernel(
     const int ks = (S - k0) < kS2Slots ? (S - k0) : kS2Slots;        // slots in this run
     const int nout = outs * (ks - 1) + nw;                            // y^ needed
     const int need = nout + L3 - 1;                                   // stage-1 samples needed
-    float2 *zs = (float2 *)lds4;                                      // [need + 5]
-    float *m2 = (float *)(zs + ((outs * (kS2Slots - 1) + nw + L3 + 6) & ~1));   // [nout]
+    float2 *zs = (float2 *)lds4;                                      // [need + 8]
+    float *m2 = (float *)(zs + s2_samples(outs, nw, L3));             // [nout]
     const float2 *z = Z + (size_t)c * zstride + (long long)k0 * outs;
     __shared__ float h3s[128];                                        // taps (L3 <= 128), read as LDS broadcasts
     for (int i = threadIdx.x; i < L3; i += blockDim.x) h3s[i] = h3[i];
     // unconditional (clamped) loads in batches of five, so that a lane's loads are in flight
     // together instead of one memory round trip per element
-    for (int base = 0; base < need + 5; base += 5 * (int)blockDim.x) {
+    for (int base = 0; base < need + 8; base += 5 * (int)blockDim.x) {
         float2 v[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -718,37 +783,60 @@ __global__ __launch_bounds__(256) void noise_stage2_kernel(
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int i = base + k * (int)blockDim.x + (int)threadIdx.x;
-            if (i < need + 5) zs[i] = i < need ? v[k] : make_float2(0.f, 0.f);
+            if (i < need + 8) zs[i] = i < need ? v[k] : make_float2(0.f, 0.f);
         }
     }
     __syncthreads();
-    // four adjacent outputs per lane: one 16-byte LDS read feeds 16 FMAs (taps ascending per
-    // output, same order as the two-output form)
+    // SIX adjacent outputs per lane: one 16-byte LDS read (two samples) feeds 24 FMAs, taps ascending per output (the
+    // order of the two- and four-output forms: the same sums bit for bit).  Six, not four or eight: neighbouring
+    // lanes then read 16-byte chunks THREE apart, and the four groups of 16 lanes a ds_read_b128 is serviced in
+    // ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS) land on 16 distinct chunks mod 16 -- no bank conflict, no
+    // swizzle.  (Four per lane, round 2: chunks two apart, every read a two-way conflict -- 34 % of the kernel's LDS
+    // cycles -- and the kernel LDS-bound; eight per lane with an XOR swizzle: conflict-free too, but five address
+    // instructions per read and only 184 of 256 lanes busy: slower than four.)  A slot's lanes start 3 * 31 = 93
+    // chunks after the previous slot's and the slots are outs / 2 = 125 chunks apart: 32 more, a multiple of 16, so the
+    // pattern holds across slot boundaries at 100 Msps; other geometries only lose the guarantee, not correctness.
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f *zv = (const v4f *)zs;
     // only the outputs a slot's quadrature weights touch are formed: nw (182) of every `outs` (250) -- the
     // squelch averages the reference's noise_out = 850 of the 1250 2-Msps outputs of a slot.  Compact index
-    // jc -> (slot jc / nwp, output jc % nwp) with nwp = nw rounded up to four.
-    const int nwp = (nw + 3) & ~3;
-    for (int jc = 4 * threadIdx.x; jc < ks * nwp; jc += 4 * blockDim.x) {
+    // jc -> (slot jc / nwp, output jc % nwp) with nwp = nw rounded up to six: 31 lanes per slot, 248 of 256 lanes busy.
+    const int nwp = (nw + 5) / 6 * 6;
+    for (int jc = 6 * threadIdx.x; jc < ks * nwp; jc += 6 * blockDim.x) {
         const int sl = jc / nwp, r = jc - sl * nwp;
-        const int j = sl * outs + r;                                 // even: outs is even, r a multiple of four
-        v2f y0 = {0.f, 0.f}, y1 = y0, y2 = y0, y3 = y0;              // (re, im) pairs -> v_pk_fma_f32
-        v4f q0 = zv[j >> 1], q1 = zv[(j >> 1) + 1];
-        for (int m = 0; m < L3 / 2; m++) {                           // taps 2m, 2m+1 (L3 is even)
-            const v4f q2 = zv[(j >> 1) + m + 2];
-            const float ha = h3s[2 * m], hb = h3s[2 * m + 1];
-            const v2f a = {ha, ha}, b = {hb, hb};
-            y0 = __builtin_elementwise_fma(a, q0.xy, y0); y0 = __builtin_elementwise_fma(b, q0.zw, y0);
-            y1 = __builtin_elementwise_fma(a, q0.zw, y1); y1 = __builtin_elementwise_fma(b, q1.xy, y1);
-            y2 = __builtin_elementwise_fma(a, q1.xy, y2); y2 = __builtin_elementwise_fma(b, q1.zw, y2);
-            y3 = __builtin_elementwise_fma(a, q1.zw, y3); y3 = __builtin_elementwise_fma(b, q2.xy, y3);
-            q0 = q1; q1 = q2;
+        const int j = sl * outs + r;                                 // even: outs is even, r a multiple of six
+        v2f y0 = {0.f, 0.f}, y1 = y0, y2 = y0, y3 = y0, y4 = y0, y5 = y0;   // (re, im) pairs -> v_pk_fma_f32
+        const v4f *zq = zv + (j >> 1);
+        v4f q0 = zq[0], q1 = zq[1], q2 = zq[2], q3;
+        // taps 2m, 2m+1 against the eight samples A, B, C, D.xy; the four registers rotate through the steps (no moves)
+#define BTGPU_S2STEP(A, B, C, D, mm)                                                                      \
+        {                                                                                                 \
+            D = zq[3 + (mm)];                                                                             \
+            const float ha = h3s[2 * (mm)], hb = h3s[2 * (mm) + 1];                                       \
+            const v2f a = {ha, ha}, b = {hb, hb};                                                         \
+            y0 = __builtin_elementwise_fma(a, A.xy, y0); y0 = __builtin_elementwise_fma(b, A.zw, y0);     \
+            y1 = __builtin_elementwise_fma(a, A.zw, y1); y1 = __builtin_elementwise_fma(b, B.xy, y1);     \
+            y2 = __builtin_elementwise_fma(a, B.xy, y2); y2 = __builtin_elementwise_fma(b, B.zw, y2);     \
+            y3 = __builtin_elementwise_fma(a, B.zw, y3); y3 = __builtin_elementwise_fma(b, C.xy, y3);     \
+            y4 = __builtin_elementwise_fma(a, C.xy, y4); y4 = __builtin_elementwise_fma(b, C.zw, y4);     \
+            y5 = __builtin_elementwise_fma(a, C.zw, y5); y5 = __builtin_elementwise_fma(b, D.xy, y5);     \
         }
-        const v2f yy[4] = {y0, y1, y2, y3};
+        int m = 0;
+        for (; m + 4 <= L3 / 2; m += 4) {                            // L3 is even
+            BTGPU_S2STEP(q0, q1, q2, q3, m)
+            BTGPU_S2STEP(q1, q2, q3, q0, m + 1)
+            BTGPU_S2STEP(q2, q3, q0, q1, m + 2)
+            BTGPU_S2STEP(q3, q0, q1, q2, m + 3)
+        }
+        for (; m < L3 / 2; m++) {
+            BTGPU_S2STEP(q0, q1, q2, q3, m)
+            q0 = q1; q1 = q2; q2 = q3;
+        }
+#undef BTGPU_S2STEP
+        const v2f yy[6] = {y0, y1, y2, y3, y4, y5};
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (j + k < nout) m2[j + k] = (yy[k].x * yy[k].x) + (yy[k].y * yy[k].y);
+        for (int k = 0; k < 6; k++) if (r + k < nw) m2[j + k] = (yy[k].x * yy[k].x) + (yy[k].y * yy[k].y);
     }
     __syncthreads();
     // slot sums: 32 lanes per slot, fixed order (lane partial sums combined by shuffles)

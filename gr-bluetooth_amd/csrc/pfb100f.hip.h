@@ -128,7 +128,8 @@ __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &
     for (int k = 0; k < NI; k++) U[(NT + R + 2 * k) * UST + pp] = acc[k];
 }
 
-// OPT (experiments, A/B on the device): 1 = epilogue not fenced, 2 = march reads 8 steps ahead, 4 = packed channel MACs
+// OPT (experiments, A/B on the device): 1 = epilogue not fenced, 2 = march reads 8 steps ahead, 4 = packed channel MACs,
+// 8 = lean epilogue (needs rho = +-1: p.rho_real), 16 = epilogue instants interleaved in pairs on whole tiles
 template <int NTH, bool REAL, int KT, int OPT = 0>
 __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbParams p)
 {
@@ -225,8 +226,13 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     float4 v0, v1, v2, v3, v4, v5;
     v0 = v1 = v2 = v3 = v4 = v5 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_span = [&](int tile, int l) {
-        const float4 *xb = (const float4 *)(p.x + span_start(tile));
-        auto at = [&](int j) { return xb[l + j * NTH < N4 ? l + j * NTH : N4 - 1]; };
+        // uniform base + 32-bit lane offset (scalar base registers, no 64-bit lane arithmetic); only the last piece clamps
+        const char *xb = (const char *)(p.x + span_start(tile));
+        const unsigned o = (unsigned)l * 16u;
+        auto at = [&](int j) {
+            const unsigned oj = (j + 1) * NTH <= N4 ? o : (unsigned)(l + j * NTH < N4 ? l : N4 - 1 - j * NTH) * 16u;
+            return *(const float4 *)(xb + (size_t)j * NTH * 16 + oj);
+        };
         v0 = at(0); if (PER > 1) v1 = at(1); if (PER > 2) v2 = at(2); if (PER > 3) v3 = at(3);
         if (PER > 4) v4 = at(4); if (PER > 5) v5 = at(5);
     };
@@ -254,13 +260,15 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         const int n_d = (int)rows * 20, i1 = l + NTH;
         const f4 a0 = ((const f4 *)s_d)[l], a1 = ((const f4 *)s_d)[i1 < TT * 20 ? i1 : l];
         const f4 b0 = ((const f4 *)s_dc)[l], b1 = ((const f4 *)s_dc)[i1 < TT * 20 ? i1 : l];
-        f4 *dst = (f4 *)(p.d + (size_t)g1 * 80);
-        if (l < n_d) __builtin_nontemporal_store(a0, dst + l);
-        if (i1 < n_d) __builtin_nontemporal_store(a1, dst + i1);
+        // (uniform base + 32-bit lane offset: the store takes the base from scalar registers, no 64-bit lane arithmetic)
+        char *dst = (char *)(p.d + (size_t)g1 * 80);
+        const unsigned o0 = (unsigned)l * 16u, o1 = (unsigned)i1 * 16u;
+        if (l < n_d) __builtin_nontemporal_store(a0, (f4 *)(dst + o0));
+        if (i1 < n_d) __builtin_nontemporal_store(a1, (f4 *)(dst + o1));
         if (p.dcol) {
-            f4 *dc = (f4 *)(p.dcol + (size_t)tile * (80 * TT));
-            if (l < TT * 20) __builtin_nontemporal_store(b0, dc + l);
-            if (i1 < TT * 20) __builtin_nontemporal_store(b1, dc + i1);
+            char *dc = (char *)(p.dcol + (size_t)tile * (80 * TT));
+            if (l < TT * 20) __builtin_nontemporal_store(b0, (f4 *)(dc + o0));
+            if (i1 < TT * 20) __builtin_nontemporal_store(b1, (f4 *)(dc + o1));
         }
         if (l < p.nsel) {
             double sum = 0.0, head = 0.0;
@@ -269,18 +277,21 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                 sum += (double)s_part[(k * 80 + l) * 2];
                 head += (double)s_part[(k * 80 + l) * 2 + 1];
             }
-            p.ptile[(size_t)l * p.ntiles + tile] = sum;
-            p.phead[(size_t)l * p.ntiles + tile] = head;         // first (tail % TT) instants of this tile
+            const unsigned po = ((unsigned)l * (unsigned)p.ntiles + (unsigned)tile) * 8u;
+            *(double *)((char *)p.ptile + po) = sum;
+            *(double *)((char *)p.phead + po) = head;            // first (tail % TT) instants of this tile
         }
     };
 
     // optional per-phase cycle sums, per wave (BTGPU_PFB_PROF diagnostics; scripts/pfb_phases.py): slot k of wave w of this
     // workgroup = cycles from the previous mark to mark k, barrier waits included
+    // (ten tiles per workgroup: 16 slots per wave -- marks 5.. split each interval into its work and its barrier wait)
+    constexpr int PSL = KT >= 10 ? 16 : 8;
     unsigned long long tprev = p.prof ? clock64() : 0ULL;
     auto mark = [&](int k) {
         if (p.prof) {
             const unsigned long long now = clock64();
-            if ((l0 & 63) == 0) p.prof[((size_t)blockIdx.x * (NTH / 64) + (l0 >> 6)) * 8 + k] += now - tprev;
+            if ((l0 & 63) == 0) p.prof[((size_t)blockIdx.x * (NTH / 64) + (l0 >> 6)) * PSL + k] += now - tprev;
             tprev = now;
         }
     };
@@ -291,13 +302,26 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     bool prev_any = false;
     static_assert(NZT <= 2, "two named register pairs carry the squelch outputs");
     cf zv0 = mk(0.f, 0.f), zv1 = zv0, zr0 = zv0, zr1 = zv0;      // squelch bins of this lane and their de-rotation factors
+    unsigned nzu0, nzu1 = 0x80000000u, nzo0, nzo1 = 0, nzk0, nzk1 = 0;           // ui (0..4) and byte offset of (c, ui) in n_Z of this lane's outputs
+    {
+        auto nz_where = [&](int i, unsigned &ui, unsigned &zo, unsigned &ko) {
+            ui = i < p.nsel * NU ? (unsigned)(i % NU) : 0x80000000u;
+            zo = i < p.nsel * NU ? ((unsigned)(i / NU) * (unsigned)p.n_zstride + (unsigned)(i % NU)) * 8u : 0u;
+            ko = i < p.nsel * NU ? (unsigned)(i / NU) * (unsigned)p.n_period : 0u;     // row of the de-rotation table
+        };
+        nz_where(l0, nzu0, nzo0, nzk0);
+        if (NZT > 1) nz_where(l0 + NTH, nzu1, nzo1, nzk1);
+    }
     auto flush_prev = [&](int ptile, int pu0, int l) {
+        // squelch outputs (c, u = pu0 + ui) -> n_Z[c][u]: byte offset and ui of this lane's two outputs were formed once, in
+        // front of the tile loop (32-bit: the launch checks that the plane fits), the base pointer is uniform
 #pragma unroll
         for (int j = 0; j < NZT; j++) {
-            const int i = l + j * NTH;
-            const int u = pu0 + i % NU;
-            if (i < p.nsel * NU && u >= 0 && u < p.n_T)
-                ((cf *)p.n_Z)[(size_t)(i / NU) * p.n_zstride + u] = cmulf(j == 0 ? zv0 : zv1, j == 0 ? zr0 : zr1);
+            const unsigned ui = j == 0 ? nzu0 : nzu1, zo = j == 0 ? nzo0 : nzo1;
+            const unsigned u = (unsigned)pu0 + ui;               // lanes without an output carry ui = 2^31: never < n_T
+            char *zb = (char *)p.n_Z + (long long)pu0 * 8;
+            if (u < (unsigned)p.n_T)                             // (negative u wraps far above n_T)
+                *(cf *)(zb + zo) = cmulf(j == 0 ? zv0 : zv1, j == 0 ? zr0 : zr1);
         }
         if (ptile >= 0) copy_out(ptile, l);
     };
@@ -321,7 +345,9 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
             put(0, v0); if (PER > 1) put(1, v1); if (PER > 2) put(2, v2); if (PER > 3) put(3, v3);
             if (PER > 4) put(4, v4); if (PER > 5) put(5, v5);
         } else stage_edge(tile, l);
+        if (PSL > 8) mark(5);
         if (prev_any) flush_prev(prev_tile, prev_u0, l);
+        if (PSL > 8) mark(6);
         prev_tile = tile; prev_any = true;
         __syncthreads();
         mark(0);
@@ -332,13 +358,14 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
             const int ph0 = ((nz_u0 % np) + np) % np;            // block-uniform
 #pragma unroll
             for (int j = 0; j < NZT; j++) {
-                const int i = l + j * NTH < p.nsel * NU ? l + j * NTH : p.nsel * NU - 1;
-                int ph = ph0 + i % NU;
+                // (row offset c * np and ui formed once per workgroup; lanes without an output read row 0)
+                int ph = ph0 + (int)((j == 0 ? nzu0 : nzu1) & 7u);
                 ph = ph >= np ? ph - np : ph;
-                (j == 0 ? zr0 : zr1) = ((const cf *)p.n_krot)[(size_t)(i / NU) * np + ph];
+                (j == 0 ? zr0 : zr1) = *(const cf *)((const char *)p.n_krot + ((j == 0 ? nzk0 : nzk1) + (unsigned)ph) * 8u);
             }
         }
 
+        if (PSL > 8) mark(7);
         // ---- phase A: branch filters of the channel bank and of squelch stage 1, one march of the span ----
         if (a_on) {
             const cf *z = xs + shift + DH * a_r + a_pp;
@@ -346,6 +373,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
             if (a_r == 0) march_branch<0, REAL, OPT>(z, a, an, U, a_pp);      // wave-uniform
             else march_branch<1, REAL, OPT>(z, a, an, U, a_pp);
         }
+        if (PSL > 8) mark(8);
         __syncthreads();
         mark(1);
 
@@ -366,6 +394,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                 for (int k = 1; k < 10; k++) col[10 * k] = cmulf(x[k], twp[10 * k]);
             }
         }
+        if (PSL > 8) mark(9);
         __syncthreads();
         mark(2);
 
@@ -390,6 +419,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                 }
             }
         }
+        if (PSL > 8) mark(10);
         __syncthreads();
         mark(3);
 
@@ -418,6 +448,84 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
             // one instant per step, the bins read two steps ahead; fenced like the march (the unrolled run is
             // independent work the scheduler would otherwise overlap at the price of a hundred registers)
             cf yb = yc[(tl0 - 1) * YST], ya = yc[tl0 * YST];
+            if (OPT & 8) {
+                // lean form (rho = +-1, checked by the host): 29 vector instructions per instant instead of 41.
+                //  * scalar multiply-adds with the conjugation in their sign modifiers (the packed form pays a swap
+                //    and a sign flip per instant to build (y.im, -y.re));
+                //  * the first product is an FMA onto +0, so an exact zero comes out as +0 without the two
+                //    canonicalising additions demod_poly starts with ((0, 0) must give the angle 0);
+                //  * the head sum (one tile per block asks for it) is formed behind the loop, from the bin rows;
+                //  * reads one row ahead without a clamp: rows past the tile's last instant are the (finite or not,
+                //    never used) rest of this LDS allocation.
+                float c5 = kc.c[5];
+                BTGPU_OPAQUE(c5);                        // (a vector register for good: two scalar operands need a move per use)
+                const float rho1 = e_rho.x;
+                auto instant = [&](const cf &yp, const cf &yc_, int k) {
+                    const float bx = yp.x * rho1, by = yp.y * rho1;
+                    sum = fmaf(yc_.x, yc_.x, sum);
+                    sum = fmaf(yc_.y, yc_.y, sum);
+                    float pr = fmaf(bx, yc_.x, 0.0f), pi = fmaf(bx, yc_.y, 0.0f);            // Y[t] conj(Y[t-1]) rho
+                    pr = fmaf(by, yc_.y, pr);
+                    pi = fmaf(-by, yc_.x, pi);
+                    const float ang = demod_poly_pz(kc, c5, pr, pi);
+                    drow[k * 80] = ang;
+                    dcolp[k] = ang;
+                };
+                constexpr int LAST = TT - (CH - 1) * RUN;        // instants of the last run
+                if ((OPT & 16) && LAST % 2 == 1 && RUN % 2 == 1 && t0 + NT <= p.T) {              // block-uniform: every instant of the tile is inside the stream
+                    // no per-instant predicate, two instants at a time in lockstep (demod_poly_pz2): one instant is a chain
+                    // of ~25 dependent instructions (the arctangent polynomial), and a wave that is alone on its SIMD between
+                    // two barriers waits out every link of it
+                    auto pair = [&](const cf &y0, const cf &y1, const cf &y2, int k) {     // instants k (y0 -> y1) and k + 1 (y1 -> y2)
+                        const float bx0 = y0.x * rho1, by0 = y0.y * rho1, bx1 = y1.x * rho1, by1 = y1.y * rho1;
+                        sum = fmaf(y1.x, y1.x, sum);
+                        sum = fmaf(y1.y, y1.y, sum);
+                        sum = fmaf(y2.x, y2.x, sum);
+                        sum = fmaf(y2.y, y2.y, sum);
+                        float pr0 = fmaf(bx0, y1.x, 0.0f), pi0 = fmaf(bx0, y1.y, 0.0f), pr1 = fmaf(bx1, y2.x, 0.0f), pi1 = fmaf(bx1, y2.y, 0.0f);
+                        pr0 = fmaf(by0, y1.y, pr0); pr1 = fmaf(by1, y2.y, pr1);
+                        pi0 = fmaf(-by0, y1.x, pi0); pi1 = fmaf(-by1, y2.x, pi1);
+                        float a0, a1;
+                        demod_poly_pz2(kc, c5, pr0, pi0, pr1, pi1, a0, a1);
+                        drow[k * 80] = a0; dcolp[k] = a0;
+                        drow[(k + 1) * 80] = a1; dcolp[k + 1] = a1;
+                    };
+                    // (LAST and RUN odd: pairs (0,1) .. (LAST-3, LAST-2); then LAST-1 alone, or (LAST-1, LAST) .. and RUN-1 alone)
+#pragma unroll
+                    for (int k = 0; k + 1 < LAST; k += 2) {
+                        const cf y1 = yc[(tl0 + k + 1) * YST], y2 = yc[(tl0 + k + 2) * YST];
+                        pair(yb, ya, y1, k);
+                        yb = y1; ya = y2;                        // rows tl0 + k + 1, tl0 + k + 2: previous and current of instant k + 2
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (e_chunk < CH - 1) {
+#pragma unroll
+                        for (int k = LAST - 1; k + 1 < RUN; k += 2) {
+                            const cf y1 = yc[(tl0 + k + 1) * YST], y2 = yc[(tl0 + k + 2) * YST];
+                            pair(yb, ya, y1, k);
+                            yb = y1; ya = y2;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        instant(yb, ya, RUN - 1);
+                    } else instant(yb, ya, LAST - 1);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < RUN; k++) {
+                        const cf yn = yc[(tl0 + k + 1) * YST];
+                        if (k < nval) instant(yb, ya, k);
+                        yb = ya; ya = yn;
+                        if (!(OPT & 1)) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (hr > 0) {                                    // block-uniform, one tile in tiles_per_block
+#pragma unroll 1
+                    for (int k = 0; k < nval && tl0 + k - 1 < hr; k++) {
+                        const cf y = yc[(tl0 + k) * YST];
+                        head = fmaf(y.x, y.x, head);
+                        head = fmaf(y.y, y.y, head);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < RUN; k++) {
                 const int rn = tl0 + k + 1 < NT ? tl0 + k + 1 : NT - 1;
@@ -435,6 +543,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                 yb = ya; ya = yn;
                 if (!(OPT & 1)) __builtin_amdgcn_sched_barrier(0);
             }
+            }
             s_part[(e_chunk * 80 + e_c) * 2 + 0] = sum;
             s_part[(e_chunk * 80 + e_c) * 2 + 1] = head;
             if (p.Z) {                                           // BTGPU_FLAG_DEBUG_Y: the de-rotated channel output
@@ -447,6 +556,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                 }
             }
         }
+        if (PSL > 8) mark(11);
         __syncthreads();
         mark(4);                                         // angle tiles complete; Y (= the span region) is dead
     }

@@ -42,13 +42,26 @@ if variant in ("legacy", "wide"):
 else:
     # pfb100f_kernel: [workgroup][wave][8]; marks 0..4 = cycles up to the barrier that ends: copy-out + staging | A | B1 | B2 | C
     nw = 5 if variant == "run320" else 4
-    used = raw[: (len(raw) // nw) * nw].reshape(-1, nw, 8)
+    kt = 10 if variant in ("run256", "run256d", "run256e") else 5          # tiles per workgroup (bank_launch.h)
+    psl = 16 if kt >= 10 else 8                                            # slots per wave (pfb100f.hip.h)
+    raw = raw.reshape(-1)
+    used = raw[: (len(raw) // (nw * psl)) * nw * psl].reshape(-1, nw, psl)
     used = used[used[:, 0, :].sum(axis=1) > 0]
-    names = ["copy-out(n-1) + stage + barrier", "A march + barrier", "B1 + barrier", "B2 + barrier", "C epilogue + Z + barrier"]
-    tot = used[:, :, :5].sum(axis=(0, 2))
-    print("cycles per tile and wave (mean over %d workgroups x %d tiles):" % (len(used), 5 * nb))
-    for k, n in enumerate(names):
-        print("%-34s " % n + " ".join("w%d %7.0f (%4.1f %%)" % (w, used[:, w, k].sum() / len(used) / 5 / nb, 100 * used[:, w, k].sum() / tot[w]) for w in range(nw)))
-    print("tile life (cycles), per wave:", [round(float(t) / len(used) / 5 / nb) for t in tot])
+    n = len(used) * kt * nb
+    if psl == 16:
+        # marks 5..11 end the WORK of an interval, marks 0..4 the barrier behind it
+        rows = [("stage span -> LDS", 5, None), ("flush tile n-1 (Z, d, dcol, sums)", 6, 0), ("prefetch + rot loads issue", 7, None),
+                ("A march", 8, 1), ("B1", 9, 2), ("B2", 10, 3), ("C epilogue", 11, 4)]
+        print("cycles per tile and wave: work | barrier wait (mean over %d workgroups x %d tiles)" % (len(used), kt * nb))
+        for name, kw, kb in rows:
+            print("%-36s " % name + " ".join("w%d %6.0f | %5.0f" % (w, used[:, w, kw].sum() / n, (used[:, w, kb].sum() / n) if kb is not None else 0) for w in range(nw)))
+        tot = used[:, :, :12].sum(axis=(0, 2))
+    else:
+        names = ["copy-out(n-1) + stage + barrier", "A march + barrier", "B1 + barrier", "B2 + barrier", "C epilogue + Z + barrier"]
+        tot = used[:, :, :5].sum(axis=(0, 2))
+        print("cycles per tile and wave (mean over %d workgroups x %d tiles):" % (len(used), kt * nb))
+        for k, nm in enumerate(names):
+            print("%-34s " % nm + " ".join("w%d %7.0f (%4.1f %%)" % (w, used[:, w, k].sum() / n, 100 * used[:, w, k].sum() / tot[w]) for w in range(nw)))
+    print("tile life (cycles), per wave:", [round(float(t) / n) for t in tot])
 tm = blk.timing()
 print("ddc_channel avg ms %.4f (with marks enabled)" % (tm.kernel_ms[0] / max(tm.kernel_launches[0], 1)))

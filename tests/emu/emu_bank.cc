@@ -199,6 +199,19 @@ int emu_stage2_design(double fs, double fc, int mode, float *h3, double *w, int 
     return 0;
 }
 
+// noise_stage2_kernel alone, on a given stage-1 plane Z [nch][zstride] (the tests compare with a numpy restatement)
+int emu_stage2_run(int outs, int nw, int L3, const float *h3, const double *w, const float *Z, long long zstride, int nch, int S,
+                   double *Qn)
+{
+    const size_t lds2 = s2_lds_bytes(outs, nw, L3);
+    if (lds2 > sizeof emu::dyn_lds) return BTGPU_EUNSUPPORTED;
+    std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);            // NaNs: a read of anything not staged shows
+    emu::launch(dim3((unsigned)((S + kS2Slots - 1) / kS2Slots), (unsigned)nch), dim3(256), [&]() {
+        noise_stage2_kernel((const float2 *)Z, zstride, outs, nw, L3, h3, w, Qn, S, BlockSumArgs{});
+    });
+    return 0;
+}
+
 // the pass-2 lane map, for the bank-conflict check of the tests
 int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
 {
@@ -319,8 +332,7 @@ extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double sq
     const NoiseStage &ns = fp.noise;
     std::vector<double> Qn((size_t)nch * S);
     {
-        const int run = ns.outs * (kS2Slots - 1) + ns.nw;
-        const size_t lds2 = (size_t)((run + ns.L3 + 6) & ~1) * sizeof(float2) + (size_t)(run + 4) * sizeof(float);
+        const size_t lds2 = s2_lds_bytes(ns.outs, ns.nw, ns.L3);
         if (lds2 > sizeof emu::dyn_lds) return BTGPU_EUNSUPPORTED;
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
         emu::launch(dim3((unsigned)((S + kS2Slots - 1) / kS2Slots), (unsigned)nch), dim3(256), [&]() {

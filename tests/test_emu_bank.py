@@ -169,6 +169,29 @@ def test_fused_and_standalone_noise_banks_agree(emu, c79_capture):
         assert np.allclose(a[k], b[k], rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("outs,nw,L3,S", [(250, 182, 80, 11), (250, 182, 80, 8), (250, 182, 80, 1), (40, 46, 80, 9), (250, 177, 74, 3)])
+def test_noise_stage2_kernel_vs_numpy(emu, outs, nw, L3, S):
+    """noise_stage2_kernel by itself (eight outputs per lane, swizzled slot windows in LDS, runs of eight slots with a
+    short last run) against numpy: Q[c][s] = sum_j w[j] |sum_i h3[i] Z[c][s outs + j + i]|^2.  The LDS is filled with NaNs
+    first, so a read of a sample the staging loop did not place would show."""
+    rng = np.random.default_rng(outs + nw + L3 + S)
+    nch = 3
+    zstride = outs * (S - 1) + nw + L3 - 1 + 7
+    Z = (rng.standard_normal((nch, zstride)) + 1j * rng.standard_normal((nch, zstride))).astype(np.complex64)
+    h3 = rng.standard_normal(L3).astype(np.float32)
+    w = rng.random(nw)
+    Qn = np.zeros((nch, S))
+    emu.emu_stage2_run.restype = ctypes.c_int
+    emu.emu_stage2_run.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    assert emu.emu_stage2_run(outs, nw, L3, h3.ctypes.data, w.ctypes.data, Z.ctypes.data, zstride, nch, S, Qn.ctypes.data) == 0
+    for c in range(nch):
+        for s in range(S):
+            z = Z[c, s * outs:s * outs + nw + L3 - 1].astype(np.complex128)
+            yh = np.array([np.dot(h3.astype(np.float64), z[j:j + L3]) for j in range(nw)])
+            ref = float(np.dot(w, np.abs(yh) ** 2))
+            assert abs(Qn[c, s] - ref) <= 2e-5 * ref, (c, s, Qn[c, s], ref)
+
+
 @pytest.mark.parametrize("fc,mode", [(2441e6, 0), (2441.5e6, 1), (2440.25e6, 1)])
 def test_channel_bank_other_geometries(emu, po, synth, fc, mode):
     """multi_LAP geometry (window tail of 130 outputs: the block-head sums come from tile 5 of a block)
