@@ -19,9 +19,9 @@ constexpr int kBankThreadsWide = 512;        // fused channel + noise bank: eigh
 constexpr int kBankThreadsF = 320;           // pfb100f_kernel: five waves per run of tiles (every DFT pass in one sweep)
 // which kernel runs the fused C79 bank (launch_channel_bank)
 enum BankVariant { kBankLegacy = 0, kBankLegacyWide = 1, kBankRun256 = 2, kBankRun320 = 3,
-                   kBankRun256b = 4, kBankRun256c = 5, kBankRun256d = 6,        // run256 with OPT 1 / 3 / 7 (pfb100f.hip.h)
-                   kBankRun256e = 7,                                            // OPT 3, runs of ten tiles
-                   kBankRun256a = 8 };                                          // OPT 0, five tiles (the first form)
+                   kBankRun256d = 6,        // run256 as of profiles/r03_j_* (OPT 7: no lean epilogue, no wave priorities)
+                   kBankRun256e = 7,        // the default without the wave priorities (OPT 31)
+                   kBankRun256a = 8 };      // ... with the priorities read from BTGPU_PFB_DBG (OPT 31 + 256)
 constexpr int kBankNT = 26;                 // channel instants per tile (25 new + 1 halo for the demod)
 constexpr int kNoiseNT = 10;                // instants per tile of the stand-alone noise stage 1
 
@@ -126,19 +126,20 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
                 p.b2map = b.b2map_f320;
                 if (bk.real_taps) L(pfb100f_kernel<kBankThreadsF, true, kBankKT>, nruns, kBankThreadsF, lds, p);
                 else L(pfb100f_kernel<kBankThreadsF, false, kBankKT>, nruns, kBankThreadsF, lds, p);
-            } else if (variant == kBankRun256b && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 1>, nruns, kBankThreads, lds, p);
-            else if (variant == kBankRun256c && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 3>, nruns, kBankThreads, lds, p);
-            else if (variant == kBankRun256d && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // the default without the lean epilogue
-            else if (variant == kBankRun256e && bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 15>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // the default without the paired instants
-            else if (variant == kBankRun256a && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, kBankKT, 0>, nruns, kBankThreads, lds, p);
+            } else if (variant == kBankRun256d && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // the default without the lean epilogue
+            else if (variant == kBankRun256e && bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 31>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // the default without the wave priorities
+            else if (variant == kBankRun256a && bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 31 + 256>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // priorities from BTGPU_PFB_DBG (scripts/r03_n_prio.sh)
             else {
-                // default: ten tiles per workgroup, epilogue left to the scheduler, march reads eight steps ahead, packed
-                // channel MACs (A/B on the device, profiles/r03_h_bank_times.txt: 1.355 against 1.380 ms for OPT 0 / five tiles)
-                const int nr10 = (grid + 2 * kBankKT - 1) / (2 * kBankKT);
+                // default: ten tiles per workgroup, march reads eight steps ahead, packed channel MACs, lean epilogue in lockstep
+                // pairs, wave priorities staging 2 / march 0 / DFT passes 3 / epilogue 1 (A/B on the device:
+                // profiles/r03_h_bank_times.txt, r03_k_bank_times.txt, r03_n_prio_sweep.txt)
+                // (BTGPU_BANK_RUNS, diagnostics: the number of workgroups -- tile k of workgroup b is b + k runs)
+                static const int runs_env = [] { const char *e = getenv("BTGPU_BANK_RUNS"); return e ? atoi(e) : 0; }();
+                const int nr10 = runs_env > 0 ? (runs_env < grid ? runs_env : grid) : (grid + 2 * kBankKT - 1) / (2 * kBankKT);
                 // + the lean epilogue where the per-step rotation of every channel is +-1 (100 Msps: always)
-                if (bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 31>, nr10, kBankThreads, lds, p);
-                else if (bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, nr10, kBankThreads, lds, p);
-                else L(pfb100f_kernel<kBankThreads, false, 2 * kBankKT, 3>, nr10, kBankThreads, lds, p);
+                if (bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 255>, nr10, kBankThreads, lds, p);
+                else if (bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7 + 224>, nr10, kBankThreads, lds, p);
+                else L(pfb100f_kernel<kBankThreads, false, 2 * kBankKT, 3 + 224>, nr10, kBankThreads, lds, p);
             }
         } else if (wide) {
             if (bk.real_taps) L(pfb100_kernel<7, 1, NT, true, true, kBankThreadsWide, true>, grid, kBankThreadsWide, lds, p);

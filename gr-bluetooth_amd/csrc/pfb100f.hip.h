@@ -128,8 +128,17 @@ __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &
     for (int k = 0; k < NI; k++) U[(NT + R + 2 * k) * UST + pp] = acc[k];
 }
 
+// (exploration, OPT 256: wave priority per phase from p.dbg bits 8..23, one nibble each for staging, march, DFT passes, epilogue)
+__device__ __forceinline__ void setprio_dyn(int v)
+{
+    if (v == 0) __builtin_amdgcn_s_setprio(0);
+    else if (v == 1) __builtin_amdgcn_s_setprio(1);
+    else if (v == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 // OPT (experiments, A/B on the device): 1 = epilogue not fenced, 2 = march reads 8 steps ahead, 4 = packed channel MACs,
-// 8 = lean epilogue (needs rho = +-1: p.rho_real), 16 = epilogue instants interleaved in pairs on whole tiles
+// 8 = lean epilogue (needs rho = +-1: p.rho_real), 16 = epilogue instants in lockstep pairs on whole tiles, 32 = the DFT passes at raised wave priority, 64 = staging / stores too (2), 128 = epilogue at 1
 template <int NTH, bool REAL, int KT, int OPT = 0>
 __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbParams p)
 {
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
 
     // ---- the run of tiles of this workgroup (XCD-aware: neighbouring runs share their halo in one L2) ----
     const int ntl = p.ntiles + p.pre_tiles;                      // pre-tiles own squelch instants only
-    const int nruns = (ntl + KT - 1) / KT;
+    const int nruns = (int)gridDim.x;                            // (about KT tiles each: bank_runs, bank_launch.h)
     // Tile k of this workgroup is tu0 + k nruns: at any moment the resident workgroups work on (about) CONSECUTIVE tiles,
     // like one-tile workgroups would -- so the filter-length overlap of neighbouring input spans is read by neighbours at
     // the same time (L2 hit) and the partial cache lines of Z that neighbouring tiles share are merged in the L2.  With a
@@ -340,6 +349,8 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         // outputs, angle tiles, tile sums -- are issued only now, behind the staging, in the same barrier interval: issued
         // in front of it (as the epilogue's last act, round-3 first form) they sat between the loads and their s_waitcnt,
         // and every tile waited for freshly issued HBM writes to retire.
+        if (OPT & 256) setprio_dyn((p.dbg >> 8) & 15);
+        else if (OPT & 64) __builtin_amdgcn_s_setprio(2);        // (staging + the previous tile's stores: little arithmetic)
         if (interior(tile)) {
             auto put = [&](int j, const float4 &q) { const int i = l + j * NTH; if (i < N4) ((float4 *)xs)[i] = q; };
             put(0, v0); if (PER > 1) put(1, v1); if (PER > 2) put(2, v2); if (PER > 3) put(3, v3);
@@ -350,6 +361,8 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         if (PSL > 8) mark(6);
         prev_tile = tile; prev_any = true;
         __syncthreads();
+        if (OPT & 256) setprio_dyn((p.dbg >> 12) & 15);
+        else if (OPT & 64) __builtin_amdgcn_s_setprio(0);
         mark(0);
         // the next tile's input: in flight under this tile's arithmetic
         if (tu + tstep < ntl && interior(tile + tstep)) load_span(tile + tstep, l);
@@ -378,9 +391,15 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         mark(1);
 
         // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100}, in place ----
+        // (OPT 32: the two DFT passes -- LDS round trips with little arithmetic between them -- run ahead of the other
+        // workgroups' waves on the SIMD, which are mostly in the arithmetic-heavy march and epilogue)
+        if (OPT & 256) setprio_dyn((p.dbg >> 16) & 15);
+        else if (OPT & 32) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int sw = 0; sw < NSW; sw++) {
             const int bi = l + sw * NTH;
+            // (the one wave with a second sweep is what the other three wait for at the barrier: ahead of the waves of the
+            // other workgroups on its SIMD while it lasts)
             if (bi < NTASK) {
                 const int brow = bi / 10, bp2 = bi - 10 * brow;
                 cf *col = U + brow * UST + bp2;
@@ -419,6 +438,8 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
                 }
             }
         }
+        if (OPT & 256) setprio_dyn((p.dbg >> 20) & 15);
+        else if (OPT & 32) __builtin_amdgcn_s_setprio((OPT & 128) ? 1 : 0);
         if (PSL > 8) mark(10);
         __syncthreads();
         mark(3);
@@ -558,6 +579,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         }
         if (PSL > 8) mark(11);
         __syncthreads();
+        if (!(OPT & 256) && (OPT & 128)) __builtin_amdgcn_s_setprio(0);
         mark(4);                                         // angle tiles complete; Y (= the span region) is dead
     }
     if (prev_any) flush_prev(prev_tile, prev_u0, l0);
