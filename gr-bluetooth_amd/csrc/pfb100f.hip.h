@@ -25,6 +25,12 @@
 //    instead of two) is kept as BTGPU_BANK=run320 for A/B: it still spills and is slower (profiles/r03_h_*).
 //  * The lane index is laundered once per tile (BTGPU_OPAQUE): without it LICM hoists every per-phase address out
 //    of the tile loop and the kernel spills ~80 registers.
+//  * Second half of round 3 (the default, OPT 255): a lean epilogue (27 instead of 41 vector instructions per
+//    demodulated instant, instants in lockstep pairs), stores and prefetch loads addressed as uniform base + 32-bit
+//    lane offset, and a wave priority per phase (staging 2, march 0, DFT passes 3, epilogue 1): three workgroups in
+//    different phases share a CU, and a tile's life is the latency of its waves' dependent chains (14 300 cycles with
+//    the workgroup alone on the CU, 19 500 with three: profiles/r03_l_*), not issue slots -- the phases that end in a
+//    barrier the whole workgroup waits at go first.  502 M -> 417 M vector instructions, 1.34 -> 1.20 ms on one box.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
