@@ -194,29 +194,42 @@ def run_rank(args):
     gatherer = bdist.HitGatherer(cap=4096 * max(1, args.gather_every), device=coll_device, force=args.force_gather)
     gathering = world > 1 or args.force_gather
 
-    def step(last=False, gather=True, blk=None):
+    def step(last=False, gather=True, blk=None, every=False):
         """One pass of the hot path over the rank's batch.  In the (default) pipelined mode the
         records of a batch are harvested while the next batch runs; the last step of a timed
         region flushes, so every record of every step is on the host inside the timed region.
         N > 1: the records this rank has ready are posted to one asynchronous all_gather; what
-        comes back here is the previous post (collected while this batch computes)."""
+        comes back here is the post of two rounds ago (HitGatherer keeps two in flight: a round only gets onto a
+        device full of compute at kernel boundaries, and is collected when it has long finished)."""
         blk = blk or head_blk
+        dump = os.environ.get("BENCH_DUMP_STEPS")
+        tt = [time.perf_counter()]
         blk.process_device(seg.data_ptr(), n_complex, first, S, left_margin=margin)
+        tt.append(time.perf_counter())
         if last:
             blk.flush()
+        tt.append(time.perf_counter())
         ints, snr = bdist.struct_to_arrays(blk.poll_arrays())
+        tt.append(time.perf_counter())
         if not gathering or not gather:
+            if dump and last:
+                print("last step ms: process %.2f flush %.2f poll %.2f" % tuple(1e3 * (b - a) for a, b in zip(tt, tt[1:])), file=sys.stderr)
             return ints, snr
         # one round every --gather-every batches (every rank counts the same batches) and at the flush
         step.count = getattr(step, "count", 0) + 1
-        if not last and step.count % max(1, args.gather_every):
+        if not last and not every and step.count % max(1, args.gather_every):
             gatherer.hold(ints, snr)
             return ints[:0], snr[:0]
-        got = gatherer.collect() if gatherer.pending is not None else (ints[:0], snr[:0])
+        got = gatherer.collect(sort=False) if gatherer.full else (ints[:0], snr[:0])      # the round posted two cadence periods ago
+        tt.append(time.perf_counter())
         gatherer.post(ints, snr)
+        tt.append(time.perf_counter())
         if last:
-            more = gatherer.collect(drain=True)
+            more = gatherer.collect(drain=True, sort=False)
             got = (np.concatenate([got[0], more[0]], axis=0), np.concatenate([got[1], more[1]], axis=0))
+        tt.append(time.perf_counter())
+        if dump:
+            print("gather step ms (last %d): process %.2f flush %.2f poll %.2f collect %.2f post %.2f drain %.2f" % ((int(last),) + tuple(1e3 * (b - a) for a, b in zip(tt, tt[1:]))), file=sys.stderr)
         return got
 
     head_blk = blk
@@ -248,8 +261,10 @@ def run_rank(args):
             step(last=False, gather=False, blk=b)
         step(last=True, gather=False, blk=b)
         fence()
+        # (warm-up with a gather round per step: the first collective posted while the device is full of queued batches has
+        # been seen to block the host for 5-8 ms, one-off -- it belongs to the warm-up, not to any steady state)
         for i in range(args.warmup):
-            step(last=(i == args.warmup - 1), gather=gather, blk=b)
+            step(last=(i == args.warmup - 1), gather=gather, blk=b, every=True)
         fence()
         tm0 = b.timing()
         t0 = time.perf_counter()

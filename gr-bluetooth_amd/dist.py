@@ -64,37 +64,55 @@ class HitGatherer:
     [1 + cap, 8] -- row 0 = (number of records this round, number still to come), rows 1.. =
     the seven integer fields and the bits of snr_db -- to one asynchronous all_gather into ONE
     stacked receive buffer [world, 1 + cap, 8].  Nothing about sizes crosses the host beforehand (no
-    counts exchange, no .item()); post() returns at once and collect() of the PREVIOUS post is
-    called while the next batch computes.  More than `cap` records in a batch (rare) spill into
-    extra rounds that every rank agrees on from the headers it received.
+    counts exchange, no .item()); post() returns at once.  Up to `depth` rounds are in flight: the caller collects round
+    r when it is about to post round r + depth (`full`), a whole cadence period or more after that round was posted.
+    More than `cap` records in a round (rare) spill into extra rounds that every rank agrees on from the headers it received.
 
     With a device (backend nccl = RCCL) the whole exchange lives on a stream of its own: the block is
     packed into a pinned host buffer, copied to the device, gathered, and the stacked result comes
     back with a single device-to-host copy -- the compute streams of the handle are never touched.
+    Why depth 2: beside kernels that fill every CU, each of the three device operations of a round (copy in, collective,
+    copy out) only gets onto the device at the next kernel boundary of the compute stream -- measured on one MI355X, a round
+    posted beside 1.9 ms batches was still ~1 ms from done four batches later, and a collect() at that point stalled
+    the host for that millisecond (3-18 % of the cadence period).  One more period of slack and collect() never waits.
     force=True runs the collective even in a one-rank group (the single-GPU first-contact test of
     the RCCL path)."""
 
-    def __init__(self, cap=8192, device="cpu", group=None, force=False):
+    def __init__(self, cap=8192, device="cpu", group=None, force=False, depth=2):
+        import collections
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
-        self.cap, self.device = int(cap), device
+        self.cap, self.device, self.depth = int(cap), device, max(1, int(depth))
         inited = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if inited else 1
         self.on = inited and (self.world > 1 or force)
-        self.pending = None                 # (work handle, stacked receive buffer)
+        self.inflight = collections.deque()     # rounds posted and not yet collected, oldest first
         self.backlog_i = np.zeros((0, len(HIT_INT_FIELDS)), np.int64)
         self.backlog_s = np.zeros((0,), np.float64)
         self.rounds = 0
         self.on_device = str(device) != "cpu"
         self.stream = None
-        self.done = None
+        self.slots = []                         # device path: `depth` buffer sets, used round-robin
         if self.on and self.on_device:
             self.stream = torch.cuda.Stream(device=device)
-            self.h_send = torch.zeros((1 + self.cap, 8), dtype=torch.int64).pin_memory()
-            self.h_recv = torch.zeros((self.world * (1 + self.cap), 8), dtype=torch.int64).pin_memory()
-            self.d_send = torch.zeros((1 + self.cap, 8), dtype=torch.int64, device=device)
-            self.d_recv = torch.zeros((self.world * (1 + self.cap), 8), dtype=torch.int64, device=device)
+            for _ in range(self.depth):
+                self.slots.append(dict(
+                    h_send=torch.zeros((1 + self.cap, 8), dtype=torch.int64).pin_memory(),
+                    h_recv=torch.zeros((self.world * (1 + self.cap), 8), dtype=torch.int64).pin_memory(),
+                    d_send=torch.zeros((1 + self.cap, 8), dtype=torch.int64, device=device),
+                    d_recv=torch.zeros((self.world * (1 + self.cap), 8), dtype=torch.int64, device=device),
+                    done=None))
+
+    @property
+    def pending(self):
+        """The oldest round in flight (None if there is none)."""
+        return self.inflight[0] if self.inflight else None
+
+    @property
+    def full(self):
+        """True when the next post() needs a collect() first."""
+        return len(self.inflight) >= self.depth
 
     def _pack(self):
         n = min(len(self.backlog_i), self.cap)
@@ -119,50 +137,50 @@ class HitGatherer:
         self.hold(ints, snr)
         if not self.on:
             return
-        assert self.pending is None, "collect() the previous round first"
+        assert not self.full, "collect() the oldest round first"
         blockh = self._pack()
         if self.on_device:
             # the whole round is enqueued here, on the gatherer's stream: pack -> device, the collective, the stacked blocks
-            # back to pinned memory, one event.  collect() then only waits for that event -- a whole batch later, when
-            # it has long fired -- instead of enqueueing a copy and waiting for it on the spot.
-            if self.done is not None:
-                self.done.synchronize()                  # (the previous round is through with the pinned buffers)
-            self.h_send.numpy()[...] = blockh
+            # back to pinned memory, one event.  collect() then only waits for that event.
+            sl = self.slots[self.rounds % self.depth]
+            if sl["done"] is not None:
+                sl["done"].synchronize()                 # (the round that used this buffer set is through with it)
+            sl["h_send"].numpy()[...] = blockh
             with torch.cuda.stream(self.stream):
-                self.d_send.copy_(self.h_send, non_blocking=True)
-                work = self.dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group, async_op=True)
+                sl["d_send"].copy_(sl["h_send"], non_blocking=True)
+                work = self.dist.all_gather_into_tensor(sl["d_recv"], sl["d_send"], group=self.group, async_op=True)
                 work.wait()                              # orders this stream behind the collective (no host wait)
-                self.h_recv.copy_(self.d_recv, non_blocking=True)    # ONE copy of the stacked blocks
-                self.done = torch.cuda.Event()
-                self.done.record(self.stream)
-            self.pending = (work, self.d_recv)
+                sl["h_recv"].copy_(sl["d_recv"], non_blocking=True)     # ONE copy of the stacked blocks
+                sl["done"] = torch.cuda.Event()
+                sl["done"].record(self.stream)
+            self.inflight.append((work, sl))
         else:
             send = torch.from_numpy(blockh)
             recv = torch.empty((self.world * (1 + self.cap), 8), dtype=torch.int64)      # the blocks of all ranks, concatenated
             work = self.dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
-            self.pending = (work, recv, send)
+            self.inflight.append((work, recv, send))
         self.rounds += 1
 
-    def collect(self, drain=False):
-        """Records of the posted round from every rank, sorted (slot, channel, kind, offset).  With
-        drain=True keeps going (synchronously) until no rank has records left."""
-        torch = self.torch
+    def collect(self, drain=False, sort=True):
+        """Records of the OLDEST posted round from every rank, sorted (slot, channel, kind, offset) unless sort=False
+        (rank order then: a caller that merges many rounds sorts once at the end -- np.lexsort of the 12 000 records of
+        four C79 batches is 0.8 ms of host time per round).  With drain=True: every round in flight, then
+        (synchronously) further rounds until no rank has records left."""
         if not self.on:
             i, s = self.backlog_i, self.backlog_s
             self.backlog_i, self.backlog_s = i[:0], s[:0]
-            return sort_hits(i, s)
+            return sort_hits(i, s) if sort else (i, s)
         out_i, out_s = [], []
         while True:
-            if self.pending is None:
+            if not self.inflight:
                 self.post(self.backlog_i[:0], self.backlog_s[:0])
-            work, recv = self.pending[0], self.pending[1]
+            rnd = self.inflight.popleft()
             if self.on_device:
-                self.done.synchronize()
-                blocks = self.h_recv.numpy().reshape(self.world, 1 + self.cap, 8)
+                rnd[1]["done"].synchronize()
+                blocks = rnd[1]["h_recv"].numpy().reshape(self.world, 1 + self.cap, 8)
             else:
-                work.wait()
-                blocks = recv.numpy().reshape(self.world, 1 + self.cap, 8)
-            self.pending = None
+                rnd[0].wait()
+                blocks = rnd[1].numpy().reshape(self.world, 1 + self.cap, 8)
             more = False
             for r in range(self.world):
                 blk = blocks[r]
@@ -171,8 +189,9 @@ class HitGatherer:
                 if n:
                     out_i.append(blk[1:1 + n, :7].copy())
                     out_s.append(blk[1:1 + n, 7].copy().view(np.float64))
-            if not (drain and more):
+            if not drain or not (self.inflight or more):
                 break
         if not out_i:
             return np.zeros((0, len(HIT_INT_FIELDS)), np.int64), np.zeros((0,), np.float64)
-        return sort_hits(np.concatenate(out_i, axis=0), np.concatenate(out_s, axis=0))
+        oi, os_ = np.concatenate(out_i, axis=0), np.concatenate(out_s, axis=0)
+        return sort_hits(oi, os_) if sort else (oi, os_)

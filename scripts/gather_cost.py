@@ -29,7 +29,7 @@ def run(every, cap, steps=40):
         ints, snr = bd.struct_to_arrays(blk.poll_arrays())
         if every and i % every == every - 1:
             a = time.perf_counter()
-            if g.pending is not None: r = g.collect(); n += len(r[0])
+            if g.full: r = g.collect(); n += len(r[0])
             b = time.perf_counter()
             g.post(ints, snr)
             c = time.perf_counter(); tc += b - a; tp += c - b

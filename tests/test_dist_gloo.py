@@ -70,6 +70,20 @@ def _worker(rank, world, port, tmp):
     g2.post(ints[half:], snr[half:])
     hi, hs = g2.collect(drain=True)
     assert g2.rounds == 1 and np.array_equal(hi, gi) and np.array_equal(hs, gs)
+    # ... and the bench's cadence: two rounds in flight, the oldest collected only when a third is due, thirds of the
+    # records per round with a capacity that makes the middle one spill
+    g3 = bd.HitGatherer(cap=2, device="cpu")                         # (the same capacity on every rank: it sizes the collective)
+    t1, t2 = len(ints) // 3, 2 * len(ints) // 3
+    got = []
+    for lo, hi_ in ((0, t1), (t1, t2), (t2, len(ints))):
+        if g3.full:
+            got.append(g3.collect())
+        g3.post(ints[lo:hi_], snr[lo:hi_])
+        assert len(g3.inflight) <= 2
+    assert g3.full                                                   # rounds 2 and 3 still in flight
+    got.append(g3.collect(drain=True))
+    di, ds = bd.sort_hits(np.concatenate([g_[0] for g_ in got], axis=0), np.concatenate([g_[1] for g_ in got], axis=0))
+    assert np.array_equal(di, gi) and np.array_equal(ds, gs)
     if rank == 0:
         np.save(os.path.join(tmp, "gathered.npy"), gi)
     dist.barrier()
