@@ -16,6 +16,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Optimiser fences that emit no instruction (what they are for: pfb100f.hip.h, window_kernel).  BTGPU_OPAQUE(x): the value of x
+// is unknown to the optimiser from here on; BTGPU_AFTER(x, dep): x cannot be formed before dep exists.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BTGPU_AFTER(x, dep) asm volatile("" : "+v"(x) : "v"(dep))
+#define BTGPU_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define BTGPU_OPAQUE(x) ((void)0)
+#define BTGPU_AFTER(x, dep) ((void)(dep))                        /* host emulation of the kernels (tests/emu) */
+#endif
+
 namespace btgpu {
 
 struct DeviceHit {            // 40 bytes, written by the window kernel
@@ -603,25 +613,59 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         while (ii <= lim && oo < nmax) {
             // interpolate: sum_q T[imu][7-q] * in[ii+q], q ascending
             // mu = x - floor(x) lies in [0, 1] (1.0 when x is a tiny negative number): imu in 0..128, no clamp needed
-            const int imu = (int)rintf(mu * 128.0f);
-            const char *trow = (const char *)mmse + __mul24(imu, kMmseStride * 4);
-            const float4 ta = *(const float4 *)(trow + 16);                    // T[4..7]
-            const float4 tb = *(const float4 *)trow;                           // T[0..3]
-            const float *in = (const float *)((const char *)tile + (__umul24(ii, (uint32_t)(kWinRowStride * 4)) + colb));
+            // rintf(mu * 128) through the mantissa: mu * 128 + 1.5 * 2^23 is rounded to the nearest integer (ties to even, as
+            // rintf does) and carries it in its low bits -- 0x4B400000 + imu, of which the 24-bit multiply takes 0x400000 + imu:
+            // one FMA and one multiply-add instead of multiply, round, convert, multiply
+            const uint32_t tb24 = __float_as_uint(fmaf(mu, 128.0f, 12582912.0f));
+            const uint32_t toff = __umul24(tb24, (uint32_t)(kMmseStride * 4)) - 0x400000u * (uint32_t)(kMmseStride * 4);
+            // the interpolator row (two 16-byte reads) and eight 4-byte sample reads with immediate offsets, written out: left
+            // to the compiler the sample reads are paired into ds_read2_b32, whose offsets reach 1020 bytes while the rows
+            // are 4 * kWinRowStride apart -- three address additions per symbol at the same number of LDS cycles, in a loop
+            // that is bound by vector-instruction issue
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f ta, tb;                                                        // T[4..7], T[0..3]
+            float x0, x1, x2, x3, x4, x5, x6, x7;
+            const uint32_t ioff = __umul24(ii, (uint32_t)(kWinRowStride * 4)) + colb;
+#if defined(__HIP_DEVICE_COMPILE__)
+            {
+                constexpr int RB = kWinRowStride * 4;
+                const uint32_t ia = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)tile + ioff;
+                const uint32_t tadr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)mmse + toff;
+                asm volatile("ds_read_b128 %0, %11 offset:16\n\tds_read_b128 %1, %11\n\t"
+                             "ds_read_b32 %2, %10\n\tds_read_b32 %3, %10 offset:%12\n\tds_read_b32 %4, %10 offset:%13\n\t"
+                             "ds_read_b32 %5, %10 offset:%14\n\tds_read_b32 %6, %10 offset:%15\n\tds_read_b32 %7, %10 offset:%16\n\t"
+                             "ds_read_b32 %8, %10 offset:%17\n\tds_read_b32 %9, %10 offset:%18\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(ta), "=&v"(tb), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)
+                             : "v"(ia), "v"(tadr), "i"(RB), "i"(2 * RB), "i"(3 * RB), "i"(4 * RB), "i"(5 * RB), "i"(6 * RB), "i"(7 * RB)
+                             : "memory");
+            }
+#else
+            {
+                const char *trow = (const char *)mmse + toff;
+                const float *in = (const float *)((const char *)tile + ioff);
+                ta = *(const v4f *)(trow + 16); tb = *(const v4f *)trow;
+                x0 = in[0]; x1 = in[kWinRowStride]; x2 = in[2 * kWinRowStride]; x3 = in[3 * kWinRowStride];
+                x4 = in[4 * kWinRowStride]; x5 = in[5 * kWinRowStride]; x6 = in[6 * kWinRowStride]; x7 = in[7 * kWinRowStride];
+            }
+#endif
             float acc = 0.f;
-            acc = fmaf(ta.w, in[0 * kWinRowStride], acc);
-            acc = fmaf(ta.z, in[1 * kWinRowStride], acc);
-            acc = fmaf(ta.y, in[2 * kWinRowStride], acc);
-            acc = fmaf(ta.x, in[3 * kWinRowStride], acc);
-            acc = fmaf(tb.w, in[4 * kWinRowStride], acc);
-            acc = fmaf(tb.z, in[5 * kWinRowStride], acc);
-            acc = fmaf(tb.y, in[6 * kWinRowStride], acc);
-            acc = fmaf(tb.x, in[7 * kWinRowStride], acc);
+            acc = fmaf(ta.w, x0, acc);
+            acc = fmaf(ta.z, x1, acc);
+            acc = fmaf(ta.y, x2, acc);
+            acc = fmaf(ta.x, x3, acc);
+            acc = fmaf(tb.w, x4, acc);
+            acc = fmaf(tb.z, x5, acc);
+            acc = fmaf(tb.y, x6, acc);
+            acc = fmaf(tb.x, x7, acc);
             const float out = acc;
             ii += (unsigned int)mm_update(out, last, omega, mu, p);
             // slicer: one bit per symbol
             cur = sym_push(cur, out);
-            if ((oo & 31) == 31) gbits[(oo >> 5) * kWinThreads] = sym_word(cur, 32);
+            if ((oo & 31) == 31) {
+                int o2 = oo;
+                BTGPU_OPAQUE(o2);                                // (the word index is formed here, once per 32 symbols, not carried through the loop)
+                gbits[(o2 >> 5) * kWinThreads] = sym_word(cur, 32);
+            }
             oo++;
         }
         if (oo < nmax && ii < ni) s_live[it & 1] = 1;            // this lane needs another chunk
@@ -920,9 +964,11 @@ __global__ __launch_bounds__(64) void finish_kernel(
         fetch(v);
         // consume every step whose 8-tap window lies inside the resident rows [.., hi)
         while (ii + 8 <= hi && ii < ni && oo < demod_n) {
-            const int imu = (int)rintf(mu * 128.0f);             // mu in [0, 1) -> 0..128
-            const float4 ta = *(const float4 *)&mmse[imu * 8 + 4];
-            const float4 tb = *(const float4 *)&mmse[imu * 8];
+            // rintf(mu * 128) through the mantissa (window_kernel): 0x4B400000 + imu, shifted to the 32-byte row
+            const uint32_t tb24 = __float_as_uint(fmaf(mu, 128.0f, 12582912.0f));
+            const char *trow = (const char *)mmse + ((tb24 << 5) - (0x4B400000u << 5));
+            const float4 ta = *(const float4 *)(trow + 16);
+            const float4 tb = *(const float4 *)trow;
             const float *in = my + (ii & MASK);
             float acc = 0.f;
             acc = fmaf(ta.w, in[0], acc);

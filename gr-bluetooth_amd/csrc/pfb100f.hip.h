@@ -78,13 +78,7 @@ __device__ __forceinline__ cf chan_mac(const ChanTaps<REAL> &t, int q, cf w, cf 
 // through it at the top of every tile: everything derived from it -- LDS and HBM addresses of every phase -- is then
 // recomputed per tile (a few dozen integer operations) instead of being hoisted out of the tile loop, where ~40 such
 // invariants stayed live through all phases and pushed the prefetched input out of the register file.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define BTGPU_AFTER(x, dep) asm volatile("" : "+v"(x) : "v"(dep))
-#define BTGPU_OPAQUE(x) asm volatile("" : "+v"(x))
-#else
-#define BTGPU_OPAQUE(x) ((void)0)
-#define BTGPU_AFTER(x, dep) ((void)(dep))                        /* host emulation of the kernels (tests/emu) */
-#endif
+// (the two macros live in kernels.hip.h)
 
 template <int R, bool REAL, int OPT>
 __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &a, const cf (&an)[15], cf *U, int pp)
