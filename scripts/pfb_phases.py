@@ -42,7 +42,7 @@ if variant in ("legacy", "wide"):
 else:
     # pfb100f_kernel: [workgroup][wave][8]; marks 0..4 = cycles up to the barrier that ends: copy-out + staging | A | B1 | B2 | C
     nw = 5 if variant == "run320" else 4
-    kt = 10 if variant in ("run256", "run256d", "run256e") else 5          # tiles per workgroup (bank_launch.h)
+    kt = 10 if variant in ("run256", "run256a", "run256d", "run256e") else 5   # tiles per workgroup (bank_launch.h)
     psl = 16 if kt >= 10 else 8                                            # slots per wave (pfb100f.hip.h)
     raw = raw.reshape(-1)
     used = raw[: (len(raw) // (nw * psl)) * nw * psl].reshape(-1, nw, psl)
