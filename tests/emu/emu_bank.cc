@@ -212,6 +212,20 @@ int emu_stage2_run(int outs, int nw, int L3, const float *h3, const double *w, c
     return 0;
 }
 
+// the three forms of the polynomial arctangent (pfb100.hip.h): demod_poly (canonicalises -0), demod_poly_pz (arguments never
+// -0), demod_poly_pz2 (two in lockstep) -- the tests want them bit-identical wherever the arguments carry no -0
+int emu_demod_variants(int n, float gain, const float *pr, const float *pi, float *a_ref, float *a_pz, float *a_pz2)
+{
+    const DemodConst k = demod_constants(gain);
+    for (int i = 0; i < n; i++) {
+        a_ref[i] = demod_poly(k, pr[i], pi[i]);
+        a_pz[i] = demod_poly_pz(k, k.c[5], pr[i], pi[i]);
+    }
+    for (int i = 0; i + 1 < n; i += 2) demod_poly_pz2(k, k.c[5], pr[i], pi[i], pr[i + 1], pi[i + 1], a_pz2[i], a_pz2[i + 1]);
+    if (n & 1) a_pz2[n - 1] = a_pz[n - 1];
+    return 0;
+}
+
 // the pass-2 lane map, for the bank-conflict check of the tests
 int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
 {

@@ -169,6 +169,32 @@ def test_fused_and_standalone_noise_banks_agree(emu, c79_capture):
         assert np.allclose(a[k], b[k], rtol=1e-6, atol=0)
 
 
+def test_demod_polynomial_forms_are_bit_identical(emu):
+    """demod_poly (round 2), demod_poly_pz (lean epilogue: no canonicalising additions, arguments formed by an FMA onto +0)
+    and demod_poly_pz2 (two instants in lockstep) give the same bits for every argument pair without a -0, all four
+    quadrants, both octants, tiny and huge magnitudes; (0, 0) is the angle 0 and the result tracks atan2 to 1e-5 rad."""
+    rng = np.random.default_rng(11)
+    n = 20000
+    mag = 10.0 ** rng.uniform(-20, 20, n)
+    th = rng.uniform(-np.pi, np.pi, n)
+    pr = (mag * np.cos(th)).astype(np.float32); pi = (mag * np.sin(th)).astype(np.float32)
+    pr[:8] = [0, 1, -1, 0, 0, 1, -1, 3]; pi[:8] = [0, 0, 0, 1, -1, 1, 1, -3]      # axes, diagonals, the origin (+0 only)
+    pr = np.where(pr == 0, np.float32(0.0), pr); pi = np.where(pi == 0, np.float32(0.0), pi)
+    a = [np.zeros(n, np.float32) for _ in range(3)]
+    fp = ctypes.POINTER(ctypes.c_float)
+    emu.emu_demod_variants.restype = ctypes.c_int
+    emu.emu_demod_variants.argtypes = [ctypes.c_int, ctypes.c_float] + [fp] * 5
+    gain = 0.8
+    assert emu.emu_demod_variants(n, gain, *(x.ctypes.data_as(fp) for x in (pr, pi, *a))) == 0
+    assert np.array_equal(a[0].view(np.uint32), a[1].view(np.uint32))
+    assert np.array_equal(a[0].view(np.uint32), a[2].view(np.uint32))
+    assert a[0][0] == 0.0
+    ref = gain * np.arctan2(pi.astype(np.float64), pr.astype(np.float64))
+    err = np.abs(a[0] - ref)
+    err = np.minimum(err, np.abs(err - 2 * np.pi * gain))                         # (-pi and +pi are the same angle)
+    assert err.max() <= 1e-5 * gain, err.max()
+
+
 @pytest.mark.parametrize("outs,nw,L3,S", [(250, 182, 80, 11), (250, 182, 80, 8), (250, 182, 80, 1), (40, 46, 80, 9), (250, 177, 74, 3)])
 def test_noise_stage2_kernel_vs_numpy(emu, outs, nw, L3, S):
     """noise_stage2_kernel by itself (eight outputs per lane, swizzled slot windows in LDS, runs of eight slots with a
