@@ -357,6 +357,20 @@ def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff,
     assert d["other_only_gpu"] + d["other_only_ref"] <= 2, d
 
 
+def test_emulated_fast_path_random_captures(emu):      # (the fixture builds tests/emu/libemu_bank.so, which the script loads)
+    """Ten captures of `scripts/emu_fuzz_fast.py` (seed 5: the generator of the GPU fuzz -- 100 / 20 / 8 Msps, both blocks, LE on
+    and off, 12-30 dB, three squelch settings) through the emulated FAST front end against the oracle: 137 planted records,
+    all identical, offsets identical, nsym within +-3; records born from noise 5 / 5, none on one side only.  (The 4000-capture
+    run of the same script is profiles/r03_p_emu_fuzz_fast_4000_seed2026.txt.)"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_fuzz_fast.py"), "10", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tot = eval(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
+    assert tot["cases"] == 10 and tot["planted"] > 100, tot
+    assert tot["failed"] == 0 and tot["planted_differing"] == 0 and tot["planted_offset_differs"] == 0, tot
+    assert tot["nsym_dev_max"] <= 8 and tot["other_only_emu"] + tot["other_only_ref"] <= 2, tot
+
+
 def test_fuzz_seed77_case_312_offset_one_symbol_apart(emu, po, synth):
     """Case 312 of `scripts/gpu_fuzz_fast.py 800 77` (profiles/r03_p_fuzz_fast_800_seed77.txt), replayed on the emulator, which
     gives the GPU's answer: multi_LAP, 100 Msps, 24.1 dB.  All 13 planted records agree with the oracle on (slot, channel, kind,
