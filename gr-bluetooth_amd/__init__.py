@@ -31,6 +31,7 @@ CHANNELIZER_AUTO, CHANNELIZER_DIRECT, CHANNELIZER_POLYPHASE = 0, 1, 2
 SQUELCH_AUTO, SQUELCH_DIRECT, SQUELCH_STAGED = 0, 1, 2
 CORRELATOR_AUTO, CORRELATOR_INTREE, CORRELATOR_BTBB = 0, 1, 2   # multi_LAP default: BTBB (libbtbb, as the reference)
 FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS, FLAG_HEADERS, FLAG_TIMING, FLAG_NO_NSYM, FLAG_TIMING_BANK = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_NO_VERIFY = 256      # polyphase path without the exact confirmation of its records (A/B)
 KIND_AC, KIND_AA = 0, 1
 
 
@@ -70,7 +71,8 @@ KERNEL_NAMES = ["ddc_channel", "demod_energy", "ddc_noise", "noise_energy", "win
 class Timing(ctypes.Structure):
     _fields_ = [("kernel_ms", ctypes.c_float * 8), ("kernel_launches", ctypes.c_uint32 * 8),
                 ("total_ms", ctypes.c_float), ("batches", ctypes.c_uint32),
-                ("samples", ctypes.c_uint64), ("slots", ctypes.c_uint64)]
+                ("samples", ctypes.c_uint64), ("slots", ctypes.c_uint64),
+                ("verify_windows", ctypes.c_uint64), ("verify_rows", ctypes.c_uint64), ("verify_turned_away", ctypes.c_uint64)]
 
 
 EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_strerror",
@@ -98,7 +100,7 @@ class BtgpuError(RuntimeError):
 def build(force=False):
     """hipcc --offload-arch=gfx950 build of libbtgpu.so, in-tree."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("btgpu.hip", "kernels.hip.h", "design.cc", "design.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("btgpu.hip", "kernels.hip.h", "verify.hip.h", "design.cc", "design.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "btgpu.h"))
     stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:

@@ -4,6 +4,7 @@
 // very code that runs in production.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -11,6 +12,7 @@
 #include "pfb100.hip.h"
 #include "pfb100f.hip.h"
 #include "pfbm.hip.h"
+#include "verify.hip.h"
 
 namespace btgpu {
 
@@ -202,6 +204,65 @@ inline WindowParams make_window_params(const Design &des, int S, int nb, long lo
     p.btbb_pcol = btbb_pcol;
     p.fin_prio = 3;
     p.want_len = 1;
+    p.qn_stride = S; p.rows_per_slot = des.outs_per_slot;
+    return p;
+}
+
+// ---- exact confirmation (verify.hip.h): geometry and parameters shared by the runtime and the emulator ----
+struct VerifyBuffers {                                   // device (or emulated) memory of one in-flight batch
+    VerifyTask *tasks = nullptr; uint32_t *tiles = nullptr; unsigned int *vcount = nullptr;
+    float *dx = nullptr, *dxt = nullptr;
+    int vcap = 0;
+};
+inline int verify_capacity(int S, int nch) { return (int)std::min<long long>((long long)S * nch, 32768); }
+inline int verify_rows(const Design &des) { return des.d.ddc_out < kVerRows ? des.d.ddc_out : kVerRows; }
+constexpr int kVerGridDdc = 2048, kVerGridFill = 1024;
+// tile length (outputs) of the |Y|^2 tile sums the polyphase banks leave behind
+inline int verify_tile_outs(const FastPath &fp, bool small) { return small ? pfbm_tile(fp.channel.M) : kBankNT - 1; }
+
+// first run (the polyphase path's window_kernel): which windows go to the exact stage
+inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPath &fp, bool small, int mode /*1 hits + energy, 2 hits only*/,
+                                const double *ptile, int ntiles, const VerifyBuffers &vb, bool headers)
+{
+    p.verify = mode;
+    p.ptile = ptile; p.ptile_stride = ntiles; p.tile_outs = verify_tile_outs(fp, small);
+    p.tiles_per_slot = des.outs_per_slot / p.tile_outs;
+    p.vtasks = vb.tasks; p.vtiles = vb.tiles; p.vcount = vb.vcount; p.vcap = vb.vcap;
+    p.burst_ratio = 4.0f / (1.0f - 2.3f / std::sqrt((float)p.tile_outs));   // smallest of ~57 tiles of TT outputs ~ (1 - 2.3 / sqrt(TT)) mean
+    p.span_extra = headers ? 58 : 0;                     // 54 header symbols + the 4-symbol trailer
+}
+inline VerifyParams make_verify_params(const Design &des, size_t x_len, long long w0, int mp, int F, const float2 *rot,
+                                       const double *rot_step_turns, const float *atan_tab, const VerifyBuffers &vb)
+{
+    const btgpu_design &d = des.d;
+    VerifyParams v{};
+    v.x_len = (long long)x_len; v.first0 = w0 + d.first_channel_sample;
+    v.D = d.decimation; v.ntp = des.channel.ntp; v.slot = d.samples_per_slot;
+    v.inv2d = (uint32_t)((1ull << 32) / (unsigned long long)(2 * d.decimation) + 1ull);
+    v.mp = mp; v.F = F;
+    v.rot = rot; v.Q = des.channel.rot_period; v.rot_step_turns = rot_step_turns;
+    v.atan_tab = atan_tab; v.gain = des.demod_gain;
+    v.tasks = vb.tasks; v.tiles = vb.tiles; v.vcount = vb.vcount; v.vcap = vb.vcap;
+    v.nch = d.high_channel - d.low_channel + 1;
+    return v;
+}
+inline VerifyFillParams make_verify_fill_params(const Design &des, const float *d_stream, const float *dcol, int drow, long long G,
+                                                const VerifyBuffers &vb)
+{
+    VerifyFillParams f{};
+    f.tasks = vb.tasks; f.vcount = vb.vcount; f.vcap = vb.vcap; f.dx = vb.dx;
+    f.d = d_stream; f.dcol = dcol; f.drow = drow; f.d_rows = G;
+    f.nch = des.d.high_channel - des.d.low_channel + 1; f.outs_per_slot = des.outs_per_slot; f.rows = verify_rows(des);
+    f.dxt = vb.dxt;
+    return f;
+}
+// the exact stage's window_kernel<LAY, true> launch: tasks as lanes, nch per pseudo-slot
+inline WindowParams make_verify_window_params(const WindowParams &first, const VerifyBuffers &vb)
+{
+    WindowParams p = first;
+    p.verify = 0;
+    p.S = (vb.vcap + first.nch - 1) / first.nch;          // pseudo-slots (workgroups beyond the task count leave at once)
+    p.rows_per_slot = kVerRows;
     return p;
 }
 

@@ -61,14 +61,16 @@ struct btgpu_handle {
         DevBuf d_dcol;                        // 100-bin bank: the same stream tile by tile channel-major [tile][80][25], what finish_kernel reads
         DevBuf d_ptile, d_phead;              // polyphase banks: |Y|^2 tile sums (-> block_sum_kernel on the post stream)
         DevBuf d_Z;                           // staged squelch: stage-1 output (-> noise_stage2_kernel on the post stream)
+        DevBuf d_vtasks, d_vtiles, d_vcount, d_dx, d_dxt, d_winbits_v;   // exact confirmation (verify.hip.h): task list, exact rows, task stream
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
-        unsigned int *h_count = nullptr;      // pinned: {hits, finish records}
+        unsigned int *h_count = nullptr;      // pinned: {hits, finish records, -, -, verify tasks, verify tiles, turned away, -}
         DeviceHit *h_hits = nullptr;          // pinned: first kEagerHits records, copied by the tail stream
         // timing events (recorded only with BTGPU_FLAG_TIMING): front 0 start, 1 channel bank, 2 demod / energy (direct
         // form), 3 noise stage 1 / direct noise bank, 4 direct noise energy; post 5 start, 6 block sums, 7 squelch
         // stage 2, 8 window; tail 9 start, 10 end
-        hipEvent_t ev[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        // ... 11 exact stage done (tail)
+        hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr;
         int S = 0;
         uint64_t abs_first_slot = 0;
@@ -80,6 +82,9 @@ struct btgpu_handle {
     bool timing_on = false;          // BTGPU_FLAG_TIMING / _BANK: bracket the kernels with events (btgpu_last_timing)
     bool timing_full = false;        // every kernel (BTGPU_FLAG_TIMING), not just the channel bank
     bool no_nsym = false;            // BTGPU_FLAG_NO_NSYM: skip the M&M continuation that produces hit.nsym
+    int verify = 0;                  // exact confirmation of the polyphase path's records: 0 off, 1 hits + burst energy, 2 hits only
+    int vcap = 0, ver_mp = 0, ver_F = 0;
+    DevBuf d_tapsv;                  // class-major taps of the direct-form channel bank (verify_ddc_kernel)
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
     hipStream_t copy_stream = nullptr;
     hipStream_t spill_stream = nullptr;          // harvest: records beyond the eager copies (never behind an input copy)
@@ -151,11 +156,11 @@ struct btgpu_handle {
                          &d_Y, &d_Yn, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_eon, &d_eoff, &d_snr, &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_b2map_f320, &d_dftw_ch, &d_dftw_n,
-                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18};
+                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18, &d_tapsv};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (TailCtx &t : tc) {
             DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol,
-                            &t.d_ptile, &t.d_phead, &t.d_Z};
+                            &t.d_ptile, &t.d_phead, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -168,6 +173,7 @@ struct btgpu_handle {
             if (h_stage[k]) { (void)hipHostFree(h_stage[k]); h_stage[k] = nullptr; }
             if (ev_copied[k]) { (void)hipEventDestroy(ev_copied[k]); ev_copied[k] = nullptr; }
             if (ev_consumed[k]) { (void)hipEventDestroy(ev_consumed[k]); ev_consumed[k] = nullptr; }
+            if (ev_vdone[k]) { (void)hipEventDestroy(ev_vdone[k]); ev_vdone[k] = nullptr; }
         }
         for (hipStream_t *st : {&stream, &post_stream, &tail_stream, &copy_stream, &spill_stream})
             if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
@@ -198,6 +204,7 @@ struct btgpu_handle {
     // buffers, so that the copy of batch n+1 (host memcpy + DMA on the copy stream) overlaps the kernels of batch n
     float2 *h_stage[2] = {nullptr, nullptr};
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    hipEvent_t ev_vdone[2] = {nullptr, nullptr};      // the batch's tail (whose exact stage re-reads the input) has left the tail stream
     bool stage_used[2] = {false, false};
     unsigned stage_turn = 0;
     int stage_batch(const float *head, size_t n_head_zero, const float *body, size_t n_body, long long w0,
@@ -237,6 +244,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     // =========================== FRONT (stream `st`): the banks ===========================
     // (The post stage runs behind it on the same stream unless BTGPU_PIPE=1, see btgpu_create.)
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
+    if (verify) HIPCHK(this, hipMemsetAsync(t.d_vcount.p, 0, 4 * sizeof(unsigned int), st));
     HIPCHK(this, mark(0, st));
     int ntiles = 0, tiles_per_block = 1, tail_tiles = 0;
 
@@ -366,6 +374,14 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
         { static const int fp_ = getenv("BTGPU_FIN_PRIO") ? atoi(getenv("BTGPU_FIN_PRIO")) : 3; p.fin_prio = fp_; }
         p.want_len = no_nsym ? 0 : 1;
+        // exact confirmation (verify.hip.h): the window kernel hands the windows that can carry a packet's record to the exact
+        // stage, which runs on the tail stream below (beside the next batch's banks)
+        VerifyBuffers vb;
+        if (verify) {
+            vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.tiles = (uint32_t *)t.d_vtiles.p; vb.vcount = (unsigned int *)t.d_vcount.p;
+            vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap;
+            set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
+        }
         auto launch_window = [&](auto lay) {
             using LAY = decltype(lay);
             hipLaunchKernelGGL(window_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, ps, p,
@@ -392,6 +408,35 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         HIPCHK(this, hipEventRecord(t.detect_done, ps));
         HIPCHK(this, hipStreamWaitEvent(tail_stream, t.detect_done, 0));
         HIPCHK(this, mark(9, tail_stream));
+        if (verify) {
+            const VerifyParams vp = make_verify_params(des, x_len, w0, ver_mp, ver_F, (const float2 *)d_rot_ch.p,
+                                                       (const double *)d_rotstep_ch.p, (const float *)d_atan.p, vb);
+            hipLaunchKernelGGL(verify_ddc_kernel, dim3(kVerGridDdc), dim3(kVerThreads), verify_lds_bytes(d.decimation, des.channel.ntp),
+                               tail_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+            const VerifyFillParams fz = make_verify_fill_params(des, (const float *)d_d.p, (const float *)(use_dcol ? t.d_dcol.p : nullptr),
+                                                                drow, G, vb);
+            hipLaunchKernelGGL(verify_fill_kernel, dim3(kVerGridFill), dim3(256), 0, tail_stream, fz);
+            const WindowParams pv = make_verify_window_params(p, vb);
+            auto launch_exact = [&](auto lay) {
+                using LAY = decltype(lay);
+                hipLaunchKernelGGL((window_kernel<LAY, true>), dim3((pv.S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, tail_stream, pv,
+                                   (const float *)t.d_dxt.p, (long long)pv.S * kVerRows,
+                                   (const double *)d_P.p, (const double *)d_Pt.p, (const double *)d_Q.p,
+                                   (const float *)d_mmse.p, (const uint64_t *)d_aclo.p, (const uint32_t *)d_achi.p,
+                                   (double *)d_eon.p, (double *)d_eoff.p, (double *)d_snr.p, (int *)d_winlen.p,
+                                   (DeviceHit *)d_hits.p, (unsigned int *)d_hitcount.p, (FinishRec *)d_fin.p,
+                                   (unsigned int *)d_hitcount.p + 1, (const uint8_t *)d_le_hdr.p,
+                                   (const uint16_t *)d_le_whiten.p, (const int8_t *)d_le_index.p, (int *)d_winfin.p,
+                                   (uint32_t *)d_symbits.p, (uint32_t *)t.d_winbits_v.p);
+            };
+            if (drow == 80) launch_exact(WinLayout<3, 96, 20>{});
+            else if (drow == 40) launch_exact(WinLayout<6, 40, 10>{});
+            else if (drow == 20) launch_exact(WinLayout<12, 20, 5>{});
+            else if (drow == 8) launch_exact(WinLayout<32, 8, 2>{});
+            else launch_exact(WinLayout<64, 4, 1>{});
+            HIPCHK(this, hipMemcpyAsync(t.h_count + 4, t.d_vcount.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
+        }
+        if (timing_on && timing_full) HIPCHK(this, hipEventRecord(ev[11], tail_stream));
         {
             // windows with hits: at most one FinishRec per window; lanes beyond fin_count exit
             // (the kernel strides over the records: the grid only bounds the waves in flight)
@@ -458,9 +503,13 @@ int btgpu_handle::stage_batch(const float *head, size_t n_head, const float *bod
         }
         HIPCHK(this, hipEventCreateWithFlags(&ev_copied[k], hipEventDisableTiming));
         HIPCHK(this, hipEventCreateWithFlags(&ev_consumed[k], hipEventDisableTiming));
+        HIPCHK(this, hipEventCreateWithFlags(&ev_vdone[k], hipEventDisableTiming));
         if (k == 1 && !d_in_b.p) { int rc = alloc(d_in_b, cap * sizeof(float2)); if (rc) return rc; }
     }
-    if (stage_used[k]) HIPCHK(this, hipEventSynchronize(ev_consumed[k]));        // the batch that used this pair is done with it
+    if (stage_used[k]) {                                                         // the batch that used this pair is done with it
+        HIPCHK(this, hipEventSynchronize(ev_consumed[k]));
+        if (verify) HIPCHK(this, hipEventSynchronize(ev_vdone[k]));
+    }
     float *dst = (float *)h_stage[k];
     if (n_head) {
         if (head) std::memcpy(dst, head, n_head * sizeof(float2));
@@ -473,6 +522,7 @@ int btgpu_handle::stage_batch(const float *head, size_t n_head, const float *bod
     HIPCHK(this, hipStreamWaitEvent(stream, ev_copied[k], 0));
     const int rc = process_batch(d_buf, n_head + n_body, w0, abs_first_slot, S, stream);
     HIPCHK(this, hipEventRecord(ev_consumed[k], stream));
+    if (verify) HIPCHK(this, hipEventRecord(ev_vdone[k], tail_stream));
     stage_used[k] = true;
     return rc;
 }
@@ -489,9 +539,9 @@ int btgpu_handle::harvest(TailCtx &t)
         // direct noise bank | squelch stage 2 or direct noise energy | window | tail
         float ms = 0;
         const bool blk = use_pfb;
-        hipEvent_t a[6] = {t.ev[0], blk ? t.ev[5] : t.ev[1], t.ev[2], use_staged ? t.ev[6] : t.ev[3], t.ev[7], t.ev[9]};
-        hipEvent_t e[6] = {t.ev[1], blk ? t.ev[6] : t.ev[2], t.ev[3], use_staged ? t.ev[7] : t.ev[4], t.ev[8], t.ev[10]};
-        for (int i = 0; i < (timing_full ? 6 : 1); i++) {
+        hipEvent_t a[7] = {t.ev[0], blk ? t.ev[5] : t.ev[1], t.ev[2], use_staged ? t.ev[6] : t.ev[3], t.ev[7], t.ev[11], t.ev[9]};
+        hipEvent_t e[7] = {t.ev[1], blk ? t.ev[6] : t.ev[2], t.ev[3], use_staged ? t.ev[7] : t.ev[4], t.ev[8], t.ev[10], t.ev[11]};
+        for (int i = 0; i < (timing_full ? 7 : 1); i++) {
             HIPCHK(this, hipEventElapsedTime(&ms, a[i], e[i]));
             timing.kernel_ms[i] += ms;
             timing.kernel_launches[i] += 1;
@@ -499,6 +549,11 @@ int btgpu_handle::harvest(TailCtx &t)
         if (timing_full) { HIPCHK(this, hipEventElapsedTime(&ms, t.ev[0], t.ev[10])); timing.total_ms += ms; }
     }
     timing.batches += 1;
+    if (verify) {
+        timing.verify_windows += std::min<unsigned>(t.h_count[4], (unsigned)vcap);
+        timing.verify_rows += (uint64_t)t.h_count[5] * kVerTile;
+        timing.verify_turned_away += t.h_count[6];
+    }
     timing.slots += (uint64_t)t.S;
     timing.samples += (uint64_t)t.S * (uint64_t)d.samples_per_slot;
 
@@ -861,6 +916,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     h->timing_full = (cfg->flags & BTGPU_FLAG_TIMING) != 0 || getenv("BTGPU_TIMING") != nullptr;
     h->timing_on = h->timing_full || (cfg->flags & BTGPU_FLAG_TIMING_BANK) != 0;
     h->no_nsym = (cfg->flags & BTGPU_FLAG_NO_NSYM) != 0;
+    // exact confirmation: on wherever the channelizer is the polyphase one (BTGPU_VERIFY=0 | 1 | 2: A/B timing and tests)
+    h->verify = (h->use_pfb && !(cfg->flags & BTGPU_FLAG_NO_VERIFY)) ? 1 : 0;
+    if (h->use_pfb && getenv("BTGPU_VERIFY")) h->verify = std::max(0, std::min(2, atoi(getenv("BTGPU_VERIFY"))));
     // front(n+1) beside post(n) (BTGPU_PIPE=1; possible only where the front writes nothing but per-context buffers).
     // OFF by default -- measured (profiles/r03_a_*): with today's kernels the overlap LOSES.  Every one of them is
     // occupancy-bound by LDS (bank tile 49.8 KB, window workgroup 51 KB, squelch stage 2 24 KB per workgroup of four
@@ -967,6 +1025,11 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_eoff, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_snr, (size_t)S * nch * sizeof(double)));
     TRY(h->alloc(h->d_winbits, (size_t)((S + 2) / 3) * kBitWords * kWinThreads * sizeof(uint32_t)));   // most workgroups: 3 slots each
+    if (h->verify) {
+        h->vcap = verify_capacity(S, nch);
+        const std::vector<float> tv = pack_class_major(des.channel, d.decimation, h->ver_mp, h->ver_F);
+        TRY(h->upload(h->d_tapsv, tv.data(), tv.size() * sizeof(float)));
+    }
     for (int i = 0; i < h->nctx; i++) {
         auto &t = h->tc[i];
         if (h->use_pfb) {
@@ -978,6 +1041,15 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         TRY(h->alloc(t.d_hits, (size_t)h->max_hits * sizeof(DeviceHit)));
         TRY(h->alloc(t.d_hitcount, 2 * sizeof(unsigned int)));
         TRY(h->alloc(t.d_fin, (size_t)S * nch * sizeof(FinishRec)));
+        if (h->verify) {
+            const int vcap = h->vcap, nps = (vcap + nch - 1) / nch;
+            TRY(h->alloc(t.d_vtasks, (size_t)vcap * sizeof(VerifyTask)));
+            TRY(h->alloc(t.d_vtiles, (size_t)vcap * 12 * sizeof(uint32_t)));
+            TRY(h->alloc(t.d_vcount, 4 * sizeof(unsigned int)));
+            TRY(h->alloc(t.d_dx, (size_t)vcap * kVerRows * sizeof(float)));
+            TRY(h->alloc(t.d_dxt, ((size_t)nps * kVerRows + 64) * h->drow * sizeof(float)));
+            TRY(h->alloc(t.d_winbits_v, (size_t)(nps + 1) * kBitWords * kWinThreads * sizeof(uint32_t)));
+        }
         TRY(h->alloc(t.d_d, (size_t)h->drow * (h->ystride + 64) * sizeof(float)));   // [G][drow], time-major
         if (h->use_dcol) TRY(h->alloc(t.d_dcol, (size_t)((h->ystride + 64) / (kBankNT - 1) + 2) * 80 * (kBankNT - 1) * sizeof(float)));
         if (h->want_hdrs) TRY(h->alloc(t.d_hdr, (size_t)h->max_hits * sizeof(HeaderRec)));
@@ -991,12 +1063,14 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         auto &t = h->tc[i];
         if (h->want_hdrs && hipHostMalloc((void **)&t.h_hdr, (size_t)btgpu_handle::kEagerFin * sizeof(HeaderRec), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)btgpu_handle::kEagerFin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
-        if (hipHostMalloc((void **)&t.h_count, 2 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
+        if (hipHostMalloc((void **)&t.h_count, 8 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
+        std::memset(t.h_count, 0, 8 * sizeof(unsigned int));
         if (hipHostMalloc((void **)&t.h_hits, (size_t)btgpu_handle::kEagerHits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
     }
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void *)verify_ddc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

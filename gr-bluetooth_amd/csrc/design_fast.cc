@@ -248,6 +248,20 @@ bool solve_dense(std::vector<double> &A, std::vector<double> &b, int n)
 
 }  // namespace
 
+std::vector<float> pack_class_major(const FilterBank &b, int D, int &mp, int &F)
+{
+    F = (D + 7) / 8;
+    mp = b.ntp / 8 + 2 * F + 8;
+    std::vector<float> out((size_t)b.nch * 8 * mp * 2, 0.f);
+    for (int c = 0; c < b.nch; c++)
+        for (int j = 0; j < b.ntp; j++) {
+            const size_t o = (((size_t)c * 8 + (j & 7)) * mp + F + (j >> 3)) * 2;
+            out[o] = b.taps[((size_t)c * b.ntp + j) * 2];
+            out[o + 1] = b.taps[((size_t)c * b.ntp + j) * 2 + 1];
+        }
+    return out;
+}
+
 int make_fast_path(const Design &des, FastPath &fp)
 {
     const btgpu_design &d = des.d;

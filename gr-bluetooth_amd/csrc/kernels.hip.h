@@ -53,6 +53,17 @@ struct FinishRec {            // M&M state of a window that reported hits, hande
 
 constexpr int kSymWords = 120;    // packed symbols kept per hit window (3840 >= ~3760 symbols)
 
+// Exact confirmation (verify.hip.h): a window of the polyphase path that reported a classic hit, or whose channel energy
+// shows a burst inside the detection span, is handed to the exact stage as one of these; its records then come from the
+// direct-form (bit-exact) arithmetic over the first n_exact demodulated rows of the window.
+struct VerifyTask {
+    int32_t w;                // window index k * nch + c
+    int32_t n_exact;          // demodulated rows [0, n_exact) of the window are recomputed exactly
+    double  snr;              // the window's squelch figure (the exact stage runs beside the next batch, whose sums reuse P / Qn)
+};
+constexpr int kVerRows = 1416;    // rows of a window the exact stage's clock recovery can reach in 693 symbols (693 * 2.01 + 8), rounded up
+constexpr int kVerTile = 127;     // new demodulated rows per tile of verify_ddc_kernel (128 outputs, the first is the demod halo)
+
 // ------------------------------------------------------------------------------------
 // K1: direct-form decimating complex band-pass FIR bank (channel bank and noise bank).
 //   y[c][g] = ( sum_j taps[c][j] * x[first + g*D + j] ) * rot[c][g]
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(256) void demod_rows_kernel(
 // ------------------------------------------------------------------------------------
 struct WindowParams {
     int nch, S;
+    int qn_stride;              // slots per channel row of Qn (= S of the batch; the exact stage's launch has its own S)
     int outs_per_slot;          // grid points per slot (slot / decim)
     int ddc_out, noise_out;
     int blocks_per_window, tail;
@@ -313,6 +325,16 @@ struct WindowParams {
     const uint64_t *btbb_pcol;  // [24] parity column of each LAP bit (device memory)
     int fin_prio;               // wave priority of finish_kernel (0..3)
     int want_len;               // 0 (BTGPU_FLAG_NO_NSYM): windows that outlast the detection span are not continued, nsym = -1
+    // exact confirmation of the polyphase path's records (verify.hip.h)
+    int verify;                 // 1: this launch hands windows with a classic hit or burst energy to the exact stage and emits no
+                                //    record for them (2: without the energy scan); the exact stage's own launch is window_kernel<LAY, true>
+    int rows_per_slot;          // stream rows from one slot's first row to the next slot's (outs_per_slot; exact stage: kVerRows)
+    const double *ptile;        // [nch][ptile_stride] |Y|^2 sums per tile of tile_outs outputs (the polyphase banks' by-product)
+    int ptile_stride, tile_outs, tiles_per_slot;
+    VerifyTask *vtasks; uint32_t *vtiles; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 tile entries, 2 windows turned away (list full)
+    int vcap;                   // capacity of vtasks
+    float burst_ratio;          // a tile counts as burst energy above burst_ratio * (smallest tile of the detection span)
+    int span_extra;             // symbols behind an access code that stay exact as well (the 54-symbol header + margin)
     int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
 };
 
@@ -485,7 +507,10 @@ __device__ __forceinline__ uint32_t sym_word(uint32_t acc, int n)
     return (~__brev(acc)) >> (32 - n);
 }
 
-template <class LAY>
+// VER = true: the exact stage's run (verify.hip.h).  Lanes are the tasks of p.vtasks, 79 (nch) per pseudo-slot, and the stream
+// `d` is the task buffer dxt[pseudo-slot][kVerRows][row]: exact demodulated rows in front, the polyphase path's behind them.
+// Squelch, records, window lengths and symbol export address the task's REAL window (slot, channel).
+template <class LAY, bool VER = false>
 __global__ __launch_bounds__(kWinThreads) void window_kernel(
     WindowParams p, const float *__restrict__ d, long long d_rows, const double *__restrict__ P,
     const double *__restrict__ Pt, const double *__restrict__ Qn,
@@ -520,25 +545,108 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
 
     const int nch = p.nch;
     const int sl = (int)threadIdx.x / nch;                       // slot of this lane inside the workgroup
-    const int c = (int)threadIdx.x - sl * nch;
-    const int k = blockIdx.x * kWinSlots + sl;
-    const bool lane_ok = sl < kWinSlots && k < p.S;
-    const long long w = (long long)k * nch + c;
+    const int c = (int)threadIdx.x - sl * nch;                   // column of the stream rows this lane reads
+    const int k = blockIdx.x * kWinSlots + sl;                   // slot (VER: pseudo-slot) whose rows this lane reads
+    // the window the lane stands for: (k, c) itself, or the task's
+    int kq = k, cq = c;
+    bool lane_ok = sl < kWinSlots && k < p.S;
+    if (VER) {
+        unsigned int ntask = p.vcount[0];
+        if (ntask > (unsigned int)p.vcap) ntask = (unsigned int)p.vcap;
+        if ((unsigned int)(blockIdx.x * kWinSlots * nch) >= ntask) return;          // uniform: no task for this workgroup
+        const unsigned int q = (unsigned int)(k * nch + c);
+        lane_ok = sl < kWinSlots && q < ntask;
+        const int wr = lane_ok ? p.vtasks[q].w : 0;
+        kq = wr / nch; cq = wr - kq * nch;
+    }
+    const long long w = (long long)kq * nch + cq;
     int nmax = 0;                                    // symbols this lane will produce in phase 1
     double snr = 0.0;
+    if (VER && lane_ok) {                            // a task passed the squelch in the first run
+        snr = p.vtasks[k * nch + c].snr;
+        win_len[w] = -1;
+        nmax = kDetectSyms;
+    }
 
     // ---- squelch: multi_block::channel_samples energy + check_snr (multi_block.cc:206-293) ----
-    if (lane_ok) {
+    if (!VER && lane_ok) {
         double e_on = 0.0;
-        for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)c * p.nb + k + j];
-        if (p.tail > 0) e_on += Pt[(size_t)c * p.nb + k + p.blocks_per_window];
+        for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)cq * p.nb + kq + j];
+        if (p.tail > 0) e_on += Pt[(size_t)cq * p.nb + kq + p.blocks_per_window];
         e_on /= (double)p.ddc_out;
-        const double e_off = Qn[(size_t)c * p.S + k] / (double)p.noise_out;
+        const double e_off = Qn[(size_t)cq * p.qn_stride + kq] / (double)p.noise_out;
         snr = 10.0 * log10(e_on / e_off);
         e_on_out[w] = e_on; e_off_out[w] = e_off; snr_out[w] = snr;
         win_len[w] = -1;
         if (snr >= p.target_snr) nmax = kDetectSyms;
     }
+
+    // ---- exact confirmation, first half: which windows go to the exact stage ----
+    // A window is handed over (and emits no record here) when its classic search finds a hit (below) or when the channel's
+    // |Y|^2 tile sums show burst energy inside the detection span: the clock-recovery loop quantises its phase to 1/128
+    // sample, so a 1e-6 difference of the polyphase stream parts the two trajectories in ~10 % of the windows within 150
+    // symbols; in noise that is invisible, across a burst it can move the access code by a symbol, change an error count
+    // or -- where a carrier offset puts one symbol level near zero -- lose the packet on one side.
+    int vslot = -1, vspan = 0;
+    bool vtried = false;
+    if (!VER && p.verify == 1 && nmax > 0) {
+        const int TT = p.tile_outs;
+        const int t0 = kq * p.tiles_per_slot;
+        int nt = (2 * kDetectSyms + 16 + TT - 1) / TT;
+        if (nt > p.ptile_stride - t0) nt = p.ptile_stride - t0;
+        const double *pt = p.ptile + (size_t)cq * p.ptile_stride + t0;
+        // noise level of the span: its smallest tile that holds signal at all (the zeros GNU Radio puts in front of a stream
+        // are not a noise level).  burst_ratio is calibrated per tile length to mean "four times the mean noise tile":
+        // what a packet at ~5 dB brings -- below that the correlator has nothing to find -- and what a neighbour channel's
+        // leakage does not reach below ~30 dB
+        float mn = 3.0e38f;
+        {
+            // (a tile next to silence may be partly silent itself: not a level either; four tiles in front of the window
+            // belong to the search: a packet that starts in the first tile and outlasts the span leaves no noise inside it)
+            const int jb = t0 >= 5 ? -4 : (t0 > 0 ? 1 - t0 : 0);
+            float ep = t0 > 0 ? (float)pt[jb - 1] : 1.f;
+            const int jl = t0 + nt == p.ptile_stride ? nt - 1 : nt;      // the batch's last tile may be a partial one
+            for (int j = jb; j < jl; j++) { const float e = (float)pt[j]; mn = (e > 0.f && ep > 0.f && e < mn) ? e : mn; ep = e; }
+        }
+        const float thr = mn * p.burst_ratio, thr_lo = 0.5f * thr;
+        // rising edges with hysteresis: a burst starts where a tile exceeds thr after one below thr / 2; a packet that is
+        // already on the air in the tile before the window starts nothing here (its access code lies in an earlier window)
+        bool in_burst = t0 > 0 ? (float)pt[-1] > thr : false;
+        int rise = -1;
+        const float noise = 0.25f * thr;                               // mean noise tile
+        float eprev = t0 > 0 ? (float)pt[-1] : 0.f;
+        for (int j = 0; j < nt; j++) {
+            const float e = (float)pt[j];
+            const bool jump = e > thr && e > 4.f * eprev;                // a much stronger packet on top of one already on the air
+            eprev = e;
+            if ((!in_burst || jump) && e > thr) {
+                in_burst = true;
+                // Where inside tile j the burst starts, from how much of a full burst tile it holds.  An access code is
+                // reportable at the offsets below 625 (lib/multi_sniffer_impl.cc:108), i.e. up to row ~1257 at the loop's
+                // slowest clock: a burst that starts later is the next window's (in a sniffer window the following slot
+                // begins near symbol 635 -- every burst would be taken twice, the second time with a full-length span).
+                const float full = (j + 1 < nt && (float)pt[j + 1] > e) ? (float)pt[j + 1] : e;
+                float frac = (e - noise) / (full - noise);
+                frac = frac < 0.f ? 0.f : (frac > 1.f ? 1.f : frac);
+                const float onset_row = ((float)(j + 1) - frac) * (float)TT;
+                // what a packet fifty times stronger on a neighbour channel leaks through the channel filter is not a packet
+                // here (and one that hides 17 dB below such a neighbour cannot be received)
+                const float en = full > e ? full : e;
+                const float nl = cq > 0 ? (float)p.ptile[(size_t)(cq - 1) * p.ptile_stride + t0 + j + (full > e ? 1 : 0)] : 0.f;
+                const float nr = cq + 1 < nch ? (float)p.ptile[(size_t)(cq + 1) * p.ptile_stride + t0 + j + (full > e ? 1 : 0)] : 0.f;
+                const bool leak = nl > 50.f * en || nr > 50.f * en;
+                if (!leak && onset_row < 1260.f + 0.04f * (float)TT) rise = j;
+            } else if (in_burst && e < thr_lo) in_burst = false;
+        }
+        if (rise >= 0) vspan = ((rise + 1) * TT) / 2 + 72 + p.span_extra + 8;
+    }
+    auto vreserve = [&]() {
+        vtried = true;
+        const unsigned int s_ = atomicAdd(&p.vcount[0], 1u);
+        if (s_ < (unsigned int)p.vcap) vslot = (int)s_;
+        else atomicAdd(&p.vcount[2], 1u);                         // list full: this window keeps the polyphase path's records
+    };
+    if (vspan > 0) vreserve();
 
     if (p.dbg_stop == 1) return;
     // ---- phase 1: M&M ----
@@ -578,10 +686,10 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         const int ic = i < kTot ? i : kTot - 1;
         const int s = ic / kVec, iv = ic - s * kVec;
         const int r = iv / kVecPerRow, q4 = iv - r * kVecPerRow;
-        goff[j] = (uint32_t)((s * p.outs_per_slot + r) * kRowBytes + q4 * 16);
+        goff[j] = (uint32_t)((s * p.rows_per_slot + r) * kRowBytes + q4 * 16);
         loff[j] = (uint32_t)(s * (kTileFloats / 4) + r * (kWinRowStride / 4) + q4) | (r == 0 ? 0x80000000u : 0u);
     }
-    const long long wg_row0 = (long long)blockIdx.x * kWinSlots * p.outs_per_slot;
+    const long long wg_row0 = (long long)blockIdx.x * kWinSlots * p.rows_per_slot;
     const char *wgb = (const char *)(d + (size_t)wg_row0 * (kVecPerRow * 4));
     const long long span = (d_rows - wg_row0) * kRowBytes - 16;             // last float4 of the stream (d_rows > wg_row0)
     const uint32_t max_off = span > 0xFFFFFFF0LL ? 0xFFFFFFF0u : (uint32_t)span;
@@ -706,6 +814,25 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int len1 = oo;                                         // 693, or the whole window if shorter
     int limit = len1 - 68 < 625 ? len1 - 68 : 625;
     int resume = 0, nhits = 0;
+    auto emit_classic = [&](int cpos, uint32_t lap, int err) {
+        if (!VER && p.verify) {
+            // a classic hit of the polyphase path is a claim the exact stage settles: the span that must be exact reaches to
+            // the end of this access code (+ header)
+            if (!vtried) vreserve();
+            if (vslot >= 0) {
+                const int e_ = cpos + 72 + p.span_extra + 8;
+                vspan = e_ > vspan ? e_ : vspan;
+                return;
+            }
+        }
+        const unsigned int slot_h = atomicAdd(hit_count, 1u);
+        if (slot_h < (unsigned int)p.max_hits) {
+            DeviceHit h;
+            h.slot = (uint32_t)kq; h.channel_idx = cq; h.offset = cpos;
+            h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0; h.sym = -1; h.pad_ = 0;
+            hits[slot_h] = h;
+        }
+    };
     if (p.btbb) {
         // [EXT libbtbb, unpinned] btbb_find_ac(symbols, latest_ac, LAP_ANY, 1, &pkt) as multi_LAP calls it
         // (lib/multi_LAP_impl.cc:93): per offset the 64-symbol sync word; gate on the 7-bit Barker field
@@ -751,13 +878,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                         if (synd == p.btbb_pcol[kb]) { lap ^= 1u << kb; err = 1; break; }
                 }
                 if (err >= 0) {
-                    const unsigned int slot_h = atomicAdd(hit_count, 1u);
-                    if (slot_h < (unsigned int)p.max_hits) {
-                        DeviceHit h;
-                        h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
-                        h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0; h.sym = -1; h.pad_ = 0;
-                        hits[slot_h] = h;
-                    }
+                    emit_classic(cpos, lap, err);
                     nhits++;
                     resume = cpos + 68;
                 }
@@ -766,22 +887,27 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         }
         limit = 0;                                                 // skip the in-tree search below
     }
-    search_classic(mybits, limit, kSymbolsShortAcDev, p.mode == 0, p.a0_lo, p.a0_hi, ac_lo, ac_hi, resume, nhits,
-                   [&](int cpos, uint32_t lap, int err) {
-                       const unsigned int slot_h = atomicAdd(hit_count, 1u);
-                       if (slot_h < (unsigned int)p.max_hits) {
-                           DeviceHit h;
-                           h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
-                           h.lap = lap; h.ac_errors = err; h.kind = 0; h.snr = snr; h.nsym = -1; h.sub = 0; h.sym = -1; h.pad_ = 0;
-                           hits[slot_h] = h;
-                       }
-                   });
+    search_classic(mybits, limit, kSymbolsShortAcDev, p.mode == 0, p.a0_lo, p.a0_hi, ac_lo, ac_hi, resume, nhits, emit_classic);
     if (p.dbg_stop == 3) return;
+    if (vslot >= 0) {
+        // exact confirmation: this window's records come from the exact stage.  Rows the clock recovery can reach within
+        // vspan symbols: at most omega_mid + omega_relative_limit input rows per symbol, + the 8-tap interpolator
+        int rows = (int)((float)vspan * (p.omega_mid + p.omega_relative_limit)) + 12;
+        const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
+        if (rows > cap_rows) rows = cap_rows;
+        VerifyTask t_;
+        t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr;
+        p.vtasks[vslot] = t_;
+        const int ntl = (rows + kVerTile - 1) / kVerTile;
+        const unsigned int tp = atomicAdd(&p.vcount[1], (unsigned int)ntl);
+        for (int j = 0; j < ntl; j++) p.vtiles[tp + j] = (uint32_t)vslot | ((uint32_t)j << 24);
+        return;
+    }
     // ---- LE pass: le_packet::sniff_aa (lib/packet_impl.cc:1452-1527) with the loop of
     // lib/multi_sniffer_impl.cc:129-149.  `len` keeps what the classic pass left (Q6): the search
     // limit is min(len' - 68, 625) with len' = len - (last classic hit + 68); records carry
     // sub = len - len' so that nsym = len' - offset.
-    const int le_index = (p.le && p.mode != 0) ? (int)le_index_g[p.low_channel + c] : -1;
+    const int le_index = (p.le && p.mode != 0) ? (int)le_index_g[p.low_channel + cq] : -1;
     if (le_index >= 0) {
         const int sub = nhits > 0 ? resume : 0;                  // resume = last classic hit + 68
         // phase 1 produced min(len, 693) symbols; len' - 68 >= 625 whenever the window was
@@ -836,7 +962,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                     const unsigned int slot_h = atomicAdd(hit_count, 1u);
                     if (slot_h < (unsigned int)p.max_hits) {
                         DeviceHit h;
-                        h.slot = (uint32_t)k; h.channel_idx = c; h.offset = cpos;
+                        h.slot = (uint32_t)kq; h.channel_idx = cq; h.offset = cpos;
                         h.lap = aa; h.ac_errors = 0; h.kind = 1; h.snr = snr; h.nsym = -1; h.sub = sub; h.sym = -1; h.pad_ = 0;
                         hits[slot_h] = h;
                     }

@@ -1,0 +1,236 @@
+// verify.hip.h -- exact confirmation of the polyphase (FAST) path's records.  gfx950, wave = 64 lanes.
+//
+// The polyphase channelizer's demodulated stream equals the per-channel direct-form DDC's to ~1e-6, and the reference's
+// clock recovery (multi_block::mm_cr, lib/multi_block.cc:128-155) quantises its phase to 1/128 sample: the two
+// trajectories part somewhere in most windows.  Over noise nobody can tell; across a burst the access code can come out
+// a symbol earlier or later, with a different error count, or -- a carrier offset that puts one symbol level near zero --
+// be found on one side only.  So every window that can carry a record of a real packet is RE-RUN through the arithmetic
+// of the bit-exact path: the windows window_kernel hands over (a classic hit, or burst energy inside the detection span)
+// get
+//   verify_ddc_kernel   the reference's per-channel DDC (freq_xlating_fir_filter_ccf [EXT], lib/multi_block.cc:180-205) in
+//                       ddc_direct_kernel's summation order, rotator, quadrature demod (multi_block::demod, :158-168) --
+//                       only for the channel and the rows of the window the detection can reach
+//   verify_fill_kernel  those rows, continued by the polyphase path's own rows, as the task's column of the time-major
+//                       task stream dxt[pseudo-slot][kVerRows][drow]
+//   window_kernel<LAY, true>   squelch figure carried over, clock recovery + slicer + access-code / LE search on that
+//                       stream: the window's records (kernels.hip.h)
+// and finish_kernel continues them as before.  Cost: 4 * ntp multiply-adds per recomputed row -- 2.2 M for the ~420 rows
+// in front of a packet 85 symbols into its window -- per packet in the capture, not per window.
+#pragma once
+#include "kernels.hip.h"
+
+namespace btgpu {
+
+constexpr int kVerThreads = 512;      // 8 waves: wave l sums the taps j = l (mod 8) -- the 8 partial sums of the summation order
+constexpr int kVerOuts = 128;         // outputs per tile: lane i of every wave takes outputs 2 i and 2 i + 1 (they share input samples)
+
+struct VerifyParams {
+    long long x_len;
+    long long first0;                 // x index of (window 0, output 0, tap 0): w0 + first_channel_sample
+    int D, ntp, slot;                 // decimation, padded filter length (multiple of 8), samples per slot
+    uint32_t inv2d;                   // 2^32 / (2 D) + 1: n / (2 D) = mulhi(n, inv2d) for the n of a tile
+    int mp, F;                        // tapsv: [nch][8][mp] complex, class-major copy of the reversed taps, F zeros in front and behind
+    const float2 *rot; int Q;         // de-rotation table [nch][Q] by window-local output index (Q = 0: rot_step_turns)
+    const double *rot_step_turns;
+    const float *atan_tab; float gain;
+    const VerifyTask *tasks; const uint32_t *tiles; const unsigned int *vcount; int vcap;
+    int nch;
+};
+// class-major, zero-padded copy of a direct-form bank's taps for verify_ddc_kernel: out[(c * 8 + l) * mp + F + m] = taps[c][l + 8 m]
+// (+ 8 zeros behind: the march runs in blocks of four steps and fetches the next block's taps while it works on the current one)
+inline void verify_tap_shape(int D, int ntp, int &mp, int &F) { F = (D + 7) / 8; mp = ntp / 8 + 2 * F + 8; }
+
+// LDS words (float2) of one tile: the padded input span, reused for the partial sums
+inline int verify_span(int D, int ntp) { return (kVerOuts - 1) * D + ntp + D + 48; }
+inline size_t verify_lds_bytes(int D, int ntp)
+{
+    const int ns = verify_span(D, ntp);
+    int words = ns + ns / (2 * D) + 2;
+    if (words < 8 * kVerOuts) words = 8 * kVerOuts;
+    return (size_t)words * sizeof(float2) + (size_t)(kVerOuts + 1) * sizeof(float2) + 260 * sizeof(float);
+}
+
+// One tile = 128 consecutive outputs t = 127 j - 1 + u of one task (u = 0 is the halo the demodulator needs).
+// Summation order of ddc_direct_kernel / the oracle (bit-exact contract): partial l takes the taps j = l, l + 8, ... ascending,
+// four fmaf per complex multiply-add; ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)).  Wave l forms partial l of all 128 outputs: its
+// taps are wave-uniform (scalar loads), lane i holds the two outputs u = 2 i, 2 i + 1, whose windows overlap by ntp - D samples:
+// the sample that meets tap j of the first meets tap j - D of the second, so one LDS read feeds eight multiply-adds.  Lanes are
+// 2 D samples apart; one pad word per 2 D samples makes that 2 (2 D + 1) dwords -- an odd multiple of two -- so the 32 lanes of a
+// 64-bit read pass hit 32 different bank pairs.  (Taps outside the filter are exact zeros: an accumulator that has seen a
+// sample is never -0, and adding +-0 leaves it as it is.)
+__device__ __forceinline__ uint32_t ver_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) >> 32); }
+
+// x: the batch's input; tapsv: VerifyParams; dx: [vcap][kVerRows] exact demodulated rows of each task
+__global__ __launch_bounds__(kVerThreads) void verify_ddc_kernel(VerifyParams p, const float2 *__restrict__ x,
+                                                                 const float2 *__restrict__ tapsv, float *__restrict__ dx)
+{
+    HIP_DYNAMIC_SHARED(float2, lds)
+    const int D = p.D, ntp = p.ntp;
+    const int ns = (kVerOuts - 1) * D + ntp + D + 48;
+    int words = ns + ns / (2 * D) + 2;
+    if (words < 8 * kVerOuts) words = 8 * kVerOuts;
+    float2 *ys = lds + words;                                     // [kVerOuts + 1]
+    float *atab = (float *)(ys + kVerOuts + 1);                   // [257]
+    unsigned int ntiles = p.vcount[1];
+    {
+        unsigned int ntask = p.vcount[0];
+        if (ntask > (unsigned int)p.vcap) ntask = (unsigned int)p.vcap;
+        if (ntiles > ntask * 12u) ntiles = ntask * 12u;
+    }
+    for (int i = threadIdx.x; i < 257; i += kVerThreads) atab[i] = p.atan_tab[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int l = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#else
+    const int l = (int)threadIdx.x >> 6;
+#endif
+    const int lane = (int)threadIdx.x & 63;
+    for (unsigned int item = blockIdx.x; item < ntiles; item += gridDim.x) {
+        const uint32_t e = p.tiles[item];
+        const int q = (int)(e & 0xffffffu), jt = (int)(e >> 24);
+        const VerifyTask tk = p.tasks[q];
+        const int k = tk.w / p.nch, c = tk.w - k * p.nch;
+        const int t_first = kVerTile * jt - 1;                     // output index of u = 0
+        const long long sb = p.first0 + (long long)k * p.slot + (long long)t_first * D;
+        __syncthreads();                                           // the previous item's partial sums are consumed
+        // ---- stage the input span: sample n of the tile at word n + n / (2 D) ----
+        for (int n0 = (int)threadIdx.x; n0 < ns; n0 += 4 * kVerThreads) {
+            float2 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const long long a = sb + n0 + r * kVerThreads;
+                const long long ac = a < 0 ? 0 : (a < p.x_len ? a : p.x_len - 1);
+                v[r] = x[ac];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + r * kVerThreads;
+                const long long a = sb + n;
+                if (n < ns) lds[n + (int)ver_mulhi((uint32_t)n, p.inv2d)] = (a >= 0 && a < p.x_len) ? v[r] : make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- the march: step m meets tap l + 8 m of output 2 i and tap l + 8 m - D of output 2 i + 1 ----
+        const int lc = ((l - D) % 8 + 8) % 8;                       // class of the second output's tap
+        const int sh = (D - l + lc) / 8;                            // its step lag
+        const float2 *t0 = tapsv + ((size_t)c * 8 + l) * p.mp + p.F;
+        const float2 *t1 = tapsv + ((size_t)c * 8 + lc) * p.mp + p.F - sh;
+        const int steps = (ntp / 8 + (D + 7) / 8 + 3) & ~3;         // whole blocks of four (the extra steps meet zero taps)
+        float ar0 = 0.f, ai0 = 0.f, ar1 = 0.f, ai1 = 0.f;
+        const int lbase = 2 * D * lane + lane;                      // word of the lane's first sample (sample 2 D lane, its pad words)
+        int xw = l + l / (2 * D), rem = l % (2 * D);                // wave-uniform: word offset l + 8 m + (its pad words), (l + 8 m) mod 2 D
+        const int twoD = 2 * D;
+        float2 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = t0[u]; b[u] = t1[u]; }
+        for (int m = 0; m < steps; m += 4) {
+            float2 an[4], bn[4];                                    // the next block's taps: scalar loads in flight under 32 multiply-adds
+#pragma unroll
+            for (int u = 0; u < 4; u++) { an[u] = t0[m + 4 + u]; bn[u] = t1[m + 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float2 v = lds[lbase + xw];
+                xw += 8; rem += 8;
+                if (rem >= twoD) { rem -= twoD; xw += 1; }
+                if (rem >= twoD) { rem -= twoD; xw += 1; }          // (2 D >= 4: at most two pad words per eight samples)
+                ar0 = fmaf(a[u].x, v.x, ar0);
+                ar0 = fmaf(-a[u].y, v.y, ar0);
+                ai0 = fmaf(a[u].x, v.y, ai0);
+                ai0 = fmaf(a[u].y, v.x, ai0);
+                ar1 = fmaf(b[u].x, v.x, ar1);
+                ar1 = fmaf(-b[u].y, v.y, ar1);
+                ai1 = fmaf(b[u].x, v.y, ai1);
+                ai1 = fmaf(b[u].y, v.x, ai1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = an[u]; b[u] = bn[u]; }
+        }
+        __syncthreads();                                           // every wave is done with the samples
+        lds[l * kVerOuts + 2 * lane] = make_float2(ar0, ai0);
+        lds[l * kVerOuts + 2 * lane + 1] = make_float2(ar1, ai1);
+        __syncthreads();
+        if (threadIdx.x < kVerOuts) {
+            const int u = (int)threadIdx.x;
+            float2 pz[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) pz[j] = lds[j * kVerOuts + u];
+            const float yr = ((pz[0].x + pz[1].x) + (pz[2].x + pz[3].x)) + ((pz[4].x + pz[5].x) + (pz[6].x + pz[7].x));
+            const float yi = ((pz[0].y + pz[1].y) + (pz[2].y + pz[3].y)) + ((pz[4].y + pz[5].y) + (pz[6].y + pz[7].y));
+            const int t = t_first + u;                              // window-local output index: the rotator restarts per window
+            float rr = 1.f, ri = 0.f;
+            if (t >= 0) {
+                if (p.Q > 0) {
+                    const float2 r = p.rot[(size_t)c * p.Q + (t % p.Q)];
+                    rr = r.x; ri = r.y;
+                } else {
+                    double tt = p.rot_step_turns[c] * (double)t;
+                    tt -= floor(tt);
+                    double sn, co;
+                    sincospi(2.0 * tt, &sn, &co);
+                    rr = (float)co; ri = (float)sn;
+                }
+            }
+            float2 out;
+            out.x = fmaf(-yi, ri, yr * rr);
+            out.y = fmaf(yi, rr, yr * ri);
+            ys[u] = out;
+        }
+        __syncthreads();
+        if (threadIdx.x >= 1 && threadIdx.x < kVerOuts) {
+            const int u = (int)threadIdx.x, t = t_first + u;
+            if (t >= 1 && t < tk.n_exact) dx[(size_t)q * kVerRows + t] = demod_one(atab, p.gain, ys[u], ys[u - 1]);
+        }
+    }
+}
+
+// The task stream the exact stage's window_kernel reads: dxt[(pseudo-slot * kVerRows + row) * drow + column], task q in
+// column q % nch of pseudo-slot q / nch.  Rows [1, n_exact) are the exact ones (row 0 is zeroed by the consumer, policy Q1),
+// the rest the polyphase path's -- from the 100-bin bank's tile-blocked copy dcol[tile][80][25] where it exists, else the
+// strided column of d -- so the clock recovery can run on behind the exact span.  One workgroup = 64 rows of one pseudo-slot;
+// the values cross an LDS tile and leave as whole rows.
+struct VerifyFillParams {
+    const VerifyTask *tasks; const unsigned int *vcount; int vcap;
+    const float *dx;                  // [vcap][kVerRows]
+    const float *d; const float *dcol; int drow; long long d_rows;
+    int nch, outs_per_slot, rows;     // rows of a task that are filled (min(ddc_out, kVerRows))
+    float *dxt;
+};
+__global__ __launch_bounds__(256) void verify_fill_kernel(VerifyFillParams p)
+{
+    __shared__ float tile[64 * 81];
+    unsigned int ntask = p.vcount[0];
+    if (ntask > (unsigned int)p.vcap) ntask = (unsigned int)p.vcap;
+    const int nps = (int)((ntask + (unsigned int)p.nch - 1u) / (unsigned int)p.nch);
+    const int nrb = (p.rows + 63) / 64;
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    for (int item = blockIdx.x; item < nps * nrb; item += gridDim.x) {
+        const int ps = item / nrb, rb = item - ps * nrb;
+        const int r = rb * 64 + lane;                              // row this lane fetches
+        __syncthreads();
+        for (int col = wv; col < p.nch; col += 4) {
+            const unsigned int q = (unsigned int)(ps * p.nch + col);
+            float v = 0.f;
+            if (q < ntask && r < p.rows) {
+                const VerifyTask tk = p.tasks[q];
+                if (r < tk.n_exact) v = r >= 1 ? p.dx[(size_t)q * kVerRows + r] : 0.f;
+                else {
+                    const int k = tk.w / p.nch, c = tk.w - k * p.nch;
+                    long long g = (long long)k * p.outs_per_slot + r;
+                    if (g >= p.d_rows) g = p.d_rows - 1;
+                    if (p.dcol) {
+                        const unsigned int gq = (unsigned int)g, tq = gq / 25u;
+                        v = p.dcol[(size_t)(gq + 25u * (79u * tq + (unsigned int)c))];
+                    } else v = p.d[(size_t)g * p.drow + c];
+                }
+            }
+            tile[lane * 81 + col] = v;
+        }
+        __syncthreads();
+        const int nrows = p.rows - rb * 64 < 64 ? p.rows - rb * 64 : 64;
+        for (int i = threadIdx.x; i < nrows * p.nch; i += 256) {
+            const int rr = i / p.nch, cc = i - rr * p.nch;
+            p.dxt[((size_t)ps * kVerRows + rb * 64 + rr) * p.drow + cc] = tile[rr * 81 + cc];
+        }
+    }
+}
+
+}  // namespace btgpu

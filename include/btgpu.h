@@ -78,6 +78,12 @@ extern "C" {
                                            only produces hit.nsym; nsym is then -1 unless the window ended inside
                                            the 693-symbol detection span.  Ignored with BTGPU_FLAG_SYMBOLS / HEADERS */
 
+#define BTGPU_FLAG_NO_VERIFY 0x100      /* polyphase channelizer only: do NOT re-run the windows that can carry a packet's record (a classic
+                                           hit, or burst energy inside the detection span) through the bit-exact direct-form
+                                           arithmetic.  By default they are (exact confirmation): their records
+                                           then equal the CPU reference's in slot, channel, kind, offset, LAP and ac_errors; with this
+                                           flag ~1.4e-4 of them come out a symbol apart or on one side only (the round-3 behaviour) */
+
 #define BTGPU_KIND_AC 0
 #define BTGPU_KIND_AA 1
 
@@ -137,6 +143,7 @@ typedef struct btgpu_hit {
 #define BTGPU_K_NOISE_ENERGY  3   /* noise |Y|^2 per-slot sums                           */
 #define BTGPU_K_WINDOW        4   /* squelch + M&M + slicer + access-code search         */
 #define BTGPU_K_FINISH        5   /* M&M continuation of the windows that reported hits  */
+#define BTGPU_K_VERIFY        6   /* exact confirmation: direct-form DDC of the handed-over windows + their window kernel */
 #define BTGPU_K_COUNT         8
 typedef struct btgpu_timing {
     float    kernel_ms[BTGPU_K_COUNT];        /* summed over launches                  */
@@ -145,6 +152,9 @@ typedef struct btgpu_timing {
     uint32_t batches;
     uint64_t samples;                         /* new complex samples consumed          */
     uint64_t slots;
+    uint64_t verify_windows;                  /* windows re-run through the exact stage (always counted)                 */
+    uint64_t verify_rows;                     /* demodulated rows recomputed by the direct-form DDC, in 127-row tiles    */
+    uint64_t verify_turned_away;              /* windows that should have been re-run but found the task list full       */
 } btgpu_timing;
 
 /* ---- host-only helpers (no GPU needed) ---- */
@@ -182,7 +192,9 @@ int btgpu_push(btgpu_handle *h, const float *iq, size_t n_complex);
  * front (real stream data when the segment is cut out of a longer stream; 0 at the stream
  * start, where GNU Radio's pre-filled zeros are implied) let the staged squelch filter see
  * the same samples the reference's noise filter would; btgpu_design.left_margin is enough.
- * `hip_stream` is a hipStream_t (NULL = the handle's own stream). */
+ * `hip_stream` is a hipStream_t (NULL = the handle's own stream).  The segment must stay valid until the
+ * batch's records have been handed out (btgpu_flush, or a btgpu_poll that returns them): the exact
+ * confirmation of the polyphase path re-reads the samples of the windows it takes on the handle's tail stream. */
 int btgpu_process_device(btgpu_handle *h, const void *d_iq, size_t n_complex, size_t left_margin,
                          uint64_t first_slot, uint64_t n_slots, void *hip_stream);
 
