@@ -283,10 +283,20 @@ def run_rank(args):
         elapsed = time.perf_counter() - t0
         fence_ms = (time.perf_counter() - t_loop) * 1e3
         gc.enable()
-        kms, kl = tdiff(tm0, b.timing())
+        tm1 = b.timing()
+        kms, kl = tdiff(tm0, tm1)
+        # exact confirmation of the polyphase path's records (always counted by the library): windows re-run per step etc.
+        b._verify_stats = {"windows_per_step": round((tm1.verify_windows - tm0.verify_windows) / max(1, args.steps), 1),
+                           "rows_per_step": round((tm1.verify_rows - tm0.verify_rows) / max(1, args.steps), 1),
+                           "turned_away": int(tm1.verify_turned_away - tm0.verify_turned_away)}
         return elapsed, ints, snr, marks, fence_ms, kms, kl
 
     elapsed, ints, snr, marks, fence_ms, kernel_ms, kernel_launches = timed_region(blk)
+    # the exact stage re-runs every window that can carry a packet's record through the direct-form arithmetic:
+    # 4 * ntaps multiply-adds per recomputed demodulated row
+    verify_obj = dict(blk._verify_stats)
+    verify_obj["enabled"] = bool(verify_obj["windows_per_step"] > 0 or os.environ.get("BTGPU_VERIFY", "1") != "0")
+    verify_obj["gfma_per_step"] = round(verify_obj["rows_per_step"] * 4.0 * ((des.ntaps_channel + 7) // 8 * 8) / 1e9, 3)
     rank_elapsed = [elapsed]
     if world > 1:
         t = torch.zeros(world, dtype=torch.float64, device=coll_device)
@@ -319,6 +329,7 @@ def run_rank(args):
                      "hits_aa": int((b_ints[:, 2] == 1).sum()) if len(b_ints) else 0,
                      "kernel_avg_ms": {pkg.KERNEL_NAMES[i]: round(float(b_kms[i] / b_kl[i]), 4) if b_kl[i] else 0.0
                                        for i in range(len(pkg.KERNEL_NAMES))},
+                     "verify": dict(blk._verify_stats),
                      "ac_records_equal_headline": bool(np.array_equal(b_ints[b_ints[:, 2] == 0], ints[ints[:, 2] == 0])) if not args.le else None}
 
     total_samples = float(world) * S * slot * args.steps
@@ -346,7 +357,7 @@ def run_rank(args):
         avg = [kernel_ms[i] / kernel_launches[i] if kernel_launches[i] else 0.0 for i in range(NK)]
         # the dominant kernel is looked for on the critical path: in pipelined mode the tail
         # (finish_kernel) of batch n runs on its own stream underneath batch n+1
-        crit = [i for i in range(NK) if not (names[i] == "finish" and not args.sync)]
+        crit = [i for i in range(NK) if not (names[i] in ("finish", "verify") and not args.sync)]
         dom = max(crit, key=lambda i: avg[i])                  # (light timing: only ddc_channel is non-zero -- it is the dominant one)
         bytes_per_launch = 8.0 * S * slot                      # 8 B per complex input sample, read once
         ach = bytes_per_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
@@ -473,6 +484,7 @@ def run_rank(args):
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},
             "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed],
             "block_config": block_cfg,
+            "verify": verify_obj,
             "fence_ms": round(fence_ms, 3),
             "step_enqueue_ms": [round(float(v), 3) for v in np.percentile(np.diff(np.array(marks)) * 1e3, [0, 50, 100])],
             "roofline": roof,

@@ -213,10 +213,13 @@ struct VerifyBuffers {                                   // device (or emulated)
     VerifyTask *tasks = nullptr; uint32_t *tiles = nullptr; unsigned int *vcount = nullptr;
     float *dx = nullptr, *dxt = nullptr;
     int vcap = 0;
+    unsigned int tiles_cap = 0;                           // entries `tiles` holds: verify_tiles_capacity(S, nch)
 };
+inline size_t verify_tiles_capacity(int S, int nch) { return (size_t)S * nch * kVerMaxTiles; }
 inline int verify_capacity(int S, int nch) { return (int)std::min<long long>((long long)S * nch, 32768); }
 inline int verify_rows(const Design &des) { return des.d.ddc_out < kVerRows ? des.d.ddc_out : kVerRows; }
-constexpr int kVerGridDdc = 2048, kVerGridFill = 1024;
+constexpr int kVerGridDdc = 2048, kVerGridFill = 1024;  // workgroups of verify_ddc_kernel (they stride over the tiles; two fit a CU at 100 Msps: 2048 balanced the
+                                                         // uneven tile counts better than 512 persistent ones, 0.42 against 0.49 ms)
 // tile length (outputs) of the |Y|^2 tile sums the polyphase banks leave behind
 inline int verify_tile_outs(const FastPath &fp, bool small) { return small ? pfbm_tile(fp.channel.M) : kBankNT - 1; }
 
@@ -228,6 +231,7 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
     p.ptile = ptile; p.ptile_stride = ntiles; p.tile_outs = verify_tile_outs(fp, small);
     p.tiles_per_slot = des.outs_per_slot / p.tile_outs;
     p.vtasks = vb.tasks; p.vtiles = vb.tiles; p.vcount = vb.vcount; p.vcap = vb.vcap;
+    if ((2 * kDetectSyms + 16 + p.tile_outs - 1) / p.tile_outs + 5 > 64) p.verify = 2;   // (the scan stages <= 64 tiles per channel)
     p.burst_ratio = 4.0f / (1.0f - 2.3f / std::sqrt((float)p.tile_outs));   // smallest of ~57 tiles of TT outputs ~ (1 - 2.3 / sqrt(TT)) mean
     p.span_extra = headers ? 58 : 0;                     // 54 header symbols + the 4-symbol trailer
 }
@@ -242,7 +246,7 @@ inline VerifyParams make_verify_params(const Design &des, size_t x_len, long lon
     v.mp = mp; v.F = F;
     v.rot = rot; v.Q = des.channel.rot_period; v.rot_step_turns = rot_step_turns;
     v.atan_tab = atan_tab; v.gain = des.demod_gain;
-    v.tasks = vb.tasks; v.tiles = vb.tiles; v.vcount = vb.vcount; v.vcap = vb.vcap;
+    v.tasks = vb.tasks; v.tiles = vb.tiles; v.vcount = vb.vcount; v.vcap = vb.vcap; v.tiles_cap = vb.tiles_cap;
     v.nch = d.high_channel - d.low_channel + 1;
     return v;
 }

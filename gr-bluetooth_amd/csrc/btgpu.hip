@@ -39,6 +39,7 @@ struct DevBuf {
 
 }  // namespace
 
+constexpr int kCtxMax = 3;
 struct btgpu_handle {
     Design des;
     FastPath fp;
@@ -54,7 +55,12 @@ struct btgpu_handle {
     // banks of batch n+1 therefore start the moment the banks of batch n end, with post(n) and tail(n) running beside
     // them on the CUs' spare issue slots (round 2: only the tail overlapped, 0.54 ms of a 2.05 ms step waited in line).
     hipStream_t post_stream = nullptr, tail_stream = nullptr;
-    static constexpr int kCtx = 3;       // in-flight batches (BTGPU_FLAG_ASYNC): front(n+2) | post(n+1) | tail(n)
+    // With the exact stage the tail of a batch (direct-form DDC of the handed-over windows -> their window kernel -> finish -> copies)
+    // is a dependent chain longer than a step: consecutive batches' tails run on different streams and overlap each other
+    hipStream_t tail_extra[kCtxMax - 1] = {nullptr, nullptr};
+    int ntail = 1;
+    hipStream_t last_tail = nullptr;
+    static constexpr int kCtx = kCtxMax; // in-flight batches (BTGPU_FLAG_ASYNC): front(n+2) | post(n+1) | tail(n)
     struct TailCtx {                 // per in-flight batch: everything the front writes and the post / tail stages read
         DevBuf d_winlen, d_hits, d_hitcount, d_fin, d_winfin, d_symbits, d_hdr;
         DevBuf d_d;                           // demodulated stream of the batch
@@ -83,7 +89,7 @@ struct btgpu_handle {
     bool timing_full = false;        // every kernel (BTGPU_FLAG_TIMING), not just the channel bank
     bool no_nsym = false;            // BTGPU_FLAG_NO_NSYM: skip the M&M continuation that produces hit.nsym
     int verify = 0;                  // exact confirmation of the polyphase path's records: 0 off, 1 hits + burst energy, 2 hits only
-    int vcap = 0, ver_mp = 0, ver_F = 0;
+    int vcap = 0, ver_mp = 0, ver_F = 0, ver_grid = kVerGridDdc;
     DevBuf d_tapsv;                  // class-major taps of the direct-form channel bank (verify_ddc_kernel)
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
     hipStream_t copy_stream = nullptr;
@@ -175,7 +181,7 @@ struct btgpu_handle {
             if (ev_consumed[k]) { (void)hipEventDestroy(ev_consumed[k]); ev_consumed[k] = nullptr; }
             if (ev_vdone[k]) { (void)hipEventDestroy(ev_vdone[k]); ev_vdone[k] = nullptr; }
         }
-        for (hipStream_t *st : {&stream, &post_stream, &tail_stream, &copy_stream, &spill_stream})
+        for (hipStream_t *st : {&stream, &post_stream, &tail_stream, &copy_stream, &spill_stream, &tail_extra[0], &tail_extra[1]})
             if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     }
 
@@ -232,6 +238,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     last_S = S;
     last_G = G;
     TailCtx &t = tc[cur];
+    hipStream_t tail_stream = ntail > 1 && (cur % ntail) > 0 ? tail_extra[(cur % ntail) - 1] : this->tail_stream;   // this batch's tail
+    last_tail = tail_stream;
     int carried = BTGPU_OK;                                      // overflow of the batch harvested here
     if (t.pending) { int hrc = harvest(t); if (hrc == BTGPU_EOVERFLOW) carried = hrc; else if (hrc != BTGPU_OK) return hrc; }
     hipEvent_t *ev = t.ev;
@@ -379,7 +387,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         VerifyBuffers vb;
         if (verify) {
             vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.tiles = (uint32_t *)t.d_vtiles.p; vb.vcount = (unsigned int *)t.d_vcount.p;
-            vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap;
+            vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap; vb.tiles_cap = (unsigned int)verify_tiles_capacity(max_slots, nch);
             set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
         }
         auto launch_window = [&](auto lay) {
@@ -404,15 +412,28 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});
         else launch_window(WinLayout<64, 4, 1>{});
         HIPCHK(this, mark(8, ps));
+        // exact stage, first kernel: the direct-form DDC of the handed-over windows.  It runs HERE, in line behind the window
+        // kernel, not on the tail stream: it fills the device by itself (0.42 ms for 9 G multiply-adds at C79) and 62 KB of LDS
+        // per workgroup fit beside neither the banks' tiles nor the window kernel's -- beside the next batch's front it took
+        // 1.4 ms and stretched the bank from 1.24 to 1.6 and the window kernel from 0.32 to 0.6 ms (profiles/r04_b_*).
+        // BTGPU_VERIFY_TAIL=1 puts it back on the tail stream (A/B).
+        static const bool ddc_on_tail = getenv("BTGPU_VERIFY_TAIL") && atoi(getenv("BTGPU_VERIFY_TAIL")) == 1;
+        VerifyParams vp{};
+        if (verify) {
+            vp = make_verify_params(des, x_len, w0, ver_mp, ver_F, (const float2 *)d_rot_ch.p, (const double *)d_rotstep_ch.p,
+                                    (const float *)d_atan.p, vb);
+            if (!ddc_on_tail)
+                hipLaunchKernelGGL(verify_ddc_kernel, dim3(ver_grid), dim3(kVerThreads), verify_lds_bytes(d.decimation, des.channel.ntp),
+                                   ps, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+        }
         // =========================== TAIL (tail_stream): finish + nsym + record copies ===========================
         HIPCHK(this, hipEventRecord(t.detect_done, ps));
         HIPCHK(this, hipStreamWaitEvent(tail_stream, t.detect_done, 0));
         HIPCHK(this, mark(9, tail_stream));
         if (verify) {
-            const VerifyParams vp = make_verify_params(des, x_len, w0, ver_mp, ver_F, (const float2 *)d_rot_ch.p,
-                                                       (const double *)d_rotstep_ch.p, (const float *)d_atan.p, vb);
-            hipLaunchKernelGGL(verify_ddc_kernel, dim3(kVerGridDdc), dim3(kVerThreads), verify_lds_bytes(d.decimation, des.channel.ntp),
-                               tail_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+            if (ddc_on_tail)
+                hipLaunchKernelGGL(verify_ddc_kernel, dim3(ver_grid), dim3(kVerThreads), verify_lds_bytes(d.decimation, des.channel.ntp),
+                                   tail_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
             const VerifyFillParams fz = make_verify_fill_params(des, (const float *)d_d.p, (const float *)(use_dcol ? t.d_dcol.p : nullptr),
                                                                 drow, G, vb);
             hipLaunchKernelGGL(verify_fill_kernel, dim3(kVerGridFill), dim3(256), 0, tail_stream, fz);
@@ -522,7 +543,7 @@ int btgpu_handle::stage_batch(const float *head, size_t n_head, const float *bod
     HIPCHK(this, hipStreamWaitEvent(stream, ev_copied[k], 0));
     const int rc = process_batch(d_buf, n_head + n_body, w0, abs_first_slot, S, stream);
     HIPCHK(this, hipEventRecord(ev_consumed[k], stream));
-    if (verify) HIPCHK(this, hipEventRecord(ev_vdone[k], tail_stream));
+    if (verify) HIPCHK(this, hipEventRecord(ev_vdone[k], last_tail));
     stage_used[k] = true;
     return rc;
 }
@@ -895,6 +916,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             if (hipExtStreamCreateWithCUMask(&h->tail_stream, 8, mask) != hipSuccess) return fail(BTGPU_EDEVICE);
         } else
         if (hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
+        for (auto &te : h->tail_extra) if (hipStreamCreateWithPriority(&te, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
     if (hipStreamCreateWithFlags(&h->spill_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
@@ -918,7 +940,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     h->no_nsym = (cfg->flags & BTGPU_FLAG_NO_NSYM) != 0;
     // exact confirmation: on wherever the channelizer is the polyphase one (BTGPU_VERIFY=0 | 1 | 2: A/B timing and tests)
     h->verify = (h->use_pfb && !(cfg->flags & BTGPU_FLAG_NO_VERIFY)) ? 1 : 0;
+    if (verify_span(h->des.d.decimation, h->des.channel.ntp) > kVerPre * kVerThreads) h->verify = 0;   // (span of a tile beyond the kernel's prefetch registers: no such rate today)
     if (h->use_pfb && getenv("BTGPU_VERIFY")) h->verify = std::max(0, std::min(2, atoi(getenv("BTGPU_VERIFY"))));
+    h->ntail = h->verify ? h->nctx : 1;
+    if (getenv("BTGPU_TAILS")) h->ntail = std::max(1, std::min(h->nctx, atoi(getenv("BTGPU_TAILS"))));   // A/B timing
     // front(n+1) beside post(n) (BTGPU_PIPE=1; possible only where the front writes nothing but per-context buffers).
     // OFF by default -- measured (profiles/r03_a_*): with today's kernels the overlap LOSES.  Every one of them is
     // occupancy-bound by LDS (bank tile 49.8 KB, window workgroup 51 KB, squelch stage 2 24 KB per workgroup of four
@@ -1044,7 +1069,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (h->verify) {
             const int vcap = h->vcap, nps = (vcap + nch - 1) / nch;
             TRY(h->alloc(t.d_vtasks, (size_t)vcap * sizeof(VerifyTask)));
-            TRY(h->alloc(t.d_vtiles, (size_t)vcap * 12 * sizeof(uint32_t)));
+            TRY(h->alloc(t.d_vtiles, verify_tiles_capacity(S, nch) * sizeof(uint32_t)));
             TRY(h->alloc(t.d_vcount, 4 * sizeof(unsigned int)));
             TRY(h->alloc(t.d_dx, (size_t)vcap * kVerRows * sizeof(float)));
             TRY(h->alloc(t.d_dxt, ((size_t)nps * kVerRows + 64) * h->drow * sizeof(float)));
@@ -1097,6 +1122,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, false, 2 * kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    {
+        if (getenv("BTGPU_VERIFY_GRID")) h->ver_grid = std::max(1, atoi(getenv("BTGPU_VERIFY_GRID")));
+    }
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))
         fprintf(stderr, "btgpu_create: %d contexts, d=%p Z=%p ptile=%p\n", h->nctx, h->tc[0].d_d.p, h->tc[0].d_Z.p, h->tc[0].d_ptile.p);
@@ -1240,7 +1268,7 @@ int btgpu_flush(btgpu_handle *h)
     // on", the caller's next device-wide synchronise (torch.cuda.synchronize / hipDeviceSynchronize) took
     // 23-32 ms in one run out of four on an idle device -- after these per-stream waits it takes 20 us
     // (0 long ones in 24 runs, one of 6 ms in the 12 before).
-    for (hipStream_t st : {h->stream, h->post_stream, h->tail_stream, h->copy_stream, h->spill_stream}) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {h->stream, h->post_stream, h->tail_stream, h->copy_stream, h->spill_stream, h->tail_extra[0], h->tail_extra[1]}) if (st) (void)hipStreamSynchronize(st);
     return rc;
 }
 

@@ -141,7 +141,7 @@ struct FastPath {
 int make_fast_path(const Design &des, FastPath &fp);
 
 // Exact confirmation (verify.hip.h): the direct-form bank's reversed taps class by class -- out[((c * 8 + l) * mp + F + m) * 2 ..]
-// = taps[c][l + 8 m] -- with F = ceil(D / 8) exact zeros in front of and behind each row (mp = ntp / 8 + 2 F + 8: the kernel marches in blocks of four steps with one block of look-ahead).
+// = taps[c][l + 8 m] -- with F = ceil(D / 8) exact zeros in front of and behind each row (mp = ntp / 8 + 2 F + 16: the kernel marches in double blocks of four steps with one block of look-ahead).
 std::vector<float> pack_class_major(const FilterBank &b, int D, int &mp, int &F);
 
 // direct-form bank builder shared by the reference-filter banks and the staged squelch

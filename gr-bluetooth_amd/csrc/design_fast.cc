@@ -251,7 +251,7 @@ bool solve_dense(std::vector<double> &A, std::vector<double> &b, int n)
 std::vector<float> pack_class_major(const FilterBank &b, int D, int &mp, int &F)
 {
     F = (D + 7) / 8;
-    mp = b.ntp / 8 + 2 * F + 8;
+    mp = b.ntp / 8 + 2 * F + 16;
     std::vector<float> out((size_t)b.nch * 8 * mp * 2, 0.f);
     for (int c = 0; c < b.nch; c++)
         for (int j = 0; j < b.ntp; j++) {

@@ -331,7 +331,7 @@ struct WindowParams {
     int rows_per_slot;          // stream rows from one slot's first row to the next slot's (outs_per_slot; exact stage: kVerRows)
     const double *ptile;        // [nch][ptile_stride] |Y|^2 sums per tile of tile_outs outputs (the polyphase banks' by-product)
     int ptile_stride, tile_outs, tiles_per_slot;
-    VerifyTask *vtasks; uint32_t *vtiles; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 tile entries, 2 windows turned away (list full)
+    VerifyTask *vtasks; uint32_t *vtiles; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 entries of vtiles (task | tile << 24), 2 windows turned away (list full)
     int vcap;                   // capacity of vtasks
     float burst_ratio;          // a tile counts as burst energy above burst_ratio * (smallest tile of the detection span)
     int span_extra;             // symbols behind an access code that stay exact as well (the 54-symbol header + margin)
@@ -587,58 +587,114 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     // sample, so a 1e-6 difference of the polyphase stream parts the two trajectories in ~10 % of the windows within 150
     // symbols; in noise that is invisible, across a burst it can move the access code by a symbol, change an error count
     // or -- where a carrier offset puts one symbol level near zero -- lose the packet on one side.
-    int vslot = -1, vspan = 0;
+    int vslot = -1, vspan = 0, vtiles0 = 0;                                // vtiles0: entries of the tile list this window already owns
     bool vtried = false;
-    if (!VER && p.verify == 1 && nmax > 0) {
+    // rows the clock recovery can reach within `span` symbols: at most omega_mid + omega_relative_limit input rows per symbol, + the
+    // 8-tap interpolator
+    auto ver_rows = [&](int span) {
+        int rows = (int)((float)span * (p.omega_mid + p.omega_relative_limit)) + 12;
+        const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
+        return rows > cap_rows ? cap_rows : rows;
+    };
+    if (!VER && p.verify == 1) {
+        // The tile sums of a slot's channels cross LDS (the dead demod tile): read straight from ptile[channel][tile] the 79
+        // lanes of a slot touch 79 cache lines per load -- 2 x 57 such loads per lane doubled the kernel's time.
         const int TT = p.tile_outs;
-        const int t0 = kq * p.tiles_per_slot;
-        int nt = (2 * kDetectSyms + 16 + TT - 1) / TT;
-        if (nt > p.ptile_stride - t0) nt = p.ptile_stride - t0;
-        const double *pt = p.ptile + (size_t)cq * p.ptile_stride + t0;
-        // noise level of the span: its smallest tile that holds signal at all (the zeros GNU Radio puts in front of a stream
-        // are not a noise level).  burst_ratio is calibrated per tile length to mean "four times the mean noise tile":
-        // what a packet at ~5 dB brings -- below that the correlator has nothing to find -- and what a neighbour channel's
-        // leakage does not reach below ~30 dB
-        float mn = 3.0e38f;
-        {
-            // (a tile next to silence may be partly silent itself: not a level either; four tiles in front of the window
-            // belong to the search: a packet that starts in the first tile and outlasts the span leaves no noise inside it)
-            const int jb = t0 >= 5 ? -4 : (t0 > 0 ? 1 - t0 : 0);
-            float ep = t0 > 0 ? (float)pt[jb - 1] : 1.f;
-            const int jl = t0 + nt == p.ptile_stride ? nt - 1 : nt;      // the batch's last tile may be a partial one
-            for (int j = jb; j < jl; j++) { const float e = (float)pt[j]; mn = (e > 0.f && ep > 0.f && e < mn) ? e : mn; ep = e; }
+        const int ntm = (2 * kDetectSyms + 16 + TT - 1) / TT;          // tiles of the detection span
+        const int NTW = ntm + 5, PW = NTW | 1;                         // + five tiles in front of the window; odd pitch: no bank conflicts
+        float *et = tile;                                              // [nch][PW], tile t0 - 5 + jj of channel cc at et[cc * PW + jj]; -1 = no such tile
+        for (int s = 0; s < kWinSlots; s++) {
+            const int ks = blockIdx.x * kWinSlots + s;
+            if (ks >= p.S) break;                                      // uniform
+            const int t0 = ks * p.tiles_per_slot;
+            __syncthreads();
+            // (NTW <= 64: a wave takes a channel's tiles -- contiguous doubles -- and the four waves every fourth channel)
+            for (int cc = (int)threadIdx.x >> 6; cc < nch; cc += kWinThreads / 64) {
+                const int jj = (int)threadIdx.x & 63;
+                const int t = t0 - 5 + jj;
+                if (jj < NTW) et[cc * PW + jj] = (t >= 0 && t < p.ptile_stride) ? (float)p.ptile[(size_t)cc * p.ptile_stride + t] : -1.f;
+            }
+            __syncthreads();
+            if (sl != s || nmax == 0) continue;
+            const float *pe = et + cq * PW + 5;                        // pe[j]: tile j of this window's span
+            int nt = ntm;
+            if (nt > p.ptile_stride - t0) nt = p.ptile_stride - t0;
+            // noise level of the span: its smallest tile that holds signal at all (the zeros GNU Radio puts in front of a
+            // stream are not a noise level, and a tile next to silence may be partly silent itself).  Four tiles in front of
+            // the window belong to the search: a packet that starts in the first tile and outlasts the span leaves no noise
+            // inside it.  burst_ratio is calibrated per tile length to mean "four times the mean noise tile": what a packet at
+            // ~5 dB brings -- below that the correlator has nothing to find -- and what a neighbour channel's leakage does not
+            // reach below ~30 dB
+            float mn = 3.0e38f;
+            {
+                const int jl = t0 + nt == p.ptile_stride ? nt - 1 : nt;  // the batch's last tile may be a partial one
+                float ep = pe[-5];
+#pragma unroll 4
+                for (int jx = -4; jx < jl; jx++) { const float e = pe[jx]; mn = (e > 0.f && ep > 0.f && e < mn) ? e : mn; ep = e; }
+            }
+            const float thr = mn * p.burst_ratio, thr_lo = 0.5f * thr;
+            // rising edges with hysteresis: a burst starts where a tile exceeds thr after one below thr / 2; a packet that is
+            // already on the air in the tile before the window starts nothing here (its access code lies in an earlier window)
+            bool in_burst = pe[-1] > thr;
+            int rise = -1;
+            const float noise = 0.25f * thr;                           // mean noise tile
+            float eprev = pe[-1] > 0.f ? pe[-1] : 0.f;
+#pragma unroll 4
+            for (int jx = 0; jx < nt; jx++) {
+                const float e = pe[jx];
+                const bool jump = e > thr && e > 4.f * eprev;            // a much stronger packet on top of one already on the air
+                eprev = e;
+                if ((!in_burst || jump) && e > thr) {
+                    in_burst = true;
+                    // Where inside tile jx the burst starts, from how much of a full burst tile it holds.  An access code is
+                    // reportable at the offsets below 625 (lib/multi_sniffer_impl.cc:108), i.e. up to row ~1257 at the loop's
+                    // slowest clock: a burst that starts later is the next window's (in a sniffer window the following slot
+                    // begins near symbol 635 -- every burst would be taken twice, the second time with a full-length span).
+                    const bool nxt = jx + 1 < nt && pe[jx + 1] > e;
+                    const float full = nxt ? pe[jx + 1] : e;
+                    float frac = (e - noise) / (full - noise);
+                    frac = frac < 0.f ? 0.f : (frac > 1.f ? 1.f : frac);
+                    const float onset_row = ((float)(jx + 1) - frac) * (float)TT;
+                    // what a packet fifty times stronger on a neighbour channel leaks through the channel filter is not a
+                    // packet here (and one that hides 17 dB below such a neighbour cannot be received)
+                    const float nl = cq > 0 ? pe[jx + (nxt ? 1 : 0) - PW] : 0.f;
+                    const float nr = cq + 1 < nch ? pe[jx + (nxt ? 1 : 0) + PW] : 0.f;
+                    const bool leak = nl > 50.f * full || nr > 50.f * full;
+                    if (!leak && onset_row < 1260.f + 0.04f * (float)TT) rise = jx;
+                } else if (in_burst && e < thr_lo) in_burst = false;
+            }
+            if (rise >= 0) vspan = ((rise + 1) * TT) / 2 + 72 + p.span_extra + 8;
         }
-        const float thr = mn * p.burst_ratio, thr_lo = 0.5f * thr;
-        // rising edges with hysteresis: a burst starts where a tile exceeds thr after one below thr / 2; a packet that is
-        // already on the air in the tile before the window starts nothing here (its access code lies in an earlier window)
-        bool in_burst = t0 > 0 ? (float)pt[-1] > thr : false;
-        int rise = -1;
-        const float noise = 0.25f * thr;                               // mean noise tile
-        float eprev = t0 > 0 ? (float)pt[-1] : 0.f;
-        for (int j = 0; j < nt; j++) {
-            const float e = (float)pt[j];
-            const bool jump = e > thr && e > 4.f * eprev;                // a much stronger packet on top of one already on the air
-            eprev = e;
-            if ((!in_burst || jump) && e > thr) {
-                in_burst = true;
-                // Where inside tile j the burst starts, from how much of a full burst tile it holds.  An access code is
-                // reportable at the offsets below 625 (lib/multi_sniffer_impl.cc:108), i.e. up to row ~1257 at the loop's
-                // slowest clock: a burst that starts later is the next window's (in a sniffer window the following slot
-                // begins near symbol 635 -- every burst would be taken twice, the second time with a full-length span).
-                const float full = (j + 1 < nt && (float)pt[j + 1] > e) ? (float)pt[j + 1] : e;
-                float frac = (e - noise) / (full - noise);
-                frac = frac < 0.f ? 0.f : (frac > 1.f ? 1.f : frac);
-                const float onset_row = ((float)(j + 1) - frac) * (float)TT;
-                // what a packet fifty times stronger on a neighbour channel leaks through the channel filter is not a packet
-                // here (and one that hides 17 dB below such a neighbour cannot be received)
-                const float en = full > e ? full : e;
-                const float nl = cq > 0 ? (float)p.ptile[(size_t)(cq - 1) * p.ptile_stride + t0 + j + (full > e ? 1 : 0)] : 0.f;
-                const float nr = cq + 1 < nch ? (float)p.ptile[(size_t)(cq + 1) * p.ptile_stride + t0 + j + (full > e ? 1 : 0)] : 0.f;
-                const bool leak = nl > 50.f * en || nr > 50.f * en;
-                if (!leak && onset_row < 1260.f + 0.04f * (float)TT) rise = j;
-            } else if (in_burst && e < thr_lo) in_burst = false;
+        // one task-list reservation per workgroup: thousands of lanes asking the same counter at the same moment queued up
+        // at the L2 for ~80 us (a quarter of this kernel's time, profiles/r04_c_*)
+        // (the tiles of the span the energy asks for are listed here as well; a later hit that reaches further appends the rest)
+        __syncthreads();                                               // (also: the tile is staged over next)
+        int *s_tl = (int *)tile;                                       // [0] tiles asked for by this workgroup, [1] their base in the list
+        if (threadIdx.x == 0) { s_live[0] = 0; s_tl[0] = 0; }
+        __syncthreads();
+        vtiles0 = vspan > 0 ? (ver_rows(vspan) + kVerTile - 1) / kVerTile : 0;
+        const int mine = vspan > 0 ? atomicAdd(&s_live[0], 1) : -1;
+        const int mine_t = vspan > 0 ? atomicAdd(&s_tl[0], vtiles0) : 0;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_live[0] > 0) {
+            s_live[1] = (int)atomicAdd(&p.vcount[0], (unsigned int)s_live[0]);
+            s_tl[1] = (int)atomicAdd(&p.vcount[1], (unsigned int)s_tl[0]);
         }
-        if (rise >= 0) vspan = ((rise + 1) * TT) / 2 + 72 + p.span_extra + 8;
+        __syncthreads();
+        if (mine >= 0) {
+            vtried = true;
+            const unsigned int s_ = (unsigned int)s_live[1] + (unsigned int)mine;
+            if (s_ < (unsigned int)p.vcap) {
+                vslot = (int)s_;
+                for (int j = 0; j < vtiles0; j++) p.vtiles[s_tl[1] + mine_t + j] = (uint32_t)vslot | ((uint32_t)j << 24);
+            } else {
+                atomicAdd(&p.vcount[2], 1u);
+                // (its reserved list entries: a tile of a task nobody fills in -- mark them empty)
+                for (int j = 0; j < vtiles0; j++) p.vtiles[s_tl[1] + mine_t + j] = 0xffffffffu;
+                vtiles0 = 0;
+            }
+        }
+        __syncthreads();                                               // s_live is the chunk loop's flag, the tile is staged over next
     }
     auto vreserve = [&]() {
         vtried = true;
@@ -646,7 +702,6 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         if (s_ < (unsigned int)p.vcap) vslot = (int)s_;
         else atomicAdd(&p.vcount[2], 1u);                         // list full: this window keeps the polyphase path's records
     };
-    if (vspan > 0) vreserve();
 
     if (p.dbg_stop == 1) return;
     // ---- phase 1: M&M ----
@@ -890,17 +945,16 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     search_classic(mybits, limit, kSymbolsShortAcDev, p.mode == 0, p.a0_lo, p.a0_hi, ac_lo, ac_hi, resume, nhits, emit_classic);
     if (p.dbg_stop == 3) return;
     if (vslot >= 0) {
-        // exact confirmation: this window's records come from the exact stage.  Rows the clock recovery can reach within
-        // vspan symbols: at most omega_mid + omega_relative_limit input rows per symbol, + the 8-tap interpolator
-        int rows = (int)((float)vspan * (p.omega_mid + p.omega_relative_limit)) + 12;
-        const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
-        if (rows > cap_rows) rows = cap_rows;
+        // exact confirmation: this window's records come from the exact stage
+        const int rows = ver_rows(vspan);
+        const int ntl = (rows + kVerTile - 1) / kVerTile;
+        if (ntl > vtiles0) {                                          // a hit reaches further than the energy's span (or there was no such span)
+            const unsigned int tp = atomicAdd(&p.vcount[1], (unsigned int)(ntl - vtiles0));
+            for (int j = vtiles0; j < ntl; j++) p.vtiles[tp + (j - vtiles0)] = (uint32_t)vslot | ((uint32_t)j << 24);
+        }
         VerifyTask t_;
         t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr;
         p.vtasks[vslot] = t_;
-        const int ntl = (rows + kVerTile - 1) / kVerTile;
-        const unsigned int tp = atomicAdd(&p.vcount[1], (unsigned int)ntl);
-        for (int j = 0; j < ntl; j++) p.vtiles[tp + j] = (uint32_t)vslot | ((uint32_t)j << 24);
         return;
     }
     // ---- LE pass: le_packet::sniff_aa (lib/packet_impl.cc:1452-1527) with the loop of

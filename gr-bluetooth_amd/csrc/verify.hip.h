@@ -22,6 +22,7 @@
 namespace btgpu {
 
 constexpr int kVerThreads = 512;      // 8 waves: wave l sums the taps j = l (mod 8) -- the 8 partial sums of the summation order
+constexpr int kVerPre = 16;           // 8-byte loads per thread that fetch a tile's input span (8192 samples at most: D <= 50)
 constexpr int kVerOuts = 128;         // outputs per tile: lane i of every wave takes outputs 2 i and 2 i + 1 (they share input samples)
 
 struct VerifyParams {
@@ -33,15 +34,17 @@ struct VerifyParams {
     const float2 *rot; int Q;         // de-rotation table [nch][Q] by window-local output index (Q = 0: rot_step_turns)
     const double *rot_step_turns;
     const float *atan_tab; float gain;
-    const VerifyTask *tasks; const uint32_t *tiles; const unsigned int *vcount; int vcap;
+    const VerifyTask *tasks; const uint32_t *tiles; const unsigned int *vcount; int vcap;     // vcount[1]: entries of `tiles`
+    unsigned int tiles_cap;           // its capacity: kVerMaxTiles per window of the batch
     int nch;
 };
+constexpr int kVerMaxTiles = (kVerRows + kVerTile - 1) / kVerTile;     // tiles of a task at most (12)
 // class-major, zero-padded copy of a direct-form bank's taps for verify_ddc_kernel: out[(c * 8 + l) * mp + F + m] = taps[c][l + 8 m]
-// (+ 8 zeros behind: the march runs in blocks of four steps and fetches the next block's taps while it works on the current one)
-inline void verify_tap_shape(int D, int ntp, int &mp, int &F) { F = (D + 7) / 8; mp = ntp / 8 + 2 * F + 8; }
+// (+ 16 zeros behind: the march runs in blocks of four steps and fetches the next block's taps while it works on the current one)
+inline void verify_tap_shape(int D, int ntp, int &mp, int &F) { F = (D + 7) / 8; mp = ntp / 8 + 2 * F + 16; }   // (look-ahead room)
 
 // LDS words (float2) of one tile: the padded input span, reused for the partial sums
-inline int verify_span(int D, int ntp) { return (kVerOuts - 1) * D + ntp + D + 48; }
+inline int verify_span(int D, int ntp) { return (kVerOuts - 1) * D + ntp + D + 80; }
 inline size_t verify_lds_bytes(int D, int ntp)
 {
     const int ns = verify_span(D, ntp);
@@ -61,22 +64,20 @@ inline size_t verify_lds_bytes(int D, int ntp)
 __device__ __forceinline__ uint32_t ver_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) >> 32); }
 
 // x: the batch's input; tapsv: VerifyParams; dx: [vcap][kVerRows] exact demodulated rows of each task
-__global__ __launch_bounds__(kVerThreads) void verify_ddc_kernel(VerifyParams p, const float2 *__restrict__ x,
+__global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams p, const float2 *__restrict__ x,
                                                                  const float2 *__restrict__ tapsv, float *__restrict__ dx)
 {
     HIP_DYNAMIC_SHARED(float2, lds)
     const int D = p.D, ntp = p.ntp;
-    const int ns = (kVerOuts - 1) * D + ntp + D + 48;
+    const int ns = (kVerOuts - 1) * D + ntp + D + 80;
     int words = ns + ns / (2 * D) + 2;
     if (words < 8 * kVerOuts) words = 8 * kVerOuts;
     float2 *ys = lds + words;                                     // [kVerOuts + 1]
     float *atab = (float *)(ys + kVerOuts + 1);                   // [257]
+    // Work items: the entries (task | tile << 24) of the list the window kernel laid out -- one reservation per workgroup, so a
+    // task's tiles sit next to each other and the tasks of one slot (same input span) are adjacent; 0xffffffff = no tile
     unsigned int ntiles = p.vcount[1];
-    {
-        unsigned int ntask = p.vcount[0];
-        if (ntask > (unsigned int)p.vcap) ntask = (unsigned int)p.vcap;
-        if (ntiles > ntask * 12u) ntiles = ntask * 12u;
-    }
+    if (ntiles > p.tiles_cap) ntiles = p.tiles_cap;
     for (int i = threadIdx.x; i < 257; i += kVerThreads) atab[i] = p.atan_tab[i];
 #if defined(__HIP_DEVICE_COMPILE__)
     const int l = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -84,31 +85,50 @@ __global__ __launch_bounds__(kVerThreads) void verify_ddc_kernel(VerifyParams p,
     const int l = (int)threadIdx.x >> 6;
 #endif
     const int lane = (int)threadIdx.x & 63;
-    for (unsigned int item = blockIdx.x; item < ntiles; item += gridDim.x) {
+    // The input span of a workgroup's NEXT tile is requested (kVerPre 8-byte loads per thread, registers) before the march over
+    // the current one and written to LDS behind it: staging a tile costs four memory round trips -- more than the march itself.
+    float2 pv[kVerPre];
+    long long sb_next = 0;
+    auto skip = [&](unsigned int it) { while (it < ntiles && p.tiles[it] == 0xffffffffu) it += gridDim.x; return it; };
+    auto issue = [&](unsigned int it) {
+        const uint32_t e_ = p.tiles[it];
+        const unsigned int jt_ = e_ >> 24, q_ = e_ & 0xffffffu;
+        const VerifyTask tk_ = p.tasks[q_];
+        const int k_ = tk_.w / p.nch;
+        sb_next = p.first0 + (long long)k_ * p.slot + (long long)(kVerTile * (int)jt_ - 1) * D;
+        if (sb_next >= 0 && sb_next + (long long)kVerPre * kVerThreads <= p.x_len) {   // uniform: the span lies inside the stream
+            const float2 *xb = x + sb_next;                                 // (scalar base + one 32-bit lane offset: no 64-bit address per load)
+#pragma unroll
+            for (int r = 0; r < kVerPre; r++) pv[r] = xb[(int)threadIdx.x + r * kVerThreads];
+        } else {
+#pragma unroll
+            for (int r = 0; r < kVerPre; r++) {                             // (static indices: a rolled loop would put pv in scratch memory)
+                const long long a = sb_next + (int)threadIdx.x + r * kVerThreads;
+                const long long ac = a < 0 ? 0 : (a < p.x_len ? a : p.x_len - 1);   // clamped; the value is replaced by 0 at the store
+                pv[r] = x[ac];
+            }
+        }
+    };
+    unsigned int item = skip(blockIdx.x);
+    if (item < ntiles) issue(item);
+    while (item < ntiles) {
         const uint32_t e = p.tiles[item];
         const int q = (int)(e & 0xffffffu), jt = (int)(e >> 24);
         const VerifyTask tk = p.tasks[q];
         const int k = tk.w / p.nch, c = tk.w - k * p.nch;
         const int t_first = kVerTile * jt - 1;                     // output index of u = 0
-        const long long sb = p.first0 + (long long)k * p.slot + (long long)t_first * D;
+        const long long sb = sb_next;
         __syncthreads();                                           // the previous item's partial sums are consumed
-        // ---- stage the input span: sample n of the tile at word n + n / (2 D) ----
-        for (int n0 = (int)threadIdx.x; n0 < ns; n0 += 4 * kVerThreads) {
-            float2 v[4];
+        // ---- the staged input span: sample n of the tile at word n + n / (2 D) ----
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const long long a = sb + n0 + r * kVerThreads;
-                const long long ac = a < 0 ? 0 : (a < p.x_len ? a : p.x_len - 1);
-                v[r] = x[ac];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int n = n0 + r * kVerThreads;
-                const long long a = sb + n;
-                if (n < ns) lds[n + (int)ver_mulhi((uint32_t)n, p.inv2d)] = (a >= 0 && a < p.x_len) ? v[r] : make_float2(0.f, 0.f);
-            }
+        for (int r = 0; r < kVerPre; r++) {
+            const int n = (int)threadIdx.x + r * kVerThreads;
+            const long long a = sb + n;
+            if (n < ns) lds[n + (int)ver_mulhi((uint32_t)n, p.inv2d)] = (a >= 0 && a < p.x_len) ? pv[r] : make_float2(0.f, 0.f);
         }
         __syncthreads();
+        const unsigned int next = skip(item + gridDim.x);
+        if (next < ntiles) issue(next);                            // in flight under the march
         // ---- the march: step m meets tap l + 8 m of output 2 i and tap l + 8 m - D of output 2 i + 1 ----
         const int lc = ((l - D) % 8 + 8) % 8;                       // class of the second output's tap
         const int sh = (D - l + lc) / 8;                            // its step lag
@@ -119,13 +139,10 @@ __global__ __launch_bounds__(kVerThreads) void verify_ddc_kernel(VerifyParams p,
         const int lbase = 2 * D * lane + lane;                      // word of the lane's first sample (sample 2 D lane, its pad words)
         int xw = l + l / (2 * D), rem = l % (2 * D);                // wave-uniform: word offset l + 8 m + (its pad words), (l + 8 m) mod 2 D
         const int twoD = 2 * D;
-        float2 a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = t0[u]; b[u] = t1[u]; }
         for (int m = 0; m < steps; m += 4) {
-            float2 an[4], bn[4];                                    // the next block's taps: scalar loads in flight under 32 multiply-adds
+            float2 a[4], b[4];                                      // wave-uniform: scalar loads
 #pragma unroll
-            for (int u = 0; u < 4; u++) { an[u] = t0[m + 4 + u]; bn[u] = t1[m + 4 + u]; }
+            for (int u = 0; u < 4; u++) { a[u] = t0[m + u]; b[u] = t1[m + u]; }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const float2 v = lds[lbase + xw];
@@ -141,8 +158,6 @@ __global__ __launch_bounds__(kVerThreads) void verify_ddc_kernel(VerifyParams p,
                 ai1 = fmaf(b[u].x, v.y, ai1);
                 ai1 = fmaf(b[u].y, v.x, ai1);
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { a[u] = an[u]; b[u] = bn[u]; }
         }
         __syncthreads();                                           // every wave is done with the samples
         lds[l * kVerOuts + 2 * lane] = make_float2(ar0, ai0);
@@ -179,6 +194,7 @@ __global__ __launch_bounds__(kVerThreads) void verify_ddc_kernel(VerifyParams p,
             const int u = (int)threadIdx.x, t = t_first + u;
             if (t >= 1 && t < tk.n_exact) dx[(size_t)q * kVerRows + t] = demod_one(atab, p.gain, ys[u], ys[u - 1]);
         }
+        item = next;
     }
 }
 

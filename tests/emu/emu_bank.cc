@@ -291,7 +291,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     const bool verify = ve && ve->mode > 0;
     if (verify) {
         vb.vcap = verify_capacity(S, nch);
-        vtasks.resize((size_t)vb.vcap); vtiles.resize((size_t)vb.vcap * 12); dx.assign((size_t)vb.vcap * kVerRows, -55.f);
+        vtasks.resize((size_t)vb.vcap); vtiles.resize(verify_tiles_capacity(S, nch)); vb.tiles_cap = (unsigned int)vtiles.size(); dx.assign((size_t)vb.vcap * kVerRows, -55.f);
         const int nps = (vb.vcap + nch - 1) / nch;
         dxt4.assign(((size_t)nps * kVerRows * drow + 3) / 4 + 16, make_float4(-66.f, -66.f, -66.f, -66.f));
         vb.tasks = vtasks.data(); vb.tiles = vtiles.data(); vb.vcount = vcount; vb.dx = dx.data(); vb.dxt = (float *)dxt4.data();
@@ -316,8 +316,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         const size_t lds = verify_lds_bytes(des.d.decimation, des.channel.ntp);
         if (lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", lds); std::abort(); }
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
-        const unsigned ntl = std::min<unsigned>(vcount[1], (unsigned)vb.vcap * 12u);
-        if (ntl) emu::launch(dim3(std::min<unsigned>(ntl, 64u)), dim3(kVerThreads), [&]() {
+        if (vcount[1]) emu::launch(dim3(61u), dim3(kVerThreads), [&]() {
             verify_ddc_kernel(vp, ve->x, (const float2 *)tv.data(), dx.data());
         });
         const VerifyFillParams fpz = make_verify_fill_params(des, d, dcol_p, drow, G, vb);
