@@ -1360,6 +1360,12 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
         case 7: src = h->tc[h->last_ctx].d_winlen.p; elem = sizeof(int); avail = (size_t)h->last_S * nch; break;
         case 8: src = h->tc[h->last_ctx].d_fin.p; elem = sizeof(FinishRec); avail = (size_t)h->last_S * nch; break;
         case 9: if (!h->d_prof.p) return BTGPU_EINVAL; src = h->d_prof.p; elem = sizeof(unsigned long long); avail = (size_t)(h->ntiles_max + 64) * 8; break;
+        case 10:                                             // exact stage: the tasks of the last batch (VerifyTask: w, n_exact, snr)
+            if (!h->verify) return BTGPU_EINVAL;
+            src = h->tc[h->last_ctx].d_vtasks.p; elem = sizeof(VerifyTask); avail = std::min<size_t>(h->tc[h->last_ctx].h_count[4], (size_t)h->vcap); break;
+        case 11:                                             // ... and their exact demodulated rows, [task][kVerRows] float
+            if (!h->verify) return BTGPU_EINVAL;
+            src = h->tc[h->last_ctx].d_dx.p; elem = sizeof(float); avail = std::min<size_t>(h->tc[h->last_ctx].h_count[4], (size_t)h->vcap) * kVerRows; break;
         case 2: src = h->d_eon.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 3: src = h->d_eoff.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 4: src = h->d_snr.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;

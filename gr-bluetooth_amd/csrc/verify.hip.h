@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
         }
         __syncthreads();                                           // every wave is done with the samples
         lds[l * kVerOuts + 2 * lane] = make_float2(ar0, ai0);
-        lds[l * kVerOuts + 2 * lane + 1] = make_float2(ar1, ai1);
+        lds[lc * kVerOuts + 2 * lane + 1] = make_float2(ar1, ai1);   // (the second output's partial is class lc, not l: the combine below sums by class)
         __syncthreads();
         if (threadIdx.x < kVerOuts) {
             const int u = (int)threadIdx.x;

@@ -234,7 +234,9 @@ int btgpu_last_timing(const btgpu_handle *h, btgpu_timing *out);
  * what: 0 channel-bank output Y (complex64 [channel][g]; DIRECT channelizer or BTGPU_FLAG_DEBUG_Y),
  *       1 demodulated stream d (float32, time-major [g][nch]: pass channel to get a strided copy),
  *       2 E_on per window (float64, [slot][channel]), 3 E_off per window, 4 snr per window,
- *       5 noise-bank output (complex64; DIRECT squelch only).
+ *       5 noise-bank output (complex64; DIRECT squelch only),
+ *       10 the exact stage's tasks ({int32 window = slot * nch + channel index, int32 rows, float64 snr}), 11 their exact
+ *       demodulated rows (float32 [task][1416]; rows 1 .. rows-1 of a task are valid).
  * channel is a classic channel number (ignored for 2..4); returns elements copied. */
 long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, size_t count, void *out);
 

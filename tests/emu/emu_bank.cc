@@ -244,7 +244,8 @@ int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
 
 // window_kernel + finish_kernel + nsym_patch_kernel over the demodulated stream d (time-major, `drow` floats per row;
 // dcol = the 100-bin bank's tile-blocked copy or null), the channel block energies P / Pt and the noise energies Qn
-struct StudyCapture { std::vector<float> d; std::vector<double> snr; long long G = 0; int drow = 0, nch = 0, S = 0; };
+struct StudyCapture { std::vector<float> d; std::vector<double> snr; long long G = 0; int drow = 0, nch = 0, S = 0;
+                      std::vector<VerifyTask> tasks; std::vector<float> dx; };
 static uint32_t *g_sym_out = nullptr; static uint8_t *g_hdr_out = nullptr;     // set by emu_front_direct_headers_run
 static StudyCapture *g_study = nullptr;                 // emu_margin_study: keep the demodulated stream and the squelch SNRs
 
@@ -344,6 +345,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         std::fprintf(stderr, "\n");
     }
     g_verify_tasks.assign(vtasks.begin(), vtasks.begin() + std::min<size_t>(vtasks.size(), vcount[0]));
+    if (g_study) { g_study->tasks = g_verify_tasks; g_study->dx = dx; }
     {
         const unsigned nblk = (unsigned)((counts[1] + kFinLanes - 1) / kFinLanes + 1);
         emu::launch(dim3(nblk), dim3(kFinLanes), [&]() {
@@ -642,4 +644,41 @@ extern "C" int emu_margin_study(double fs, double fc, int mode, double squelch_d
             r[3] = oo;
         }
     return n;
+}
+
+
+// The exact stage's demodulated rows against the bit-exact front end's (diagnostics / test): for every task of the polyphase run,
+// rows [1, n_exact) of dx must equal the DIRECT path's stream bit for bit.  Returns the number of differing rows (0 = exact), or
+// a negative error; first_bad[0..2] = task window, row, task rows of the first difference.
+extern "C" long emu_verify_check(double fs, double fc, int mode, double squelch_db, const float *iq, long long x_len, int S, long long *first_bad)
+{
+    StudyCapture fast, exact;
+    std::vector<long long> rec((size_t)8 * 65536); std::vector<double> sn(65536);
+    g_study = &fast;
+    int rc = emu_front_m_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
+    g_study = &exact;
+    if (rc >= 0) rc = emu_front_direct_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
+    g_study = nullptr;
+    if (rc < 0) return rc;
+    btgpu_config cfg{};
+    cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = squelch_db; cfg.mode = mode;
+    static Design des;
+    des = Design();
+    rc = make_design(cfg, des);
+    if (rc) return rc;
+    const int nch = fast.nch, ops = des.outs_per_slot;
+    long bad = 0;
+    for (size_t q = 0; q < fast.tasks.size(); q++) {
+        const VerifyTask &t = fast.tasks[q];
+        const int k = t.w / nch, c = t.w % nch;
+        for (int i = 1; i < t.n_exact; i++) {
+            const float a = fast.dx[q * kVerRows + i], b = exact.d[((size_t)k * ops + i) * exact.drow + c];
+            if (std::memcmp(&a, &b, 4) != 0) {
+                if (!bad && first_bad) { first_bad[0] = t.w; first_bad[1] = i; first_bad[2] = t.n_exact; }
+                if (getenv("EMU_DBG_ROWS") && bad < 60) std::fprintf(stderr, "task %zu w %d row %d: %.9g vs %.9g\n", q, t.w, i, a, b);
+                bad++;
+            }
+        }
+    }
+    return bad;
 }

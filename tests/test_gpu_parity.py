@@ -620,8 +620,8 @@ def test_full_size_fast_path_vs_all_core_oracle_c79(pkg, po, synth):
 def test_c79_time_partition_with_left_margin_equals_whole_stream(pkg, synth):
     """BASELINE configs[3] on one GPU: the C79 stream cut into contiguous slot ranges (halo history()-1
     + left_margin for the staged squelch, dist.segment_bounds) gives, range by range, exactly the
-    records of the unpartitioned run -- every field, bit for bit (same kernels, same arithmetic per
-    output; only the tile a sample falls into changes)."""
+    records of the unpartitioned run (same kernels, same arithmetic per output; only the tile a sample falls into
+    changes): every field but nsym bit for bit, nsym within the polyphase path's bound."""
     import importlib
     import torch
     bdist = importlib.import_module("gr_bluetooth_amd.dist")
@@ -648,7 +648,11 @@ def test_c79_time_partition_with_left_margin_equals_whole_stream(pkg, synth):
             part = seg[lo - a_all: start + cnt - a_all].contiguous()
             blk.process_device(part.data_ptr(), part.shape[0], first, n, left_margin=mg - (lo - start))
             got += _keys(blk.poll())
-        assert got == whole, "world %d" % world
+        # (slot, channel, kind, offset, LAP, ac_errors) identical; nsym -- the run length over the noise behind the packet, the
+        # polyphase path's tolerance field -- within its bound: how many rows of a window the exact stage recomputes depends on
+        # the tile energies in FRONT of the window, which a range that starts there does not have
+        assert [k[:6] for k in got] == [k[:6] for k in whole], "world %d" % world
+        assert max(abs(a[6] - b[6]) for a, b in zip(got, whole)) <= 8, "world %d" % world
         parts.append(world)
     blk.close()
 
@@ -730,45 +734,129 @@ def test_cfo_sweep_gpu_equals_oracle(pkg, po, synth, name, fs, fc, S):
         json.dump(curve, open(os.path.join(out, "cfo_curve_%s.json" % name), "w"))
 
 
-def test_fuzz_case_201_regression(pkg, po, synth):
-    """The one failing case of the 400-case randomised run of round 2 (profiles/r02_fuzz_fast_400.txt, case 201:
-    multi_LAP, 100 Msps, 16.6 dB, libbtbb-style search; scripts/gpu_fuzz_fast.py 400 32), replayed from the script's
-    random stream.  Its planted record (slot 6, channel 49, LAP 7cef4b) came out one symbol earlier on the GPU with 0
-    instead of 1 corrected bit: the symbol in front of the sync word is a noise symbol, and the first-hit search of
-    btbb_find_ac accepts the earlier alignment when that symbol happens to fit.  Classification:
-    a tolerance-path difference of the OFFSET of a correct detection, never of the LAP list.  Asserted: the LAP
-    multiset equals the oracle's, every detection of the oracle is present, and a record that differs does so by
-    at most one symbol of offset with the same LAP on the same slot and channel."""
-    import importlib
-    import paritylib
-    bdist = importlib.import_module("gr_bluetooth_amd.dist")
-    rng = np.random.default_rng(32)
+def _fuzz_fast_case(seed, want_case):
+    """Parameters of case `want_case` of scripts/gpu_fuzz_fast.py with that seed (the script's draw order)."""
+    rng = np.random.default_rng(seed)
     RATES = [(100e6, 2441e6), (8e6, 2476.5e6), (20e6, 2441e6), (100e6, 2441e6)]
-    for case in range(202):
+    for case in range(want_case + 1):
         fs, fc = RATES[int(rng.integers(0, len(RATES)))]
         nsl = int(rng.integers(8, 14)); snr_db = float(rng.uniform(12, 30)); occ = float(rng.uniform(0.2, 0.9))
         sq = float(rng.choice([5.0, 10.0, 14.0])); sniff = bool(rng.integers(0, 2)); le = sniff and bool(rng.integers(0, 2))
         laps = tuple(int(x) for x in rng.integers(0, 1 << 24, 6))
-        seed = int(rng.integers(0, 1 << 30))
-    assert (fs, sniff, le, sq, nsl) == (100e6, False, False, 10.0, 12) and abs(snr_db - 16.6) < 0.05
-    iq, truth = synth.make_capture(fs, fc, nsl, laps=laps, seed=seed, snr_db=snr_db, occupancy=occ)
-    want, _ = po.Oracle(fs, fc, sq, po.MODE_LAP).run_stream(iq, threads=os.cpu_count() or 1)
-    blk = pkg.multi_LAP(fs, fc, sq)
+        seed_c = int(rng.integers(0, 1 << 30))
+    return fs, fc, nsl, snr_db, occ, sq, sniff, le, laps, seed_c
+
+
+def _fast_differential(pkg, po, synth, params, flags=0):
+    import importlib
+    import paritylib
+    bdist = importlib.import_module("gr_bluetooth_amd.dist")
+    fs, fc, nsl, snr_db, occ, sq, sniff, le, laps, seed_c = params
+    iq, truth = synth.make_capture(fs, fc, nsl, laps=laps, seed=seed_c, snr_db=snr_db, occupancy=occ)
+    want, _ = po.Oracle(fs, fc, sq, po.MODE_SNIFFER if sniff else po.MODE_LAP, le=le).run_stream(iq, threads=os.cpu_count() or 1)
+    blk = pkg.multi_sniffer(fs, fc, sq, False, le=le, flags=flags) if sniff else pkg.multi_LAP(fs, fc, sq, flags=flags)
+    assert blk.design.channelizer == pkg.CHANNELIZER_POLYPHASE and blk.design.squelch == pkg.SQUELCH_STAGED
     blk.push(iq)
     got = blk.poll()
+    tm = blk.timing()
     blk.close()
     gi, _ = bdist.hits_to_arrays(got)
     wi, _ = bdist.hits_to_arrays(want)
-    d = paritylib.differential(gi, wi, truth, lag=1)
+    return paritylib.differential(gi, wi, truth, lag=6 if sniff else 1), tm
+
+
+def test_fuzz_case_201_regression(pkg, po, synth):
+    """The one failing case of the 400-case randomised run of round 2 (profiles/r02_fuzz_fast_400.txt, case 201:
+    multi_LAP, 100 Msps, 16.6 dB, libbtbb-style search; scripts/gpu_fuzz_fast.py 400 32), replayed from the script's
+    random stream.  On the tolerance path alone (BTGPU_FLAG_NO_VERIFY, rounds 2-3) its planted record (slot 6, channel 49,
+    LAP 7cef4b) comes out one symbol earlier with 0 instead of 1 corrected bit: the symbol in front of the sync word is a
+    noise symbol and btbb_find_ac's first-hit search accepts the earlier alignment when it happens to fit.  With the exact
+    stage (default since round 4) the window is re-run through the direct-form arithmetic: all 24 planted records equal the
+    oracle's on slot, channel, kind, offset, LAP and ac_errors."""
+    params = _fuzz_fast_case(32, 201)
+    fs, fc, nsl, snr_db, occ, sq, sniff, le, laps, seed_c = params
+    assert (fs, sniff, le, sq, nsl) == (100e6, False, False, 10.0, 12) and abs(snr_db - 16.6) < 0.05
+    d, tm = _fast_differential(pkg, po, synth, params)
     print("fuzz case 201:", json.dumps(d))
-    assert d["planted_ref"] == 24 and d["lap_multiset_equal"], d
-    assert d["planted_only_gpu"] == d["planted_only_ref"] <= 1, d
-    gk = {(int(r[0]), int(r[1]), int(r[4])): r for r in gi if r[2] == 0}
-    for r in wi:
-        if r[2] != 0:
-            continue
-        g = gk.get((int(r[0]), int(r[1]), int(r[4])))
-        assert g is not None and abs(int(g[3]) - int(r[3])) <= 1, (r, g)
+    assert d["planted_ref"] == 24 and d["planted_identical"] and d["planted_offset_differs"] == 0 and d["lap_multiset_equal"], d
+    assert tm.verify_windows >= 24 and tm.verify_turned_away == 0
+    d0, tm0 = _fast_differential(pkg, po, synth, params, flags=pkg.FLAG_NO_VERIFY)
+    assert tm0.verify_windows == 0
+    assert d0["lap_multiset_equal"] and d0["planted_only_gpu"] == d0["planted_only_ref"] == 1, d0      # what it was
+
+
+# every 20th case of the two 400- / 800-capture runs + the cases that deviated without the exact stage (seed 77: 312, 626, 743)
+@pytest.mark.parametrize("seed,cases", [(32, list(range(0, 400, 20))), (77, list(range(7, 800, 40)) + [312, 626, 743])])
+def test_randomised_differential_polyphase_path(pkg, po, synth, seed, cases):
+    """A fixed slice of scripts/gpu_fuzz_fast.py (100 / 8 / 20 Msps banks, both blocks, LE on / off, 12-30 dB, three squelch
+    levels) in the driver-run suite: PLANTED records identical to the oracle's on slot, channel, kind, offset, LAP and
+    ac_errors -- no offset a symbol apart, none on one side only -- and nsym within +-8."""
+    tot = dict(planted=0, verified=0)
+    for c in cases:
+        d, tm = _fast_differential(pkg, po, synth, _fuzz_fast_case(seed, c))
+        assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= 8, (seed, c, d)
+        assert tm.verify_turned_away == 0
+        tot["planted"] += d["planted_ref"]; tot["verified"] += int(tm.verify_windows)
+    print("randomised differential, seed %d: %d captures, %d planted records identical, %d windows through the exact stage" %
+          (seed, len(cases), tot["planted"], tot["verified"]))
+    assert tot["planted"] > 200
+
+
+def test_randomised_differential_direct_path(pkg, po, synth):
+    """A fixed slice of scripts/gpu_fuzz_parity.py (the DIRECT path's bit-exact contract over random rates incl. the odd ones,
+    modes, squelch levels, LE on / off, ragged pushes, small batches): records equal the oracle's in EVERY field."""
+    rng = np.random.default_rng(1)
+    RATES = [(2e6, 2476e6), (3e6, 2450e6), (4e6, 2476e6), (5e6, 2470e6), (8e6, 2476.5e6), (8e6, 2402e6), (10e6, 2450e6),
+             (16e6, 2440e6), (20e6, 2441e6), (25e6, 2441e6)]
+    for case in range(40):
+        fs, fc = RATES[int(rng.integers(0, len(RATES)))]
+        nsl = int(rng.integers(8, 30)) if fs < 16e6 else int(rng.integers(7, 12))
+        snr_db = float(rng.uniform(9, 30)); occ = float(rng.uniform(0.1, 0.9)); sq = float(rng.choice([-5.0, 5.0, 10.0, 14.0]))
+        sniff = bool(rng.integers(0, 2)); le = sniff and bool(rng.integers(0, 2))
+        iq, _ = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=int(rng.integers(0, 1 << 30)), snr_db=snr_db,
+                                   occupancy=occ, max_payload_bits=int(rng.choice([0, 240, 2800])))
+        o = po.Oracle(fs, fc, sq, po.MODE_SNIFFER if sniff else po.MODE_LAP, le=le)
+        want, _ = o.run_stream(iq, threads=os.cpu_count() or 1)
+        kw = dict(channelizer=pkg.CHANNELIZER_DIRECT, squelch=pkg.SQUELCH_DIRECT, max_batch_slots=int(rng.choice([0, 3, 8])))
+        blk = pkg.multi_sniffer(fs, fc, sq, False, le=le, **kw) if sniff else pkg.multi_LAP(fs, fc, sq, **kw)
+        pos = 0
+        while pos < len(iq):                                   # ragged pushes
+            n = int(rng.integers(1, 3 * o.slot))
+            blk.push(iq[pos:pos + n]); pos += n
+        got = blk.poll()
+        blk.close()
+        assert [h.key() for h in got] == [h.key() for h in want], (case, fs, sniff, le, sq)
+
+
+@pytest.mark.parametrize("fs,fc,nsl", [(100e6, 2441e6, 10), (8e6, 2476.5e6, 24), (20e6, 2441e6, 12)])
+def test_exact_stage_rows_equal_the_direct_path(pkg, synth, fs, fc, nsl):
+    """verify_ddc_kernel on the MI355X against the DIRECT path's ddc_direct_kernel + demod_rows_kernel (which
+    test_intermediates_bit_exact pins to the oracle): every demodulated row the exact stage recomputed for the windows it took
+    is bit-identical to the bit-exact path's stream."""
+    iq, _ = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=11, snr_db=22, occupancy=0.6,
+                               cfo_hz=60e3, max_payload_bits=1200)
+    fast = pkg.multi_sniffer(fs, fc, 10.0, False, max_batch_slots=nsl)
+    assert fast.design.channelizer == pkg.CHANNELIZER_POLYPHASE
+    fast.push(iq); fast.poll()
+    tasks = fast.debug_fetch(10, 0, 0, 1 << 16)
+    assert len(tasks) > 10
+    dx = fast.debug_fetch(11, 0, 0, len(tasks) * 1416).reshape(len(tasks), 1416)
+    exact, _ = _run_gpu(pkg, pkg.multi_sniffer, fs, fc, iq, max_batch_slots=nsl)
+    d = exact.design
+    nch = d.high_channel - d.low_channel + 1
+    ops = d.samples_per_slot // d.decimation
+    cols = {}
+    rows_checked = 0
+    for t, row in zip(tasks, dx):
+        k, c = int(t["w"]) // nch, int(t["w"]) % nch
+        if c not in cols:
+            cols[c] = exact.debug_fetch(1, d.low_channel + c, 0, 1 << 24)
+        n = int(t["rows"])
+        assert 100 < n <= 1416
+        assert np.array_equal(row[1:n], cols[c][k * ops + 1: k * ops + n]), (k, c, n)
+        rows_checked += n - 1
+    print("exact stage: %d windows, %d rows bit-identical to the direct path" % (len(tasks), rows_checked))
+    fast.close(); exact.close()
 
 
 def test_no_nsym_flag_skips_the_continuation(pkg, synth):
