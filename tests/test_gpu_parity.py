@@ -828,7 +828,7 @@ def test_randomised_differential_direct_path(pkg, po, synth):
         assert [h.key() for h in got] == [h.key() for h in want], (case, fs, sniff, le, sq)
 
 
-@pytest.mark.parametrize("fs,fc,nsl", [(100e6, 2441e6, 10), (8e6, 2476.5e6, 24), (20e6, 2441e6, 12)])
+@pytest.mark.parametrize("fs,fc,nsl", [(100e6, 2441e6, 14), (8e6, 2476.5e6, 24), (20e6, 2441e6, 12)])
 def test_exact_stage_rows_equal_the_direct_path(pkg, synth, fs, fc, nsl):
     """verify_ddc_kernel on the MI355X against the DIRECT path's ddc_direct_kernel + demod_rows_kernel (which
     test_intermediates_bit_exact pins to the oracle): every demodulated row the exact stage recomputed for the windows it took
@@ -839,7 +839,7 @@ def test_exact_stage_rows_equal_the_direct_path(pkg, synth, fs, fc, nsl):
     assert fast.design.channelizer == pkg.CHANNELIZER_POLYPHASE
     fast.push(iq); fast.poll()
     tasks = fast.debug_fetch(10, 0, 0, 1 << 16)
-    assert len(tasks) > 10
+    assert len(tasks) >= 8
     dx = fast.debug_fetch(11, 0, 0, len(tasks) * 1416).reshape(len(tasks), 1416)
     exact, _ = _run_gpu(pkg, pkg.multi_sniffer, fs, fc, iq, max_batch_slots=nsl)
     d = exact.design
