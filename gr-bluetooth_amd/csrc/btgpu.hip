@@ -271,7 +271,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         // BTGPU_BANK_LDS_PAD (diagnostics): extra dynamic LDS per workgroup, i.e. fewer resident tiles per CU (occupancy sweeps)
         static const size_t lds_pad = [] { const char *e = getenv("BTGPU_BANK_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
-            if (lds_pad) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad));
+            // more than 48 KiB of dynamic LDS is an opt-in per kernel: asked for here, next to the launch, once per
+            // instantiation actually launched (a list kept elsewhere drifts from what launch_channel_bank picks)
+            static std::vector<const void *> opted;
+            if (lds + lds_pad > 48 * 1024 && std::find(opted.begin(), opted.end(), (const void *)kern) == opted.end()) {
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds + lds_pad, 64 * 1024));
+                opted.push_back((const void *)kern);
+            }
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds + lds_pad, st, p);
         };
         // BTGPU_BANK: run256 (default) | run320 -- pfb100f_kernel, runs of tiles per workgroup, four / five waves;

@@ -164,6 +164,9 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     float *s_d = (float *)U + CH * 80 * 2;                       // [TT][80]      angles on their way to d
     float *s_dc = s_d + TT * 80;                                 // [80][TT]      the same tile channel-major (-> dcol)
     static_assert((CH * 80 * 2) % 4 == 0 && CH * 80 * 2 + 2 * TT * 80 <= 2 * NT * UST, "epilogue tiles must fit the dead DFT rows");
+    // the lean epilogue reads up to two bin rows past the tile's last instant without a clamp (values never used): they must
+    // at least lie inside this workgroup's LDS allocation (the span / bin-row region and the DFT rows are one piece)
+    static_assert((NT + 2) * YST + M <= ASZ + NROWS * UST, "the epilogue's read-ahead must stay inside the allocation");
     const int l0 = threadIdx.x;
 
     // ---- the run of tiles of this workgroup (XCD-aware: neighbouring runs share their halo in one L2) ----

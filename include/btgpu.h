@@ -170,7 +170,8 @@ void btgpu_destroy(btgpu_handle *h);
 int  btgpu_get_design(const btgpu_handle *h, btgpu_design *out);
 int  btgpu_history(const btgpu_handle *h);
 int  btgpu_device(const btgpu_handle *h);     /* HIP ordinal the handle lives on (what device = -1 resolved to) */
-int  btgpu_device_count(void);                /* visible gfx950-capable HIP devices, or BTGPU_ENODEVICE          */
+int  btgpu_device_count(void);                /* visible HIP devices (whatever their architecture: btgpu_create checks
+                                                 for gfx950), or BTGPU_ENODEVICE                                  */
 const char *btgpu_last_error(const btgpu_handle *h);
 
 /* ---- work() ----
