@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--parity-slots", type=int, default=1600,
                     help="slots of the capture the all-core oracle differential covers (N = 1; 0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (btgpu_process_host, PCIe-inclusive) leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
@@ -332,6 +333,49 @@ def run_rank(args):
                      "verify": dict(blk._verify_stats),
                      "ac_records_equal_headline": bool(np.array_equal(b_ints[b_ints[:, 2] == 0], ints[ints[:, 2] == 0])) if not args.le else None}
 
+    # ---- the host-fed rate (N = 1): what btrx_amd and the GNU Radio block see -- the batch lies in HOST memory and goes through
+    # btgpu_process_host (PCIe-inclusive; never `value`).  Source page-locked (a block can register the scheduler's buffer once):
+    # copied to the device as it lies; pageable: through the library's pinned staging buffers.  H2D alone = the same bytes with
+    # hipMemcpyAsync from page-locked memory, the ceiling of this box's link.
+    host_fed = None
+    if world == 1 and not args.no_host_fed:
+        hb = 8
+        seg_host = seg.cpu()
+        pinned = seg_host.pin_memory()
+        pageable = seg_host.numpy()
+        def fed(src):
+            b = make_block(0, timing=0)
+            for _ in range(2):                                                              # warm-up: both staging / device buffer pairs get allocated
+                b.process_host(src, first, S, left_margin=margin)
+            b.flush(); b.poll_arrays()
+            t0 = time.perf_counter()
+            nrec = 0
+            for i in range(hb):
+                b.process_host(src, first, S, left_margin=margin)
+                nrec += len(b.poll_arrays())
+            b.flush(); nrec += len(b.poll_arrays())
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            b.close()
+            return el, nrec
+        el_pin, n_pin = fed((pinned.data_ptr(), n_complex))
+        el_page, n_page = fed((pageable.ctypes.data, n_complex))
+        dst = torch.empty_like(seg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(hb):
+            dst.copy_(pinned, non_blocking=True)
+        torch.cuda.synchronize()
+        el_copy = time.perf_counter() - t0
+        nbytes = float(n_complex) * 8.0
+        host_fed = {"entry": "btgpu_process_host", "batches": hb, "slots_per_batch": S,
+                    "pinned_source": {"value": round(S * slot * hb / el_pin / 1e6, 1), "unit": "Msamples/s", "h2d_GBps": round(nbytes * hb / el_pin / 1e9, 2)},
+                    "pageable_source": {"value": round(S * slot * hb / el_page / 1e6, 1), "unit": "Msamples/s", "GBps": round(nbytes * hb / el_page / 1e9, 2)},
+                    "h2d_alone_GBps": round(nbytes * hb / el_copy / 1e9, 2),
+                    "frac_of_h2d_alone": round(el_copy / el_pin, 3),
+                    "records_per_batch_equal_device_fed": (bool(n_pin == n_page == hb * len(ints)) if not (args.le or args.headers) else None)}
+        del dst, pinned, seg_host
+
     total_samples = float(world) * S * slot * args.steps
     value = total_samples / elapsed / 1e6
 
@@ -485,6 +529,7 @@ def run_rank(args):
             "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed],
             "block_config": block_cfg,
             "verify": verify_obj,
+            "host_fed": host_fed,
             "fence_ms": round(fence_ms, 3),
             "step_enqueue_ms": [round(float(v), 3) for v in np.percentile(np.diff(np.array(marks)) * 1e3, [0, 50, 100])],
             "roofline": roof,

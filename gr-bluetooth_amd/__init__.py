@@ -152,6 +152,8 @@ def lib():
     L.btgpu_push.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t]
     L.btgpu_process_device.restype = ctypes.c_int
     L.btgpu_process_device.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64, vp]
+    L.btgpu_process_host.restype = ctypes.c_int
+    L.btgpu_process_host.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint64]
     L.btgpu_poll.restype = ctypes.c_int
     L.btgpu_poll.argtypes = [vp, ctypes.POINTER(Hit), ctypes.c_int]
     L.btgpu_pending.restype = ctypes.c_int
@@ -348,6 +350,18 @@ class _MultiBlock:
         rc = self._L.btgpu_process_device(self._h, ctypes.c_void_p(dev_ptr), n_complex, left_margin,
                                           first_slot, n_slots, ctypes.c_void_p(stream or 0))
         self._check(rc, "btgpu_process_device")
+
+    def process_host(self, iq, first_slot, n_slots, left_margin=0):
+        """btgpu_process_host: the segment lies in HOST memory (a numpy array, or the address of page-locked memory as an int
+        together with its length in complex samples: (ptr, n_complex)); iq[left_margin] = absolute sample
+        first_slot*slot-(history()-1)."""
+        if isinstance(iq, tuple):
+            ptr, n = ctypes.cast(ctypes.c_void_p(int(iq[0])), ctypes.POINTER(ctypes.c_float)), int(iq[1])
+        else:
+            a = _as_f32(iq)
+            ptr, n = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(a) // 2
+        rc = self._L.btgpu_process_host(self._h, ptr, n, left_margin, first_slot, n_slots)
+        self._check(rc, "btgpu_process_host")
 
     def flush(self):
         rc = self._L.btgpu_flush(self._h)

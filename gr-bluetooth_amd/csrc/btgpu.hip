@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "btgpu.h"
@@ -542,12 +543,44 @@ int btgpu_handle::stage_batch(const float *head, size_t n_head, const float *bod
         if (head) std::memcpy(dst, head, n_head * sizeof(float2));
         else std::memset(dst, 0, n_head * sizeof(float2));
     }
-    std::memcpy(dst + 2 * n_head, body, n_body * sizeof(float2));
     float2 *d_buf = (float2 *)(k == 0 ? d_in.p : d_in_b.p);
-    HIPCHK(this, hipMemcpyAsync(d_buf, h_stage[k], (n_head + n_body) * sizeof(float2), hipMemcpyHostToDevice, copy_stream));
+    // A caller's buffer that is page-locked already (hipHostMalloc / hipHostRegister: what a block can do once with the
+    // scheduler's buffer) is copied to the device as it lies -- no pass through the staging buffer; the call
+    // then returns when that copy is done (the buffer is the caller's again), the kernels of this and the previous batches
+    // run on regardless.  Pageable memory goes through the pinned staging buffer, the host copy split over a few threads (one
+    // thread moves ~10 GB/s, a PCIe Gen5 link takes 50).
+    bool direct = false;
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, body) == hipSuccess && attr.type == hipMemoryTypeHost) direct = true;
+        else (void)hipGetLastError();                                        // (an unregistered pointer is reported as an error: cleared)
+        static const bool no_direct = getenv("BTGPU_NO_DIRECT_H2D") != nullptr;
+        if (no_direct) direct = false;
+    }
+    if (direct) {
+        if (n_head) HIPCHK(this, hipMemcpyAsync(d_buf, h_stage[k], n_head * sizeof(float2), hipMemcpyHostToDevice, copy_stream));
+        HIPCHK(this, hipMemcpyAsync(d_buf + n_head, body, n_body * sizeof(float2), hipMemcpyHostToDevice, copy_stream));
+    } else {
+        const size_t bytes = n_body * sizeof(float2);
+        const unsigned nthr = bytes >= ((size_t)64 << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        if (nthr <= 1) std::memcpy(dst + 2 * n_head, body, bytes);
+        else {
+            std::vector<std::thread> pool;
+            const size_t chunk = (bytes / nthr + 4095) & ~(size_t)4095;
+            for (unsigned i = 0; i < nthr; i++) {
+                const size_t o = (size_t)i * chunk;
+                if (o >= bytes) break;
+                const size_t len = std::min(chunk, bytes - o);
+                pool.emplace_back([=] { std::memcpy((char *)(dst + 2 * n_head) + o, (const char *)body + o, len); });
+            }
+            for (auto &th : pool) th.join();
+        }
+        HIPCHK(this, hipMemcpyAsync(d_buf, h_stage[k], (n_head + n_body) * sizeof(float2), hipMemcpyHostToDevice, copy_stream));
+    }
     HIPCHK(this, hipEventRecord(ev_copied[k], copy_stream));
     HIPCHK(this, hipStreamWaitEvent(stream, ev_copied[k], 0));
     const int rc = process_batch(d_buf, n_head + n_body, w0, abs_first_slot, S, stream);
+    if (direct) HIPCHK(this, hipEventSynchronize(ev_copied[k]));                  // (behind the enqueue: the kernels queue up under the copy)
     HIPCHK(this, hipEventRecord(ev_consumed[k], stream));
     if (verify) HIPCHK(this, hipEventRecord(ev_vdone[k], last_tail));
     stage_used[k] = true;

@@ -663,7 +663,9 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                     if (!leak && onset_row < 1260.f + 0.04f * (float)TT) rise = jx;
                 } else if (in_burst && e < thr_lo) in_burst = false;
             }
-            if (rise >= 0) vspan = ((rise + 1) * TT) / 2 + 72 + p.span_extra + 8;
+            // (to the end of the access code that may start there: whether one does is what the exact stage settles; the header
+            // behind it is added to the span by the hit that finds it, emit_classic)
+            if (rise >= 0) vspan = ((rise + 1) * TT) / 2 + 72 + 8;
         }
         // one task-list reservation per workgroup: thousands of lanes asking the same counter at the same moment queued up
         // at the L2 for ~80 us (a quarter of this kernel's time, profiles/r04_c_*)
