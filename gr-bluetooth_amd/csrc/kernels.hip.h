@@ -325,6 +325,11 @@ struct WindowParams {
     const uint64_t *btbb_pcol;  // [24] parity column of each LAP bit (device memory)
     int fin_prio;               // wave priority of finish_kernel (0..3)
     int want_len;               // 0 (BTGPU_FLAG_NO_NSYM): windows that outlast the detection span are not continued, nsym = -1
+    // deferred squelch: the window kernel runs BESIDE squelch stage 2 instead of behind it -- every window is taken through clock
+    // recovery and search (at the reference's default threshold they all pass anyway), the SNR decision is applied
+    // where records leave: the exact stage's run skips a task that fails it, nsym_patch_kernel drops the other records
+    int deferred;
+    const double *snr_arr;      // [S * nch] 10 log10(E_on / E_off) per window, from squelch_kernel (deferred mode)
     // exact confirmation of the polyphase path's records (verify.hip.h)
     int verify;                 // 1: this launch hands windows with a classic hit or burst energy to the exact stage and emits no
                                 //    record for them (2: without the energy scan); the exact stage's own launch is window_kernel<LAY, true>
@@ -562,14 +567,18 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const long long w = (long long)kq * nch + cq;
     int nmax = 0;                                    // symbols this lane will produce in phase 1
     double snr = 0.0;
-    if (VER && lane_ok) {                            // a task passed the squelch in the first run
-        snr = p.vtasks[k * nch + c].snr;
+    if (VER && lane_ok) {                            // a task passed the squelch in the first run -- or, deferred, is judged here
+        snr = p.deferred ? p.snr_arr[w] : p.vtasks[k * nch + c].snr;
+        win_len[w] = -1;
+        if (!p.deferred || snr >= p.target_snr) nmax = kDetectSyms;
+    }
+    if (!VER && lane_ok && p.deferred) {             // deferred squelch: every window runs, the decision comes with the records
         win_len[w] = -1;
         nmax = kDetectSyms;
     }
 
     // ---- squelch: multi_block::channel_samples energy + check_snr (multi_block.cc:206-293) ----
-    if (!VER && lane_ok) {
+    if (!VER && lane_ok && !p.deferred) {
         double e_on = 0.0;
         for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)cq * p.nb + kq + j];
         if (p.tail > 0) e_on += Pt[(size_t)cq * p.nb + kq + p.blocks_per_window];
@@ -1191,7 +1200,8 @@ __global__ __launch_bounds__(64) void finish_kernel(
 // nsym = len - offset for every hit record, once finish_kernel has produced the window lengths
 __global__ void nsym_patch_kernel(DeviceHit *__restrict__ hits, const unsigned int *__restrict__ hit_count,
                                   int max_hits, const int *__restrict__ win_len, int nch,
-                                  const int *__restrict__ win_fin)
+                                  const int *__restrict__ win_fin, const double *__restrict__ snr_arr = nullptr,
+                                  double target_snr = 0.0)
 {
     unsigned int n = *hit_count;
     if (n > (unsigned int)max_hits) n = (unsigned int)max_hits;
@@ -1201,7 +1211,29 @@ __global__ void nsym_patch_kernel(DeviceHit *__restrict__ hits, const unsigned i
         const int len = win_len[w];
         hits[i].nsym = len < 0 ? -1 : len - hits[i].sub - hits[i].offset;     // len < 0: BTGPU_FLAG_NO_NSYM, window not continued
         if (win_fin) hits[i].sym = win_fin[w];
+        if (snr_arr) {                                                        // deferred squelch: the window's SNR, and its verdict
+            const double s = snr_arr[w];
+            hits[i].snr = s;
+            if (!(s >= target_snr)) hits[i].kind = -1;                         // the reference never looked into this window: no record
+        }
     }
+}
+
+// multi_block::channel_samples' energy + check_snr's ratio (lib/multi_block.cc:206-293) per (slot, channel) window, from the
+// block sums P / Pt and the per-slot noise sums Qn: what window_kernel computes in line when the squelch is not deferred.
+__global__ __launch_bounds__(256) void squelch_kernel(WindowParams p, const double *__restrict__ P, const double *__restrict__ Pt,
+                                                      const double *__restrict__ Qn, double *__restrict__ e_on_out,
+                                                      double *__restrict__ e_off_out, double *__restrict__ snr_out)
+{
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= (long long)p.S * p.nch) return;
+    const int k = (int)(w / p.nch), c = (int)(w - (long long)k * p.nch);
+    double e_on = 0.0;
+    for (int j = 0; j < p.blocks_per_window; j++) e_on += P[(size_t)c * p.nb + k + j];
+    if (p.tail > 0) e_on += Pt[(size_t)c * p.nb + k + p.blocks_per_window];
+    e_on /= (double)p.ddc_out;
+    const double e_off = Qn[(size_t)c * p.qn_stride + k] / (double)p.noise_out;
+    e_on_out[w] = e_on; e_off_out[w] = e_off; snr_out[w] = 10.0 * log10(e_on / e_off);
 }
 
 // ------------------------------------------------------------------------------------
