@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--parity-slots", type=int, default=1600,
                     help="slots of the capture the all-core oracle differential covers (N = 1; 0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
+    ap.add_argument("--no-ab", action="store_true", help="skip the A/B region without the exact stage (BTGPU_FLAG_NO_VERIFY)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (btgpu_process_host, PCIe-inclusive) leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
@@ -317,6 +318,17 @@ def run_rank(args):
     # ---- the drop-in block's configuration (N = 1): gr::bluetooth::multi_sniffer always runs the LE pass after the
     # classic one and hands the symbols of every hit to its packet handlers (lib/multi_sniffer_impl.cc:107-149), so
     # host/blocks.cc creates its handle with BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS: the same K steps in that configuration
+    # ---- A/B of the exact stage (N = 1): the same K steps with BTGPU_FLAG_NO_VERIFY -- what the confirmation of the records costs
+    if world == 1 and not args.no_ab and verify_obj["windows_per_step"] > 0:
+        blk.close()
+        blk = make_block(head_flags | pkg.FLAG_NO_VERIFY)
+        a_el, a_ints, a_snr, _m, _f, _k1, _k2 = timed_region(blk, gather=False)
+        a_ints, a_snr = one_copy(a_ints, a_snr)
+        verify_obj["ab_no_verify"] = {"flags": "the same + BTGPU_FLAG_NO_VERIFY", "value": round(float(S) * slot * args.steps / a_el / 1e6, 3),
+                                      "unit": "Msamples/s", "ms_per_step": round(a_el / args.steps * 1e3, 3), "hits": int(len(a_ints)),
+                                      "records_equal_on_6_fields": bool(len(a_ints) == len(ints) and np.array_equal(a_ints[:, :6], ints[:, :6]))}
+        verify_obj["cost_frac_of_step"] = round(1.0 - a_el / elapsed, 4)
+
     block_cfg = None
     if world == 1 and not args.no_block_config and not (args.le and args.headers):
         blk.close()
