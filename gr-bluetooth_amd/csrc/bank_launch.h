@@ -58,6 +58,7 @@ struct BankBuffers {                        // device (or emulated) memory
     const int *binpos_ch = nullptr, *binnat_ch = nullptr;
     const uint16_t *b2map_fused = nullptr, *b2map_fused_wide = nullptr, *b2map_ch = nullptr, *b2map_noise = nullptr, *b2map_f320 = nullptr;
     float *d = nullptr; float *dcol = nullptr; double *ptile = nullptr, *phead = nullptr;
+    double *pfine = nullptr;                // small-M F8 bank: |Y|^2 sums per 25 instants (exact stage's burst scan)
     float2 *Ydebug = nullptr; long long ystride = 0;
     const float2 *taps_n = nullptr, *krot_n = nullptr; const int *binpos_n = nullptr;
     float2 *Z = nullptr; long long zstride = 0;
@@ -217,6 +218,12 @@ struct VerifyBuffers {                                   // device (or emulated)
 };
 inline size_t verify_tiles_capacity(int S, int nch) { return (size_t)S * nch * kVerMaxTiles; }
 inline int verify_capacity(int S, int nch) { return (int)std::min<long long>((long long)S * nch, 32768); }
+// the small-M bank in its F8 form (C8) also leaves 25-instant sums: finer than its 250-instant tiles
+inline bool verify_has_fine(const Design &des, const FastPath &fp, int drow)
+{
+    const int nch = des.d.high_channel - des.d.low_channel + 1;
+    return fp.channel.natural && fp.channel.M == 8 && nch == 8 && drow == 8 && pfbm_tile(8) + 1 <= kPfbmThreads && pfbm_tile(8) % 25 == 0;
+}
 inline int verify_rows(const Design &des) { return des.d.ddc_out < kVerRows ? des.d.ddc_out : kVerRows; }
 constexpr int kVerGridDdc = 2048, kVerGridFill = 1024;  // workgroups of verify_ddc_kernel (they stride over the tiles; two fit a CU at 100 Msps: 2048 balanced the
                                                          // uneven tile counts better than 512 persistent ones, 0.42 against 0.49 ms)
@@ -224,11 +231,12 @@ constexpr int kVerGridDdc = 2048, kVerGridFill = 1024;  // workgroups of verify_
 inline int verify_tile_outs(const FastPath &fp, bool small) { return small ? pfbm_tile(fp.channel.M) : kBankNT - 1; }
 
 // first run (the polyphase path's window_kernel): which windows go to the exact stage
+// (ptile / ntiles / tile_outs: the tile sums the scan reads -- the bank's own tiles, or the F8 bank's 25-instant sums)
 inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPath &fp, bool small, int mode /*1 hits + energy, 2 hits only*/,
-                                const double *ptile, int ntiles, const VerifyBuffers &vb, bool headers)
+                                const double *ptile, int ntiles, const VerifyBuffers &vb, bool headers, int tile_outs = 0)
 {
     p.verify = mode;
-    p.ptile = ptile; p.ptile_stride = ntiles; p.tile_outs = verify_tile_outs(fp, small);
+    p.ptile = ptile; p.ptile_stride = ntiles; p.tile_outs = tile_outs > 0 ? tile_outs : verify_tile_outs(fp, small);
     p.tiles_per_slot = des.outs_per_slot / p.tile_outs;
     p.vtasks = vb.tasks; p.vtiles = vb.tiles; p.vcount = vb.vcount; p.vcap = vb.vcap;
     if ((2 * kDetectSyms + 16 + p.tile_outs - 1) / p.tile_outs + 5 > 64) p.verify = 2;   // (the scan stages <= 64 tiles per channel)
@@ -286,11 +294,13 @@ inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const Ba
     p.krot = b.krot_ch; p.rot_period = bk.rot_period;
     p.ntiles = (int)((G + p.TT - 1) / p.TT);
     p.d = b.d; p.drow = b.drow; p.ptile = b.ptile; p.phead = b.phead;
+    p.pfine = nullptr;
     p.tiles_per_block = des.outs_per_slot / p.TT; p.tail = des.tail;
     p.gain = des.demod_gain;
     p.Z = b.Ydebug; p.zstride = b.ystride;
     const size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, true);
     const bool f8 = bk.natural && bk.M == 8 && nch == 8 && b.drow == 8 && p.TT + 1 <= kPfbmThreads;
+    if (f8 && p.TT % 25 == 0) p.pfine = b.pfine;
     if (f8 && bk.Q == 7 && !bk.real_taps) L(pfbm_kernel<false, true, 8, 7, true>, p.ntiles, kPfbmThreads, lds, p);          // C8: half-MHz grid
     else if (f8 && bk.Q == 7) L(pfbm_kernel<true, true, 8, 7, true>, p.ntiles, kPfbmThreads, lds, p);
     else if (bk.M == 8 && bk.Q == 7 && !bk.real_taps) L(pfbm_kernel<false, true, 8, 7>, p.ntiles, kPfbmThreads, lds, p);

@@ -72,6 +72,7 @@ struct btgpu_handle {
         DevBuf d_d;                           // demodulated stream of the batch
         DevBuf d_dcol;                        // 100-bin bank: the same stream tile by tile channel-major [tile][80][25], what finish_kernel reads
         DevBuf d_ptile, d_phead;              // polyphase banks: |Y|^2 tile sums (-> block_sum_kernel on the post stream)
+        DevBuf d_pfine;                       // small-M F8 bank: |Y|^2 sums per 25 instants (the exact stage's burst scan)
         DevBuf d_Z;                           // staged squelch: stage-1 output (-> noise_stage2_kernel on the post stream)
         DevBuf d_vtasks, d_vtiles, d_vcount, d_dx, d_dxt, d_winbits_v;
         DevBuf d_eon, d_eoff, d_snr;          // E_on, E_off, SNR per window (window_kernel, or squelch_kernel when the squelch is deferred)   // exact confirmation (verify.hip.h): task list, exact rows, task stream
@@ -173,7 +174,7 @@ struct btgpu_handle {
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (TailCtx &t : tc) {
             DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol,
-                            &t.d_ptile, &t.d_phead, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_eon, &t.d_eoff, &t.d_snr};
+                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_eon, &t.d_eoff, &t.d_snr};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -204,7 +205,7 @@ struct btgpu_handle {
         b.b2map_fused = (const uint16_t *)d_b2map_fused.p; b.b2map_fused_wide = (const uint16_t *)d_b2map_fused_wide.p;
         b.b2map_ch = (const uint16_t *)d_b2map_ch.p;
         b.b2map_noise = (const uint16_t *)d_b2map_noise.p; b.b2map_f320 = (const uint16_t *)d_b2map_f320.p;
-        b.d = (float *)d_d.p; b.ptile = (double *)d_ptile.p; b.phead = (double *)d_phead.p;
+        b.d = (float *)d_d.p; b.ptile = (double *)d_ptile.p; b.phead = (double *)d_phead.p; b.pfine = (double *)t.d_pfine.p;
         b.Ydebug = (keep_Y && use_pfb) ? (float2 *)d_Y.p : nullptr; b.ystride = ystride;
         b.taps_n = (const float2 *)d_pfb_taps_n.p; b.krot_n = (const float2 *)d_krot_n.p;
         b.binpos_n = (const int *)d_binpos_n.p;
@@ -412,7 +413,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         if (verify) {
             vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.tiles = (uint32_t *)t.d_vtiles.p; vb.vcount = (unsigned int *)t.d_vcount.p;
             vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap; vb.tiles_cap = (unsigned int)verify_tiles_capacity(max_slots, nch);
-            set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
+            if (pfb_small && t.d_pfine.p && verify_has_fine(des, fp, drow))
+                set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_pfine.p, ntiles * (pfbm_tile(fp.channel.M) / 25), vb, want_syms, 25);
+            else
+                set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
         }
         auto launch_window = [&](auto lay) {
             using LAY = decltype(lay);
@@ -1127,6 +1131,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (h->use_pfb) {
             TRY(h->alloc(t.d_ptile, (size_t)nch * h->ntiles_max * sizeof(double)));
             TRY(h->alloc(t.d_phead, (size_t)nch * h->ntiles_max * sizeof(double)));
+            if (h->verify && h->pfb_small && verify_has_fine(des, h->fp, win_drow(nch)))
+                TRY(h->alloc(t.d_pfine, (size_t)nch * h->ntiles_max * (pfbm_tile(h->fp.channel.M) / 25) * sizeof(double)));
         }
         if (h->use_staged) TRY(h->alloc(t.d_Z, (size_t)nch * h->zstride * sizeof(float2)));
         TRY(h->alloc(t.d_winlen, (size_t)S * nch * sizeof(int)));

@@ -41,6 +41,8 @@ struct PfbmParams {
     int ntiles;
     float *d; int drow;          // [T][drow] time-major
     double *ptile, *phead; int tiles_per_block, tail;
+    double *pfine;               // [nsel][ntiles * TT / 25] or null: |Y|^2 sums per 25 instants (F8 form; the exact stage's burst scan,
+                                 // which the 250-instant tiles of this bank are too coarse for)
     float gain;
     float2 *Z; long long zstride;
 };
@@ -241,6 +243,12 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
             for (int r = 0; r < NTH / 8; r++) { sacc += (double)s_part[2 * (r * 8 + l)]; hacc += (double)s_part[2 * (r * 8 + l) + 1]; }
             p.ptile[(size_t)l * p.ntiles + tile] = sacc;
             p.phead[(size_t)l * p.ntiles + tile] = hacc;
+        }
+        if (p.pfine && l < 8 * (TT / 25)) {                        // lane = (channel, 25 instants): the per-instant |Y|^2 are still in LDS
+            const int c = l & 7, f = l >> 3;
+            double s = 0.0;
+            for (int r = 25 * f; r < 25 * f + 25; r++) s += (double)s_m[r * 8 + c];
+            p.pfine[(size_t)c * ((size_t)p.ntiles * (TT / 25)) + (size_t)tile * (TT / 25) + f] = s;
         }
     } else if (F8) {
         // noise bank, lane = instant: FFT, de-rotate, eight coalesced row stores

@@ -26,6 +26,7 @@ extern "C" {
 static std::vector<float> *g_keep_dcol = nullptr;      // emu_front_run: keep the tile-blocked copy the bank kernel wrote
 static std::vector<double> *g_keep_ptile = nullptr;    // ... and the |Y|^2 tile sums (exact confirmation: burst energy)
 static int g_keep_ntiles = 0;
+static std::vector<double> *g_keep_pfine = nullptr;    // small-M F8 bank: the 25-instant sums
 
 int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_len, long long w0, int S, int fuse,
                  float *d_out, double *P_out, double *Pt_out, float *Z_out, float *Y_out, long long *sizes)
@@ -154,6 +155,8 @@ int emu_bank_m_run(double fs, double fc, int mode, const float *iq, long long x_
     b.taps_ch = (const float2 *)fp.channel.taps.data(); b.dftw_ch = (const float2 *)fp.channel.dftw.data();
     b.krot_ch = (const float2 *)fp.channel.krot.data(); b.rho_ch = (const float2 *)fp.channel.rho.data();
     b.d = d_out; b.drow = drow; b.ptile = ptile.data(); b.phead = phead.data();
+    std::vector<double> pfine;
+    if (verify_has_fine(des, fp, drow)) { pfine.assign((size_t)nch * ntiles_max * (TTm / 25), -1.0); b.pfine = pfine.data(); }
     b.Ydebug = (float2 *)Y_out; b.ystride = ystride;
     b.taps_n = (const float2 *)ns.pfb.taps.data(); b.dftw_n = (const float2 *)ns.pfb.dftw.data();
     b.krot_n = (const float2 *)ns.pfb.krot.data();
@@ -166,6 +169,7 @@ int emu_bank_m_run(double fs, double fc, int mode, const float *iq, long long x_
     const int ntiles = launch_channel_bank_m(des, fp, b, (size_t)x_len, w0, G, L);
     launch_noise_bank_m(des, fp, b, (size_t)x_len, w0, S, L);
     if (g_keep_ptile) { *g_keep_ptile = ptile; g_keep_ntiles = ntiles; }
+    if (g_keep_pfine) *g_keep_pfine = pfine;
     const int tpb = ops / TTm, tail_tiles = des.tail / TTm;
     for (int c = 0; c < nch; c++)
         for (int bi = 0; bi < nb; bi++) {
@@ -252,7 +256,7 @@ static StudyCapture *g_study = nullptr;                 // emu_margin_study: kee
 // exact confirmation in the emulated front end: what the runtime's tail stream does (btgpu.hip process_batch)
 struct VerifyEmu {
     const float2 *x = nullptr; long long x_len = 0; const FastPath *fp = nullptr; bool small = false;
-    const double *ptile = nullptr; int ntiles = 0; int mode = 1;
+    const double *ptile = nullptr; int ntiles = 0; int mode = 1; int tile_outs = 0;
     unsigned int counts[4] = {0, 0, 0, 0};              // out: tasks, tiles, turned away
 };
 static int g_verify_mode = 1;                            // emu_set_verify: 0 off, 1 hits + burst energy, 2 hits only
@@ -296,7 +300,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         const int nps = (vb.vcap + nch - 1) / nch;
         dxt4.assign(((size_t)nps * kVerRows * drow + 3) / 4 + 16, make_float4(-66.f, -66.f, -66.f, -66.f));
         vb.tasks = vtasks.data(); vb.tiles = vtiles.data(); vb.vcount = vcount; vb.dx = dx.data(); vb.dxt = (float *)dxt4.data();
-        set_verify_flagging(p, des, *ve->fp, ve->small, ve->mode, ve->ptile, ve->ntiles, vb, want_syms);
+        set_verify_flagging(p, des, *ve->fp, ve->small, ve->mode, ve->ptile, ve->ntiles, vb, want_syms, ve->tile_outs);
     }
     auto launch_window = [&](auto lay) {
         using LAY = decltype(lay);
@@ -410,14 +414,14 @@ extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double sq
     std::vector<double> P((size_t)nch * nb), Pt((size_t)nch * nb);
     std::vector<float> Z((size_t)nch * zstride * 2, 0.f);
     std::vector<float> dcol;
-    std::vector<double> ptile_keep;
-    g_keep_ptile = &ptile_keep;
+    std::vector<double> ptile_keep, pfine_keep;
+    g_keep_ptile = &ptile_keep; g_keep_pfine = &pfine_keep;
     if (big) {
         g_keep_dcol = &dcol;
         rc = emu_bank_run(fs, fc, mode, iq, x_len, 0, S, 1, d, P.data(), Pt.data(), Z.data(), nullptr, sizes);
         g_keep_dcol = nullptr;
     } else rc = emu_bank_m_run(fs, fc, mode, iq, x_len, 0, S, d, P.data(), Pt.data(), Z.data(), nullptr, sizes);
-    g_keep_ptile = nullptr;
+    g_keep_ptile = nullptr; g_keep_pfine = nullptr;
     if (rc) return rc;
 
     // noise stage 2: the kernel itself (its wave-shuffle reduction runs on the emulator's exchange buffer)
@@ -435,6 +439,7 @@ extern "C" int emu_front_m_run(double fs, double fc, int mode, int le, double sq
     std::memcpy(xv.data(), iq, (size_t)x_len * sizeof(float2));
     VerifyEmu ve;
     ve.x = xv.data(); ve.x_len = x_len; ve.fp = &fp; ve.small = !big; ve.ptile = ptile_keep.data(); ve.ntiles = g_keep_ntiles; ve.mode = g_verify_mode;
+    if (!big && !pfine_keep.empty()) { ve.ptile = pfine_keep.data(); ve.ntiles = g_keep_ntiles * (pfbm_tile(fp.channel.M) / 25); ve.tile_outs = 25; }
     return run_detect(des, S, nb, nch, drow, G, d, big ? dcol.data() : nullptr, P.data(), Pt.data(), Qn.data(), rec_out, snr_out, cap, g_sym_out, g_hdr_out, &ve);
 }
 
