@@ -611,21 +611,27 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         const int TT = p.tile_outs;
         const int ntm = (2 * kDetectSyms + 16 + TT - 1) / TT;          // tiles of the detection span
         const int NTW = ntm + 5, PW = NTW | 1;                         // + five tiles in front of the window; odd pitch: no bank conflicts
-        float *et = tile;                                              // [nch][PW], tile t0 - 5 + jj of channel cc at et[cc * PW + jj]; -1 = no such tile
-        for (int s = 0; s < kWinSlots; s++) {
-            const int ks = blockIdx.x * kWinSlots + s;
-            if (ks >= p.S) break;                                      // uniform
-            const int t0 = ks * p.tiles_per_slot;
+        // as many slots per pass as the tile holds (all three at C79 do not fit; the narrow layouts -- 32 slots of 8 channels --
+        // take 19 at a time: one pass per slot was 32 x two barriers)
+        int spp = (kWinSlots * kTileFloats) / (nch * PW);
+        spp = spp < 1 ? 1 : (spp > kWinSlots ? kWinSlots : spp);
+        float *et = tile;                                              // [spp][nch][PW]: tile t0 - 5 + jj of (slot, channel) at et[(sp * nch + cc) * PW + jj]; -1 = no such tile
+        for (int s0 = 0; s0 < kWinSlots; s0 += spp) {
+            if (blockIdx.x * kWinSlots + s0 >= p.S) break;             // uniform
             __syncthreads();
-            // (NTW <= 64: a wave takes a channel's tiles -- contiguous doubles -- and the four waves every fourth channel)
-            for (int cc = (int)threadIdx.x >> 6; cc < nch; cc += kWinThreads / 64) {
+            // (NTW <= 64: a wave takes the tiles of one (slot, channel) -- contiguous doubles --, the four waves every fourth pair)
+            for (int pr = (int)threadIdx.x >> 6; pr < spp * nch; pr += kWinThreads / 64) {
+                const int sp = pr / nch, cc = pr - sp * nch;
+                const int ks = blockIdx.x * kWinSlots + s0 + sp;
                 const int jj = (int)threadIdx.x & 63;
-                const int t = t0 - 5 + jj;
-                if (jj < NTW) et[cc * PW + jj] = (t >= 0 && t < p.ptile_stride) ? (float)p.ptile[(size_t)cc * p.ptile_stride + t] : -1.f;
+                const int t = ks * p.tiles_per_slot - 5 + jj;
+                if (jj < NTW)
+                    et[pr * PW + jj] = (s0 + sp < kWinSlots && ks < p.S && t >= 0 && t < p.ptile_stride) ? (float)p.ptile[(size_t)cc * p.ptile_stride + t] : -1.f;
             }
             __syncthreads();
-            if (sl != s || nmax == 0) continue;
-            const float *pe = et + cq * PW + 5;                        // pe[j]: tile j of this window's span
+            if (sl < s0 || sl >= s0 + spp || nmax == 0) continue;      // this lane's slot is not in this pass
+            const int t0 = kq * p.tiles_per_slot;
+            const float *pe = et + ((sl - s0) * nch + cq) * PW + 5;    // pe[j]: tile j of this window's span
             int nt = ntm;
             if (nt > p.ptile_stride - t0) nt = p.ptile_stride - t0;
             // noise level of the span: its smallest tile that holds signal at all (the zeros GNU Radio puts in front of a
