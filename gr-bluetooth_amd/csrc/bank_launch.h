@@ -211,12 +211,13 @@ inline WindowParams make_window_params(const Design &des, int S, int nb, long lo
 
 // ---- exact confirmation (verify.hip.h): geometry and parameters shared by the runtime and the emulator ----
 struct VerifyBuffers {                                   // device (or emulated) memory of one in-flight batch
-    VerifyTask *tasks = nullptr; uint32_t *tiles = nullptr; unsigned int *vcount = nullptr;
+    VerifyTask *tasks = nullptr; uint32_t *tiles = nullptr; unsigned int *vcount = nullptr;   // vcount[4 + c]: tiles listed for channel c
     float *dx = nullptr, *dxt = nullptr;
     int vcap = 0;
-    unsigned int tiles_cap = 0;                           // entries `tiles` holds: verify_tiles_capacity(S, nch)
+    unsigned int tiles_cap = 0;                           // entries per CHANNEL's list: verify_tiles_capacity(S)
 };
-inline size_t verify_tiles_capacity(int S, int nch) { return (size_t)S * nch * kVerMaxTiles; }
+inline size_t verify_tiles_capacity(int S) { return (size_t)S * kVerMaxTiles; }
+constexpr int kVerCountWords = 4 + 80;                  // vcount: 4 counters + one tile count per channel
 inline int verify_capacity(int S, int nch) { return (int)std::min<long long>((long long)S * nch, 32768); }
 // the small-M bank in its F8 form (C8) also leaves 25-instant sums: finer than its 250-instant tiles
 inline bool verify_has_fine(const Design &des, const FastPath &fp, int drow)
@@ -238,7 +239,7 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
     p.verify = mode;
     p.ptile = ptile; p.ptile_stride = ntiles; p.tile_outs = tile_outs > 0 ? tile_outs : verify_tile_outs(fp, small);
     p.tiles_per_slot = des.outs_per_slot / p.tile_outs;
-    p.vtasks = vb.tasks; p.vtiles = vb.tiles; p.vcount = vb.vcount; p.vcap = vb.vcap;
+    p.vtasks = vb.tasks; p.vtiles = vb.tiles; p.vcount = vb.vcount; p.vcap = vb.vcap; p.vtcount = vb.vcount + 4; p.vtcap = vb.tiles_cap;
     if ((2 * kDetectSyms + 16 + p.tile_outs - 1) / p.tile_outs + 5 > 64) p.verify = 2;   // (the scan stages <= 64 tiles per channel)
     p.burst_ratio = 4.0f / (1.0f - 2.3f / std::sqrt((float)p.tile_outs));   // smallest of ~57 tiles of TT outputs ~ (1 - 2.3 / sqrt(TT)) mean
     p.span_extra = headers ? 58 : 0;                     // 54 header symbols + the 4-symbol trailer
@@ -254,7 +255,7 @@ inline VerifyParams make_verify_params(const Design &des, size_t x_len, long lon
     v.mp = mp; v.F = F;
     v.rot = rot; v.Q = des.channel.rot_period; v.rot_step_turns = rot_step_turns;
     v.atan_tab = atan_tab; v.gain = des.demod_gain;
-    v.tasks = vb.tasks; v.tiles = vb.tiles; v.vcount = vb.vcount; v.vcap = vb.vcap; v.tiles_cap = vb.tiles_cap;
+    v.tasks = vb.tasks; v.tiles = vb.tiles; v.vcount = vb.vcount; v.vcap = vb.vcap; v.tiles_cap = vb.tiles_cap; v.tcount = vb.vcount + 4;
     v.nch = d.high_channel - d.low_channel + 1;
     return v;
 }

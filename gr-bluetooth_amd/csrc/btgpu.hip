@@ -260,7 +260,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     // =========================== FRONT (stream `st`): the banks ===========================
     // (The post stage runs behind it on the same stream unless BTGPU_PIPE=1, see btgpu_create.)
     HIPCHK(this, hipMemsetAsync(d_hitcount.p, 0, 2 * sizeof(unsigned int), st));
-    if (verify) HIPCHK(this, hipMemsetAsync(t.d_vcount.p, 0, 4 * sizeof(unsigned int), st));
+    if (verify) HIPCHK(this, hipMemsetAsync(t.d_vcount.p, 0, kVerCountWords * sizeof(unsigned int), st));
     HIPCHK(this, mark(0, st));
     int ntiles = 0, tiles_per_block = 1, tail_tiles = 0;
 
@@ -412,7 +412,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         VerifyBuffers vb;
         if (verify) {
             vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.tiles = (uint32_t *)t.d_vtiles.p; vb.vcount = (unsigned int *)t.d_vcount.p;
-            vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap; vb.tiles_cap = (unsigned int)verify_tiles_capacity(max_slots, nch);
+            vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap; vb.tiles_cap = (unsigned int)verify_tiles_capacity(max_slots);
             if (pfb_small && t.d_pfine.p && verify_has_fine(des, fp, drow))
                 set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_pfine.p, ntiles * (pfbm_tile(fp.channel.M) / 25), vb, want_syms, 25);
             else
@@ -1145,8 +1145,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (h->verify) {
             const int vcap = h->vcap, nps = (vcap + nch - 1) / nch;
             TRY(h->alloc(t.d_vtasks, (size_t)vcap * sizeof(VerifyTask)));
-            TRY(h->alloc(t.d_vtiles, verify_tiles_capacity(S, nch) * sizeof(uint32_t)));
-            TRY(h->alloc(t.d_vcount, 4 * sizeof(unsigned int)));
+            TRY(h->alloc(t.d_vtiles, verify_tiles_capacity(S) * nch * sizeof(uint32_t)));
+            TRY(h->alloc(t.d_vcount, kVerCountWords * sizeof(unsigned int)));
             TRY(h->alloc(t.d_dx, (size_t)vcap * kVerRows * sizeof(float)));
             TRY(h->alloc(t.d_dxt, ((size_t)nps * kVerRows + 64) * h->drow * sizeof(float)));
             TRY(h->alloc(t.d_winbits_v, (size_t)(nps + 1) * kBitWords * kWinThreads * sizeof(uint32_t)));

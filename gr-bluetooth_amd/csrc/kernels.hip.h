@@ -336,7 +336,8 @@ struct WindowParams {
     int rows_per_slot;          // stream rows from one slot's first row to the next slot's (outs_per_slot; exact stage: kVerRows)
     const double *ptile;        // [nch][ptile_stride] |Y|^2 sums per tile of tile_outs outputs (the polyphase banks' by-product)
     int ptile_stride, tile_outs, tiles_per_slot;
-    VerifyTask *vtasks; uint32_t *vtiles; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 entries of vtiles (task | tile << 24), 2 windows turned away (list full)
+    VerifyTask *vtasks; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 tiles listed (statistics), 2 windows turned away (list full)
+    uint32_t *vtiles; unsigned int *vtcount; unsigned int vtcap;     // tile lists BY CHANNEL: entries task | tile << 24 at vtiles[c * vtcap ..], vtcount[c] of them
     int vcap;                   // capacity of vtasks
     float burst_ratio;          // a tile counts as burst energy above burst_ratio * (smallest tile of the detection span)
     int span_extra;             // symbols behind an access code that stay exact as well (the 54-symbol header + margin)
@@ -691,11 +692,11 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         __syncthreads();
         vtiles0 = vspan > 0 ? (ver_rows(vspan) + kVerTile - 1) / kVerTile : 0;
         const int mine = vspan > 0 ? atomicAdd(&s_live[0], 1) : -1;
-        const int mine_t = vspan > 0 ? atomicAdd(&s_tl[0], vtiles0) : 0;
+        if (vspan > 0) atomicAdd(&s_tl[0], vtiles0);
         __syncthreads();
         if (threadIdx.x == 0 && s_live[0] > 0) {
             s_live[1] = (int)atomicAdd(&p.vcount[0], (unsigned int)s_live[0]);
-            s_tl[1] = (int)atomicAdd(&p.vcount[1], (unsigned int)s_tl[0]);
+            atomicAdd(&p.vcount[1], (unsigned int)s_tl[0]);            // (statistics)
         }
         __syncthreads();
         if (mine >= 0) {
@@ -703,11 +704,13 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             const unsigned int s_ = (unsigned int)s_live[1] + (unsigned int)mine;
             if (s_ < (unsigned int)p.vcap) {
                 vslot = (int)s_;
-                for (int j = 0; j < vtiles0; j++) p.vtiles[s_tl[1] + mine_t + j] = (uint32_t)vslot | ((uint32_t)j << 24);
+                // the tiles go to the list of this lane's CHANNEL (one counter per channel: ~70 lanes each, not 5000 on one): a
+                // workgroup of verify_ddc_kernel stays with one channel, whose taps then stay in its CU's scalar cache
+                const unsigned int tp = atomicAdd(&p.vtcount[cq], (unsigned int)vtiles0);
+                uint32_t *tl = p.vtiles + (size_t)cq * p.vtcap;
+                for (int j = 0; j < vtiles0; j++) if (tp + j < p.vtcap) tl[tp + j] = (uint32_t)vslot | ((uint32_t)j << 24);
             } else {
                 atomicAdd(&p.vcount[2], 1u);
-                // (its reserved list entries: a tile of a task nobody fills in -- mark them empty)
-                for (int j = 0; j < vtiles0; j++) p.vtiles[s_tl[1] + mine_t + j] = 0xffffffffu;
                 vtiles0 = 0;
             }
         }
@@ -966,8 +969,10 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         const int rows = ver_rows(vspan);
         const int ntl = (rows + kVerTile - 1) / kVerTile;
         if (ntl > vtiles0) {                                          // a hit reaches further than the energy's span (or there was no such span)
-            const unsigned int tp = atomicAdd(&p.vcount[1], (unsigned int)(ntl - vtiles0));
-            for (int j = vtiles0; j < ntl; j++) p.vtiles[tp + (j - vtiles0)] = (uint32_t)vslot | ((uint32_t)j << 24);
+            atomicAdd(&p.vcount[1], (unsigned int)(ntl - vtiles0));
+            const unsigned int tp = atomicAdd(&p.vtcount[cq], (unsigned int)(ntl - vtiles0));
+            uint32_t *tl = p.vtiles + (size_t)cq * p.vtcap;
+            for (int j = vtiles0; j < ntl; j++) if (tp + (j - vtiles0) < p.vtcap) tl[tp + (j - vtiles0)] = (uint32_t)vslot | ((uint32_t)j << 24);
         }
         VerifyTask t_;
         t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr;

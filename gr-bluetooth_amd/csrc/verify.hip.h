@@ -34,8 +34,8 @@ struct VerifyParams {
     const float2 *rot; int Q;         // de-rotation table [nch][Q] by window-local output index (Q = 0: rot_step_turns)
     const double *rot_step_turns;
     const float *atan_tab; float gain;
-    const VerifyTask *tasks; const uint32_t *tiles; const unsigned int *vcount; int vcap;     // vcount[1]: entries of `tiles`
-    unsigned int tiles_cap;           // its capacity: kVerMaxTiles per window of the batch
+    const VerifyTask *tasks; const unsigned int *vcount; int vcap;
+    const uint32_t *tiles; const unsigned int *tcount; unsigned int tiles_cap;   // tile lists by channel: tiles[c * tiles_cap ..], tcount[c] entries
     int nch;
 };
 constexpr int kVerMaxTiles = (kVerRows + kVerTile - 1) / kVerTile;     // tiles of a task at most (12)
@@ -74,9 +74,16 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
     if (words < 8 * kVerOuts) words = 8 * kVerOuts;
     float2 *ys = lds + words;                                     // [kVerOuts + 1]
     float *atab = (float *)(ys + kVerOuts + 1);                   // [257]
-    // Work items: the entries (task | tile << 24) of the list the window kernel laid out -- one reservation per workgroup, so a
-    // task's tiles sit next to each other and the tasks of one slot (same input span) are adjacent; 0xffffffff = no tile
-    unsigned int ntiles = p.vcount[1];
+    // Work items: the entries (task | tile << 24) of ONE CHANNEL's list (the window kernel files a task's tiles under its
+    // channel).  A workgroup stays with channel blockIdx.x % nch: the class rows of that channel's taps -- 5.8 KB at 100 Msps,
+    // read once per tile -- then stay in the CU's scalar cache; with the channel changing from tile to tile every block of the
+    // march waited ~600 cycles for its taps to come from the L2 (0.42 ms per launch where the arithmetic needs 0.12).
+    const int wg_per_ch = (int)gridDim.x / p.nch;
+    if ((int)blockIdx.x >= wg_per_ch * p.nch) return;
+    const int my_c = (int)blockIdx.x % p.nch;
+    const unsigned int kstep = (unsigned int)wg_per_ch;
+    const uint32_t *tlist = p.tiles + (size_t)my_c * p.tiles_cap;
+    unsigned int ntiles = p.tcount[my_c];
     if (ntiles > p.tiles_cap) ntiles = p.tiles_cap;
     for (int i = threadIdx.x; i < 257; i += kVerThreads) atab[i] = p.atan_tab[i];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -89,9 +96,9 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
     // the current one and written to LDS behind it: staging a tile costs four memory round trips -- more than the march itself.
     float2 pv[kVerPre];
     long long sb_next = 0;
-    auto skip = [&](unsigned int it) { while (it < ntiles && p.tiles[it] == 0xffffffffu) it += gridDim.x; return it; };
+    auto skip = [&](unsigned int it) { return it; };            // (every listed tile belongs to a task)
     auto issue = [&](unsigned int it) {
-        const uint32_t e_ = p.tiles[it];
+        const uint32_t e_ = tlist[it];
         const unsigned int jt_ = e_ >> 24, q_ = e_ & 0xffffffu;
         const VerifyTask tk_ = p.tasks[q_];
         const int k_ = tk_.w / p.nch;
@@ -109,10 +116,10 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
             }
         }
     };
-    unsigned int item = skip(blockIdx.x);
+    unsigned int item = skip((unsigned int)blockIdx.x / (unsigned int)p.nch);
     if (item < ntiles) issue(item);
     while (item < ntiles) {
-        const uint32_t e = p.tiles[item];
+        const uint32_t e = tlist[item];
         const int q = (int)(e & 0xffffffu), jt = (int)(e >> 24);
         const VerifyTask tk = p.tasks[q];
         const int k = tk.w / p.nch, c = tk.w - k * p.nch;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
             if (n < ns) lds[n + (int)ver_mulhi((uint32_t)n, p.inv2d)] = (a >= 0 && a < p.x_len) ? pv[r] : make_float2(0.f, 0.f);
         }
         __syncthreads();
-        const unsigned int next = skip(item + gridDim.x);
+        const unsigned int next = skip(item + kstep);
         if (next < ntiles) issue(next);                            // in flight under the march
         // ---- the march: step m meets tap l + 8 m of output 2 i and tap l + 8 m - D of output 2 i + 1 ----
         const int lc = ((l - D) % 8 + 8) % 8;                       // class of the second output's tap

@@ -292,11 +292,11 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     // exact confirmation: task list, exact rows, task stream
     VerifyBuffers vb;
     std::vector<VerifyTask> vtasks; std::vector<uint32_t> vtiles; std::vector<float> dx; std::vector<float4> dxt4;
-    unsigned int vcount[4] = {0, 0, 0, 0};
+    unsigned int vcount[kVerCountWords] = {0};
     const bool verify = ve && ve->mode > 0;
     if (verify) {
         vb.vcap = verify_capacity(S, nch);
-        vtasks.resize((size_t)vb.vcap); vtiles.resize(verify_tiles_capacity(S, nch)); vb.tiles_cap = (unsigned int)vtiles.size(); dx.assign((size_t)vb.vcap * kVerRows, -55.f);
+        vtasks.resize((size_t)vb.vcap); vtiles.resize(verify_tiles_capacity(S) * nch); vb.tiles_cap = (unsigned int)verify_tiles_capacity(S); dx.assign((size_t)vb.vcap * kVerRows, -55.f);
         const int nps = (vb.vcap + nch - 1) / nch;
         dxt4.assign(((size_t)nps * kVerRows * drow + 3) / 4 + 16, make_float4(-66.f, -66.f, -66.f, -66.f));
         vb.tasks = vtasks.data(); vb.tiles = vtiles.data(); vb.vcount = vcount; vb.dx = dx.data(); vb.dxt = (float *)dxt4.data();
@@ -321,7 +321,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         const size_t lds = verify_lds_bytes(des.d.decimation, des.channel.ntp);
         if (lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", lds); std::abort(); }
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
-        if (vcount[1]) emu::launch(dim3(61u), dim3(kVerThreads), [&]() {
+        if (vcount[1]) emu::launch(dim3((unsigned)(2 * nch + 1)), dim3(kVerThreads), [&]() {
             verify_ddc_kernel(vp, ve->x, (const float2 *)tv.data(), dx.data());
         });
         const VerifyFillParams fpz = make_verify_fill_params(des, d, dcol_p, drow, G, vb);
@@ -340,7 +340,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     else if (drow == 20) launch_window(WinLayout<12, 20, 5>{});
     else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});
     else launch_window(WinLayout<64, 4, 1>{});
-    std::memcpy(g_verify_counts, vcount, sizeof vcount);
+    std::memcpy(g_verify_counts, vcount, sizeof g_verify_counts);
     if (verify && getenv("EMU_DBG_W")) {                  // tile energies of one window's detection span (diagnostics)
         const int wd = atoi(getenv("EMU_DBG_W")), kd = wd / nch, cd = wd % nch;
         const int t0 = kd * p.tiles_per_slot;
