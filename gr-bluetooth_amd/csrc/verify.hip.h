@@ -64,11 +64,17 @@ inline size_t verify_lds_bytes(int D, int ntp)
 __device__ __forceinline__ uint32_t ver_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) >> 32); }
 
 // x: the batch's input; tapsv: VerifyParams; dx: [vcap][kVerRows] exact demodulated rows of each task
+// DT, NTPT > 0: the decimation and the padded filter length at compile time (50, 672: the 100 Msps bank).  The march is then
+// unrolled and every LDS read carries its sample offset AND its pad words as an immediate: with run-time D the pad-word
+// bookkeeping (a compare and a select or two per step, on the one scalar unit a CU's four SIMDs share) made this kernel
+// SCALAR-bound -- 157 M scalar against 105 M vector wave-instructions per launch, of which 70 M are the multiply-adds
+// (profiles/r04_q_c79_pmc_sq.txt).  <0, 0> is the form for every other rate.
+template <int DT, int NTPT>
 __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams p, const float2 *__restrict__ x,
                                                                  const float2 *__restrict__ tapsv, float *__restrict__ dx)
 {
     HIP_DYNAMIC_SHARED(float2, lds)
-    const int D = p.D, ntp = p.ntp;
+    const int D = DT > 0 ? DT : p.D, ntp = NTPT > 0 ? NTPT : p.ntp;
     const int ns = (kVerOuts - 1) * D + ntp + D + 80;
     int words = ns + ns / (2 * D) + 2;
     if (words < 8 * kVerOuts) words = 8 * kVerOuts;
@@ -146,6 +152,46 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
         const int lbase = 2 * D * lane + lane;                      // word of the lane's first sample (sample 2 D lane, its pad words)
         int xw = l + l / (2 * D), rem = l % (2 * D);                // wave-uniform: word offset l + 8 m + (its pad words), (l + 8 m) mod 2 D
         const int twoD = 2 * D;
+        if (DT > 0) {
+            // compile-time geometry: sample offset x = l + 8 m sits x / (2 D) pad words further -- (8 m) / (2 D) of them known
+            // here, one more where (8 m) mod (2 D) + l reaches 2 D (only the steps whose remainder is within 7 of 2 D can)
+            constexpr int D2 = 2 * (DT > 0 ? DT : 1);
+            constexpr int STEPS = ((NTPT > 0 ? NTPT : 8) / 8 + ((DT > 0 ? DT : 1) + 7) / 8 + 3) & ~3;
+            const float2 *zb = lds + lbase + l;                     // (l < 8 <= 2 D: no pad word in front of the class offset)
+            auto sample = [&](int mm) {
+                const int x8 = 8 * mm, r8 = x8 % D2;
+                int off = x8 + x8 / D2;
+                if (r8 + 7 >= D2) off += (r8 + l >= D2) ? 1 : 0;
+                return zb[off];
+            };
+            float2 vv[4], nv[4];                                    // the block's four samples, and the next block's: read a block ahead
+#pragma unroll
+            for (int u = 0; u < 4; u++) vv[u] = sample(u);
+#pragma unroll
+            for (int m = 0; m < STEPS; m += 4) {
+                float2 a[4], b[4];                                  // wave-uniform: scalar loads
+#pragma unroll
+                for (int u = 0; u < 4; u++) { a[u] = t0[m + u]; b[u] = t1[m + u]; }
+                if (m + 4 < STEPS) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) nv[u] = sample(m + 4 + u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float2 v = vv[u];
+                    ar0 = fmaf(a[u].x, v.x, ar0);
+                    ar0 = fmaf(-a[u].y, v.y, ar0);
+                    ai0 = fmaf(a[u].x, v.y, ai0);
+                    ai0 = fmaf(a[u].y, v.x, ai0);
+                    ar1 = fmaf(b[u].x, v.x, ar1);
+                    ar1 = fmaf(-b[u].y, v.y, ar1);
+                    ai1 = fmaf(b[u].x, v.y, ai1);
+                    ai1 = fmaf(b[u].y, v.x, ai1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) vv[u] = nv[u];
+            }
+        } else
         for (int m = 0; m < steps; m += 4) {
             float2 a[4], b[4];                                      // wave-uniform: scalar loads
 #pragma unroll
@@ -203,6 +249,13 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
         }
         item = next;
     }
+}
+
+typedef void (*VerifyDdcKernel)(VerifyParams, const float2 *, const float2 *, float *);
+inline VerifyDdcKernel verify_ddc_pick(int D, int ntp)
+{
+    if (D == 50 && ntp == 672) return verify_ddc_kernel<50, 672>;       // 100 Msps
+    return verify_ddc_kernel<0, 0>;
 }
 
 // The task stream the exact stage's window_kernel reads: dxt[(pseudo-slot * kVerRows + row) * drow + column], task q in

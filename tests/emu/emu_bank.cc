@@ -322,7 +322,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         if (lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", lds); std::abort(); }
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
         if (vcount[1]) emu::launch(dim3((unsigned)(2 * nch + 1)), dim3(kVerThreads), [&]() {
-            verify_ddc_kernel(vp, ve->x, (const float2 *)tv.data(), dx.data());
+            verify_ddc_pick(des.d.decimation, des.channel.ntp)(vp, ve->x, (const float2 *)tv.data(), dx.data());
         });
         const VerifyFillParams fpz = make_verify_fill_params(des, d, dcol_p, drow, G, vb);
         emu::launch(dim3(16), dim3(256), [&]() { verify_fill_kernel(fpz); });
