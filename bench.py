@@ -332,17 +332,26 @@ def run_rank(args):
     block_cfg = None
     if world == 1 and not args.no_block_config and not (args.le and args.headers):
         blk.close()
-        blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS, timing=0 if args.no_timing else pkg.FLAG_TIMING)
+        # `value` with the event records of the headline region (one pair per batch, around the bank); the kernel breakdown from a
+        # second pass with records around every kernel (eleven per batch: ~5 % slower, reported as ms_per_step_full_timing)
+        blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS, timing=head_timing)
         b_el, b_ints, b_snr, _m, _f, b_kms, b_kl = timed_region(blk, gather=False)
         b_ints, b_snr = one_copy(b_ints, b_snr)
+        b_verify = dict(blk._verify_stats)
+        b_el_full = None
+        if not args.no_timing and head_timing != pkg.FLAG_TIMING:
+            blk.close()
+            blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS, timing=pkg.FLAG_TIMING)
+            b_el_full, _i, _s, _m, _f, b_kms, b_kl = timed_region(blk, gather=False)
         block_cfg = {"flags": "BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS (what host/blocks.cc sets for multi_sniffer)",
                      "value": round(float(S) * slot * args.steps / b_el / 1e6, 3), "unit": "Msamples/s",
                      "ms_per_step": round(b_el / args.steps * 1e3, 3), "hits": int(len(b_ints)),
+                     "ms_per_step_full_timing": round(b_el_full / args.steps * 1e3, 3) if b_el_full else None,
                      "hits_ac": int((b_ints[:, 2] == 0).sum()) if len(b_ints) else 0,
                      "hits_aa": int((b_ints[:, 2] == 1).sum()) if len(b_ints) else 0,
                      "kernel_avg_ms": {pkg.KERNEL_NAMES[i]: round(float(b_kms[i] / b_kl[i]), 4) if b_kl[i] else 0.0
                                        for i in range(len(pkg.KERNEL_NAMES))},
-                     "verify": dict(blk._verify_stats),
+                     "verify": b_verify,
                      "ac_records_equal_headline": bool(np.array_equal(b_ints[b_ints[:, 2] == 0], ints[ints[:, 2] == 0])) if not args.le else None}
 
     # ---- the host-fed rate (N = 1): what btrx_amd and the GNU Radio block see -- the batch lies in HOST memory and goes through

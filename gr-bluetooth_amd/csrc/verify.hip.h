@@ -100,14 +100,20 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
     const int lane = (int)threadIdx.x & 63;
     // The input span of a workgroup's NEXT tile is requested (kVerPre 8-byte loads per thread, registers) before the march over
     // the current one and written to LDS behind it: staging a tile costs four memory round trips -- more than the march itself.
+    // The list entry and the task of an item are fetched a whole item earlier still: entry -> task -> address -> samples were
+    // three dependent trips to memory in front of every prefetch.
     float2 pv[kVerPre];
     long long sb_next = 0;
-    auto skip = [&](unsigned int it) { return it; };            // (every listed tile belongs to a task)
-    auto issue = [&](unsigned int it) {
-        const uint32_t e_ = tlist[it];
-        const unsigned int jt_ = e_ >> 24, q_ = e_ & 0xffffffu;
-        const VerifyTask tk_ = p.tasks[q_];
-        const int k_ = tk_.w / p.nch;
+    uint32_t e_cur = 0, e_nxt = 0;                              // entries of the current item and of the one being prefetched
+    int w_cur = 0, w_nxt = 0, nx_cur = 0, nx_nxt = 0;           // their tasks: window, exact rows
+    auto fetch = [&](unsigned int it) {                         // -> (e_nxt, w_nxt, nx_nxt)
+        e_nxt = tlist[it];
+        const VerifyTask tk_ = p.tasks[e_nxt & 0xffffffu];
+        w_nxt = tk_.w; nx_nxt = tk_.n_exact;
+    };
+    auto issue = [&]() {                                        // the samples of (e_nxt, w_nxt)
+        const unsigned int jt_ = e_nxt >> 24;
+        const int k_ = w_nxt / p.nch;
         sb_next = p.first0 + (long long)k_ * p.slot + (long long)(kVerTile * (int)jt_ - 1) * D;
         if (sb_next >= 0 && sb_next + (long long)kVerPre * kVerThreads <= p.x_len) {   // uniform: the span lies inside the stream
             const float2 *xb = x + sb_next;                                 // (scalar base + one 32-bit lane offset: no 64-bit address per load)
@@ -122,13 +128,17 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
             }
         }
     };
-    unsigned int item = skip((unsigned int)blockIdx.x / (unsigned int)p.nch);
-    if (item < ntiles) issue(item);
+    unsigned int item = (unsigned int)blockIdx.x / (unsigned int)p.nch;
+    if (item < ntiles) {
+        fetch(item); issue();
+        e_cur = e_nxt; w_cur = w_nxt; nx_cur = nx_nxt;
+        if (item + kstep < ntiles) fetch(item + kstep);
+    }
     while (item < ntiles) {
-        const uint32_t e = tlist[item];
+        const uint32_t e = e_cur;
         const int q = (int)(e & 0xffffffu), jt = (int)(e >> 24);
-        const VerifyTask tk = p.tasks[q];
-        const int k = tk.w / p.nch, c = tk.w - k * p.nch;
+        const int n_exact = nx_cur;
+        const int k = w_cur / p.nch, c = w_cur - k * p.nch;
         const int t_first = kVerTile * jt - 1;                     // output index of u = 0
         const long long sb = sb_next;
         __syncthreads();                                           // the previous item's partial sums are consumed
@@ -140,8 +150,12 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
             if (n < ns) lds[n + (int)ver_mulhi((uint32_t)n, p.inv2d)] = (a >= 0 && a < p.x_len) ? pv[r] : make_float2(0.f, 0.f);
         }
         __syncthreads();
-        const unsigned int next = skip(item + kstep);
-        if (next < ntiles) issue(next);                            // in flight under the march
+        const unsigned int next = item + kstep;
+        if (next < ntiles) {
+            issue();                                               // in flight under the march
+            e_cur = e_nxt; w_cur = w_nxt; nx_cur = nx_nxt;
+            if (next + kstep < ntiles) fetch(next + kstep);
+        }
         // ---- the march: step m meets tap l + 8 m of output 2 i and tap l + 8 m - D of output 2 i + 1 ----
         const int lc = ((l - D) % 8 + 8) % 8;                       // class of the second output's tap
         const int sh = (D - l + lc) / 8;                            // its step lag
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
         __syncthreads();
         if (threadIdx.x >= 1 && threadIdx.x < kVerOuts) {
             const int u = (int)threadIdx.x, t = t_first + u;
-            if (t >= 1 && t < tk.n_exact) dx[(size_t)q * kVerRows + t] = demod_one(atab, p.gain, ys[u], ys[u - 1]);
+            if (t >= 1 && t < n_exact) dx[(size_t)q * kVerRows + t] = demod_one(atab, p.gain, ys[u], ys[u - 1]);
         }
         item = next;
     }
