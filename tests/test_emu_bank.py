@@ -469,6 +469,44 @@ def test_exact_stage_settles_the_deviating_fuzz_cases(emu, po, synth, seed, case
     assert (not d0["planted_identical"]) or d0["planted_offset_differs"] > 0, d0       # the case is one of those that deviated
 
 
+def test_false_alarm_behind_the_exact_span_is_what_still_differs(emu, po, synth):
+    """What the exact stage does NOT settle, pinned: case 1471 of seed 31337 (100 Msps, sniffer, LE on).  A
+    planted packet in (slot 8, channel 77) is found by both sides with identical fields; the sniffer goes on searching behind
+    it, and the oracle meets a six-error access code at offset 196 -- in the packet's payload, behind the rows the exact stage
+    recomputes for that window -- which the polyphase stream's symbols do not show.  No packet is there: every planted record
+    of the capture is identical."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import paritylib
+    fs, fc, nsl, snr_db, occ, sq, sniff, le, laps, seed_c = _fuzz_fast_case(31337, 1471)
+    assert (fs, sniff, le) == (100e6, True, True)
+    iq, truth = synth.make_capture(fs, fc, nsl, laps=laps, seed=seed_c, snr_db=snr_db, occupancy=occ)
+    o = po.Oracle(fs, fc, sq, po.MODE_SNIFFER, le=True)
+    want, _ = o.run_stream(iq, threads=8)
+    wi = np.array([[h.slot, h.channel, h.kind, h.offset, h.lap, h.ac_errors, h.nsym] for h in want], np.int64).reshape(-1, 7)
+    L = emu
+    L.emu_front_m_run.restype = ctypes.c_int
+    L.emu_front_m_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                  ctypes.POINTER(ctypes.c_float), ctypes.c_longlong, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    x = np.concatenate([np.zeros(o.history - 1, np.complex64), iq.astype(np.complex64)])
+    xf = np.ascontiguousarray(x).view(np.float32)
+    cap = 8192
+    rec = np.zeros((cap, 8), np.int64); snr = np.zeros(cap, np.float64)
+    L.emu_set_verify(1)
+    n = L.emu_front_m_run(fs, fc, po.MODE_SNIFFER, 1, sq, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), nsl,
+                          rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap)
+    d = paritylib.differential(rec[:n, :7], wi, truth, lag=6)
+    assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= 8, d
+    gs, ws = set(map(tuple, rec[:n, :6].tolist())), set(map(tuple, wi[:, :6].tolist()))
+    assert gs - ws == set()
+    only_ref = sorted(ws - gs)
+    assert len(only_ref) == 1, only_ref
+    slot, ch, kind, off, lap, err = only_ref[0]
+    assert (slot, ch, kind, err) == (8, 77, 0, 6) and off > 150                     # a classic six-error code deep in a payload
+    assert any(t["slot"] == 8 and t["channel"] == 77 for t in truth) and lap not in laps   # ... of a planted packet; no planted LAP
+
+
 @pytest.mark.parametrize("fs,fc,sniff,nsl", [(8e6, 2476.5e6, True, 14), (20e6, 2441e6, False, 10), (100e6, 2441e6, True, 9)])
 def test_exact_stage_rows_equal_the_direct_path_bit_for_bit(emu, synth, fs, fc, sniff, nsl):
     """verify_ddc_kernel (the product's source under the emulator) against ddc_direct_kernel + demod_rows_kernel: every
