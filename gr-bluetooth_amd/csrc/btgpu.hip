@@ -451,9 +451,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         if (verify) {
             vp = make_verify_params(des, x_len, w0, ver_mp, ver_F, (const float2 *)d_rot_ch.p, (const double *)d_rotstep_ch.p,
                                     (const float *)d_atan.p, vb);
-            if (!ddc_on_tail)
-                hipLaunchKernelGGL(verify_ddc_pick(d.decimation, des.channel.ntp), dim3(ver_grid), dim3(kVerThreads), verify_lds_bytes(d.decimation, des.channel.ntp),
-                                   ps, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+            if (!ddc_on_tail) {
+                const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
+                hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, ps, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+            }
         }
         // =========================== TAIL (tail_stream): finish + nsym + record copies ===========================
         HIPCHK(this, hipEventRecord(t.detect_done, ps));
@@ -461,9 +462,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         if (deferred) HIPCHK(this, hipStreamWaitEvent(tail_stream, t.squelch_done, 0));
         HIPCHK(this, mark(9, tail_stream));
         if (verify) {
-            if (ddc_on_tail)
-                hipLaunchKernelGGL(verify_ddc_pick(d.decimation, des.channel.ntp), dim3(ver_grid), dim3(kVerThreads), verify_lds_bytes(d.decimation, des.channel.ntp),
-                                   tail_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+            if (ddc_on_tail) {
+                const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
+                hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, tail_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+            }
             const VerifyFillParams fz = make_verify_fill_params(des, (const float *)d_d.p, (const float *)(use_dcol ? t.d_dcol.p : nullptr),
                                                                 drow, G, vb);
             hipLaunchKernelGGL(verify_fill_kernel, dim3(kVerGridFill), dim3(256), 0, tail_stream, fz);
@@ -1173,6 +1175,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)verify_ddc_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)verify_ddc_kernel<50, 672>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)verify_ddc_small_kernel<4, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)verify_ddc_small_kernel<10, 136>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

@@ -265,11 +265,156 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
     }
 }
 
-typedef void (*VerifyDdcKernel)(VerifyParams, const float2 *, const float2 *, float *);
-inline VerifyDdcKernel verify_ddc_pick(int D, int ntp)
+// The same work for the SMALL decimations (8 Msps: D = 4, 56 taps; 20 Msps: D = 10, 136): a tile's march is 12-20 steps there, and
+// eight waves that meet at four barriers to share them spend their time on the tile's fixed costs (55 000 tiles per C8 batch:
+// 0.63 ms for 1.6 G multiply-adds).  Here ONE WAVE owns a tile: lane i forms all eight partial sums of outputs 2 i and 2 i + 1 in
+// registers (class by class, the taps wave-uniform as before, the same LDS read feeding both outputs), combines them, de-rotates;
+// only the demodulator's neighbour crosses LDS.  Four waves = four tiles per workgroup pass, two barriers (the waves share
+// nothing; the barriers order each wave's own LDS traffic, and keep the CPU emulator's lane-by-lane run faithful).
+constexpr int kVerSmallWaves = 4;
+inline int verify_small_ns(int D, int ntp) { return (kVerOuts - 2) * D + ntp + 8 * ((D + 7) / 8); }     // samples a tile's march touches
+inline size_t verify_small_lds_bytes(int D, int ntp)
 {
-    if (D == 50 && ntp == 672) return verify_ddc_kernel<50, 672>;       // 100 Msps
-    return verify_ddc_kernel<0, 0>;
+    const int ns = verify_small_ns(D, ntp);
+    return (size_t)kVerSmallWaves * (ns + ns / (2 * D) + 1 + kVerOuts) * sizeof(float2) + 260 * sizeof(float);
+}
+template <int DT, int NTPT>
+__global__ __launch_bounds__(64 * kVerSmallWaves, 4) void verify_ddc_small_kernel(VerifyParams p, const float2 *__restrict__ x,
+                                                                             const float2 *__restrict__ tapsv, float *__restrict__ dx)
+{
+    HIP_DYNAMIC_SHARED(float2, lds)
+    constexpr int D = DT, D2 = 2 * DT, F = (DT + 7) / 8, M = NTPT / 8 + F;
+    constexpr int ns = (kVerOuts - 2) * D + NTPT + 8 * F;
+    constexpr int W = ns + ns / D2 + 1;                           // words of a wave's staged span
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#else
+    const int wave = (int)threadIdx.x >> 6;
+#endif
+    const int lane = (int)threadIdx.x & 63;
+    float2 *smp = lds + wave * W;
+    float2 *ys = lds + kVerSmallWaves * W + wave * kVerOuts;      // [kVerOuts]: the wave's de-rotated outputs
+    float *atab = (float *)(lds + kVerSmallWaves * (W + kVerOuts));
+    const int wg_per_ch = (int)gridDim.x / p.nch;
+    if ((int)blockIdx.x >= wg_per_ch * p.nch) return;
+    const int c = (int)blockIdx.x % p.nch;                        // a workgroup stays with one channel (verify_ddc_kernel)
+    const uint32_t *tlist = p.tiles + (size_t)c * p.tiles_cap;
+    unsigned int ntiles = p.tcount[c];
+    if (ntiles > p.tiles_cap) ntiles = p.tiles_cap;
+    for (int i = threadIdx.x; i < 257; i += 64 * kVerSmallWaves) atab[i] = p.atan_tab[i];
+    const int lbase = D2 * lane + lane;                           // word of the lane's first sample (one pad word per 2 D samples)
+    for (unsigned int base = ((unsigned int)blockIdx.x / (unsigned int)p.nch) * kVerSmallWaves; base < ntiles;
+         base += (unsigned int)wg_per_ch * kVerSmallWaves) {
+        const unsigned int it = base + (unsigned int)wave;
+        const bool act = it < ntiles;                             // wave-uniform
+        int q = 0, n_exact = 0, t_first = 0;
+        if (act) {
+            const uint32_t e = tlist[it];
+            q = (int)(e & 0xffffffu);
+            const int jt = (int)(e >> 24);
+            const VerifyTask tk = p.tasks[q];
+            n_exact = tk.n_exact;
+            t_first = kVerTile * jt - 1;
+            const long long sb = p.first0 + (long long)(tk.w / p.nch) * p.slot + (long long)t_first * D;
+            constexpr int NR = (ns + 63) / 64;
+            float2 pv[NR];
+            if (sb >= 0 && sb + 64 * NR <= p.x_len) {             // wave-uniform: the span lies inside the stream -- all loads in flight together
+                const float2 *xb = x + sb;
+#pragma unroll
+                for (int r = 0; r < NR; r++) pv[r] = xb[lane + 64 * r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const long long a = sb + lane + 64 * r;
+                    const float2 v = x[a < 0 ? 0 : (a < p.x_len ? a : p.x_len - 1)];
+                    pv[r] = (a >= 0 && a < p.x_len) ? v : make_float2(0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int n = lane + 64 * r;
+                if (n < ns) smp[n + n / D2] = pv[r];
+            }
+        }
+        __syncthreads();
+        float2 y0 = make_float2(0.f, 0.f), y1 = y0;
+        if (act) {
+            // The eight partial sums of the two outputs, in registers.  The class loop is a REAL loop (unrolled, the scheduler issues
+            // all 8 M reads and 16 M tap loads up front and spills both register files); which register a finished sum goes to is a
+            // wave-uniform switch.  Sample 2 i D + l + 8 m meets tap l + 8 m of output 2 i and tap l + 8 m - D of output 2 i + 1
+            // (class lc, step lag sh).
+            float2 pa0 = y0, pa1 = y0, pa2 = y0, pa3 = y0, pa4 = y0, pa5 = y0, pa6 = y0, pa7 = y0;     // output 2 i
+            float2 pb0 = y0, pb1 = y0, pb2 = y0, pb3 = y0, pb4 = y0, pb5 = y0, pb6 = y0, pb7 = y0;     // output 2 i + 1
+#pragma unroll 1
+            for (int l = 0; l < 8; l++) {
+                const int lc = (l + 8 * F - D) & 7, sh = (D - l + lc) / 8;
+                const float2 *t0 = tapsv + ((size_t)c * 8 + l) * p.mp + p.F;
+                const float2 *t1 = tapsv + ((size_t)c * 8 + lc) * p.mp + p.F - sh;
+                float ar0 = 0.f, ai0 = 0.f, ar1 = 0.f, ai1 = 0.f;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const int xo = l + 8 * m;
+                    const float2 v = smp[lbase + xo + xo / D2];
+                    const float2 a = t0[m], b = t1[m];
+                    ar0 = fmaf(a.x, v.x, ar0);
+                    ar0 = fmaf(-a.y, v.y, ar0);
+                    ai0 = fmaf(a.x, v.y, ai0);
+                    ai0 = fmaf(a.y, v.x, ai0);
+                    ar1 = fmaf(b.x, v.x, ar1);
+                    ar1 = fmaf(-b.y, v.y, ar1);
+                    ai1 = fmaf(b.x, v.y, ai1);
+                    ai1 = fmaf(b.y, v.x, ai1);
+                }
+                const float2 sa = make_float2(ar0, ai0), sb2 = make_float2(ar1, ai1);
+                switch (l) { case 0: pa0 = sa; break; case 1: pa1 = sa; break; case 2: pa2 = sa; break; case 3: pa3 = sa; break;
+                             case 4: pa4 = sa; break; case 5: pa5 = sa; break; case 6: pa6 = sa; break; default: pa7 = sa; break; }
+                switch (lc) { case 0: pb0 = sb2; break; case 1: pb1 = sb2; break; case 2: pb2 = sb2; break; case 3: pb3 = sb2; break;
+                              case 4: pb4 = sb2; break; case 5: pb5 = sb2; break; case 6: pb6 = sb2; break; default: pb7 = sb2; break; }
+            }
+            const float ar0[8] = {pa0.x, pa1.x, pa2.x, pa3.x, pa4.x, pa5.x, pa6.x, pa7.x}, ai0[8] = {pa0.y, pa1.y, pa2.y, pa3.y, pa4.y, pa5.y, pa6.y, pa7.y};
+            const float ar1[8] = {pb0.x, pb1.x, pb2.x, pb3.x, pb4.x, pb5.x, pb6.x, pb7.x}, ai1[8] = {pb0.y, pb1.y, pb2.y, pb3.y, pb4.y, pb5.y, pb6.y, pb7.y};
+            auto finish = [&](const float *ar, const float *ai, int t) {
+                const float yr = ((ar[0] + ar[1]) + (ar[2] + ar[3])) + ((ar[4] + ar[5]) + (ar[6] + ar[7]));
+                const float yi = ((ai[0] + ai[1]) + (ai[2] + ai[3])) + ((ai[4] + ai[5]) + (ai[6] + ai[7]));
+                float rr = 1.f, ri = 0.f;                         // window-local output index: the rotator restarts per window
+                if (t >= 0) {
+                    if (p.Q > 0) {
+                        const float2 r = p.rot[(size_t)c * p.Q + (t % p.Q)];
+                        rr = r.x; ri = r.y;
+                    } else {
+                        double tt = p.rot_step_turns[c] * (double)t;
+                        tt -= floor(tt);
+                        double sn, co;
+                        sincospi(2.0 * tt, &sn, &co);
+                        rr = (float)co; ri = (float)sn;
+                    }
+                }
+                float2 out;
+                out.x = fmaf(-yi, ri, yr * rr);
+                out.y = fmaf(yi, rr, yr * ri);
+                return out;
+            };
+            y0 = finish(ar0, ai0, t_first + 2 * lane);
+            y1 = finish(ar1, ai1, t_first + 2 * lane + 1);
+            ys[2 * lane] = y0; ys[2 * lane + 1] = y1;
+        }
+        __syncthreads();
+        if (act) {
+            const int ta = t_first + 2 * lane, tb = ta + 1;
+            if (lane >= 1 && ta >= 1 && ta < n_exact) dx[(size_t)q * kVerRows + ta] = demod_one(atab, p.gain, y0, ys[2 * lane - 1]);
+            if (tb >= 1 && tb < n_exact) dx[(size_t)q * kVerRows + tb] = demod_one(atab, p.gain, y1, y0);
+        }
+    }
+}
+
+typedef void (*VerifyDdcKernel)(VerifyParams, const float2 *, const float2 *, float *);
+struct VerifyDdcLaunch { VerifyDdcKernel kern; int threads; size_t lds; };
+inline VerifyDdcLaunch verify_ddc_pick(int D, int ntp)
+{
+    if (D == 50 && ntp == 672) return {verify_ddc_kernel<50, 672>, kVerThreads, verify_lds_bytes(D, ntp)};       // 100 Msps
+    if (D == 4 && ntp == 56) return {verify_ddc_small_kernel<4, 56>, 64 * kVerSmallWaves, verify_small_lds_bytes(D, ntp)};      // 8 Msps
+    if (D == 10 && ntp == 136) return {verify_ddc_small_kernel<10, 136>, 64 * kVerSmallWaves, verify_small_lds_bytes(D, ntp)};  // 20 Msps
+    return {verify_ddc_kernel<0, 0>, kVerThreads, verify_lds_bytes(D, ntp)};
 }
 
 // The task stream the exact stage's window_kernel reads: dxt[(pseudo-slot * kVerRows + row) * drow + column], task q in

@@ -318,11 +318,12 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         for (int c = 0; c < nch; c++) st[c] = -des.channel.foff[c] * des.d.decimation / des.cfg.sample_rate;
         const VerifyParams vp = make_verify_params(des, (size_t)ve->x_len, 0, mp, F, (const float2 *)des.channel.rot.data(), st.data(),
                                                    des.atan_tab, vb);
-        const size_t lds = verify_lds_bytes(des.d.decimation, des.channel.ntp);
+        const VerifyDdcLaunch vl = verify_ddc_pick(des.d.decimation, des.channel.ntp);
+        const size_t lds = vl.lds;
         if (lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", lds); std::abort(); }
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
-        if (vcount[1]) emu::launch(dim3((unsigned)(2 * nch + 1)), dim3(kVerThreads), [&]() {
-            verify_ddc_pick(des.d.decimation, des.channel.ntp)(vp, ve->x, (const float2 *)tv.data(), dx.data());
+        if (vcount[1]) emu::launch(dim3((unsigned)(2 * nch + 1)), dim3((unsigned)vl.threads), [&]() {
+            vl.kern(vp, ve->x, (const float2 *)tv.data(), dx.data());
         });
         const VerifyFillParams fpz = make_verify_fill_params(des, d, dcol_p, drow, G, vb);
         emu::launch(dim3(16), dim3(256), [&]() { verify_fill_kernel(fpz); });
