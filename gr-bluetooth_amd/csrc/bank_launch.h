@@ -280,9 +280,28 @@ inline WindowParams make_verify_window_params(const WindowParams &first, const V
 }
 
 // ---- the rates below 100 Msps: pfbm_kernel (M = fs / 1 MHz bins) ----
+// Squelch stage 1 inside the 8-bin channel bank (C8): both banks are 8-bin natural-order banks over the same input, stage 1 at a hop
+// that is a multiple of the channel bank's, and the channel bank's tiles cover every stage-1 instant the squelch needs.
+inline bool pfbm_fuse_noise(const Design &des, const FastPath &fp, int S, long long G, int drow)
+{
+    const btgpu_design &d = des.d;
+    const PfbBank &bk = fp.channel, &nk = fp.noise.pfb;
+    const NoiseStage &ns = fp.noise;
+    const int nch = d.high_channel - d.low_channel + 1;
+    if (!(bk.available && ns.available && nk.available)) return false;
+    if (!(bk.natural && bk.M == 8 && nch == 8 && drow == 8 && bk.Q == 7 && !bk.real_taps)) return false;
+    if (!(nk.natural && nk.M == 8 && nk.Q == 15 && nk.D == ns.R)) return false;
+    const int TT = pfbm_tile(8);
+    if (TT + 1 > kPfbmThreads || (TT * bk.D) % nk.D != 0) return false;
+    const int npt = TT * bk.D / nk.D;
+    if (npt > kPfbmThreads || npt * 9 * 2 > TT * 8) return false;                 // its branch outputs borrow the angle tile
+    const long long ntiles = (G + TT - 1) / TT;
+    const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
+    return ntiles * npt >= Tn;
+}
 template <class Launcher>
 inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const BankBuffers &b, size_t x_len,
-                                 long long w0, long long G, Launcher &&L)
+                                 long long w0, long long G, Launcher &&L, int fuse_S = 0)
 {
     const btgpu_design &d = des.d;
     const PfbBank &bk = fp.channel;
@@ -299,9 +318,28 @@ inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const Ba
     p.tiles_per_block = des.outs_per_slot / p.TT; p.tail = des.tail;
     p.gain = des.demod_gain;
     p.Z = b.Ydebug; p.zstride = b.ystride;
-    const size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, true);
+    size_t lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, true);
     const bool f8 = bk.natural && bk.M == 8 && nch == 8 && b.drow == 8 && p.TT + 1 <= kPfbmThreads;
     if (f8 && p.TT % 25 == 0) p.pfine = b.pfine;
+    if (fuse_S > 0 && pfbm_fuse_noise(des, fp, fuse_S, G, b.drow)) {
+        // stage 1 from the same staged span: noise instant n reads x[xn0 + R n + 8 q + p]; a tile's channel span starts at
+        // gs = x0 + D (TT tile - 1), its noise instants at xn0 + R npt tile = xn0 + D TT tile
+        const NoiseStage &ns = fp.noise;
+        const PfbBank &nk = ns.pfb;
+        const long long xn0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
+        const int npt = p.TT * bk.D / nk.D;
+        const int delta = (int)(xn0 - p.x0) + bk.D;                                // first noise sample of a tile relative to gs
+        const int c_len = bk.D * p.TT + bk.Q * bk.M, n_len = nk.D * (npt - 1) + nk.Q * nk.M;
+        const int lo = delta < 0 ? delta : 0;
+        const int hi = delta + n_len > c_len ? delta + n_len : c_len;
+        p.n_on = 1; p.n_per_tile = npt; p.n_D = nk.D; p.n_rot_period = nk.rot_period;
+        p.stage_lo = lo; p.stage_len = hi - lo; p.n_ofs = delta - lo;
+        p.n_T = (long long)ns.outs * (fuse_S - 1) + ns.nw + ns.L3 - 1;
+        p.n_taps = b.taps_n; p.n_krot = b.krot_n; p.n_Z = b.Z; p.n_zstride = b.zstride;
+        lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, true, p.stage_len);
+        L(pfbm_kernel<false, true, 8, 7, true, true>, p.ntiles, kPfbmThreads, lds, p);
+        return p.ntiles;
+    }
     if (f8 && bk.Q == 7 && !bk.real_taps) L(pfbm_kernel<false, true, 8, 7, true>, p.ntiles, kPfbmThreads, lds, p);          // C8: half-MHz grid
     else if (f8 && bk.Q == 7) L(pfbm_kernel<true, true, 8, 7, true>, p.ntiles, kPfbmThreads, lds, p);
     else if (bk.M == 8 && bk.Q == 7 && !bk.real_taps) L(pfbm_kernel<false, true, 8, 7>, p.ntiles, kPfbmThreads, lds, p);

@@ -263,6 +263,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     if (verify) HIPCHK(this, hipMemsetAsync(t.d_vcount.p, 0, kVerCountWords * sizeof(unsigned int), st));
     HIPCHK(this, mark(0, st));
     int ntiles = 0, tiles_per_block = 1, tail_tiles = 0;
+    bool fused_m = false;                                       // small-M banks: stage 1 ran inside the channel bank's kernel
 
     // ---- channel bank -> demodulated stream d[g][nch] + |Y|^2 tile sums (polyphase) or block sums P, Pt (direct) ----
     if (use_pfb && pfb_small) {
@@ -270,7 +271,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         auto L = [&](void (*kern)(PfbmParams), int grid, int threads, size_t lds, const PfbmParams &p) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), lds, st, p);
         };
-        ntiles = launch_channel_bank_m(des, fp, bb, x_len, w0, G, L);
+        // squelch stage 1 from the channel bank's staged input where both are 8-bin banks (C8).  Opt-in (BTGPU_C8_FUSE=1) until the
+        // whole GPU suite has run with it: bit-identical outputs under the emulator and in the 8 Msps GPU tests, profiles/r04_v_*
+        static const bool fuse_m_on = getenv("BTGPU_C8_FUSE") && atoi(getenv("BTGPU_C8_FUSE")) == 1;
+        fused_m = fuse_m_on && use_staged && noise_small && pfbm_fuse_noise(des, fp, S, G, drow);
+        ntiles = launch_channel_bank_m(des, fp, bb, x_len, w0, G, L, fused_m ? S : 0);
         tiles_per_block = ops / pfbm_tile(fp.channel.M); tail_tiles = des.tail / pfbm_tile(fp.channel.M);
         HIPCHK(this, mark(1, st));
     } else if (use_pfb) {
@@ -323,7 +328,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     if (use_staged) {
         const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
         const long long xs0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
-        if (fuse_noise) {
+        if (fuse_noise || fused_m) {
             // stage 1 already ran inside the channel-bank kernel
         } else if (noise_pfb) {
             BankBuffers bb = bank_buffers(d_x, t);
@@ -1188,6 +1193,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfbm_kernel<true, true, 20, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, false, 8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, true, 8, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, true, 8, 7, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfbm_kernel<true, true, 8, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfbm_kernel<false, false, 8, 15, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

@@ -45,6 +45,14 @@ struct PfbmParams {
                                  // which the 250-instant tiles of this bank are too coarse for)
     float gain;
     float2 *Z; long long zstride;
+    // squelch stage 1 riding on the channel bank's staged input (the FN form of the 8-bin bank, pfbm_fuse_noise): the noise bank's
+    // instants n_per_tile * tile + j, j < n_per_tile, hop n_D, 15 taps per branch, out of the same LDS span
+    int n_on, n_per_tile, n_D, n_rot_period;
+    int stage_lo, stage_len;     // the staged span: samples [gs + stage_lo, + stage_len) of a tile (gs = the channel bank's first sample)
+    int n_ofs;                   // sample of (noise instant j = 0, branch 0, tap 0) relative to the staged span's first sample
+    long long n_T;               // noise instants in total
+    const float2 *n_taps, *n_krot;
+    float2 *n_Z; long long n_zstride;
 };
 
 // phase B of the channel bank, lane = (run, channel): instants per run such that nsel * ceil(TT / R) <= 256 lanes
@@ -55,10 +63,10 @@ __host__ __device__ inline int pfbm_run(int nsel, int TT)
     return R;
 }
 
-inline size_t pfbm_lds_bytes(int M, int D, int Q, int nsel, bool chan)
+inline size_t pfbm_lds_bytes(int M, int D, int Q, int nsel, bool chan, int stage_len = 0)
 {
     const int tt = pfbm_tile(M), nt = tt + (chan ? 1 : 0);
-    const int span = 2 * ((D * (nt - 1) + Q * M + 3) / 2);
+    const int span = 2 * (((stage_len > 0 ? stage_len : D * (nt - 1) + Q * M) + 3) / 2);
     size_t cf = (size_t)span + (size_t)Q * M + (size_t)M * nsel + (size_t)nt * (M + 1);
     size_t fl = chan ? (size_t)tt * nsel + 2 * 256 : 0;
     return cf * sizeof(float2) + fl * sizeof(float) + 64;
@@ -87,17 +95,21 @@ __device__ __forceinline__ void fft8(cf (&u)[8])
 
 // F8: eight bins = the eight channels in natural order (PfbBank::natural): phase B is one lane per instant
 // with the 8-point FFT above instead of the M x nch product
-template <bool REAL, bool CHAN, int MC = 0, int QC = 0, bool F8 = false>
+// FN (with F8, CHAN): squelch stage 1 (the 8-bin noise bank, 15 taps per branch, hop n_D) computed from the same staged input --
+// a launch, a second read of the input and 0.42 ms of a 2 ms step at C8 (pfbm_kernel<false, false, 8, 15, true> stays the
+// stand-alone form).
+template <bool REAL, bool CHAN, int MC = 0, int QC = 0, bool F8 = false, bool FN = false>
 __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
 {
     static_assert(!F8 || MC == 8, "the FFT variant is the 8-bin bank");
+    static_assert(!FN || (F8 && CHAN), "stage 1 rides on the 8-bin channel bank only");
     constexpr int NTH = kPfbmThreads;
     const int TT = p.TT, NT = TT + (CHAN ? 1 : 0);
     const int M = MC ? MC : p.M, D = p.D, Q = QC ? QC : p.Q, nsel = p.nsel;
     const int UST = M + 1;                                       // odd pitch for even M: lanes (t, p) of phase A spread over the banks
     HIP_DYNAMIC_SHARED(float4, lds4)
     cf *lds = (cf *)lds4;
-    const int N4 = (D * (NT - 1) + Q * M + 3) / 2;               // 16-byte pieces of the input span
+    const int N4 = ((FN ? p.stage_len : D * (NT - 1) + Q * M) + 3) / 2;   // 16-byte pieces of the input span
     cf *xs = lds;                                                // [2 N4]
     cf *s_taps = xs + 2 * N4;                                    // [Q M]
     cf *s_w = s_taps + Q * M;                                    // [M][nsel]
@@ -109,7 +121,8 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
     const long long t0 = (long long)tile * TT - (CHAN ? 1 : 0);  // global instant of local 0
 
     // ---- stage the input span (16-byte aligned start, every load unconditional) and the tables
-    const long long gs = p.x0 + (long long)D * t0;
+    const long long gs = p.x0 + (long long)D * t0 + (FN ? p.stage_lo : 0);
+    const int c_ofs = FN ? -p.stage_lo : 0;                      // the channel bank's first sample inside the staged span
     const long long a0 = gs & ~1LL;
     const int shift = (int)(gs - a0);
     {
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
 #pragma unroll
         for (int q = 0; q < QQ; q++) a[q] = s_taps[q * MM + pp];
         for (int tl = l / MM; tl < NT; tl += NTH / MM) {
-            const cf *z = xs + shift + D * tl + pp;
+            const cf *z = xs + shift + c_ofs + D * tl + pp;
             cf u = mk(0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < QQ; q++) {
@@ -155,6 +168,24 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
                 else { u = a[q].xx * v + u; u = mk(-a[q].y, a[q].y) * v.yx + u; }
             }
             U[tl * UST + pp] = u;
+        }
+        if (FN) {
+            // stage 1's branch filters, lane = (instant j, branch pp): 15 complex taps straight from global memory (a lane's branch
+            // never changes), results in the not yet used angle tile
+            cf an[15];
+#pragma unroll
+            for (int q = 0; q < 15; q++) an[q] = ((const cf *)p.n_taps)[q * 8 + pp];
+            cf *U2 = (cf *)s_d;                                    // [n_per_tile][9]
+            for (int j = l / 8; j < p.n_per_tile; j += NTH / 8) {
+                const cf *z = xs + shift + p.n_ofs + p.n_D * j + pp;
+                cf u = mk(0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 15; q++) {
+                    const cf v = z[q * 8];
+                    u = an[q].xx * v + u; u = mk(-an[q].y, an[q].y) * v.yx + u;
+                }
+                U2[j * 9 + pp] = u;
+            }
         }
     } else {
         for (int i = l; i < NT * M; i += NTH) {
@@ -184,6 +215,24 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
             fft8(y);
 #pragma unroll
             for (int c = 0; c < 8; c++) u[c] = y[c];
+        }
+        if (FN && l < p.n_per_tile) {
+            // stage 1: FFT, de-rotate, eight coalesced row stores (the stand-alone noise bank's epilogue); the angle tile it read from
+            // is written behind the barrier
+            const long long tn = (long long)tile * p.n_per_tile + l;
+            if (tn < p.n_T) {
+                const cf *u2 = (const cf *)s_d + l * 9;
+                cf z8[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) z8[c] = u2[c];
+                fft8(z8);
+                const int ph = (int)(tn % p.n_rot_period);
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const cf kr = ((const cf *)p.n_krot)[(size_t)c * p.n_rot_period + ph];
+                    ((cf *)p.n_Z)[(size_t)c * p.n_zstride + tn] = cmulf(z8[c], kr);
+                }
+            }
         }
         __syncthreads();
         if (l >= 1 && l < NT) {

@@ -26,6 +26,7 @@ extern "C" {
 static std::vector<float> *g_keep_dcol = nullptr;      // emu_front_run: keep the tile-blocked copy the bank kernel wrote
 static std::vector<double> *g_keep_ptile = nullptr;    // ... and the |Y|^2 tile sums (exact confirmation: burst energy)
 static int g_keep_ntiles = 0;
+static int g_fuse_m = 1, g_last_fused_m = 0;           // emu_set_fuse_m: squelch stage 1 inside the 8-bin channel bank (as the runtime decides) or apart
 static std::vector<double> *g_keep_pfine = nullptr;    // small-M F8 bank: the 25-instant sums
 
 int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_len, long long w0, int S, int fuse,
@@ -166,8 +167,11 @@ int emu_bank_m_run(double fs, double fc, int mode, const float *iq, long long x_
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
         emu::launch(dim3((unsigned)grid), dim3((unsigned)threads), [&]() { kern(p); });
     };
-    const int ntiles = launch_channel_bank_m(des, fp, b, (size_t)x_len, w0, G, L);
-    launch_noise_bank_m(des, fp, b, (size_t)x_len, w0, S, L);
+    // (as the runtime: stage 1 inside the 8-bin channel bank where the geometry allows it; emu_set_fuse_m(0): the two launches)
+    const bool fused_m = g_fuse_m && pfbm_fuse_noise(des, fp, S, G, drow);
+    const int ntiles = launch_channel_bank_m(des, fp, b, (size_t)x_len, w0, G, L, fused_m ? S : 0);
+    if (!fused_m) launch_noise_bank_m(des, fp, b, (size_t)x_len, w0, S, L);
+    g_last_fused_m = fused_m ? 1 : 0;
     if (g_keep_ptile) { *g_keep_ptile = ptile; g_keep_ntiles = ntiles; }
     if (g_keep_pfine) *g_keep_pfine = pfine;
     const int tpb = ops / TTm, tail_tiles = des.tail / TTm;
@@ -262,6 +266,8 @@ struct VerifyEmu {
 static int g_verify_mode = 1;                            // emu_set_verify: 0 off, 1 hits + burst energy, 2 hits only
 static unsigned int g_verify_counts[4] = {0, 0, 0, 0};  // of the last emulated front end
 extern "C" void emu_set_verify(int mode) { g_verify_mode = mode; }
+extern "C" void emu_set_fuse_m(int on) { g_fuse_m = on; }
+extern "C" int emu_last_fused_m(void) { return g_last_fused_m; }
 extern "C" void emu_verify_counts(unsigned int *out) { std::memcpy(out, g_verify_counts, sizeof g_verify_counts); }
 static std::vector<VerifyTask> g_verify_tasks;           // of the last emulated front end
 extern "C" int emu_verify_tasks(int *w_out, int *rows_out, int cap)

@@ -319,6 +319,32 @@ def test_small_m_banks_vs_oracle(emu, po, synth, fs, fc, mode):
             assert abs(q / o.noise_out - e_off) / e_off <= 1e-5, (ch, q / o.noise_out, e_off)
 
 
+@pytest.mark.parametrize("mode,S", [(1, 8), (0, 2), (1, 3)])
+def test_c8_stage1_inside_the_channel_bank_equals_the_separate_launch(emu, synth, mode, S):
+    """pfbm_kernel<..., FN>: squelch stage 1 computed from the 8-bin channel bank's staged input (C8) leaves bit for bit the Z,
+    the demodulated stream, the channel output and the tile sums of the two separate launches."""
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, S, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=5, snr_db=20, occupancy=0.8)
+    import pyoracle as po_
+    H = po_.Oracle(fs, fc, 10.0, mode).history
+    x = np.concatenate([np.zeros(4096 + H - 1, np.complex64), iq.astype(np.complex64)])
+    out = {}
+    try:
+        for fuse in (0, 1):
+            emu.emu_set_fuse_m(fuse)
+            out[fuse] = _run_m(emu, fs, fc, mode, x, 4096, S)
+            assert emu.emu_last_fused_m() == fuse
+    finally:
+        emu.emu_set_fuse_m(1)
+    a, b = out[0], out[1]
+    Tn = a["Tn"]
+    assert Tn > 0 and np.isfinite(a["Z"][:, :Tn]).all()
+    assert np.array_equal(a["Z"][:, :Tn].view(np.uint32), b["Z"][:, :Tn].view(np.uint32))
+    assert np.array_equal(a["d"][1:a["G"]].view(np.uint32), b["d"][1:a["G"]].view(np.uint32))
+    assert np.array_equal(a["P"], b["P"]) and np.array_equal(a["Pt"], b["Pt"])
+    assert np.array_equal(a["Y"][:, :a["G"]].view(np.uint32), b["Y"][:, :a["G"]].view(np.uint32))
+
+
 @pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (8e6, 2476.5e6, False, False), (20e6, 2441e6, True, False),
                                             (50e6, 2441e6, True, False), (100e6, 2441e6, True, True)])
 def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff, le):
