@@ -282,6 +282,15 @@ inline WindowParams make_verify_window_params(const WindowParams &first, const V
 // ---- the rates below 100 Msps: pfbm_kernel (M = fs / 1 MHz bins) ----
 // Squelch stage 1 inside the 8-bin channel bank (C8): both banks are 8-bin natural-order banks over the same input, stage 1 at a hop
 // that is a multiple of the channel bank's, and the channel bank's tiles cover every stage-1 instant the squelch needs.
+// first stage-1 instant of channel tile 0: the two banks start at different samples (stage 1 reads from the window's start, the channel
+// bank from its first detection sample), so tile k is paired with the stage-1 instants whose span overlaps its own
+inline int pfbm_fuse_first(const Design &des, const FastPath &fp)
+{
+    const NoiseStage &ns = fp.noise;
+    const long long d0 = (long long)des.d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R - des.d.first_channel_sample + fp.channel.D;
+    if (d0 >= 0) return 0;
+    return (int)((-d0 + ns.R / 2) / ns.R);
+}
 inline bool pfbm_fuse_noise(const Design &des, const FastPath &fp, int S, long long G, int drow)
 {
     const btgpu_design &d = des.d;
@@ -297,7 +306,7 @@ inline bool pfbm_fuse_noise(const Design &des, const FastPath &fp, int S, long l
     if (npt > kPfbmThreads || npt * 9 * 2 > TT * 8) return false;                 // its branch outputs borrow the angle tile
     const long long ntiles = (G + TT - 1) / TT;
     const long long Tn = (long long)ns.outs * (S - 1) + ns.nw + ns.L3 - 1;
-    return ntiles * npt >= Tn;
+    return ntiles * npt + pfbm_fuse_first(des, fp) >= Tn;
 }
 template <class Launcher>
 inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const BankBuffers &b, size_t x_len,
@@ -328,16 +337,29 @@ inline int launch_channel_bank_m(const Design &des, const FastPath &fp, const Ba
         const PfbBank &nk = ns.pfb;
         const long long xn0 = w0 + d.first_noise_sample - ns.pad - (long long)ns.Jm * ns.R;
         const int npt = p.TT * bk.D / nk.D;
-        const int delta = (int)(xn0 - p.x0) + bk.D;                                // first noise sample of a tile relative to gs
+        const int n_first = pfbm_fuse_first(des, fp);
+        const int delta = (int)(xn0 - p.x0) + bk.D + n_first * nk.D;               // first noise sample of a tile relative to gs
         const int c_len = bk.D * p.TT + bk.Q * bk.M, n_len = nk.D * (npt - 1) + nk.Q * nk.M;
         const int lo = delta < 0 ? delta : 0;
         const int hi = delta + n_len > c_len ? delta + n_len : c_len;
-        p.n_on = 1; p.n_per_tile = npt; p.n_D = nk.D; p.n_rot_period = nk.rot_period;
+        p.n_on = 1; p.n_per_tile = npt; p.n_D = nk.D; p.n_rot_period = nk.rot_period; p.n_first = n_first;
         p.stage_lo = lo; p.stage_len = hi - lo; p.n_ofs = delta - lo;
         p.n_T = (long long)ns.outs * (fuse_S - 1) + ns.nw + ns.L3 - 1;
         p.n_taps = b.taps_n; p.n_krot = b.krot_n; p.n_Z = b.Z; p.n_zstride = b.zstride;
         lds = pfbm_lds_bytes(bk.M, bk.D, bk.Q, nch, true, p.stage_len);
         L(pfbm_kernel<false, true, 8, 7, true, true>, p.ntiles, kPfbmThreads, lds, p);
+        if (n_first > 0) {
+            // the stage-1 instants in front of tile 0's: one or two tiles of the stand-alone form
+            PfbmParams q{};
+            q.x = b.x; q.x_len = (long long)x_len; q.x0 = xn0;
+            q.M = nk.M; q.D = nk.D; q.Q = nk.Q; q.TT = pfbm_tile(nk.M);
+            q.T = n_first < p.n_T ? n_first : p.n_T;
+            q.taps = b.taps_n; q.dftw = b.dftw_n; q.nsel = nch;
+            q.krot = b.krot_n; q.rot_period = nk.rot_period;
+            q.ntiles = (int)((q.T + q.TT - 1) / q.TT);
+            q.Z = b.Z; q.zstride = b.zstride;
+            L(pfbm_kernel<false, false, 8, 15, true>, q.ntiles, kPfbmThreads, pfbm_lds_bytes(nk.M, nk.D, nk.Q, nch, false), q);
+        }
         return p.ntiles;
     }
     if (f8 && bk.Q == 7 && !bk.real_taps) L(pfbm_kernel<false, true, 8, 7, true>, p.ntiles, kPfbmThreads, lds, p);          // C8: half-MHz grid

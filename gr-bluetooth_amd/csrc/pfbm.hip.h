@@ -46,8 +46,9 @@ struct PfbmParams {
     float gain;
     float2 *Z; long long zstride;
     // squelch stage 1 riding on the channel bank's staged input (the FN form of the 8-bin bank, pfbm_fuse_noise): the noise bank's
-    // instants n_per_tile * tile + j, j < n_per_tile, hop n_D, 15 taps per branch, out of the same LDS span
+    // instants n_first + n_per_tile * tile + j, j < n_per_tile, hop n_D, 15 taps per branch, out of the same LDS span
     int n_on, n_per_tile, n_D, n_rot_period;
+    int n_first;                 // tile 0's first noise instant (the banks start at different samples: tiles are paired where their spans overlap)
     int stage_lo, stage_len;     // the staged span: samples [gs + stage_lo, + stage_len) of a tile (gs = the channel bank's first sample)
     int n_ofs;                   // sample of (noise instant j = 0, branch 0, tap 0) relative to the staged span's first sample
     long long n_T;               // noise instants in total
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kPfbmThreads) void pfbm_kernel(PfbmParams p)
         if (FN && l < p.n_per_tile) {
             // stage 1: FFT, de-rotate, eight coalesced row stores (the stand-alone noise bank's epilogue); the angle tile it read from
             // is written behind the barrier
-            const long long tn = (long long)tile * p.n_per_tile + l;
+            const long long tn = (long long)p.n_first + (long long)tile * p.n_per_tile + l;
             if (tn < p.n_T) {
                 const cf *u2 = (const cf *)s_d + l * 9;
                 cf z8[8];

@@ -1,7 +1,7 @@
 #!/bin/bash
 # build with the opt-in fused C8 stage 1: (1) the headline's PMC summary / bench line re-stamped with this build's id, (2) 8 Msps GPU tests
 # with BTGPU_C8_FUSE=1, (3) C8 bench with and without it
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_r04_v; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_r04_w; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 PM="python $R/bench.py --steps 1 --warmup 0 --prewarm-ms 0 --no-cpu --no-block-config --no-ab --no-host-fed --sync"
 rocprofv3 --kernel-include-regex _kernel --pmc FETCH_SIZE --output-format csv -d /tmp/p1 -o p -- $PM > /dev/null 2> $O/err
 rocprofv3 --kernel-include-regex _kernel --pmc WRITE_SIZE --output-format csv -d /tmp/p2 -o p -- $PM > /dev/null 2>> $O/err
