@@ -9,7 +9,9 @@ LL = "/opt/rocm/lib/llvm/bin"
 
 def disasm(so, tmp, tag):
     fat, co = os.path.join(tmp, tag + ".fat"), os.path.join(tmp, tag + ".co")
-    subprocess.check_call([LL + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, so])
+    # (an output file is named on purpose: without one llvm-objcopy rewrites its INPUT in place -- the library's bytes, and with
+    # them the build id bench.py stamps, would change)
+    subprocess.check_call([LL + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, so, os.path.join(tmp, tag + ".copy")])
     subprocess.check_call([LL + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
     return subprocess.check_output([LL + "/llvm-objdump", "-d", "--no-show-raw-insn", co], text=True)
