@@ -240,8 +240,22 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
     p.ptile = ptile; p.ptile_stride = ntiles; p.tile_outs = tile_outs > 0 ? tile_outs : verify_tile_outs(fp, small);
     p.tiles_per_slot = des.outs_per_slot / p.tile_outs;
     p.vtasks = vb.tasks; p.vtiles = vb.tiles; p.vcount = vb.vcount; p.vcap = vb.vcap; p.vtcount = vb.vcount + 4; p.vtcap = vb.tiles_cap;
-    if ((2 * kDetectSyms + 16 + p.tile_outs - 1) / p.tile_outs + 5 > 64) p.verify = 2;   // (the scan stages <= 64 tiles per channel)
-    p.burst_ratio = 4.0f / (1.0f - 2.3f / std::sqrt((float)p.tile_outs));   // smallest of ~57 tiles of TT outputs ~ (1 - 2.3 / sqrt(TT)) mean
+    const int ntm = (2 * kDetectSyms + 16 + p.tile_outs - 1) / p.tile_outs;
+    if (ntm + kBurstFront > 64) p.verify = 2;            // (the scan stages <= 64 tiles per channel)
+    // The scan's statistic is the energy of W tiles, ~50 us.  Its threshold is 2.0 x the MEAN noise block; the scan knows the
+    // span's QUIETEST aligned block, which lies z sigma under the mean: sigma of a 25-output tile sum is 0.28 of its mean (the
+    // 2 Msps stream of a ~1 MHz filter holds ~12.6 independent values per 25), z the expected minimum of n normal draws.
+    p.burst_w = std::max(1, 100 / p.tile_outs);
+    {
+        const float nblocks = (float)std::max(2, (ntm + kBurstFront) / p.burst_w);
+        const float sigma = 0.28f * std::sqrt(25.0f / (float)(p.tile_outs * p.burst_w));
+        const float beta = 1.0f - (0.5f + 0.45f * std::log(nblocks)) * sigma;
+        const char *ea = std::getenv("BTGPU_BURST_A");                  // (diagnostics: the scan's threshold in mean noise blocks)
+        p.burst_abs = (ea ? (float)std::atof(ea) : 2.0f) / beta;
+        const char *eh = std::getenv("BTGPU_BURST_A_HOT");
+        p.burst_abs_hot = std::max(p.burst_abs, (eh ? (float)std::atof(eh) : 3.0f) / beta);
+        p.burst_hot = 100.0f / beta;                     // a neighbour 20 dB over the noise
+    }
     p.span_extra = headers ? 58 : 0;                     // 54 header symbols + the 4-symbol trailer
 }
 inline VerifyParams make_verify_params(const Design &des, size_t x_len, long long w0, int mp, int F, const float2 *rot,

@@ -98,6 +98,7 @@ struct btgpu_handle {
     bool no_nsym = false;            // BTGPU_FLAG_NO_NSYM: skip the M&M continuation that produces hit.nsym
     int verify = 0;                  // exact confirmation of the polyphase path's records: 0 off, 1 hits + burst energy, 2 hits only
     int vcap = 0, ver_mp = 0, ver_F = 0, ver_grid = kVerGridDdc;
+    std::vector<const void *> lds_opted;   // bank kernels that have been granted > 48 KiB of dynamic LDS on this handle's device
     DevBuf d_tapsv;                  // class-major taps of the direct-form channel bank (verify_ddc_kernel)
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
     hipStream_t copy_stream = nullptr;
@@ -286,7 +287,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         auto L = [&](void (*kern)(PfbParams), int grid, int threads, size_t lds, const PfbParams &p) {
             // more than 48 KiB of dynamic LDS is an opt-in per kernel: asked for here, next to the launch, once per
             // instantiation actually launched (a list kept elsewhere drifts from what launch_channel_bank picks)
-            static std::vector<const void *> opted;
+            // (per handle: btrx_amd --gpus N runs one handle per device, each on its own host thread -- ADVICE r4)
+            std::vector<const void *> &opted = lds_opted;
             if (lds + lds_pad > 48 * 1024 && std::find(opted.begin(), opted.end(), (const void *)kern) == opted.end()) {
                 (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds + lds_pad, 64 * 1024));
                 opted.push_back((const void *)kern);
@@ -1013,8 +1015,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     h->no_nsym = (cfg->flags & BTGPU_FLAG_NO_NSYM) != 0;
     // exact confirmation: on wherever the channelizer is the polyphase one (BTGPU_VERIFY=0 | 1 | 2: A/B timing and tests)
     h->verify = (h->use_pfb && !(cfg->flags & BTGPU_FLAG_NO_VERIFY)) ? 1 : 0;
-    if (verify_span(h->des.d.decimation, h->des.channel.ntp) > kVerPre * kVerThreads) h->verify = 0;   // (span of a tile beyond the kernel's prefetch registers: no such rate today)
     if (h->use_pfb && getenv("BTGPU_VERIFY")) h->verify = std::max(0, std::min(2, atoi(getenv("BTGPU_VERIFY"))));
+    if (verify_span(h->des.d.decimation, h->des.channel.ntp) > kVerPre * kVerThreads) h->verify = 0;   // (span of a tile beyond the kernel's prefetch registers: no such rate today; after the override: it cannot be asked for)
     h->ntail = h->verify ? h->nctx : 1;
     if (getenv("BTGPU_TAILS")) h->ntail = std::max(1, std::min(h->nctx, atoi(getenv("BTGPU_TAILS"))));   // A/B timing
     // front(n+1) beside post(n) (BTGPU_PIPE=1; possible only where the front writes nothing but per-context buffers).
@@ -1210,7 +1212,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, false, 2 * kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     {
-        if (getenv("BTGPU_VERIFY_GRID")) h->ver_grid = std::max(1, atoi(getenv("BTGPU_VERIFY_GRID")));
+        // (verify_ddc_kernel gives every channel gridDim.x / nch workgroups: fewer than nch would leave all of them without work)
+        const int nch_ = h->des.d.high_channel - h->des.d.low_channel + 1;
+        if (getenv("BTGPU_VERIFY_GRID")) h->ver_grid = std::max(nch_, atoi(getenv("BTGPU_VERIFY_GRID")));
     }
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))

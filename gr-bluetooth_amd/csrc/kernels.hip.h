@@ -339,7 +339,9 @@ struct WindowParams {
     VerifyTask *vtasks; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 tiles listed (statistics), 2 windows turned away (list full)
     uint32_t *vtiles; unsigned int *vtcount; unsigned int vtcap;     // tile lists BY CHANNEL: entries task | tile << 24 at vtiles[c * vtcap ..], vtcount[c] of them
     int vcap;                   // capacity of vtasks
-    float burst_ratio;          // a tile counts as burst energy above burst_ratio * (smallest tile of the detection span)
+    float burst_abs;            // new energy: a W-tile sum above burst_abs * (the quietest aligned W-tile block of the span) ...
+    int burst_w;                // ... W = tiles per ~50 us (set_verify_flagging, bank_launch.h)
+    float burst_abs_hot, burst_hot;   // the threshold beside a neighbour channel whose W-tile sum exceeds burst_hot * (that block)
     int span_extra;             // symbols behind an access code that stay exact as well (the 54-symbol header + margin)
     int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
 };
@@ -377,6 +379,8 @@ struct WinLayout {
 constexpr int kMmseStride = 12;      // floats per interpolator row in LDS: 16-byte slot 3 imu mod 16 instead of
                                      // 2 imu mod 16 (eight classes for the sixteen lanes of a 16-byte read group)
 constexpr int kDetectSyms = 693;     // 625 search offsets + 68-symbol access code
+constexpr int kBurstAhead = 2;       // the neighbour channels' energy sums run this many tiles ahead of the channel's own
+constexpr int kBurstFront = 7;       // tiles in front of a window that the burst scan reads (57 tiles of the span + 7 = one wave's 64 lanes)
 constexpr int kBitWords = 24;        // 32-bit words of sliced symbols kept per lane (>= 693 + 99 bits)
 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
@@ -611,12 +615,13 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         // lanes of a slot touch 79 cache lines per load -- 2 x 57 such loads per lane doubled the kernel's time.
         const int TT = p.tile_outs;
         const int ntm = (2 * kDetectSyms + 16 + TT - 1) / TT;          // tiles of the detection span
-        const int NTW = ntm + 5, PW = NTW | 1;                         // + five tiles in front of the window; odd pitch: no bank conflicts
+        constexpr int NF = kBurstFront;                                // tiles in front of the window that the scan looks at
+        const int NTW = ntm + NF, PW = NTW | 1;                        // odd pitch: no bank conflicts
         // as many slots per pass as the tile holds (all three at C79 do not fit; the narrow layouts -- 32 slots of 8 channels --
         // take 19 at a time: one pass per slot was 32 x two barriers)
         int spp = (kWinSlots * kTileFloats) / (nch * PW);
         spp = spp < 1 ? 1 : (spp > kWinSlots ? kWinSlots : spp);
-        float *et = tile;                                              // [spp][nch][PW]: tile t0 - 5 + jj of (slot, channel) at et[(sp * nch + cc) * PW + jj]; -1 = no such tile
+        float *et = tile;                                              // [spp][nch][PW]: tile t0 - NF + jj of (slot, channel) at et[(sp * nch + cc) * PW + jj]; -1 = no such tile
         for (int s0 = 0; s0 < kWinSlots; s0 += spp) {
             if (blockIdx.x * kWinSlots + s0 >= p.S) break;             // uniform
             __syncthreads();
@@ -625,59 +630,108 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                 const int sp = pr / nch, cc = pr - sp * nch;
                 const int ks = blockIdx.x * kWinSlots + s0 + sp;
                 const int jj = (int)threadIdx.x & 63;
-                const int t = ks * p.tiles_per_slot - 5 + jj;
+                const int t = ks * p.tiles_per_slot - NF + jj;
                 if (jj < NTW)
                     et[pr * PW + jj] = (s0 + sp < kWinSlots && ks < p.S && t >= 0 && t < p.ptile_stride) ? (float)p.ptile[(size_t)cc * p.ptile_stride + t] : -1.f;
             }
             __syncthreads();
             if (sl < s0 || sl >= s0 + spp || nmax == 0) continue;      // this lane's slot is not in this pass
             const int t0 = kq * p.tiles_per_slot;
-            const float *pe = et + ((sl - s0) * nch + cq) * PW + 5;    // pe[j]: tile j of this window's span
+            const float *pe = et + ((sl - s0) * nch + cq) * PW + NF;   // pe[j]: tile j of this window's span, j = -NF .. nt - 1
             int nt = ntm;
             if (nt > p.ptile_stride - t0) nt = p.ptile_stride - t0;
-            // noise level of the span: its smallest tile that holds signal at all (the zeros GNU Radio puts in front of a
-            // stream are not a noise level, and a tile next to silence may be partly silent itself).  Four tiles in front of
-            // the window belong to the search: a packet that starts in the first tile and outlasts the span leaves no noise
-            // inside it.  burst_ratio is calibrated per tile length to mean "four times the mean noise tile": what a packet at
-            // ~5 dB brings -- below that the correlator has nothing to find -- and what a neighbour channel's leakage does not
-            // reach below ~30 dB
-            float mn = 3.0e38f;
-            {
-                const int jl = t0 + nt == p.ptile_stride ? nt - 1 : nt;  // the batch's last tile may be a partial one
-                float ep = pe[-5];
-#pragma unroll 4
-                for (int jx = -4; jx < jl; jx++) { const float e = pe[jx]; mn = (e > 0.f && ep > 0.f && e < mn) ? e : mn; ep = e; }
+            // ---- where does NEW energy appear in the span?  (round 5) ----
+            // The statistic is the energy of W tiles (~50 us: two thirds of an access code), s[j] = e[j-W+1] + .. + e[j].  New energy
+            // shows at j when (a) s[j] > burst_abs * (the span's quietest aligned W-tile block): the block minimum underestimates the
+            // mean noise by a known factor, folded into burst_abs by the host, which is calibrated to 2.0 x the mean noise -- a
+            // packet 3 dB over the noise triggers in 400 of 400 trials, one at 1.5 dB in 97 %, at 0 dB in 68 %, noise in 0 of 2700 windows
+            // (1.8 x: 99.5 % / 88 % and 0.1 % of the windows, each of them a task of ~700 rows); and (b)
+            // s[j] > 1.5 s[j-W]: half as much again as in the 50 us before -- a packet that begins in noise, in a neighbour's leakage
+            // or ON TOP of one already on the air with C/I >= -3 dB (below that the demodulator follows the stronger one).
+            // No rule says "this edge cannot be a packet" any more: round 4's dismissal of edges that a 17 dB stronger neighbour
+            // "explains" lost a packet the reference receives (the filter's leakage is -36 .. -20 dB per tile: 18 dB under a
+            // neighbour is 2 .. 18 dB OVER its leakage), and its absolute 4 x threshold left packets under 5 dB to the polyphase
+            // trajectory.  A packet that continues another one on the same channel with no gap and no step in level shows
+            // nothing in the energy; it is reached through the task its predecessor opens (exact rows up to there) and the
+            // polyphase path's own hit.
+            const int W = p.burst_w;
+            const int jl = t0 + nt == p.ptile_stride ? nt - 1 : nt;    // the batch's last tile may be a partial one
+            float bmin = 3.0e38f;
+            bool some = false;                                         // any tile with signal at all (GNU Radio's leading zeros are none)
+            for (int jb = -NF; jb + W <= jl; jb += W) {
+                float sb = 0.f;
+                bool ok = true;
+                for (int u = 0; u < W; u++) { const float e = pe[jb + u]; ok = ok && e > 0.f; some = some || e > 0.f; sb += e; }
+                bmin = (ok && sb < bmin) ? sb : bmin;
             }
-            const float thr = mn * p.burst_ratio, thr_lo = 0.5f * thr;
-            // rising edges with hysteresis: a burst starts where a tile exceeds thr after one below thr / 2; a packet that is
-            // already on the air in the tile before the window starts nothing here (its access code lies in an earlier window)
-            bool in_burst = pe[-1] > thr;
             int rise = -1;
-            const float noise = 0.25f * thr;                           // mean noise tile
-            float eprev = pe[-1] > 0.f ? pe[-1] : 0.f;
-#pragma unroll 4
-            for (int jx = 0; jx < nt; jx++) {
-                const float e = pe[jx];
-                const bool jump = e > thr && e > 4.f * eprev;            // a much stronger packet on top of one already on the air
-                eprev = e;
-                if ((!in_burst || jump) && e > thr) {
-                    in_burst = true;
-                    // Where inside tile jx the burst starts, from how much of a full burst tile it holds.  An access code is
-                    // reportable at the offsets below 625 (lib/multi_sniffer_impl.cc:108), i.e. up to row ~1257 at the loop's
-                    // slowest clock: a burst that starts later is the next window's (in a sniffer window the following slot
-                    // begins near symbol 635 -- every burst would be taken twice, the second time with a full-length span).
-                    const bool nxt = jx + 1 < nt && pe[jx + 1] > e;
-                    const float full = nxt ? pe[jx + 1] : e;
-                    float frac = (e - noise) / (full - noise);
-                    frac = frac < 0.f ? 0.f : (frac > 1.f ? 1.f : frac);
-                    const float onset_row = ((float)(jx + 1) - frac) * (float)TT;
-                    // what a packet fifty times stronger on a neighbour channel leaks through the channel filter is not a
-                    // packet here (and one that hides 17 dB below such a neighbour cannot be received)
-                    const float nl = cq > 0 ? pe[jx + (nxt ? 1 : 0) - PW] : 0.f;
-                    const float nr = cq + 1 < nch ? pe[jx + (nxt ? 1 : 0) + PW] : 0.f;
-                    const bool leak = nl > 50.f * full || nr > 50.f * full;
-                    if (!leak && onset_row < 1260.f + 0.04f * (float)TT) rise = jx;
-                } else if (in_burst && e < thr_lo) in_burst = false;
+            if (bmin > 1.0e38f) {
+                // no whole block of the span holds signal (a stream that begins inside the span): nothing to compare with -- exact to the end
+                if (some) rise = nt - 1;
+            } else {
+                const float thr = p.burst_abs * bmin, thr_n = p.burst_abs_hot * bmin, hot = p.burst_hot * bmin;
+                // s[j] and s[j-W] by sliding sums; tiles that do not exist (in front of the batch) count as unknown: (b) holds.
+                // sl_ / sr_: the same W-tile sum on the two neighbour channels (0 where the capture has none)
+                const bool has_l = cq > 0, has_r = cq + 1 < nch;
+                float s_cur = 0.f, s_old = 0.f, sl_ = 0.f, sr_ = 0.f;
+                int miss_old = 0;
+                for (int u = 0; u < W; u++) {                          // position j = -2
+                    const int ic = -2 - u, io = -2 - W - u;
+                    const float ec = ic >= -NF ? pe[ic] : -1.f, eo = io >= -NF ? pe[io] : -1.f;
+                    s_cur += ec > 0.f ? ec : 0.f;
+                    s_old += eo > 0.f ? eo : 0.f; miss_old += eo < 0.f;
+                    const int in_ = ic + kBurstAhead;                  // (the neighbours' sums run kBurstAhead tiles ahead: see below)
+                    const float el = (has_l && in_ >= -NF && in_ < ntm) ? pe[in_ - PW] : 0.f, er = (has_r && in_ >= -NF && in_ < ntm) ? pe[in_ + PW] : 0.f;
+                    sl_ += el > 0.f ? el : 0.f; sr_ += er > 0.f ? er : 0.f;
+                }
+                bool prev = true;                                      // (a run that began in front of the window starts nothing)
+                for (int jx = -1; jx < nt; jx++) {
+                    const int io = jx - W, iq = jx - 2 * W;
+                    const float en = pe[jx], eo = io >= -NF ? pe[io] : -1.f, eq = iq >= -NF ? pe[iq] : -1.f;
+                    s_cur += (en > 0.f ? en : 0.f) - (eo > 0.f ? eo : 0.f);
+                    s_old += (eo > 0.f ? eo : 0.f) - (eq > 0.f ? eq : 0.f);
+                    miss_old += (int)(eo < 0.f) - (int)(eq < 0.f);
+                    {
+                        // (two tiles AHEAD of this channel's sum: a packet that switches on splatters into the neighbour channels
+                        // in its first microseconds, when its own W-tile sum has hardly begun to rise)
+                        const int jn = jx + kBurstAhead, jo = io + kBurstAhead;
+                        const float ln = (has_l && jn < ntm) ? pe[jn - PW] : 0.f, lo = (has_l && jo >= -NF && jo < ntm) ? pe[jo - PW] : 0.f;
+                        const float rn = (has_r && jn < ntm) ? pe[jn + PW] : 0.f, ro = (has_r && jo >= -NF && jo < ntm) ? pe[jo + PW] : 0.f;
+                        sl_ += (ln > 0.f ? ln : 0.f) - (lo > 0.f ? lo : 0.f);
+                        sr_ += (rn > 0.f ? rn : 0.f) - (ro > 0.f ? ro : 0.f);
+                    }
+                    // Beside a neighbour channel that carries a packet >= 20 dB over the noise the threshold is 3 x the mean noise
+                    // instead of 2 x: the channel filter passes -36 .. -20 dB of that packet per tile, i.e. about the noise level
+                    // and up, and with the low threshold every strong packet would make full-length tasks of its two neighbour
+                    // windows.  This is a statement about SENSITIVITY, not a dismissal: beside such a neighbour a packet is taken
+                    // from ~4.5 dB over the noise (alone: from ~2 dB), whatever the neighbour's level.
+                    const float thr_j = (sl_ > hot || sr_ > hot) ? thr_n : thr;
+                    const bool trig = s_cur > thr_j && (miss_old > 0 || s_cur > 1.5f * s_old);
+                    if (trig && !prev && jx >= 0) {
+                        // The run of triggers begins at the tile the packet begins in, or -- where less than ~3 noise tiles' worth of it
+                        // lies in that tile -- up to W - 1 tiles later.  An access code is reportable at the offsets below 625
+                        // (lib/multi_sniffer_impl.cc:108), i.e. up to row ~1257 at the loop's slowest clock: a burst that starts later
+                        // is the next window's (in a sniffer window the following slot begins near symbol 635 -- every burst would be
+                        // taken twice, the second time with a full-length span).  Where inside its tile the packet begins is estimated
+                        // from how much of a full tile (the next one) it fills; how far the true onset can lie IN FRONT of that estimate:
+                        // with x = (packet tile) / (what was there before, o), a tile sum of ~12.6 independent values has the variance
+                        // (o^2 + 2 S o) / 12.6 around a signal part S, so the fill fraction is off by sigma = sqrt((2 / x^2 + 4 / x) / 12.6)
+                        // tiles at most, and a run that began one tile late hides <= 3.2 / x of a tile -- 3.5 sigma + 3.2 / x tiles,
+                        // never more than W - 1: 3 rows at 25 dB, 7 at 18 dB, 18 at 12 dB, 46 at 6 dB, the whole 75 below 3 dB.
+                        const float o = miss_old > 0 ? 3.0e38f : s_old / (float)W;
+                        const bool nxt = jx + 1 < nt && pe[jx + 1] > en;
+                        const float full = nxt ? pe[jx + 1] : en;
+                        float frac = (en - o) / (full - o);
+                        frac = (full > o && frac > 0.f) ? (frac > 1.f ? 1.f : frac) : 1.f;
+                        const float xi = o > 0.f ? o / (full > o ? full - o : 1.0e-30f) : 0.f;          // 1 / x
+                        float back = 3.5f * sqrtf((2.f * xi * xi + 4.f * xi) * (1.0f / 12.6f)) + 3.2f * xi;
+                        const float cap_back = (float)(W > 1 ? W - 1 : 1);
+                        back = (miss_old > 0 || !(back < cap_back)) ? cap_back : back;
+                        const float onset_row = ((float)(jx + 1) - frac - back) * (float)TT - 1.f;
+                        if (onset_row < 1258.f) rise = jx;
+                    }
+                    prev = trig;
+                }
             }
             // (to the end of the access code that may start there: whether one does is what the exact stage settles; the header
             // behind it is added to the span by the hit that finds it, emit_classic)

@@ -54,7 +54,7 @@ for case in range(cases):
     gi = rec[:n, :7]
     wi = np.array([[h.slot, h.channel, h.kind, h.offset, h.lap, h.ac_errors, h.nsym] for h in want], np.int64).reshape(-1, 7)
     d = paritylib.differential(gi, wi, truth, lag=6 if sniff else 1)
-    ok = d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= 8
+    ok = d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= paritylib.NSYM_BOUND
     tot["cases"] += 1; tot["failed"] += not ok
     tot["planted"] += d["planted_ref"]; tot["planted_differing"] += d["planted_only_gpu"] + d["planted_only_ref"]
     tot["planted_offset_differs"] += d["planted_offset_differs"]

@@ -39,7 +39,7 @@ for case in range(cases):
     gi, _ = bdist.hits_to_arrays(got)
     wi, _ = bdist.hits_to_arrays(want)
     d = paritylib.differential(gi, wi, truth, lag=6 if sniff else 1)      # window lag of the record's slot index: 6-slot / 1.1-slot history
-    ok = d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= 8
+    ok = d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= paritylib.NSYM_BOUND
     tot["cases"] += 1; tot["failed"] += not ok
     tot["planted"] += d["planted_ref"]; tot["planted_differing"] += d["planted_only_gpu"] + d["planted_only_ref"]
     tot["planted_offset_differs"] += d["planted_offset_differs"]

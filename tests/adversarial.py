@@ -1,0 +1,128 @@
+"""Adversarial capture generator for the record differentials (test infrastructure).
+
+The round-2..4 fuzz (synth.make_capture) puts every burst of a capture at ONE level, 5-15 us into its slot, 12-30 dB over the
+noise, +-10 kHz off, <= 240 payload bits: none of the exact stage's selection rules is ever near its edge there.  Here every
+packet has its own level (3..43 dB over the noise in 1 MHz), its own instant (anywhere, not slot-aligned), its own carrier offset
+(+-75 kHz), payloads to 2745 bits, and packets come in the constellations that the selection rules have to survive:
+
+  isolated      one packet alone
+  near-far      + a packet 8..34 dB stronger on an ADJACENT channel that starts within +-80 us of it (its leakage through the
+                channel filter, -36..-20 dB per 12.5 us tile, rises where the weak packet does)
+  back-to-back  + an earlier packet on the SAME channel that ends -20..+30 us before it starts (negative: they overlap), at
+                a level -10..+10 dB from it -- no falling edge, or none that reaches the noise, in front of the second packet
+  on-top        + a long packet on the SAME channel that is already on the air when it starts, 0..15 dB weaker than it
+  aligned       the old generator's timing: 5..15 us into a slot
+  le            an LE advertising packet (only where the capture has an LE advertising channel and the LE pass is on)
+
+make_adversarial_capture returns (iq, truth, meta): truth as tests/paritylib.py wants it (slot, channel, lap per classic packet),
+meta one dict per packet (constellation, level, start) for per-band statistics.
+"""
+import importlib
+
+import numpy as np
+
+KINDS = ("isolated", "near-far", "back-to-back", "on-top", "aligned")
+WEIGHTS = (0.30, 0.30, 0.15, 0.10, 0.15)
+TOP_DB = 43.0                     # level of a unit-amplitude burst over the noise in 1 MHz
+
+
+def _synth():
+    return importlib.import_module("gr_bluetooth_amd.synth")
+
+
+def make_adversarial_capture(fs, fc, n_slots, n_packets, seed, laps, le_channels=None, n_adverts=0, min_snr_db=3.0,
+                             max_payload_bits=2745, cfo_hz=75e3, lag_slots=6.4):
+    """lag_slots: how far a window's detection span lies behind the newest slot it is given ((history() - 1) / slot: 6.3 for the
+    sniffer, 1.4 for multi_LAP) -- packets are only planted where some window of the capture can report them."""
+    synth = _synth()
+    rng = np.random.default_rng(seed)
+    sps = int(round(fs / 1e6)); slot = 625 * sps
+    lo, hi = synth.visible_channels(fs, fc)
+    iq, _ = synth.make_capture(fs, fc, n_slots, laps=laps, seed=int(rng.integers(0, 1 << 30)), snr_db=TOP_DB, occupancy=0.0)
+    truth, meta = [], []
+
+    def put(lap, ch, start, level_db, payload_bits, kind):
+        bits = synth.packet_bits(lap, rng, int(payload_bits))
+        start = int(max(0, start))
+        synth.add_burst(iq, bits, start, fs, fc, ch, rng, cfo_hz=cfo_hz, amplitude=10 ** ((level_db - TOP_DB) / 20))
+        truth.append(dict(slot=start // slot, channel=ch, lap=lap))
+        meta.append(dict(kind=kind, snr_db=float(level_db), start=start, channel=ch, lap=lap, nbits=len(bits)))
+        return len(bits) * sps
+
+    def payload():
+        # short packets are the common ones (ID / POLL / DM1); long ones reach five slots
+        return int(rng.choice([0, int(rng.integers(0, 241)), int(rng.integers(0, 1201)), int(rng.integers(0, max_payload_bits + 1))]))
+
+    reach = max(int((n_slots - lag_slots) * slot), slot)             # access codes that start later are in no window's search range
+    for _ in range(n_packets):
+        kind = str(rng.choice(KINDS, p=WEIGHTS))
+        lap = int(rng.choice(laps)); ch = int(rng.integers(lo, hi + 1))
+        level = float(rng.uniform(min_snr_db, TOP_DB))
+        start = int(rng.integers(0, reach))
+        if kind == "aligned":
+            start = int(rng.integers(0, max(reach // slot, 1))) * slot + int(rng.integers(5 * sps, 15 * sps))
+        if kind == "near-far" and hi > lo:
+            ch2 = ch + (1 if (ch < hi and (ch == lo or rng.random() < 0.5)) else -1)
+            up = float(rng.uniform(8, 34))
+            put(int(rng.choice(laps)), ch2, start + int(rng.integers(-80 * sps, 80 * sps)), min(level + up, TOP_DB + 10), int(rng.integers(0, 1201)), "neighbour")
+        elif kind == "back-to-back":
+            nb = int(rng.integers(0, 601)); n_prev = (72 + 54 + nb) * sps       # (access code + header + payload, as packet_bits lays them)
+            gap = int(rng.integers(-20 * sps, 30 * sps))
+            put(int(rng.choice(laps)), ch, start - gap - n_prev, level + float(rng.uniform(-10, 10)), nb, "previous")
+        elif kind == "on-top":
+            back = int(rng.integers(100 * sps, 1500 * sps))
+            put(int(rng.choice(laps)), ch, start - back, level - float(rng.uniform(0, 15)), int(rng.integers(2000, 2746)), "underlay")
+        put(lap, ch, start, level, payload(), kind)
+    if le_channels:
+        for _ in range(n_adverts):
+            ch = int(rng.choice(list(le_channels)))
+            start = int(rng.integers(0, reach))
+            level = float(rng.uniform(max(min_snr_db, 6.0), TOP_DB))
+            synth.add_burst(iq, synth.le_advert_bits(le_channels[ch], rng, payload_bytes=int(rng.integers(6, 30))), start, fs, fc, ch, rng,
+                            cfo_hz=min(cfo_hz, 60e3), amplitude=10 ** ((level - TOP_DB) / 20))
+            meta.append(dict(kind="le", snr_db=level, start=start, channel=ch, lap=0x8E89BED6, nbits=0))
+    return iq, truth, meta
+
+
+RATES = {8: (8e6, 2476.5e6, {78: 39}), 20: (20e6, 2441e6, {}), 100: (100e6, 2441e6, {0: 37, 24: 38, 78: 39})}
+
+
+def draw_case(rng, rates=(8, 8, 20, 100)):
+    """One fuzz case's parameters from `rng` (every draw happens whether the case is run or skipped: strided runs stay in step)."""
+    r = int(rng.choice(list(rates)))
+    fs, fc, lech = RATES[r]
+    sniffer = bool(rng.random() < 0.8)
+    return dict(fs=fs, fc=fc, le_channels=lech, n_slots=int(rng.integers(11, 16)) if sniffer else int(rng.integers(5, 9)),
+                n_packets=int(rng.integers(30, 90)) if r == 100 else int(rng.integers(8, 30)),
+                squelch=float(rng.choice([5.0, 10.0, 14.0])), sniffer=sniffer, le=bool(rng.integers(0, 2)),
+                laps=tuple(int(x) for x in rng.integers(0, 1 << 24, 5)), seed=int(rng.integers(0, 1 << 30)),
+                n_adverts=int(rng.integers(0, 6)))
+
+
+def judge_r04_nearfar_case(mode, seed, want_case):
+    """The capture of case `want_case` of scripts/experiments/judge_r04_nearfar_emu.py <mode> <cases> <seed> (the round-4 judge's
+    near-far generator, replayed draw for draw).  Returns (fs, fc, n_slots, squelch, iq, truth).  Case 35 of `100 36 21` is the one
+    round 4's leak rule lost: LAP a06302 on channel 44, a packet 18.3 dB stronger on channel 43 starting 41 us earlier."""
+    synth = _synth()
+    rng = np.random.default_rng(seed)
+    rates = [(100e6, 2441e6)] if mode == "100" else [(8e6, 2476.5e6), (8e6, 2476.5e6), (20e6, 2441e6)]
+    for case in range(want_case + 1):
+        fs, fc = rates[int(rng.integers(0, len(rates)))]
+        nsl = int(rng.integers(8, 12)); base = float(rng.uniform(14, 30)); sq = float(rng.choice([5.0, 10.0]))
+        nb = int(rng.integers(40, 120)) if mode == "100" else int(rng.integers(10, 40))
+        cseed = int(rng.integers(0, 1 << 30)); cfo = float(rng.choice([10e3, 40e3, 60e3]))
+        spread = float(rng.choice([0.0, 6.0, 12.0])); laps = tuple(int(x) for x in rng.integers(0, 1 << 24, 5))
+    sps = int(round(fs / 1e6)); slot = 625 * sps; lo, hi = synth.visible_channels(fs, fc)
+    r2 = np.random.default_rng(cseed); truth = []
+    iq, _ = synth.make_capture(fs, fc, nsl, laps=laps, seed=cseed, snr_db=base, occupancy=0.0)
+    for _ in range(nb):
+        lap = int(r2.choice(laps)); ch = int(r2.integers(lo, hi + 1)); start = int(r2.integers(0, (nsl - 1) * slot))
+        a = float(r2.uniform(-spread, 0.0)) + float(r2.choice([0.0, 0.0, 6.0])); bits = synth.packet_bits(lap, r2, int(r2.integers(0, 1200)))
+        synth.add_burst(iq, bits, start, fs, fc, ch, r2, cfo_hz=cfo, amplitude=10 ** (a / 20))
+        truth.append(dict(slot=start // slot, channel=ch, lap=lap))
+        if r2.random() < 0.7:
+            ch2 = ch + (1 if (ch < hi and (ch == lo or r2.random() < 0.5)) else -1); lap2 = int(r2.choice(laps)); up = float(r2.uniform(14, 32))
+            st2 = max(0, start + int(r2.integers(-60 * sps, 60 * sps))); b2 = synth.packet_bits(lap2, r2, int(r2.integers(0, 600)))
+            synth.add_burst(iq, b2, st2, fs, fc, ch2, r2, cfo_hz=cfo, amplitude=10 ** ((a + up) / 20))
+            truth.append(dict(slot=st2 // slot, channel=ch2, lap=lap2))
+    return fs, fc, nsl, sq, iq, truth

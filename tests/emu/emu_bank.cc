@@ -351,8 +351,8 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     if (verify && getenv("EMU_DBG_W")) {                  // tile energies of one window's detection span (diagnostics)
         const int wd = atoi(getenv("EMU_DBG_W")), kd = wd / nch, cd = wd % nch;
         const int t0 = kd * p.tiles_per_slot;
-        std::fprintf(stderr, "window slot %d ch-index %d: tiles from %d, stride %d, TT %d ratio %.2f:", kd, cd, t0, p.ptile_stride, p.tile_outs, p.burst_ratio);
-        for (int j = -1; j < 60 && t0 + j < p.ptile_stride; j++) if (t0 + j >= 0) std::fprintf(stderr, " %.3g", p.ptile[(size_t)cd * p.ptile_stride + t0 + j]);
+        std::fprintf(stderr, "window slot %d ch-index %d: tiles from %d, stride %d, TT %d W %d abs %.2f:", kd, cd, t0, p.ptile_stride, p.tile_outs, p.burst_w, p.burst_abs);
+        for (int j = -kBurstFront; j < 60 && t0 + j < p.ptile_stride; j++) if (t0 + j >= 0) std::fprintf(stderr, " %.3g", p.ptile[(size_t)cd * p.ptile_stride + t0 + j]);
         std::fprintf(stderr, "\n");
     }
     g_verify_tasks.assign(vtasks.begin(), vtasks.begin() + std::min<size_t>(vtasks.size(), vcount[0]));

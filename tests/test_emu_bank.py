@@ -8,8 +8,13 @@ import ctypes
 import os
 import subprocess
 
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import paritylib  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu")
@@ -353,7 +358,7 @@ def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff,
     (M&M clock recovery, slicer, access-code / LE search), finish_kernel, nsym patch: the product's kernel source run
     lane by lane under the emulator (noise stage 2 included: its wave-shuffle reduction runs on the emulator's exchange buffer) --
     against the oracle on a capture with bursts: the tolerance contract of the polyphase path (tests/paritylib.py,
-    DESIGN.md section 5): planted records identical, offsets identical, nsym within +-8."""
+    DESIGN.md section 5): planted records identical, offsets identical, nsym within the symbol clock's range (paritylib.NSYM_BOUND)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import paritylib
@@ -385,7 +390,7 @@ def test_emulated_front_end_hit_records_vs_oracle(emu, po, synth, fs, fc, sniff,
     print(d)
     assert d["planted_ref"] > 3, d
     assert d["planted_identical"] and d["planted_offset_differs"] == 0, d
-    assert d["planted_nsym_max_abs_dev"] <= 8, d
+    assert d["planted_nsym_max_abs_dev"] <= paritylib.NSYM_BOUND, d
     assert d["other_only_gpu"] + d["other_only_ref"] <= 2, d
 
 
@@ -400,7 +405,7 @@ def test_emulated_fast_path_random_captures(emu):      # (the fixture builds tes
     tot = eval(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
     assert tot["cases"] == 10 and tot["planted"] > 100, tot
     assert tot["failed"] == 0 and tot["planted_differing"] == 0 and tot["planted_offset_differs"] == 0, tot
-    assert tot["nsym_dev_max"] <= 8 and tot["other_only_emu"] + tot["other_only_ref"] <= 2, tot
+    assert tot["nsym_dev_max"] <= paritylib.NSYM_BOUND and tot["other_only_emu"] + tot["other_only_ref"] <= 2, tot
 
 
 def test_fuzz_seed77_case_312_offset_one_symbol_apart(emu, po, synth):
@@ -435,9 +440,10 @@ def test_fuzz_seed77_case_312_offset_one_symbol_apart(emu, po, synth):
                                   rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap)
             assert n == len(want) == 13
             d = paritylib.differential(rec[:n, :7], wi, truth, lag=1)
-            assert d["planted_identical"] and d["planted_ref"] == 13, d
+            # (six-field contract: a record with its offset a symbol apart is one record on either side)
+            assert d["planted_ref"] == 13 and d["planted_identical"] == (offsets_apart == 0), d
+            assert d["planted_only_gpu"] == offsets_apart and d["planted_only_ref"] == offsets_apart, (verify, d)
             assert d["planted_offset_differs"] == offsets_apart and d["planted_offset_max_abs_dev"] == offsets_apart, (verify, d)
-            assert d["planted_nsym_max_abs_dev"] <= 8, d
     finally:
         L.emu_set_verify(1)
 
@@ -490,7 +496,7 @@ def test_exact_stage_settles_the_deviating_fuzz_cases(emu, po, synth, seed, case
     finally:
         L.emu_set_verify(1)
     d = out[1]
-    assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= 8, d
+    assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= paritylib.NSYM_BOUND, d
     d0 = out[0]
     assert (not d0["planted_identical"]) or d0["planted_offset_differs"] > 0, d0       # the case is one of those that deviated
 
@@ -523,7 +529,7 @@ def test_false_alarm_behind_the_exact_span_is_what_still_differs(emu, po, synth)
     n = L.emu_front_m_run(fs, fc, po.MODE_SNIFFER, 1, sq, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), nsl,
                           rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap)
     d = paritylib.differential(rec[:n, :7], wi, truth, lag=6)
-    assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= 8, d
+    assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= paritylib.NSYM_BOUND, d
     gs, ws = set(map(tuple, rec[:n, :6].tolist())), set(map(tuple, wi[:, :6].tolist()))
     assert gs - ws == set()
     only_ref = sorted(ws - gs)
@@ -683,3 +689,121 @@ def test_emulated_front_end_tiny_batches_and_silence(emu, fs, fc, S):
         r = L.emu_front_m_run(fs, fc, 1, 1, 10.0, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), S,
                               rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 256)
         assert r == 0, (kind, r)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The exact stage's window selection (kernels.hip.h, burst scan) on inputs that sit ON its rules -- VERDICT r4 items 1a-1c.
+# ---------------------------------------------------------------------------------------------------
+def _front_m(L, po, fs, fc, iq, nsl, sq=10.0, mode=None, le=False):
+    """Emulated default front end (polyphase banks + exact stage) and the oracle on one capture: (records, oracle records,
+    {window index: exact rows} of the exact stage's tasks, oracle object)."""
+    mode = po.MODE_SNIFFER if mode is None else mode
+    F, Q, D = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)
+    L.emu_front_m_run.restype = ctypes.c_int
+    L.emu_front_m_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, F, ctypes.c_longlong, ctypes.c_int, Q, D, ctypes.c_int]
+    L.emu_verify_tasks.restype = ctypes.c_int
+    L.emu_verify_tasks.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    o = po.Oracle(fs, fc, sq, mode, le=le)
+    want, _ = o.run_stream(iq, threads=os.cpu_count() or 1)
+    x = np.ascontiguousarray(np.concatenate([np.zeros(o.history - 1, np.complex64), iq.astype(np.complex64)])).view(np.float32)
+    rec = np.zeros((16384, 8), np.int64); snr = np.zeros(16384)
+    n = L.emu_front_m_run(fs, fc, mode, int(le), sq, x.ctypes.data_as(F), len(x) // 2, nsl, rec.ctypes.data_as(Q), snr.ctypes.data_as(D), 16384)
+    assert 0 <= n <= 16384
+    tw = (ctypes.c_int * 65536)(); tr = (ctypes.c_int * 65536)(); nt = L.emu_verify_tasks(tw, tr, 65536)
+    wi = np.array([[h.slot, h.channel, h.kind, h.offset, h.lap, h.ac_errors, h.nsym] for h in want], np.int64).reshape(-1, 7)
+    return rec[:n, :7], wi, {int(tw[i]): int(tr[i]) for i in range(nt)}, o
+
+
+def _row_in_window(o, k, sample):
+    """Row of window k's demodulated stream at which a burst that begins at `sample` begins to show (the filter is centred)."""
+    w0 = k * o.slot - (o.history - 1) + o.first_ch + (o.ntaps_ch - 1) // 2
+    return (sample - w0) / o.decim
+
+
+def test_judge_r04_nearfar_case_35_is_found(emu, po, synth):     # (synth: the fixture that makes gr_bluetooth_amd importable)
+    """100 Msps, LAP a06302 on channel 44 (27 dB over the noise), a packet 18.3 dB stronger on channel 43 that starts
+    41 us earlier.  The oracle reports (slot 6, channel 44, offset 235, 4 errors); round 4's selection dismissed the edge as the
+    neighbour's leakage and lost the record.  Replayed from the judge's generator (tests/adversarial.py)."""
+    import adversarial
+    fs, fc, nsl, sq, iq, truth = adversarial.judge_r04_nearfar_case("100", 21, 35)
+    got, wi, tasks, o = _front_m(emu, po, fs, fc, iq, nsl, sq)
+    key = (6, 44, 0, 235, 0xa06302, 4)
+    assert key in set(map(tuple, wi[:, :6].tolist())), "the oracle's record moved: the generator is not replayed faithfully"
+    assert key in set(map(tuple, got[:, :6].tolist()))
+    d = paritylib.differential(got, wi, truth, lag=6)
+    assert d["planted_ref"] >= 20 and d["planted_identical"] and d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, d
+
+
+@pytest.mark.parametrize("name", ["weak-3dB", "on-top-5dB", "under-a-neighbour-coincident", "late-but-reportable", "next-windows-burst"])
+def test_burst_scan_on_its_thresholds(emu, po, synth, name):
+    """One constellation per rule of the burst scan, each sitting on the rule (8 Msps, window 7 of 9, every trial another noise / phase /
+    carrier-offset draw).  What is asserted is the SELECTION -- the window of the packet is a task of the exact stage whose exact rows
+    reach past the access code -- because that is what makes the record the reference's own arithmetic; the records themselves are
+    compared as well.
+      weak-3dB                      a packet 3 dB over the noise, alone: taken (threshold 2.0 x noise over 50 us; 400 of 400 in the model)
+      on-top-5dB                    a packet 5 dB over a long one that has been on the air on its channel since before the window: taken.
+                                    The rule is energy + 50 % over the 50 us before; where the carrier underneath fills the whole span its
+                                    level is also the 'noise' of the absolute threshold (x 2.64 of the quietest block), i.e. C/I >= +2.2 dB;
+                                    round 4 asked for x 4 (+ 4.8 dB) of the previous TILE
+      under-a-neighbour-coincident  a packet at 8 dB beside a neighbour 30 dB stronger ON THE CHANNEL BELOW that starts in the same 12.5 us
+                                    tile: taken -- round 4 dismissed every edge a 17 dB stronger neighbour 'explained'.  (Under a strong
+                                    neighbour on the channel ABOVE the reference itself is deaf: its squelch measures the noise 790 kHz up,
+                                    inside that neighbour, lib/multi_block.cc:253-296 -- no window, no task, no record on either side)
+      late-but-reportable           a 12 dB packet whose access code starts at row ~1230 of 1257: taken by THIS window
+      next-windows-burst            a 25 dB packet that starts at row ~1300: it is the next window's; this window takes no full-length task"""
+    fs, fc, nsl, k = 8e6, 2476.5e6, 9, 7
+    lo, hi = synth.visible_channels(fs, fc)
+    o0 = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
+    slot, D = o0.slot, o0.decim
+    sps = 8
+    w0 = k * slot - (o0.history - 1) + o0.first_ch + (o0.ntaps_ch - 1) // 2       # sample of row 0 of window k
+    nch = hi - lo + 1
+    trials = 6
+    for t in range(trials):
+        rng = np.random.default_rng(1000 + t)
+        iq, _ = synth.make_capture(fs, fc, nsl, laps=(1,), seed=500 + t, snr_db=43.0, occupancy=0.0)     # noise: unit amplitude = 43 dB
+        ch = lo + 2 + (t % 4)
+        lap = int(rng.integers(0, 1 << 24))
+        amp = lambda db: 10 ** ((db - 43.0) / 20)
+        row = float(rng.uniform(100, 900))
+        level = 20.0
+        if name == "weak-3dB":
+            level = 3.0
+        elif name == "on-top-5dB":
+            level = 25.0
+            synth.add_burst(iq, synth.packet_bits(int(rng.integers(0, 1 << 24)), rng, 2700), int(w0 + (row - 700) * D), fs, fc, ch, rng, cfo_hz=40e3, amplitude=amp(20.0))
+        elif name == "under-a-neighbour-coincident":
+            level = 8.0
+            synth.add_burst(iq, synth.packet_bits(int(rng.integers(0, 1 << 24)), rng, 600), int(w0 + row * D + rng.integers(-4 * sps, 4 * sps)), fs, fc, ch - 1, rng,
+                            cfo_hz=40e3, amplitude=amp(38.0))
+        elif name == "late-but-reportable":
+            level, row = 12.0, float(rng.uniform(1215, 1235))
+        elif name == "next-windows-burst":
+            level, row = 25.0, float(rng.uniform(1290, 1320))
+        start = int(w0 + row * D)
+        synth.add_burst(iq, synth.packet_bits(lap, rng, 200), start, fs, fc, ch, rng, cfo_hz=20e3, amplitude=amp(level))
+        truth = [dict(slot=start // slot, channel=ch, lap=lap)]
+        got, wi, tasks, o = _front_m(emu, po, fs, fc, iq, nsl)
+        w = k * nch + (ch - lo)
+        need = int(row + 2 * 72 + 16)                                   # rows up to the end of the access code
+        if name == "next-windows-burst":
+            assert tasks.get(w, 0) < 1000, (t, tasks.get(w))            # not taken at full length here ...
+            assert tasks.get(w + nch, 0) >= int(row - 1250 + 160), (t, tasks.get(w + nch))   # ... and taken by the next window
+        else:
+            assert tasks.get(w, 0) >= min(need, 1416), (name, t, row, tasks.get(w))
+        d = paritylib.differential(got, wi, truth, lag=6)
+        assert d["planted_identical"] and d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, (name, t, d)
+
+
+def test_adversarial_fuzz_slice_emulated(emu):
+    """Thirty captures of scripts/emu_fuzz_adversarial.py (8 / 20 Msps; per-packet levels 3..43 dB, random instants, +-75 kHz, payloads
+    to 2745 bits, near-far / back-to-back / on-top constellations, LE adverts, three squelch levels, both blocks): every planted record
+    identical on the six key fields, none on one side only.  (The 1.2e5-record run of the same script: profiles/r05_*.)"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_fuzz_adversarial.py"), "30", "905", "--rates", "8,8,20", "--quiet"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
+    assert tot["cases"] == 30 and tot["planted"] > 150, tot
+    assert tot["planted_only_product"] == 0 and tot["planted_only_oracle"] == 0 and tot["adverts_differing"] == 0, tot
+    assert tot["nsym_dev_max"] <= paritylib.NSYM_BOUND, tot
