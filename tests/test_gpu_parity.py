@@ -796,7 +796,7 @@ def test_randomised_differential_polyphase_path(pkg, po, synth, seed, cases):
     tot = dict(planted=0, verified=0)
     for c in cases:
         d, tm = _fast_differential(pkg, po, synth, _fuzz_fast_case(seed, c))
-        assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= paritylib.NSYM_BOUND, (seed, c, d)
+        assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= NSYM_BOUND, (seed, c, d)
         assert tm.verify_turned_away == 0
         tot["planted"] += d["planted_ref"]; tot["verified"] += int(tm.verify_windows)
     print("randomised differential, seed %d: %d captures, %d planted records identical, %d windows through the exact stage" %
