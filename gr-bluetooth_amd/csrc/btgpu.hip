@@ -74,7 +74,7 @@ struct btgpu_handle {
         DevBuf d_ptile, d_phead;              // polyphase banks: |Y|^2 tile sums (-> block_sum_kernel on the post stream)
         DevBuf d_pfine;                       // small-M F8 bank: |Y|^2 sums per 25 instants (the exact stage's burst scan)
         DevBuf d_Z;                           // staged squelch: stage-1 output (-> noise_stage2_kernel on the post stream)
-        DevBuf d_vtasks, d_vtiles, d_vcount, d_dx, d_dxt, d_winbits_v;
+        DevBuf d_vtasks, d_vtiles, d_vcount, d_dx, d_dxt, d_winbits_v, d_vinfo, d_vtstart;
         DevBuf d_eon, d_eoff, d_snr;          // E_on, E_off, SNR per window (window_kernel, or squelch_kernel when the squelch is deferred)   // exact confirmation (verify.hip.h): task list, exact rows, task stream
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
@@ -85,7 +85,7 @@ struct btgpu_handle {
         // stage 2, 8 window; tail 9 start, 10 end
         // ... 11 exact stage done (tail)
         hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr, squelch_done = nullptr;
+        hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr, squelch_done = nullptr, scan_done = nullptr, ddc1_done = nullptr;
         int S = 0;
         uint64_t abs_first_slot = 0;
         bool pending = false;
@@ -175,12 +175,12 @@ struct btgpu_handle {
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (TailCtx &t : tc) {
             DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol,
-                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_eon, &t.d_eoff, &t.d_snr};
+                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_vinfo, &t.d_vtstart, &t.d_eon, &t.d_eoff, &t.d_snr};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
             for (auto &e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-            for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+            for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.scan_done, &t.ddc1_done}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
             if (t.h_count) { (void)hipHostFree(t.h_count); t.h_count = nullptr; }
             if (t.h_hits) { (void)hipHostFree(t.h_hits); t.h_hits = nullptr; }
         }
@@ -377,6 +377,52 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     // kernel follows the banks directly on `ps`
     hipStream_t qs = deferred ? sq_stream : ps;
     if (deferred) HIPCHK(this, hipStreamWaitEvent(qs, t.front_done, 0));
+    // ---- window parameters, and the exact stage's burst scan right behind the banks (round 5) ----
+    WindowParams p = make_window_params(des, S, nb, ystride, max_hits, want_syms, (const uint64_t *)d_pcol.p);
+    { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
+    { static const int fp_ = getenv("BTGPU_FIN_PRIO") ? atoi(getenv("BTGPU_FIN_PRIO")) : 3; p.fin_prio = fp_; }
+    p.want_len = no_nsym ? 0 : 1;
+    p.deferred = deferred ? 1 : 0;
+    p.snr_arr = (const double *)t.d_snr.p;
+    // exact confirmation (verify.hip.h): the window kernel hands the windows that can carry a packet's record to the exact
+    // stage, which runs on the tail stream below (beside the next batch's banks)
+    VerifyBuffers vb;
+    if (verify) {
+        vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.tiles = (uint32_t *)t.d_vtiles.p; vb.vcount = (unsigned int *)t.d_vcount.p;
+        vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap; vb.tiles_cap = (unsigned int)verify_tiles_capacity(max_slots);
+        if (pfb_small && t.d_pfine.p && verify_has_fine(des, fp, drow))
+            set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_pfine.p, ntiles * (pfbm_tile(fp.channel.M) / 25), vb, want_syms, 25);
+        else
+            set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
+    }
+    // BTGPU_PRESCAN=0: the scan inside the window kernel and the DDC in line behind it (round 4's choreography, A/B)
+    static const bool prescan_env = !(getenv("BTGPU_PRESCAN") && atoi(getenv("BTGPU_PRESCAN")) == 0);
+    static const bool ddc_on_tail = getenv("BTGPU_VERIFY_TAIL") && atoi(getenv("BTGPU_VERIFY_TAIL")) == 1;
+    const bool prescan = prescan_env && verify == 1 && p.verify == 1 && !deferred && !ddc_on_tail && !pipelined;
+    VerifyParams vp{};
+    if (verify) vp = make_verify_params(des, x_len, w0, ver_mp, ver_F, (const float2 *)d_rot_ch.p, (const double *)d_rotstep_ch.p, (const float *)d_atan.p, vb);
+    if (prescan) {
+        p.prescan = 1; p.vinfo = (const int32_t *)t.d_vinfo.p;
+        auto launch_scan = [&](auto lay) {
+            using LAY = decltype(lay);
+            hipLaunchKernelGGL(burst_scan_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, ps, p, (int32_t *)t.d_vinfo.p);
+        };
+        if (drow == 80) launch_scan(WinLayout<3, 96, 20>{});
+        else if (drow == 40) launch_scan(WinLayout<6, 40, 10>{});
+        else if (drow == 20) launch_scan(WinLayout<12, 20, 5>{});
+        else if (drow == 8) launch_scan(WinLayout<32, 8, 2>{});
+        else launch_scan(WinLayout<64, 4, 1>{});
+        // the lists as the scan leaves them: the second DDC launch (below, on the tail) starts behind these entries
+        HIPCHK(this, hipMemcpyAsync(t.d_vtstart.p, (const unsigned int *)t.d_vcount.p + 4, (size_t)nch * sizeof(unsigned int), hipMemcpyDeviceToDevice, ps));
+        HIPCHK(this, hipEventRecord(t.scan_done, ps));
+        // the energy-selected tasks' DDC: on the side stream, beside squelch stage 2 (24 KB of LDS per workgroup) and the window kernel
+        HIPCHK(this, hipStreamWaitEvent(sq_stream, t.scan_done, 0));
+        {
+            const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
+            hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, sq_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+        }
+        HIPCHK(this, hipEventRecord(t.ddc1_done, sq_stream));
+    }
     HIPCHK(this, mark(5, qs));
     // tile sums -> block sums: as extra rows of the squelch stage-2 launch where both exist (a kernel of its own costs 0.05 ms
     // of launch ramp and tail for microseconds of work; on a side stream it saved those and cost 0.4 ms per step in
@@ -403,27 +449,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
 
     // ---- K3: squelch + M&M + slicer + access-code search ----
     {
-        WindowParams p = make_window_params(des, S, nb, ystride, max_hits, want_syms, (const uint64_t *)d_pcol.p);
-        { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
-        { static const int fp_ = getenv("BTGPU_FIN_PRIO") ? atoi(getenv("BTGPU_FIN_PRIO")) : 3; p.fin_prio = fp_; }
-        p.want_len = no_nsym ? 0 : 1;
-        p.deferred = deferred ? 1 : 0;
-        p.snr_arr = (const double *)t.d_snr.p;
         if (deferred) {
             hipLaunchKernelGGL(squelch_kernel, dim3((unsigned)(((long long)S * nch + 255) / 256)), dim3(256), 0, qs, p, (const double *)d_P.p,
                                (const double *)d_Pt.p, (const double *)d_Q.p, (double *)t.d_eon.p, (double *)t.d_eoff.p, (double *)t.d_snr.p);
             HIPCHK(this, hipEventRecord(t.squelch_done, qs));
-        }
-        // exact confirmation (verify.hip.h): the window kernel hands the windows that can carry a packet's record to the exact
-        // stage, which runs on the tail stream below (beside the next batch's banks)
-        VerifyBuffers vb;
-        if (verify) {
-            vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.tiles = (uint32_t *)t.d_vtiles.p; vb.vcount = (unsigned int *)t.d_vcount.p;
-            vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap; vb.tiles_cap = (unsigned int)verify_tiles_capacity(max_slots);
-            if (pfb_small && t.d_pfine.p && verify_has_fine(des, fp, drow))
-                set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_pfine.p, ntiles * (pfbm_tile(fp.channel.M) / 25), vb, want_syms, 25);
-            else
-                set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
         }
         auto launch_window = [&](auto lay) {
             using LAY = decltype(lay);
@@ -453,12 +482,8 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         // per workgroup fit beside neither the banks' tiles nor the window kernel's -- beside the next batch's front it took
         // 1.4 ms and stretched the bank from 1.24 to 1.6 and the window kernel from 0.32 to 0.6 ms (profiles/r04_b_*).
         // BTGPU_VERIFY_TAIL=1 puts it back on the tail stream (A/B).
-        static const bool ddc_on_tail = getenv("BTGPU_VERIFY_TAIL") && atoi(getenv("BTGPU_VERIFY_TAIL")) == 1;
-        VerifyParams vp{};
         if (verify) {
-            vp = make_verify_params(des, x_len, w0, ver_mp, ver_F, (const float2 *)d_rot_ch.p, (const double *)d_rotstep_ch.p,
-                                    (const float *)d_atan.p, vb);
-            if (!ddc_on_tail) {
+            if (!ddc_on_tail && !prescan) {
                 const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
                 hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, ps, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
             }
@@ -469,6 +494,15 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         if (deferred) HIPCHK(this, hipStreamWaitEvent(tail_stream, t.squelch_done, 0));
         HIPCHK(this, mark(9, tail_stream));
         if (verify) {
+            if (prescan) {
+                // the tiles the window kernel's hits have added since the scan (a window that only a hit flags; a header behind an
+                // access code): a second, short launch over the lists' new entries, once the first one has left the side stream
+                HIPCHK(this, hipStreamWaitEvent(tail_stream, t.ddc1_done, 0));
+                VerifyParams vp2 = vp;
+                vp2.tstart = (const unsigned int *)t.d_vtstart.p;
+                const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
+                hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, tail_stream, vp2, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
+            }
             if (ddc_on_tail) {
                 const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
                 hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, tail_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
@@ -1004,7 +1038,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     for (auto &t : h->tc) {
         for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
-        for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done})
+        for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.scan_done, &t.ddc1_done})
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     h->async = (cfg->flags & BTGPU_FLAG_ASYNC) != 0;
@@ -1156,6 +1190,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             TRY(h->alloc(t.d_vtasks, (size_t)vcap * sizeof(VerifyTask)));
             TRY(h->alloc(t.d_vtiles, verify_tiles_capacity(S) * nch * sizeof(uint32_t)));
             TRY(h->alloc(t.d_vcount, kVerCountWords * sizeof(unsigned int)));
+            TRY(h->alloc(t.d_vinfo, (size_t)S * nch * sizeof(int32_t)));
+            TRY(h->alloc(t.d_vtstart, 80 * sizeof(unsigned int)));
             TRY(h->alloc(t.d_dx, (size_t)vcap * kVerRows * sizeof(float)));
             TRY(h->alloc(t.d_dxt, ((size_t)nps * kVerRows + 64) * h->drow * sizeof(float)));
             TRY(h->alloc(t.d_winbits_v, (size_t)(nps + 1) * kBitWords * kWinThreads * sizeof(uint32_t)));

@@ -341,6 +341,8 @@ struct WindowParams {
     int vcap;                   // capacity of vtasks
     float burst_abs;            // new energy: a W-tile sum above burst_abs * (the quietest aligned W-tile block of the span) ...
     int burst_w;                // ... W = tiles per ~50 us (set_verify_flagging, bank_launch.h)
+    int prescan;                // 1: the scan ran in burst_scan_kernel; its verdicts are in vinfo
+    const int32_t *vinfo;       // [S * nch] task slot | tiles listed << 16 of an energy-flagged window, -1 otherwise
     float burst_abs_hot, burst_hot;   // the threshold beside a neighbour channel whose W-tile sum exceeds burst_hot * (that block)
     int span_extra;             // symbols behind an access code that stay exact as well (the 54-symbol header + margin)
     int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
@@ -517,6 +519,219 @@ __device__ __forceinline__ uint32_t sym_word(uint32_t acc, int n)
     return (~__brev(acc)) >> (32 - n);
 }
 
+// rows the clock recovery can reach within `span` symbols: at most omega_mid + omega_relative_limit input rows per symbol, + the
+// 8-tap interpolator
+__device__ __forceinline__ int ver_rows_of(const WindowParams &p, int span)
+{
+    int rows = (int)((float)span * (p.omega_mid + p.omega_relative_limit)) + 12;
+    const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
+    return rows > cap_rows ? cap_rows : rows;
+}
+
+// The exact stage's window selection by burst energy, for the lanes of one workgroup laid out like the
+// window kernel's: lane = (slot sl of the workgroup, channel cq), window (kq, cq); `tile`: kWinSlots * kTileFloats floats of LDS,
+// s_live: two ints of LDS.  Lanes with scan_on take part; a lane whose window shows new energy leaves with its task reserved
+// (vslot), the energy's span (vspan, symbols) and the tiles already listed for it (vtiles0).  Called by every lane of the
+// workgroup (barriers inside).  Shared by window_kernel (scan in line, round 4's choreography) and burst_scan_kernel (round 5:
+// the scan right behind the banks, so that the exact stage's DDC can run beside squelch stage 2).
+template <class LAY>
+__device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, int *s_live, int nch, int sl, int kq, int cq, bool scan_on,
+                                           int &vslot, int &vspan, int &vtiles0, bool &vtried)
+{
+    constexpr int kWinSlots = LAY::kSlots, kTileFloats = LAY::kTileFloats;
+    const int nmax = scan_on ? 1 : 0;
+    auto ver_rows = [&](int span) { return ver_rows_of(p, span); };
+    // The tile sums of a slot's channels cross LDS (the dead demod tile): read straight from ptile[channel][tile] the 79
+    // lanes of a slot touch 79 cache lines per load -- 2 x 57 such loads per lane doubled the kernel's time.
+    const int TT = p.tile_outs;
+    const int ntm = (2 * kDetectSyms + 16 + TT - 1) / TT;          // tiles of the detection span
+    constexpr int NF = kBurstFront;                                // tiles in front of the window that the scan looks at
+    const int NTW = ntm + NF, PW = NTW | 1;                        // odd pitch: no bank conflicts
+    // as many slots per pass as the tile holds (all three at C79 do not fit; the narrow layouts -- 32 slots of 8 channels --
+    // take 19 at a time: one pass per slot was 32 x two barriers)
+    int spp = (kWinSlots * kTileFloats) / (nch * PW);
+    spp = spp < 1 ? 1 : (spp > kWinSlots ? kWinSlots : spp);
+    float *et = tile;                                              // [spp][nch][PW]: tile t0 - NF + jj of (slot, channel) at et[(sp * nch + cc) * PW + jj]; -1 = no such tile
+    for (int s0 = 0; s0 < kWinSlots; s0 += spp) {
+        if (blockIdx.x * kWinSlots + s0 >= p.S) break;             // uniform
+        __syncthreads();
+        // (NTW <= 64: a wave takes the tiles of one (slot, channel) -- contiguous doubles --, the four waves every fourth pair)
+        for (int pr = (int)threadIdx.x >> 6; pr < spp * nch; pr += kWinThreads / 64) {
+            const int sp = pr / nch, cc = pr - sp * nch;
+            const int ks = blockIdx.x * kWinSlots + s0 + sp;
+            const int jj = (int)threadIdx.x & 63;
+            const int t = ks * p.tiles_per_slot - NF + jj;
+            if (jj < NTW)
+                et[pr * PW + jj] = (s0 + sp < kWinSlots && ks < p.S && t >= 0 && t < p.ptile_stride) ? (float)p.ptile[(size_t)cc * p.ptile_stride + t] : -1.f;
+        }
+        __syncthreads();
+        if (sl < s0 || sl >= s0 + spp || nmax == 0) continue;      // this lane's slot is not in this pass
+        const int t0 = kq * p.tiles_per_slot;
+        const float *pe = et + ((sl - s0) * nch + cq) * PW + NF;   // pe[j]: tile j of this window's span, j = -NF .. nt - 1
+        int nt = ntm;
+        if (nt > p.ptile_stride - t0) nt = p.ptile_stride - t0;
+        // ---- where does NEW energy appear in the span?  (round 5) ----
+        // The statistic is the energy of W tiles (~50 us: two thirds of an access code), s[j] = e[j-W+1] + .. + e[j].  New energy
+        // shows at j when (a) s[j] > burst_abs * (the span's quietest aligned W-tile block): the block minimum underestimates the
+        // mean noise by a known factor, folded into burst_abs by the host, which is calibrated to 2.0 x the mean noise -- a
+        // packet 3 dB over the noise triggers in 400 of 400 trials, one at 1.5 dB in 97 %, at 0 dB in 68 %, noise in 0 of 2700 windows
+        // (1.8 x: 99.5 % / 88 % and 0.1 % of the windows, each of them a task of ~700 rows); and (b)
+        // s[j] > 1.5 s[j-W]: half as much again as in the 50 us before -- a packet that begins in noise, in a neighbour's leakage
+        // or ON TOP of one already on the air with C/I >= -3 dB (below that the demodulator follows the stronger one).
+        // No rule says "this edge cannot be a packet" any more: round 4's dismissal of edges that a 17 dB stronger neighbour
+        // "explains" lost a packet the reference receives (the filter's leakage is -36 .. -20 dB per tile: 18 dB under a
+        // neighbour is 2 .. 18 dB OVER its leakage), and its absolute 4 x threshold left packets under 5 dB to the polyphase
+        // trajectory.  A packet that continues another one on the same channel with no gap and no step in level shows
+        // nothing in the energy; it is reached through the task its predecessor opens (exact rows up to there) and the
+        // polyphase path's own hit.
+        const int W = p.burst_w;
+        const int jl = t0 + nt == p.ptile_stride ? nt - 1 : nt;    // the batch's last tile may be a partial one
+        float bmin = 3.0e38f;
+        bool some = false;                                         // any tile with signal at all (GNU Radio's leading zeros are none)
+        for (int jb = -NF; jb + W <= jl; jb += W) {
+            float sb = 0.f;
+            bool ok = true;
+            for (int u = 0; u < W; u++) { const float e = pe[jb + u]; ok = ok && e > 0.f; some = some || e > 0.f; sb += e; }
+            bmin = (ok && sb < bmin) ? sb : bmin;
+        }
+        int rise = -1;
+        if (bmin > 1.0e38f) {
+            // no whole block of the span holds signal (a stream that begins inside the span): nothing to compare with -- exact to the end
+            if (some) rise = nt - 1;
+        } else {
+            const float thr = p.burst_abs * bmin, thr_n = p.burst_abs_hot * bmin, hot = p.burst_hot * bmin;
+            // s[j] and s[j-W] by sliding sums; tiles that do not exist (in front of the batch) count as unknown: (b) holds.
+            // sl_ / sr_: the same W-tile sum on the two neighbour channels (0 where the capture has none)
+            const bool has_l = cq > 0, has_r = cq + 1 < nch;
+            float s_cur = 0.f, s_old = 0.f, sl_ = 0.f, sr_ = 0.f;
+            int miss_old = 0;
+            for (int u = 0; u < W; u++) {                          // position j = -2
+                const int ic = -2 - u, io = -2 - W - u;
+                const float ec = ic >= -NF ? pe[ic] : -1.f, eo = io >= -NF ? pe[io] : -1.f;
+                s_cur += ec > 0.f ? ec : 0.f;
+                s_old += eo > 0.f ? eo : 0.f; miss_old += eo < 0.f;
+                const int in_ = ic + kBurstAhead;                  // (the neighbours' sums run kBurstAhead tiles ahead: see below)
+                const float el = (has_l && in_ >= -NF && in_ < ntm) ? pe[in_ - PW] : 0.f, er = (has_r && in_ >= -NF && in_ < ntm) ? pe[in_ + PW] : 0.f;
+                sl_ += el > 0.f ? el : 0.f; sr_ += er > 0.f ? er : 0.f;
+            }
+            bool prev = true;                                      // (a run that began in front of the window starts nothing)
+            for (int jx = -1; jx < nt; jx++) {
+                const int io = jx - W, iq = jx - 2 * W;
+                const float en = pe[jx], eo = io >= -NF ? pe[io] : -1.f, eq = iq >= -NF ? pe[iq] : -1.f;
+                s_cur += (en > 0.f ? en : 0.f) - (eo > 0.f ? eo : 0.f);
+                s_old += (eo > 0.f ? eo : 0.f) - (eq > 0.f ? eq : 0.f);
+                miss_old += (int)(eo < 0.f) - (int)(eq < 0.f);
+                {
+                    // (two tiles AHEAD of this channel's sum: a packet that switches on splatters into the neighbour channels
+                    // in its first microseconds, when its own W-tile sum has hardly begun to rise)
+                    const int jn = jx + kBurstAhead, jo = io + kBurstAhead;
+                    const float ln = (has_l && jn < ntm) ? pe[jn - PW] : 0.f, lo = (has_l && jo >= -NF && jo < ntm) ? pe[jo - PW] : 0.f;
+                    const float rn = (has_r && jn < ntm) ? pe[jn + PW] : 0.f, ro = (has_r && jo >= -NF && jo < ntm) ? pe[jo + PW] : 0.f;
+                    sl_ += (ln > 0.f ? ln : 0.f) - (lo > 0.f ? lo : 0.f);
+                    sr_ += (rn > 0.f ? rn : 0.f) - (ro > 0.f ? ro : 0.f);
+                }
+                // Beside a neighbour channel that carries a packet >= 20 dB over the noise the threshold is 3 x the mean noise
+                // instead of 2 x: the channel filter passes -36 .. -20 dB of that packet per tile, i.e. about the noise level
+                // and up, and with the low threshold every strong packet would make full-length tasks of its two neighbour
+                // windows.  This is a statement about SENSITIVITY, not a dismissal: beside such a neighbour a packet is taken
+                // from ~4.5 dB over the noise (alone: from ~2 dB), whatever the neighbour's level.
+                const float thr_j = (sl_ > hot || sr_ > hot) ? thr_n : thr;
+                const bool trig = s_cur > thr_j && (miss_old > 0 || s_cur > 1.5f * s_old);
+                if (trig && !prev && jx >= 0) {
+                    // The run of triggers begins at the tile the packet begins in, or -- where less than ~3 noise tiles' worth of it
+                    // lies in that tile -- up to W - 1 tiles later.  An access code is reportable at the offsets below 625
+                    // (lib/multi_sniffer_impl.cc:108), i.e. up to row ~1257 at the loop's slowest clock: a burst that starts later
+                    // is the next window's (in a sniffer window the following slot begins near symbol 635 -- every burst would be
+                    // taken twice, the second time with a full-length span).  Where inside its tile the packet begins is estimated
+                    // from how much of a full tile (the next one) it fills; how far the true onset can lie IN FRONT of that estimate:
+                    // with x = (packet tile) / (what was there before, o), a tile sum of ~12.6 independent values has the variance
+                    // (o^2 + 2 S o) / 12.6 around a signal part S, so the fill fraction is off by sigma = sqrt((2 / x^2 + 4 / x) / 12.6)
+                    // tiles at most, and a run that began one tile late hides <= 3.2 / x of a tile -- 3.5 sigma + 3.2 / x tiles,
+                    // never more than W - 1: 3 rows at 25 dB, 7 at 18 dB, 18 at 12 dB, 46 at 6 dB, the whole 75 below 3 dB.
+                    const float o = miss_old > 0 ? 3.0e38f : s_old / (float)W;
+                    const bool nxt = jx + 1 < nt && pe[jx + 1] > en;
+                    const float full = nxt ? pe[jx + 1] : en;
+                    float frac = (en - o) / (full - o);
+                    frac = (full > o && frac > 0.f) ? (frac > 1.f ? 1.f : frac) : 1.f;
+                    const float xi = o > 0.f ? o / (full > o ? full - o : 1.0e-30f) : 0.f;          // 1 / x
+                    float back = 3.5f * sqrtf((2.f * xi * xi + 4.f * xi) * (1.0f / 12.6f)) + 3.2f * xi;
+                    const float cap_back = (float)(W > 1 ? W - 1 : 1);
+                    back = (miss_old > 0 || !(back < cap_back)) ? cap_back : back;
+                    const float onset_row = ((float)(jx + 1) - frac - back) * (float)TT - 1.f;
+                    if (onset_row < 1258.f) rise = jx;
+                }
+                prev = trig;
+            }
+        }
+        // (to the end of the access code that may start there: whether one does is what the exact stage settles; the header
+        // behind it is added to the span by the hit that finds it, emit_classic)
+        if (rise >= 0) vspan = ((rise + 1) * TT) / 2 + 72 + 8;
+    }
+    // one task-list reservation per workgroup: thousands of lanes asking the same counter at the same moment queued up
+    // at the L2 for ~80 us (a quarter of this kernel's time, profiles/r04_c_*)
+    // (the tiles of the span the energy asks for are listed here as well; a later hit that reaches further appends the rest)
+    __syncthreads();                                               // (also: the tile is staged over next)
+    int *s_tl = (int *)tile;                                       // [0] tiles asked for by this workgroup, [1] their base in the list
+    if (threadIdx.x == 0) { s_live[0] = 0; s_tl[0] = 0; }
+    __syncthreads();
+    vtiles0 = vspan > 0 ? (ver_rows(vspan) + kVerTile - 1) / kVerTile : 0;
+    const int mine = vspan > 0 ? atomicAdd(&s_live[0], 1) : -1;
+    if (vspan > 0) atomicAdd(&s_tl[0], vtiles0);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_live[0] > 0) {
+        s_live[1] = (int)atomicAdd(&p.vcount[0], (unsigned int)s_live[0]);
+        atomicAdd(&p.vcount[1], (unsigned int)s_tl[0]);            // (statistics)
+    }
+    __syncthreads();
+    if (mine >= 0) {
+        vtried = true;
+        const unsigned int s_ = (unsigned int)s_live[1] + (unsigned int)mine;
+        if (s_ < (unsigned int)p.vcap) {
+            vslot = (int)s_;
+            // the tiles go to the list of this lane's CHANNEL (one counter per channel: ~70 lanes each, not 5000 on one): a
+            // workgroup of verify_ddc_kernel stays with one channel, whose taps then stay in its CU's scalar cache
+            const unsigned int tp = atomicAdd(&p.vtcount[cq], (unsigned int)vtiles0);
+            uint32_t *tl = p.vtiles + (size_t)cq * p.vtcap;
+            for (int j = 0; j < vtiles0; j++) if (tp + j < p.vtcap) tl[tp + j] = (uint32_t)vslot | ((uint32_t)j << 24);
+        } else {
+            atomicAdd(&p.vcount[2], 1u);
+            vtiles0 = 0;
+        }
+    }
+    __syncthreads();                                               // s_live is the chunk loop's flag, the tile is staged over next
+}
+
+// The burst scan as a kernel of its own, right behind the banks (round 5): the energy-selected tasks are then known before squelch
+// stage 2 and the window kernel have run, and the exact stage's DDC for them runs BESIDE those two instead of behind them.  The
+// squelch verdict is not known here: a task is listed for every window with new energy, its snr preset to "failed"; the window
+// kernel writes the real figure (and whatever its hits add to the span) when it comes by.  Exact rows are whole tiles of the
+// DDC kernel here -- what that launch computes anyway --, so that a hit which reaches a few rows further inside the last tile
+// finds them exact.
+template <class LAY>
+__global__ __launch_bounds__(kWinThreads) void burst_scan_kernel(WindowParams p, int32_t *__restrict__ vinfo_out)
+{
+    constexpr int kWinSlots = LAY::kSlots, kTileFloats = LAY::kTileFloats;
+    __shared__ __attribute__((aligned(16))) float tile[kWinSlots * kTileFloats];
+    __shared__ int s_live[2];
+    const int nch = p.nch;
+    const int sl = (int)threadIdx.x / nch, c = (int)threadIdx.x - sl * nch, k = blockIdx.x * kWinSlots + sl;
+    const bool lane_ok = sl < kWinSlots && k < p.S;
+    int vslot = -1, vspan = 0, vtiles0 = 0;
+    bool vtried = false;
+    burst_scan<LAY>(p, tile, s_live, nch, sl, k, c, lane_ok, vslot, vspan, vtiles0, vtried);
+    if (!lane_ok) return;
+    const long long w = (long long)k * nch + c;
+    if (vslot >= 0) {
+        const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
+        int rows = vtiles0 * kVerTile;
+        rows = rows > cap_rows ? cap_rows : rows;
+        VerifyTask t_;
+        t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = -1.0e300;
+        p.vtasks[vslot] = t_;
+        vinfo_out[w] = vslot | (vtiles0 << 16);
+    } else vinfo_out[w] = -1;
+}
+
 // VER = true: the exact stage's run (verify.hip.h).  Lanes are the tasks of p.vtasks, 79 (nch) per pseudo-slot, and the stream
 // `d` is the task buffer dxt[pseudo-slot][kVerRows][row]: exact demodulated rows in front, the polyphase path's behind them.
 // Squelch, records, window lengths and symbol export address the task's REAL window (slot, channel).
@@ -575,7 +790,8 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     if (VER && lane_ok) {                            // a task passed the squelch in the first run -- or, deferred, is judged here
         snr = p.deferred ? p.snr_arr[w] : p.vtasks[k * nch + c].snr;
         win_len[w] = -1;
-        if (!p.deferred || snr >= p.target_snr) nmax = kDetectSyms;
+        // (prescan: tasks are listed before the squelch is known; a window that failed it keeps the scan's snr = -1e300)
+        if ((!p.deferred && !p.prescan) || snr >= p.target_snr) nmax = kDetectSyms;
     }
     if (!VER && lane_ok && p.deferred) {             // deferred squelch: every window runs, the decision comes with the records
         win_len[w] = -1;
@@ -603,172 +819,13 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     // or -- where a carrier offset puts one symbol level near zero -- lose the packet on one side.
     int vslot = -1, vspan = 0, vtiles0 = 0;                                // vtiles0: entries of the tile list this window already owns
     bool vtried = false;
-    // rows the clock recovery can reach within `span` symbols: at most omega_mid + omega_relative_limit input rows per symbol, + the
-    // 8-tap interpolator
-    auto ver_rows = [&](int span) {
-        int rows = (int)((float)span * (p.omega_mid + p.omega_relative_limit)) + 12;
-        const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
-        return rows > cap_rows ? cap_rows : rows;
-    };
-    if (!VER && p.verify == 1) {
-        // The tile sums of a slot's channels cross LDS (the dead demod tile): read straight from ptile[channel][tile] the 79
-        // lanes of a slot touch 79 cache lines per load -- 2 x 57 such loads per lane doubled the kernel's time.
-        const int TT = p.tile_outs;
-        const int ntm = (2 * kDetectSyms + 16 + TT - 1) / TT;          // tiles of the detection span
-        constexpr int NF = kBurstFront;                                // tiles in front of the window that the scan looks at
-        const int NTW = ntm + NF, PW = NTW | 1;                        // odd pitch: no bank conflicts
-        // as many slots per pass as the tile holds (all three at C79 do not fit; the narrow layouts -- 32 slots of 8 channels --
-        // take 19 at a time: one pass per slot was 32 x two barriers)
-        int spp = (kWinSlots * kTileFloats) / (nch * PW);
-        spp = spp < 1 ? 1 : (spp > kWinSlots ? kWinSlots : spp);
-        float *et = tile;                                              // [spp][nch][PW]: tile t0 - NF + jj of (slot, channel) at et[(sp * nch + cc) * PW + jj]; -1 = no such tile
-        for (int s0 = 0; s0 < kWinSlots; s0 += spp) {
-            if (blockIdx.x * kWinSlots + s0 >= p.S) break;             // uniform
-            __syncthreads();
-            // (NTW <= 64: a wave takes the tiles of one (slot, channel) -- contiguous doubles --, the four waves every fourth pair)
-            for (int pr = (int)threadIdx.x >> 6; pr < spp * nch; pr += kWinThreads / 64) {
-                const int sp = pr / nch, cc = pr - sp * nch;
-                const int ks = blockIdx.x * kWinSlots + s0 + sp;
-                const int jj = (int)threadIdx.x & 63;
-                const int t = ks * p.tiles_per_slot - NF + jj;
-                if (jj < NTW)
-                    et[pr * PW + jj] = (s0 + sp < kWinSlots && ks < p.S && t >= 0 && t < p.ptile_stride) ? (float)p.ptile[(size_t)cc * p.ptile_stride + t] : -1.f;
-            }
-            __syncthreads();
-            if (sl < s0 || sl >= s0 + spp || nmax == 0) continue;      // this lane's slot is not in this pass
-            const int t0 = kq * p.tiles_per_slot;
-            const float *pe = et + ((sl - s0) * nch + cq) * PW + NF;   // pe[j]: tile j of this window's span, j = -NF .. nt - 1
-            int nt = ntm;
-            if (nt > p.ptile_stride - t0) nt = p.ptile_stride - t0;
-            // ---- where does NEW energy appear in the span?  (round 5) ----
-            // The statistic is the energy of W tiles (~50 us: two thirds of an access code), s[j] = e[j-W+1] + .. + e[j].  New energy
-            // shows at j when (a) s[j] > burst_abs * (the span's quietest aligned W-tile block): the block minimum underestimates the
-            // mean noise by a known factor, folded into burst_abs by the host, which is calibrated to 2.0 x the mean noise -- a
-            // packet 3 dB over the noise triggers in 400 of 400 trials, one at 1.5 dB in 97 %, at 0 dB in 68 %, noise in 0 of 2700 windows
-            // (1.8 x: 99.5 % / 88 % and 0.1 % of the windows, each of them a task of ~700 rows); and (b)
-            // s[j] > 1.5 s[j-W]: half as much again as in the 50 us before -- a packet that begins in noise, in a neighbour's leakage
-            // or ON TOP of one already on the air with C/I >= -3 dB (below that the demodulator follows the stronger one).
-            // No rule says "this edge cannot be a packet" any more: round 4's dismissal of edges that a 17 dB stronger neighbour
-            // "explains" lost a packet the reference receives (the filter's leakage is -36 .. -20 dB per tile: 18 dB under a
-            // neighbour is 2 .. 18 dB OVER its leakage), and its absolute 4 x threshold left packets under 5 dB to the polyphase
-            // trajectory.  A packet that continues another one on the same channel with no gap and no step in level shows
-            // nothing in the energy; it is reached through the task its predecessor opens (exact rows up to there) and the
-            // polyphase path's own hit.
-            const int W = p.burst_w;
-            const int jl = t0 + nt == p.ptile_stride ? nt - 1 : nt;    // the batch's last tile may be a partial one
-            float bmin = 3.0e38f;
-            bool some = false;                                         // any tile with signal at all (GNU Radio's leading zeros are none)
-            for (int jb = -NF; jb + W <= jl; jb += W) {
-                float sb = 0.f;
-                bool ok = true;
-                for (int u = 0; u < W; u++) { const float e = pe[jb + u]; ok = ok && e > 0.f; some = some || e > 0.f; sb += e; }
-                bmin = (ok && sb < bmin) ? sb : bmin;
-            }
-            int rise = -1;
-            if (bmin > 1.0e38f) {
-                // no whole block of the span holds signal (a stream that begins inside the span): nothing to compare with -- exact to the end
-                if (some) rise = nt - 1;
-            } else {
-                const float thr = p.burst_abs * bmin, thr_n = p.burst_abs_hot * bmin, hot = p.burst_hot * bmin;
-                // s[j] and s[j-W] by sliding sums; tiles that do not exist (in front of the batch) count as unknown: (b) holds.
-                // sl_ / sr_: the same W-tile sum on the two neighbour channels (0 where the capture has none)
-                const bool has_l = cq > 0, has_r = cq + 1 < nch;
-                float s_cur = 0.f, s_old = 0.f, sl_ = 0.f, sr_ = 0.f;
-                int miss_old = 0;
-                for (int u = 0; u < W; u++) {                          // position j = -2
-                    const int ic = -2 - u, io = -2 - W - u;
-                    const float ec = ic >= -NF ? pe[ic] : -1.f, eo = io >= -NF ? pe[io] : -1.f;
-                    s_cur += ec > 0.f ? ec : 0.f;
-                    s_old += eo > 0.f ? eo : 0.f; miss_old += eo < 0.f;
-                    const int in_ = ic + kBurstAhead;                  // (the neighbours' sums run kBurstAhead tiles ahead: see below)
-                    const float el = (has_l && in_ >= -NF && in_ < ntm) ? pe[in_ - PW] : 0.f, er = (has_r && in_ >= -NF && in_ < ntm) ? pe[in_ + PW] : 0.f;
-                    sl_ += el > 0.f ? el : 0.f; sr_ += er > 0.f ? er : 0.f;
-                }
-                bool prev = true;                                      // (a run that began in front of the window starts nothing)
-                for (int jx = -1; jx < nt; jx++) {
-                    const int io = jx - W, iq = jx - 2 * W;
-                    const float en = pe[jx], eo = io >= -NF ? pe[io] : -1.f, eq = iq >= -NF ? pe[iq] : -1.f;
-                    s_cur += (en > 0.f ? en : 0.f) - (eo > 0.f ? eo : 0.f);
-                    s_old += (eo > 0.f ? eo : 0.f) - (eq > 0.f ? eq : 0.f);
-                    miss_old += (int)(eo < 0.f) - (int)(eq < 0.f);
-                    {
-                        // (two tiles AHEAD of this channel's sum: a packet that switches on splatters into the neighbour channels
-                        // in its first microseconds, when its own W-tile sum has hardly begun to rise)
-                        const int jn = jx + kBurstAhead, jo = io + kBurstAhead;
-                        const float ln = (has_l && jn < ntm) ? pe[jn - PW] : 0.f, lo = (has_l && jo >= -NF && jo < ntm) ? pe[jo - PW] : 0.f;
-                        const float rn = (has_r && jn < ntm) ? pe[jn + PW] : 0.f, ro = (has_r && jo >= -NF && jo < ntm) ? pe[jo + PW] : 0.f;
-                        sl_ += (ln > 0.f ? ln : 0.f) - (lo > 0.f ? lo : 0.f);
-                        sr_ += (rn > 0.f ? rn : 0.f) - (ro > 0.f ? ro : 0.f);
-                    }
-                    // Beside a neighbour channel that carries a packet >= 20 dB over the noise the threshold is 3 x the mean noise
-                    // instead of 2 x: the channel filter passes -36 .. -20 dB of that packet per tile, i.e. about the noise level
-                    // and up, and with the low threshold every strong packet would make full-length tasks of its two neighbour
-                    // windows.  This is a statement about SENSITIVITY, not a dismissal: beside such a neighbour a packet is taken
-                    // from ~4.5 dB over the noise (alone: from ~2 dB), whatever the neighbour's level.
-                    const float thr_j = (sl_ > hot || sr_ > hot) ? thr_n : thr;
-                    const bool trig = s_cur > thr_j && (miss_old > 0 || s_cur > 1.5f * s_old);
-                    if (trig && !prev && jx >= 0) {
-                        // The run of triggers begins at the tile the packet begins in, or -- where less than ~3 noise tiles' worth of it
-                        // lies in that tile -- up to W - 1 tiles later.  An access code is reportable at the offsets below 625
-                        // (lib/multi_sniffer_impl.cc:108), i.e. up to row ~1257 at the loop's slowest clock: a burst that starts later
-                        // is the next window's (in a sniffer window the following slot begins near symbol 635 -- every burst would be
-                        // taken twice, the second time with a full-length span).  Where inside its tile the packet begins is estimated
-                        // from how much of a full tile (the next one) it fills; how far the true onset can lie IN FRONT of that estimate:
-                        // with x = (packet tile) / (what was there before, o), a tile sum of ~12.6 independent values has the variance
-                        // (o^2 + 2 S o) / 12.6 around a signal part S, so the fill fraction is off by sigma = sqrt((2 / x^2 + 4 / x) / 12.6)
-                        // tiles at most, and a run that began one tile late hides <= 3.2 / x of a tile -- 3.5 sigma + 3.2 / x tiles,
-                        // never more than W - 1: 3 rows at 25 dB, 7 at 18 dB, 18 at 12 dB, 46 at 6 dB, the whole 75 below 3 dB.
-                        const float o = miss_old > 0 ? 3.0e38f : s_old / (float)W;
-                        const bool nxt = jx + 1 < nt && pe[jx + 1] > en;
-                        const float full = nxt ? pe[jx + 1] : en;
-                        float frac = (en - o) / (full - o);
-                        frac = (full > o && frac > 0.f) ? (frac > 1.f ? 1.f : frac) : 1.f;
-                        const float xi = o > 0.f ? o / (full > o ? full - o : 1.0e-30f) : 0.f;          // 1 / x
-                        float back = 3.5f * sqrtf((2.f * xi * xi + 4.f * xi) * (1.0f / 12.6f)) + 3.2f * xi;
-                        const float cap_back = (float)(W > 1 ? W - 1 : 1);
-                        back = (miss_old > 0 || !(back < cap_back)) ? cap_back : back;
-                        const float onset_row = ((float)(jx + 1) - frac - back) * (float)TT - 1.f;
-                        if (onset_row < 1258.f) rise = jx;
-                    }
-                    prev = trig;
-                }
-            }
-            // (to the end of the access code that may start there: whether one does is what the exact stage settles; the header
-            // behind it is added to the span by the hit that finds it, emit_classic)
-            if (rise >= 0) vspan = ((rise + 1) * TT) / 2 + 72 + 8;
-        }
-        // one task-list reservation per workgroup: thousands of lanes asking the same counter at the same moment queued up
-        // at the L2 for ~80 us (a quarter of this kernel's time, profiles/r04_c_*)
-        // (the tiles of the span the energy asks for are listed here as well; a later hit that reaches further appends the rest)
-        __syncthreads();                                               // (also: the tile is staged over next)
-        int *s_tl = (int *)tile;                                       // [0] tiles asked for by this workgroup, [1] their base in the list
-        if (threadIdx.x == 0) { s_live[0] = 0; s_tl[0] = 0; }
-        __syncthreads();
-        vtiles0 = vspan > 0 ? (ver_rows(vspan) + kVerTile - 1) / kVerTile : 0;
-        const int mine = vspan > 0 ? atomicAdd(&s_live[0], 1) : -1;
-        if (vspan > 0) atomicAdd(&s_tl[0], vtiles0);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_live[0] > 0) {
-            s_live[1] = (int)atomicAdd(&p.vcount[0], (unsigned int)s_live[0]);
-            atomicAdd(&p.vcount[1], (unsigned int)s_tl[0]);            // (statistics)
-        }
-        __syncthreads();
-        if (mine >= 0) {
-            vtried = true;
-            const unsigned int s_ = (unsigned int)s_live[1] + (unsigned int)mine;
-            if (s_ < (unsigned int)p.vcap) {
-                vslot = (int)s_;
-                // the tiles go to the list of this lane's CHANNEL (one counter per channel: ~70 lanes each, not 5000 on one): a
-                // workgroup of verify_ddc_kernel stays with one channel, whose taps then stay in its CU's scalar cache
-                const unsigned int tp = atomicAdd(&p.vtcount[cq], (unsigned int)vtiles0);
-                uint32_t *tl = p.vtiles + (size_t)cq * p.vtcap;
-                for (int j = 0; j < vtiles0; j++) if (tp + j < p.vtcap) tl[tp + j] = (uint32_t)vslot | ((uint32_t)j << 24);
-            } else {
-                atomicAdd(&p.vcount[2], 1u);
-                vtiles0 = 0;
-            }
-        }
-        __syncthreads();                                               // s_live is the chunk loop's flag, the tile is staged over next
+    auto ver_rows = [&](int span) { return ver_rows_of(p, span); };
+    if (!VER && p.verify == 1 && !p.prescan)
+        burst_scan<LAY>(p, tile, s_live, nch, sl, kq, cq, nmax != 0, vslot, vspan, vtiles0, vtried);
+    if (!VER && p.verify == 1 && p.prescan && lane_ok) {
+        // the scan ran in burst_scan_kernel, right behind the banks: its verdict for this window
+        const int vi = p.vinfo[w];
+        if (vi >= 0) { vslot = vi & 0xffff; vtiles0 = vi >> 16; vtried = true; }
     }
     auto vreserve = [&]() {
         vtried = true;
@@ -1020,7 +1077,8 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     if (p.dbg_stop == 3) return;
     if (vslot >= 0) {
         // exact confirmation: this window's records come from the exact stage
-        const int rows = ver_rows(vspan);
+        int rows = ver_rows(vspan);
+        if (p.prescan && vtiles0 > 0) { const int r0 = p.vtasks[vslot].n_exact; rows = rows > r0 ? rows : r0; }   // the energy's span: whole tiles, computed by now
         const int ntl = (rows + kVerTile - 1) / kVerTile;
         if (ntl > vtiles0) {                                          // a hit reaches further than the energy's span (or there was no such span)
             atomicAdd(&p.vcount[1], (unsigned int)(ntl - vtiles0));

@@ -36,6 +36,7 @@ struct VerifyParams {
     const float *atan_tab; float gain;
     const VerifyTask *tasks; const unsigned int *vcount; int vcap;
     const uint32_t *tiles; const unsigned int *tcount; unsigned int tiles_cap;   // tile lists by channel: tiles[c * tiles_cap ..], tcount[c] entries
+    const unsigned int *tstart;       // nullptr, or [nch]: entries of each list that an earlier launch of this batch has taken
     int nch;
 };
 constexpr int kVerMaxTiles = (kVerRows + kVerTile - 1) / kVerTile;     // tiles of a task at most (12)
@@ -91,6 +92,10 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
     const uint32_t *tlist = p.tiles + (size_t)my_c * p.tiles_cap;
     unsigned int ntiles = p.tcount[my_c];
     if (ntiles > p.tiles_cap) ntiles = p.tiles_cap;
+    if (p.tstart) {                                             // second launch of a batch: the entries listed since the first one
+        const unsigned int t0 = p.tstart[my_c] < ntiles ? p.tstart[my_c] : ntiles;
+        tlist += t0; ntiles -= t0;
+    }
     for (int i = threadIdx.x; i < 257; i += kVerThreads) atab[i] = p.atan_tab[i];
 #if defined(__HIP_DEVICE_COMPILE__)
     const int l = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -301,6 +306,10 @@ __global__ __launch_bounds__(64 * kVerSmallWaves, 4) void verify_ddc_small_kerne
     const uint32_t *tlist = p.tiles + (size_t)c * p.tiles_cap;
     unsigned int ntiles = p.tcount[c];
     if (ntiles > p.tiles_cap) ntiles = p.tiles_cap;
+    if (p.tstart) {                                             // (second launch of a batch: see verify_ddc_kernel)
+        const unsigned int t0 = p.tstart[c] < ntiles ? p.tstart[c] : ntiles;
+        tlist += t0; ntiles -= t0;
+    }
     for (int i = threadIdx.x; i < 257; i += 64 * kVerSmallWaves) atab[i] = p.atan_tab[i];
     const int lbase = D2 * lane + lane;                           // word of the lane's first sample (one pad word per 2 D samples)
     for (unsigned int base = ((unsigned int)blockIdx.x / (unsigned int)p.nch) * kVerSmallWaves; base < ntiles;

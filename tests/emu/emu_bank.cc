@@ -308,8 +308,36 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         vb.tasks = vtasks.data(); vb.tiles = vtiles.data(); vb.vcount = vcount; vb.dx = dx.data(); vb.dxt = (float *)dxt4.data();
         set_verify_flagging(p, des, *ve->fp, ve->small, ve->mode, ve->ptile, ve->ntiles, vb, want_syms, ve->tile_outs);
     }
+    // the runtime's choreography (btgpu.hip process_batch): burst scan behind the banks, the energy-selected tasks' DDC, the window
+    // kernel, the DDC of what its hits added, fill, exact window kernel.  EMU_PRESCAN=0: round 4's (scan inside the window kernel)
+    static const bool prescan_env = !(getenv("EMU_PRESCAN") && atoi(getenv("EMU_PRESCAN")) == 0);
+    const bool prescan = prescan_env && verify && p.verify == 1;
+    std::vector<int32_t> vinfo(prescan ? W : 1, -1);
+    std::vector<unsigned int> vtstart(80, 0u);
     auto launch_window = [&](auto lay) {
         using LAY = decltype(lay);
+        int mp = 0, F = 0;
+        std::vector<float> tv;
+        std::vector<double> st(nch);
+        VerifyParams vp{};
+        VerifyDdcLaunch vl{};
+        auto run_ddc = [&](const VerifyParams &vq) {
+            if (vl.lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", (size_t)vl.lds); std::abort(); }
+            std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
+            emu::launch(dim3((unsigned)(2 * nch + 1)), dim3((unsigned)vl.threads), [&]() { vl.kern(vq, ve->x, (const float2 *)tv.data(), dx.data()); });
+        };
+        if (verify) {
+            tv = pack_class_major(des.channel, des.d.decimation, mp, F);
+            for (int c = 0; c < nch; c++) st[c] = -des.channel.foff[c] * des.d.decimation / des.cfg.sample_rate;
+            vp = make_verify_params(des, (size_t)ve->x_len, 0, mp, F, (const float2 *)des.channel.rot.data(), st.data(), des.atan_tab, vb);
+            vl = verify_ddc_pick(des.d.decimation, des.channel.ntp);
+        }
+        if (prescan) {
+            p.prescan = 1; p.vinfo = vinfo.data();
+            emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() { burst_scan_kernel<LAY>(p, vinfo.data()); });
+            for (int c = 0; c < nch; c++) vtstart[c] = vcount[4 + c];
+            if (vcount[1]) run_ddc(vp);
+        }
         emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() {
             window_kernel<LAY>(p, d, G, P, Pt, Qn, des.mmse, &des.ac.byte_lo[0][0], &des.ac.byte_hi[0][0],
                                e_on.data(), e_off.data(), snr.data(), win_len.data(), hits.data(), &counts[0], fin.data(),
@@ -318,19 +346,8 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         });
         if (!verify) return;
         // ---- the exact stage (runtime: tail stream) ----
-        int mp = 0, F = 0;
-        const std::vector<float> tv = pack_class_major(des.channel, des.d.decimation, mp, F);
-        std::vector<double> st(nch);
-        for (int c = 0; c < nch; c++) st[c] = -des.channel.foff[c] * des.d.decimation / des.cfg.sample_rate;
-        const VerifyParams vp = make_verify_params(des, (size_t)ve->x_len, 0, mp, F, (const float2 *)des.channel.rot.data(), st.data(),
-                                                   des.atan_tab, vb);
-        const VerifyDdcLaunch vl = verify_ddc_pick(des.d.decimation, des.channel.ntp);
-        const size_t lds = vl.lds;
-        if (lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", lds); std::abort(); }
-        std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
-        if (vcount[1]) emu::launch(dim3((unsigned)(2 * nch + 1)), dim3((unsigned)vl.threads), [&]() {
-            vl.kern(vp, ve->x, (const float2 *)tv.data(), dx.data());
-        });
+        if (prescan) { VerifyParams vp2 = vp; vp2.tstart = vtstart.data(); run_ddc(vp2); }
+        else if (vcount[1]) run_ddc(vp);
         const VerifyFillParams fpz = make_verify_fill_params(des, d, dcol_p, drow, G, vb);
         emu::launch(dim3(16), dim3(256), [&]() { verify_fill_kernel(fpz); });
         const WindowParams pv = make_verify_window_params(p, vb);
