@@ -395,8 +395,11 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         else
             set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
     }
-    // BTGPU_PRESCAN=0: the scan inside the window kernel and the DDC in line behind it (round 4's choreography, A/B)
-    static const bool prescan_env = !(getenv("BTGPU_PRESCAN") && atoi(getenv("BTGPU_PRESCAN")) == 0);
+    // BTGPU_PRESCAN=1: the scan as a kernel of its own behind the banks and the energy-selected tasks' DDC on a side stream beside
+    // squelch stage 2 and the window kernel.  Built, measured, OFF (profiles/r05_b_*): 2.34-2.38 ms per step against 2.31 in line --
+    // beside three 51 KB window workgroups per CU the DDC's 59 KB workgroups wait (0.9-1.9 ms instead of 0.30), and the window
+    // kernel beside them takes 0.48-0.6 instead of 0.42 ms.  Every front kernel holds its CUs by LDS; nothing overlaps for free.
+    static const bool prescan_env = getenv("BTGPU_PRESCAN") && atoi(getenv("BTGPU_PRESCAN")) == 1;
     static const bool ddc_on_tail = getenv("BTGPU_VERIFY_TAIL") && atoi(getenv("BTGPU_VERIFY_TAIL")) == 1;
     const bool prescan = prescan_env && verify == 1 && p.verify == 1 && !deferred && !ddc_on_tail && !pipelined;
     VerifyParams vp{};

@@ -555,14 +555,28 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
     for (int s0 = 0; s0 < kWinSlots; s0 += spp) {
         if (blockIdx.x * kWinSlots + s0 >= p.S) break;             // uniform
         __syncthreads();
-        // (NTW <= 64: a wave takes the tiles of one (slot, channel) -- contiguous doubles --, the four waves every fourth pair)
-        for (int pr = (int)threadIdx.x >> 6; pr < spp * nch; pr += kWinThreads / 64) {
-            const int sp = pr / nch, cc = pr - sp * nch;
-            const int ks = blockIdx.x * kWinSlots + s0 + sp;
-            const int jj = (int)threadIdx.x & 63;
-            const int t = ks * p.tiles_per_slot - NF + jj;
-            if (jj < NTW)
-                et[pr * PW + jj] = (s0 + sp < kWinSlots && ks < p.S && t >= 0 && t < p.ptile_stride) ? (float)p.ptile[(size_t)cc * p.ptile_stride + t] : -1.f;
+        // (NTW <= 64: a wave takes the tiles of one (slot, channel) -- contiguous doubles --, the four waves every fourth pair; four
+        // pairs per wave in flight: one load per trip was 40 dependent memory round trips per pass, most of the scan's time)
+        for (int pr0 = (int)threadIdx.x >> 6; pr0 < spp * nch; pr0 += 4 * (kWinThreads / 64)) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int pr = pr0 + u * (kWinThreads / 64);
+                const int prc = pr < spp * nch ? pr : pr0;
+                const int sp = prc / nch, cc = prc - sp * nch;
+                const int ks = blockIdx.x * kWinSlots + s0 + sp;
+                const int jj = (int)threadIdx.x & 63;
+                const int t = ks * p.tiles_per_slot - NF + jj;
+                const bool in = s0 + sp < kWinSlots && ks < p.S && t >= 0 && t < p.ptile_stride;
+                v[u] = (float)p.ptile[(size_t)cc * p.ptile_stride + (in ? t : 0)];
+                v[u] = in ? v[u] : -1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int pr = pr0 + u * (kWinThreads / 64);
+                const int jj = (int)threadIdx.x & 63;
+                if (pr < spp * nch && jj < NTW) et[pr * PW + jj] = v[u];
+            }
         }
         __syncthreads();
         if (sl < s0 || sl >= s0 + spp || nmax == 0) continue;      // this lane's slot is not in this pass

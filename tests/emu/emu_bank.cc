@@ -309,8 +309,8 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         set_verify_flagging(p, des, *ve->fp, ve->small, ve->mode, ve->ptile, ve->ntiles, vb, want_syms, ve->tile_outs);
     }
     // the runtime's choreography (btgpu.hip process_batch): burst scan behind the banks, the energy-selected tasks' DDC, the window
-    // kernel, the DDC of what its hits added, fill, exact window kernel.  EMU_PRESCAN=0: round 4's (scan inside the window kernel)
-    static const bool prescan_env = !(getenv("EMU_PRESCAN") && atoi(getenv("EMU_PRESCAN")) == 0);
+    // kernel, the DDC of what its hits added, fill, exact window kernel.  EMU_PRESCAN=1 (the runtime's BTGPU_PRESCAN=1; default: the scan inside the window kernel, one DDC launch)
+    static const bool prescan_env = getenv("EMU_PRESCAN") && atoi(getenv("EMU_PRESCAN")) == 1;
     const bool prescan = prescan_env && verify && p.verify == 1;
     std::vector<int32_t> vinfo(prescan ? W : 1, -1);
     std::vector<unsigned int> vtstart(80, 0u);
