@@ -288,6 +288,9 @@ def run_rank(args):
         tm1 = b.timing()
         kms, kl = tdiff(tm0, tm1)
         # exact confirmation of the polyphase path's records (always counted by the library): windows re-run per step etc.
+        b._long_stats = {"tasks_per_step": round((tm1.long_tasks - tm0.long_tasks) / max(1, args.steps), 1),
+                         "rows_per_step": round((tm1.long_rows - tm0.long_rows) / max(1, args.steps), 1),
+                         "turned_away": int(tm1.long_turned_away - tm0.long_turned_away)}
         b._verify_stats = {"windows_per_step": round((tm1.verify_windows - tm0.verify_windows) / max(1, args.steps), 1),
                            "rows_per_step": round((tm1.verify_rows - tm0.verify_rows) / max(1, args.steps), 1),
                            "turned_away": int(tm1.verify_turned_away - tm0.verify_turned_away)}
@@ -334,16 +337,24 @@ def run_rank(args):
         blk.close()
         # `value` with the event records of the headline region (one pair per batch, around the bank); the kernel breakdown from a
         # second pass with records around every kernel (eleven per batch: ~5 % slower, reported as ms_per_step_full_timing)
+        # (round 5: host/blocks.cc also sets BTGPU_FLAG_EXACT_PAYLOAD -- the symbols it decodes are exact to the end of each packet;
+        # `without_exact_payload` is the same region without it, round 4's block configuration)
+        BF = pkg.FLAG_LE | pkg.FLAG_HEADERS | pkg.FLAG_EXACT_PAYLOAD
         blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS, timing=head_timing)
+        n_el, n_ints, _ns, _m, _f, _k1, _k2 = timed_region(blk, gather=False)
+        blk.close()
+        blk = make_block(BF, timing=head_timing)
         b_el, b_ints, b_snr, _m, _f, b_kms, b_kl = timed_region(blk, gather=False)
         b_ints, b_snr = one_copy(b_ints, b_snr)
-        b_verify = dict(blk._verify_stats)
+        b_verify = dict(blk._verify_stats); b_verify["exact_payload"] = dict(blk._long_stats)
         b_el_full = None
         if not args.no_timing and head_timing != pkg.FLAG_TIMING:
             blk.close()
-            blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS, timing=pkg.FLAG_TIMING)
+            blk = make_block(BF, timing=pkg.FLAG_TIMING)
             b_el_full, _i, _s, _m, _f, b_kms, b_kl = timed_region(blk, gather=False)
-        block_cfg = {"flags": "BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS (what host/blocks.cc sets for multi_sniffer)",
+        block_cfg = {"flags": "BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS | BTGPU_FLAG_EXACT_PAYLOAD (what host/blocks.cc sets for multi_sniffer)",
+                     "without_exact_payload": {"value": round(float(S) * slot * args.steps / n_el / 1e6, 3), "ms_per_step": round(n_el / args.steps * 1e3, 3),
+                                               "hits": int(len(one_copy(n_ints, _ns)[0]))},
                      "value": round(float(S) * slot * args.steps / b_el / 1e6, 3), "unit": "Msamples/s",
                      "ms_per_step": round(b_el / args.steps * 1e3, 3), "hits": int(len(b_ints)),
                      "ms_per_step_full_timing": round(b_el_full / args.steps * 1e3, 3) if b_el_full else None,

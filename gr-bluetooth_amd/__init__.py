@@ -32,6 +32,7 @@ SQUELCH_AUTO, SQUELCH_DIRECT, SQUELCH_STAGED = 0, 1, 2
 CORRELATOR_AUTO, CORRELATOR_INTREE, CORRELATOR_BTBB = 0, 1, 2   # multi_LAP default: BTBB (libbtbb, as the reference)
 FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS, FLAG_HEADERS, FLAG_TIMING, FLAG_NO_NSYM, FLAG_TIMING_BANK = 1, 2, 4, 8, 16, 32, 64, 128
 FLAG_NO_VERIFY = 256      # polyphase path without the exact confirmation of its records (A/B)
+FLAG_EXACT_PAYLOAD = 512  # exported symbols exact to the end of the packet (include/btgpu.h)
 KIND_AC, KIND_AA = 0, 1
 
 
@@ -72,7 +73,8 @@ class Timing(ctypes.Structure):
     _fields_ = [("kernel_ms", ctypes.c_float * 8), ("kernel_launches", ctypes.c_uint32 * 8),
                 ("total_ms", ctypes.c_float), ("batches", ctypes.c_uint32),
                 ("samples", ctypes.c_uint64), ("slots", ctypes.c_uint64),
-                ("verify_windows", ctypes.c_uint64), ("verify_rows", ctypes.c_uint64), ("verify_turned_away", ctypes.c_uint64)]
+                ("verify_windows", ctypes.c_uint64), ("verify_rows", ctypes.c_uint64), ("verify_turned_away", ctypes.c_uint64),
+                ("long_tasks", ctypes.c_uint64), ("long_rows", ctypes.c_uint64), ("long_turned_away", ctypes.c_uint64)]
 
 
 EXPORTS = ["btgpu_design_query", "btgpu_acgen", "btgpu_filter_taps", "btgpu_strerror",

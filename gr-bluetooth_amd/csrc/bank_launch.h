@@ -271,7 +271,7 @@ inline VerifyParams make_verify_params(const Design &des, size_t x_len, long lon
     v.atan_tab = atan_tab; v.gain = des.demod_gain;
     v.tasks = vb.tasks; v.tiles = vb.tiles; v.vcount = vb.vcount; v.vcap = vb.vcap; v.tiles_cap = vb.tiles_cap; v.tcount = vb.vcount + 4;
     v.nch = d.high_channel - d.low_channel + 1;
-    v.tstart = nullptr;
+    v.tstart = nullptr; v.dx_stride = kVerRows;
     return v;
 }
 inline VerifyFillParams make_verify_fill_params(const Design &des, const float *d_stream, const float *dcol, int drow, long long G,

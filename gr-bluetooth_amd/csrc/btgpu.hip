@@ -75,6 +75,7 @@ struct btgpu_handle {
         DevBuf d_pfine;                       // small-M F8 bank: |Y|^2 sums per 25 instants (the exact stage's burst scan)
         DevBuf d_Z;                           // staged squelch: stage-1 output (-> noise_stage2_kernel on the post stream)
         DevBuf d_vtasks, d_vtiles, d_vcount, d_dx, d_dxt, d_winbits_v, d_vinfo, d_vtstart;
+        DevBuf d_ltasks, d_ltiles, d_lcount, d_lrows, d_dxl;   // BTGPU_FLAG_EXACT_PAYLOAD: the long tasks of the windows that hand symbols to the host
         DevBuf d_eon, d_eoff, d_snr;          // E_on, E_off, SNR per window (window_kernel, or squelch_kernel when the squelch is deferred)   // exact confirmation (verify.hip.h): task list, exact rows, task stream
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
@@ -98,6 +99,10 @@ struct btgpu_handle {
     bool no_nsym = false;            // BTGPU_FLAG_NO_NSYM: skip the M&M continuation that produces hit.nsym
     int verify = 0;                  // exact confirmation of the polyphase path's records: 0 off, 1 hits + burst energy, 2 hits only
     int vcap = 0, ver_mp = 0, ver_F = 0, ver_grid = kVerGridDdc;
+    bool exact_payload = false;            // BTGPU_FLAG_EXACT_PAYLOAD (with symbols and the exact stage)
+    int long_stride = 0;
+    static constexpr int kLongCap = 8192;                 // long tasks per batch (windows that hand symbols over); beyond: the polyphase continuation
+    static constexpr unsigned int kLongTilesCap = 65536;  // entries of one channel's list
     std::vector<const void *> lds_opted;   // bank kernels that have been granted > 48 KiB of dynamic LDS on this handle's device
     DevBuf d_tapsv;                  // class-major taps of the direct-form channel bank (verify_ddc_kernel)
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
@@ -175,7 +180,7 @@ struct btgpu_handle {
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (TailCtx &t : tc) {
             DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol,
-                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_vinfo, &t.d_vtstart, &t.d_eon, &t.d_eoff, &t.d_snr};
+                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_vinfo, &t.d_vtstart, &t.d_ltasks, &t.d_ltiles, &t.d_lcount, &t.d_lrows, &t.d_dxl, &t.d_eon, &t.d_eoff, &t.d_snr};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -384,6 +389,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     p.want_len = no_nsym ? 0 : 1;
     p.deferred = deferred ? 1 : 0;
     p.snr_arr = (const double *)t.d_snr.p;
+    p.exact_payload = (exact_payload && want_syms && verify) ? 1 : 0;
     // exact confirmation (verify.hip.h): the window kernel hands the windows that can carry a packet's record to the exact
     // stage, which runs on the tail stream below (beside the next batch's banks)
     VerifyBuffers vb;
@@ -533,6 +539,23 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             else launch_exact(WinLayout<64, 4, 1>{});
             HIPCHK(this, hipMemcpyAsync(t.h_count + 4, t.d_vcount.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
         }
+        LongView lview{nullptr, nullptr, 0, 0};
+        if (verify && exact_payload && want_syms) {
+            // exact payload: the windows that hand symbols to the host get their rows to the end of the burst from the direct-form DDC
+            HIPCHK(this, hipMemsetAsync(t.d_lcount.p, 0, kVerCountWords * sizeof(unsigned int), tail_stream));
+            LongTaskParams lp{};
+            lp.tasks = (VerifyTask *)t.d_ltasks.p; lp.tiles = (uint32_t *)t.d_ltiles.p; lp.lcount = (unsigned int *)t.d_lcount.p;
+            lp.tiles_cap = kLongTilesCap; lp.rows = (LongRows *)t.d_lrows.p; lp.cap = kLongCap; lp.stride = long_stride;
+            hipLaunchKernelGGL(long_task_kernel, dim3(kLongCap / kLongLanes), dim3(kLongLanes), 0, tail_stream, p, (const FinishRec *)d_fin.p,
+                               (const unsigned int *)d_hitcount.p + 1, lp);
+            VerifyParams vl_ = vp;
+            vl_.tasks = lp.tasks; vl_.vcount = lp.lcount; vl_.vcap = kLongCap; vl_.tiles = lp.tiles; vl_.tcount = lp.lcount + 4;
+            vl_.tiles_cap = kLongTilesCap; vl_.tstart = nullptr; vl_.dx_stride = long_stride;
+            const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
+            hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, tail_stream, vl_, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dxl.p);
+            HIPCHK(this, hipMemcpyAsync(t.h_count + 8, t.d_lcount.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
+            lview.rows = (const LongRows *)t.d_lrows.p; lview.dxl = (const float *)t.d_dxl.p; lview.stride = long_stride; lview.cap = kLongCap;
+        }
         if (timing_on && timing_full) HIPCHK(this, hipEventRecord(ev[11], tail_stream));
         {
             // windows with hits: at most one FinishRec per window; lanes beyond fin_count exit
@@ -545,7 +568,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                 hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)d_symbits.p,
-                                   (const float *)(use_dcol ? t.d_dcol.p : nullptr));
+                                   (const float *)(use_dcol ? t.d_dcol.p : nullptr), lview);
             else
                 hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
@@ -684,6 +707,7 @@ int btgpu_handle::harvest(TailCtx &t)
         timing.verify_windows += std::min<unsigned>(t.h_count[4], (unsigned)vcap);
         timing.verify_rows += (uint64_t)t.h_count[5] * kVerTile;
         timing.verify_turned_away += t.h_count[6];
+        if (exact_payload) { timing.long_tasks += t.h_count[8]; timing.long_rows += (uint64_t)t.h_count[9] * kVerTile; timing.long_turned_away += t.h_count[10]; }
     }
     timing.slots += (uint64_t)t.S;
     timing.samples += (uint64_t)t.S * (uint64_t)d.samples_per_slot;
@@ -1073,6 +1097,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
                   getenv("BTGPU_DEFER") && atoi(getenv("BTGPU_DEFER")) == 1;
     h->want_hdrs = (cfg->flags & BTGPU_FLAG_HEADERS) != 0;
     h->want_syms = (cfg->flags & BTGPU_FLAG_SYMBOLS) != 0 || h->want_hdrs;
+    h->exact_payload = (cfg->flags & BTGPU_FLAG_EXACT_PAYLOAD) != 0 && h->want_syms && h->verify == 1;
+    if (getenv("BTGPU_EXACT_PAYLOAD")) h->exact_payload = atoi(getenv("BTGPU_EXACT_PAYLOAD")) != 0 && h->want_syms && h->verify == 1;   // (A/B)
+    h->long_stride = ((h->des.d.ddc_out + kVerTile - 1) / kVerTile) * kVerTile + 8;
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != BTGPU_OK) { int c__ = rc__; std::string m__ = h->err; \
         if (getenv("BTGPU_VERBOSE")) fprintf(stderr, "btgpu_create: %s\n", m__.c_str()); return fail(c__); } } while (0)
@@ -1195,6 +1222,13 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             TRY(h->alloc(t.d_vcount, kVerCountWords * sizeof(unsigned int)));
             TRY(h->alloc(t.d_vinfo, (size_t)S * nch * sizeof(int32_t)));
             TRY(h->alloc(t.d_vtstart, 80 * sizeof(unsigned int)));
+            if (h->exact_payload) {
+                TRY(h->alloc(t.d_ltasks, (size_t)btgpu_handle::kLongCap * sizeof(VerifyTask)));
+                TRY(h->alloc(t.d_ltiles, (size_t)nch * btgpu_handle::kLongTilesCap * sizeof(uint32_t)));
+                TRY(h->alloc(t.d_lcount, kVerCountWords * sizeof(unsigned int)));
+                TRY(h->alloc(t.d_lrows, (size_t)btgpu_handle::kLongCap * sizeof(LongRows)));
+                TRY(h->alloc(t.d_dxl, (size_t)btgpu_handle::kLongCap * h->long_stride * sizeof(float)));
+            }
             TRY(h->alloc(t.d_dx, (size_t)vcap * kVerRows * sizeof(float)));
             TRY(h->alloc(t.d_dxt, ((size_t)nps * kVerRows + 64) * h->drow * sizeof(float)));
             TRY(h->alloc(t.d_winbits_v, (size_t)(nps + 1) * kBitWords * kWinThreads * sizeof(uint32_t)));
@@ -1212,8 +1246,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         auto &t = h->tc[i];
         if (h->want_hdrs && hipHostMalloc((void **)&t.h_hdr, (size_t)btgpu_handle::kEagerFin * sizeof(HeaderRec), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)btgpu_handle::kEagerFin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
-        if (hipHostMalloc((void **)&t.h_count, 8 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
-        std::memset(t.h_count, 0, 8 * sizeof(unsigned int));
+        if (hipHostMalloc((void **)&t.h_count, 12 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
+        std::memset(t.h_count, 0, 12 * sizeof(unsigned int));
         if (hipHostMalloc((void **)&t.h_hits, (size_t)btgpu_handle::kEagerHits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
     }
 #undef TRY

@@ -48,7 +48,7 @@ struct FinishRec {            // M&M state of a window that reported hits, hande
     int32_t  oo;
     float    mu, omega, last;
     int32_t  done;            // the window already ended inside the window kernel (len known)
-    int32_t  pad_;
+    int32_t  pad_;            // symbol offset of the window's last record (long_task_kernel: where the packet's level is read)
 };
 
 constexpr int kSymWords = 120;    // packed symbols kept per hit window (3840 >= ~3760 symbols)
@@ -341,6 +341,7 @@ struct WindowParams {
     int vcap;                   // capacity of vtasks
     float burst_abs;            // new energy: a W-tile sum above burst_abs * (the quietest aligned W-tile block of the span) ...
     int burst_w;                // ... W = tiles per ~50 us (set_verify_flagging, bank_launch.h)
+    int exact_payload;          // BTGPU_FLAG_EXACT_PAYLOAD (with syms): the exact window kernel hands the continuation the state at the end of its exact rows
     int prescan;                // 1: the scan ran in burst_scan_kernel; its verdicts are in vinfo
     const int32_t *vinfo;       // [S * nch] task slot | tiles listed << 16 of an energy-flagged window, -1 otherwise
     float burst_abs_hot, burst_hot;   // the threshold beside a neighbour channel whose W-tile sum exceeds burst_hot * (that block)
@@ -788,6 +789,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int k = blockIdx.x * kWinSlots + sl;                   // slot (VER: pseudo-slot) whose rows this lane reads
     // the window the lane stands for: (k, c) itself, or the task's
     int kq = k, cq = c;
+    unsigned int n_ex = 0u;                          // VER: rows [0, n_ex) of this task's stream are the exact ones
     bool lane_ok = sl < kWinSlots && k < p.S;
     if (VER) {
         unsigned int ntask = p.vcount[0];
@@ -797,6 +799,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         lane_ok = sl < kWinSlots && q < ntask;
         const int wr = lane_ok ? p.vtasks[q].w : 0;
         kq = wr / nch; cq = wr - kq * nch;
+        n_ex = lane_ok ? (unsigned int)p.vtasks[q].n_exact : 0u;
     }
     const long long w = (long long)kq * nch + cq;
     int nmax = 0;                                    // symbols this lane will produce in phase 1
@@ -901,6 +904,10 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             v[j] = *(const float4 *)(wgb + (o < max_off ? o : max_off));
         }
     };
+    // exact payload (VER): the loop's state at the last symbol that lies wholly inside the task's exact rows -- where the
+    // continuation over the long task's rows (finish_kernel) takes over
+    unsigned int snap_ii = 0u; int snap_oo = -1; float snap_mu = 0.f, snap_om = 0.f, snap_last = 0.f;
+    const bool snap_on = VER && p.exact_payload != 0;
     int base = 0;
     fetch(0);
     for (int it = 0;; it++) {
@@ -919,6 +926,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         // byte offset of this lane's column in row `base` of the tile (24-bit arithmetic: one v_mad_u32_u24 per symbol)
         const uint32_t colb = (uint32_t)(((int)(mytile - tile) + c - base * kWinRowStride) * 4);
         while (ii <= lim && oo < nmax) {
+            if (snap_on && snap_oo < 0 && ii + 8u > n_ex) { snap_ii = ii; snap_oo = oo; snap_mu = mu; snap_om = omega; snap_last = last; }
             // interpolate: sum_q T[imu][7-q] * in[ii+q], q ascending
             // mu = x - floor(x) lies in [0, 1] (1.0 when x is a tiny negative number): imu in 0..128, no clamp needed
             // rintf(mu * 128) through the mantissa: mu * 128 + 1.5 * 2^23 is rounded to the nearest integer (ties to even, as
@@ -1014,7 +1022,9 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int len1 = oo;                                         // 693, or the whole window if shorter
     int limit = len1 - 68 < 625 ? len1 - 68 : 625;
     int resume = 0, nhits = 0;
+    int last_cpos = -1;                                          // symbol offset of the window's last record (exact payload: where its packet is)
     auto emit_classic = [&](int cpos, uint32_t lap, int err) {
+        last_cpos = cpos;
         if (!VER && p.verify) {
             // a classic hit of the polyphase path is a claim the exact stage settles: the span that must be exact reaches to
             // the end of this access code (+ header)
@@ -1169,6 +1179,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                         hits[slot_h] = h;
                     }
                     nhits++;
+                    last_cpos = cpos;
                     le_resume = cpos + 40;
                 }
             }
@@ -1184,7 +1195,10 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             const unsigned int f = atomicAdd(fin_count, 1u);
             FinishRec r;
             r.w = (int32_t)w; r.ii = ii; r.oo = oo; r.mu = mu; r.omega = omega; r.last = last;
-            r.done = ended ? 1 : 0; r.pad_ = 0;
+            r.done = ended ? 1 : 0; r.pad_ = last_cpos;
+            if (snap_on && snap_oo >= 0) {                             // the continuation restarts where the exact rows end
+                r.ii = snap_ii; r.oo = snap_oo; r.mu = snap_mu; r.omega = snap_om; r.last = snap_last; r.done = 0;
+            }
             fin[f] = r;
             if (p.syms) {
                 win_fin[w] = (int)f;
@@ -1194,6 +1208,88 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Exact payload (BTGPU_FLAG_EXACT_PAYLOAD; round 5).  The exact stage makes a record's access code and header the reference's
+// own arithmetic; the symbols BEHIND them -- the payload every header-announced decode and CRC of the host layer reads
+// (lib/packet_impl.cc:1066-1160) -- came from the continuation over the polyphase stream, and in 2.3 % of the records of an
+// adversarial run (all of them multi-slot packets, the first differing symbol >= 478 symbols behind the hit) one or more of them
+// differed from the oracle's (scripts/emu_symbol_parity.py).  With the flag every window that hands symbols to the host gets a
+// LONG TASK: the direct-form DDC (verify_ddc_kernel, the same arithmetic) over the rows from where the window kernel stopped to the
+// END OF THE BURST -- read off the tile energies: until the 50-us energy has fallen to 1.5 x the noise and stays there --, and
+// finish_kernel continues over those rows.  Behind the burst the continuation is back on the polyphase stream (noise symbols; nsym).
+struct LongRows { int x, y; };
+struct LongView {
+    const LongRows *rows;            // [cap] exact rows [x, y) of the window of FinishRec f in dxl (y = 0: none)
+    const float *dxl;            // [cap][stride]
+    int stride, cap;
+};
+struct LongTaskParams {
+    VerifyTask *tasks;           // [cap]: window, exact rows (end)
+    uint32_t *tiles;             // tile lists by channel, like the exact stage's
+    unsigned int *lcount;        // [4 + nch]: 0 long tasks, 1 tiles, 2 turned away; 4 + c: entries of channel c's list
+    unsigned int tiles_cap;
+    LongRows *rows;                  // [cap]
+    int cap, stride;
+};
+constexpr int kLongLanes = 64;
+
+// one lane per FinishRec
+__global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, const FinishRec *__restrict__ fin,
+                                                               const unsigned int *__restrict__ fin_count, LongTaskParams lp)
+{
+    const unsigned int n = *fin_count;
+    const unsigned int f = blockIdx.x * kLongLanes + threadIdx.x;
+    if (f >= n || f >= (unsigned int)lp.cap) { if (f < n) atomicAdd(&lp.lcount[2], 1u); return; }
+    lp.rows[f] = LongRows{0, 0};
+    const FinishRec r = fin[f];
+    if (r.done) return;
+    const int k = r.w / p.nch, c = r.w - k * p.nch;
+    const int TT = p.tile_outs, W = p.burst_w;
+    const int t0 = k * p.tiles_per_slot;
+    const double *pt = p.ptile + (size_t)c * p.ptile_stride;
+    const int tmax = p.ptile_stride;
+    // The packet's level: the W-tile energy ~50 us behind the start of the window's last record (inside its access code).  The
+    // burst is on while the W-tile energy stays above 0.3 x that level (-5 dB) and has ended when it has been below for 2 W tiles: a
+    // packet >= 6 dB over the noise ends where it ends; a weaker one never "ends" and is taken to the end of the window (cost only).
+    // (The span's noise estimate is no help here: a long packet fills the whole span.  A gap inside a packet does not exist; a
+    // second packet right behind the first is simply taken along.)
+    const int row_lo = (int)r.ii > 8 ? (int)r.ii - 8 : 0;
+    const int jt_lo = row_lo / kVerTile;                        // first DDC tile
+    const int j0 = row_lo / TT;
+    const int jend = (p.ddc_out + TT - 1) / TT;
+    auto wsum = [&](int j) {
+        float sw = 0.f;
+        for (int u = 0; u < W; u++) { const int t = t0 + j - u; sw += (t >= 0 && t < tmax) ? fmaxf((float)pt[t], 0.f) : 0.f; }
+        return sw;
+    };
+    const int jh = ((r.pad_ > 0 ? r.pad_ : 0) * 2 + 100) / TT;  // (two rows per symbol; + 100 rows: W tiles inside the access code)
+    const float quiet = 0.3f * wsum(jh < jend ? jh : jend - 1);
+    int last_on = j0, below = 0;
+    float s_cur = wsum(j0);
+    for (int j = j0; j < jend && t0 + j < tmax; j++) {
+        if (j > j0) {
+            const int tn = t0 + j, to = t0 + j - W;
+            s_cur += fmaxf((float)pt[tn], 0.f) - ((to >= 0) ? fmaxf((float)pt[to], 0.f) : 0.f);
+        }
+        if (s_cur > quiet) { last_on = j; below = 0; }
+        else if (++below >= 2 * W) break;
+    }
+    int row_hi = (last_on + 2) * TT;                            // (+ a tile: the filter's tail and the 8-tap interpolator)
+    row_hi = row_hi > p.ddc_out ? p.ddc_out : row_hi;
+    if (row_hi <= row_lo + 8) return;
+    const int jt_hi = (row_hi + kVerTile - 1) / kVerTile;       // DDC tiles [jt_lo, jt_hi)
+    const int nt = jt_hi - jt_lo;
+    const unsigned int tp = atomicAdd(&lp.lcount[4 + c], (unsigned int)nt);
+    if (tp + (unsigned int)nt > lp.tiles_cap) { atomicAdd(&lp.lcount[2], 1u); return; }
+    uint32_t *tl = lp.tiles + (size_t)c * lp.tiles_cap;
+    for (int j = 0; j < nt; j++) tl[tp + j] = (uint32_t)f | ((uint32_t)(jt_lo + j) << 24);
+    VerifyTask t_;
+    t_.w = r.w; t_.n_exact = row_hi; t_.snr = 0.0;
+    lp.tasks[f] = t_;
+    lp.rows[f] = LongRows{jt_lo * kVerTile + 1, row_hi};      // (row t of a tile's first output is its demod halo: exact from + 1)
+    atomicAdd(&lp.lcount[0], 1u); atomicAdd(&lp.lcount[1], (unsigned int)nt);
 }
 
 // Continue the M&M recursion of the windows that reported hits (a few per cent) to the end of their
@@ -1216,7 +1312,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     WindowParams p, const float *__restrict__ d, int drow, long long d_rows,
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
     const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits,
-    const float *__restrict__ dcol = nullptr)
+    const float *__restrict__ dcol = nullptr, LongView lv = LongView{nullptr, nullptr, 0, 0})
 {
     constexpr unsigned int RING = kFinRing, MASK = RING - 1;
     __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
@@ -1252,7 +1348,10 @@ __global__ __launch_bounds__(64) void finish_kernel(
     // rows [hi - RING, hi) are resident, row q in slot q & 31 (slots 0..7 also at 32..39); refills are whole
     // 16-row blocks, so a block is either slots 0..15 (guard copy of its first half) or 16..31
     unsigned int hi = ii & ~(unsigned int)(kFinRows - 1);
-    auto fetch = [&](float *v) {                                 // rows [hi, hi + 16): unconditional loads, values selected later
+    // exact payload: rows [lrow.x, lrow.y) of this window come from the long task's exact rows
+    const LongRows lrow = (SYMS && lv.rows && f < (unsigned int)lv.cap) ? lv.rows[f] : LongRows{0, 0};
+    const float *lx = lv.dxl + (size_t)(f < (unsigned int)lv.cap ? f : 0) * (size_t)lv.stride;
+    auto fetch_poly = [&](float *v) {                            // rows [hi, hi + 16): unconditional loads, values selected later
         if (p.dbg_stop == 9) {                                   // timing experiment (BTGPU_WIN_STOP=9): no stream traffic
 #pragma unroll
             for (int j = 0; j < kFinRows; j++) v[j] = 0.01f * (float)((hi + j) & 7) - 0.03f;
@@ -1272,6 +1371,18 @@ __global__ __launch_bounds__(64) void finish_kernel(
         }
 #pragma unroll
         for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * drow]; }
+    };
+    auto fetch = [&](float *v) {
+        if (SYMS && lrow.y > 0 && (int)hi >= lrow.x && (int)hi + kFinRows <= lrow.y) {            // the whole block is exact
+#pragma unroll
+            for (int j = 0; j < kFinRows; j++) v[j] = lx[hi + j];
+            return;
+        }
+        fetch_poly(v);
+        if (SYMS && lrow.y > 0 && (int)hi + kFinRows > lrow.x && (int)hi < lrow.y) {              // a block across either end
+#pragma unroll
+            for (int j = 0; j < kFinRows; j++) { const int idx = (int)hi + j; if (idx >= lrow.x && idx < lrow.y) v[j] = lx[idx]; }
+        }
     };
     auto put = [&](const float *v) {                             // rows [hi, hi + 16) -> ring; rows past the stream read as 0
         const unsigned int s0 = hi & MASK;                       // 0 or 16

@@ -36,6 +36,7 @@ struct VerifyParams {
     const float *atan_tab; float gain;
     const VerifyTask *tasks; const unsigned int *vcount; int vcap;
     const uint32_t *tiles; const unsigned int *tcount; unsigned int tiles_cap;   // tile lists by channel: tiles[c * tiles_cap ..], tcount[c] entries
+    int dx_stride;                    // floats per task in the output (kVerRows; the long tasks of BTGPU_FLAG_EXACT_PAYLOAD: whole windows)
     const unsigned int *tstart;       // nullptr, or [nch]: entries of each list that an earlier launch of this batch has taken
     int nch;
 };
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kVerThreads, 4) void verify_ddc_kernel(VerifyParams
         __syncthreads();
         if (threadIdx.x >= 1 && threadIdx.x < kVerOuts) {
             const int u = (int)threadIdx.x, t = t_first + u;
-            if (t >= 1 && t < n_exact) dx[(size_t)q * kVerRows + t] = demod_one(atab, p.gain, ys[u], ys[u - 1]);
+            if (t >= 1 && t < n_exact) dx[(size_t)q * (size_t)p.dx_stride + t] = demod_one(atab, p.gain, ys[u], ys[u - 1]);
         }
         item = next;
     }
@@ -410,8 +411,8 @@ __global__ __launch_bounds__(64 * kVerSmallWaves, 4) void verify_ddc_small_kerne
         __syncthreads();
         if (act) {
             const int ta = t_first + 2 * lane, tb = ta + 1;
-            if (lane >= 1 && ta >= 1 && ta < n_exact) dx[(size_t)q * kVerRows + ta] = demod_one(atab, p.gain, y0, ys[2 * lane - 1]);
-            if (tb >= 1 && tb < n_exact) dx[(size_t)q * kVerRows + tb] = demod_one(atab, p.gain, y1, y0);
+            if (lane >= 1 && ta >= 1 && ta < n_exact) dx[(size_t)q * (size_t)p.dx_stride + ta] = demod_one(atab, p.gain, y0, ys[2 * lane - 1]);
+            if (tb >= 1 && tb < n_exact) dx[(size_t)q * (size_t)p.dx_stride + tb] = demod_one(atab, p.gain, y1, y0);
         }
     }
 }

@@ -30,7 +30,7 @@ multi_block::multi_block(double sample_rate, double center_freq, double squelch_
     // multi_hopper (lib/multi_hopper_impl.cc:52-56) has the sniffer's symbol history but no LE pass
     // multi_LAP prints the LAP of a hit and nothing that depends on the rest of the window
     // (lib/multi_LAP_impl.cc:93-110): no clock-recovery continuation for hit.nsym
-    const int flags = mode == BTGPU_MODE_SNIFFER ? ((hopper ? 0 : BTGPU_FLAG_LE) | BTGPU_FLAG_HEADERS) : BTGPU_FLAG_NO_NSYM;
+    const int flags = mode == BTGPU_MODE_SNIFFER ? ((hopper ? 0 : BTGPU_FLAG_LE) | BTGPU_FLAG_HEADERS | BTGPU_FLAG_EXACT_PAYLOAD) : BTGPU_FLAG_NO_NSYM;
     d_headers = (flags & BTGPU_FLAG_HEADERS) != 0;
     d_sample_rate = sample_rate;
     d_center_freq = center_freq;

@@ -254,6 +254,22 @@ def classic_dh1_bits(lap, uap, slot_clock, body, lt_addr=1, llid=2, flow=1, arqn
     return np.concatenate([access_code_bits(lap), np.repeat(header, 3), pay])
 
 
+def classic_dh_multislot_bits(lap, uap, slot_clock, body, ptype=15, lt_addr=1, llid=2, flow=1, arqn=0, seqn=0):
+    """DH3 (TYPE 11, <= 183 bytes) / DH5 (TYPE 15, <= 339 bytes): like DH1 with the two-byte payload header of the multi-slot
+    packets (LLID 2, FLOW 1, LENGTH 10 bits, 3 reserved), body, CRC(UAP); header and payload whitened, no FEC."""
+    body = bytes(body)
+    assert ptype in (11, 15) and len(body) <= (183 if ptype == 11 else 339)
+    ph = (llid & 3) | ((flow & 1) << 2) | (len(body) << 3)
+    pay = [(ph >> i) & 1 for i in range(16)]
+    for byte in body:
+        pay += [(byte >> i) & 1 for i in range(8)]
+    crc = _crc16(pay, uap)
+    pay += [(crc >> i) & 1 for i in range(16)]
+    wh = whitening_bits(slot_clock & 0x3F, 18 + len(pay))
+    header = _classic_header(lap, uap, slot_clock, ptype, lt_addr, flow, arqn, seqn) ^ wh[:18]
+    return np.concatenate([access_code_bits(lap), np.repeat(header, 3), np.array(pay, np.uint8) ^ wh[18:]])
+
+
 def make_hopping_capture(sample_rate, center_freq, n_slots, lap, uap, clk0, seed=1, snr_db=24.0, occupancy=0.9,
                          cfo_hz=5e3, start_symbol=40, dh1_fraction=1.0, aliased=False):
     """One master hopping over all 79 channels by the real selection kernel, a DH1 packet in each of

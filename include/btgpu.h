@@ -84,6 +84,13 @@ extern "C" {
                                            then equal the CPU reference's in slot, channel, kind, offset, LAP and ac_errors; with this
                                            flag ~1.4e-4 of them come out a symbol apart or on one side only (the round-3 behaviour) */
 
+#define BTGPU_FLAG_EXACT_PAYLOAD 0x200   /* with SYMBOLS / HEADERS on the polyphase channelizer: the symbols a record hands to the host layer are the
+                                           reference's own arithmetic to the END OF THE PACKET, not only through access code and header: the
+                                           direct-form DDC is also run over the rows behind the header, up to where the burst's energy ends, and
+                                           the clock-recovery continuation reads those.  What every payload decode and CRC of the host layer
+                                           sees (lib/packet_impl.cc:1066-1160) then equals the CPU reference's.  Costs the direct-form filter
+                                           over the air time of every detected packet; the gr::bluetooth::multi_sniffer mirror sets it */
+
 #define BTGPU_KIND_AC 0
 #define BTGPU_KIND_AA 1
 
@@ -155,6 +162,9 @@ typedef struct btgpu_timing {
     uint64_t verify_windows;                  /* windows re-run through the exact stage (always counted)                 */
     uint64_t verify_rows;                     /* demodulated rows recomputed by the direct-form DDC, in 127-row tiles    */
     uint64_t verify_turned_away;              /* windows that should have been re-run but found the task list full       */
+    uint64_t long_tasks;                      /* BTGPU_FLAG_EXACT_PAYLOAD: windows whose rows behind the header were recomputed to the end of the burst */
+    uint64_t long_rows;                       /* ... the rows of those, in 127-row tiles                                  */
+    uint64_t long_turned_away;                /* ... windows that found the long-task lists full (their payload symbols: the polyphase continuation) */
 } btgpu_timing;
 
 /* ---- host-only helpers (no GPU needed) ---- */

@@ -13,6 +13,7 @@ from tests.conftest import load_pkg
 load_pkg()
 ap = argparse.ArgumentParser(); ap.add_argument("cases", type=int); ap.add_argument("seed", type=int); ap.add_argument("--rates", default="8,20")
 ap.add_argument("first", type=int, nargs="?", default=0); ap.add_argument("stride", type=int, nargs="?", default=1)
+ap.add_argument("--exact-payload", action="store_true", help="BTGPU_FLAG_EXACT_PAYLOAD: long tasks to the end of each burst")
 a = ap.parse_args()
 L = ctypes.CDLL(os.environ.get("EMU_LIB", os.path.join(ROOT, "tests", "emu", "libemu_bank.so")))
 F, Q, D = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)
@@ -20,6 +21,8 @@ L.emu_front_m_syms_run.restype = ctypes.c_int
 L.emu_front_m_syms_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, F, ctypes.c_longlong, ctypes.c_int, Q, D, ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_uint32)]
 KW = 120
+L.emu_set_exact_payload(1 if a.exact_payload else 0)
+L.emu_long_counts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
 rng = np.random.default_rng(a.seed)
 tot = collections.Counter()
 for case in range(a.cases):
@@ -35,20 +38,28 @@ for case in range(a.cases):
     rec = np.zeros((cap, 8), np.int64); snr = np.zeros(cap); sym = np.zeros((cap, KW), np.uint32)
     n = L.emu_front_m_syms_run(fs, fc, po.MODE_SNIFFER, 0, c["squelch"], x.ctypes.data_as(F), len(x) // 2, c["n_slots"], rec.ctypes.data_as(Q), snr.ctypes.data_as(D), cap,
                                sym.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    lc = (ctypes.c_uint * 4)(); L.emu_long_counts(lc); tot["long_tasks"] += int(lc[0]); tot["long_tiles"] += int(lc[1]); tot["long_turned_away"] += int(lc[2])
     got = {tuple(int(v) for v in rec[i, :6]): i for i in range(n)}
-    lens = {(m["channel"], m["lap"]): m["nbits"] for m in meta}
     for h in want:
         key = (h.slot, h.channel, h.kind, h.offset, h.lap, h.ac_errors)
-        if h.kind != 0 or key not in got or (h.channel, h.lap) not in lens:
+        if h.kind != 0 or key not in got:
             continue
+        # the packet this record belongs to: same channel and LAP, its first sample where the record's access code begins
+        sps = int(round(fs / 1e6))
+        est = h.slot * o.slot - (o.history - 1) + o.first_ch + (o.ntaps_ch - 1) // 2 + h.offset * sps
+        cand = [m for m in meta if m["channel"] == h.channel and m["lap"] == h.lap and abs(m["start"] - est) < 12 * sps]
+        if not cand:
+            continue
+        pk = min(cand, key=lambda m: abs(m["start"] - est))
         win = o.window(iq, h.slot)
         osym, _ = o.channel_symbols(o.channel_samples(win, h.channel)[0] if isinstance(o.channel_samples(win, h.channel), tuple) else o.channel_samples(win, h.channel))
         bits = np.unpackbits(sym[got[key]].view(np.uint8), bitorder="little")
         m = min(len(osym), len(bits)) - h.offset
-        nb = min(lens[(h.channel, h.lap)], m)                      # the packet's own symbols: access code, header, payload
+        nb = min(pk["nbits"], m)                                   # the packet's own symbols: access code, header, payload
         diff = np.nonzero(osym[h.offset:h.offset + nb] != bits[h.offset:h.offset + nb])[0]
         tot["records"] += 1; tot["symbols"] += nb
         tot["records_with_a_differing_symbol"] += len(diff) > 0; tot["differing_symbols"] += len(diff)
         if len(diff):
             print("case %d rec %s packet bits %d: %d symbols differ, first at %d" % (case, key, nb, len(diff), diff[0]), flush=True)
+tot["exact_payload"] = int(a.exact_payload)
 print("TOTAL " + json.dumps(dict(tot)))

@@ -266,6 +266,10 @@ struct VerifyEmu {
 static int g_verify_mode = 1;                            // emu_set_verify: 0 off, 1 hits + burst energy, 2 hits only
 static unsigned int g_verify_counts[4] = {0, 0, 0, 0};  // of the last emulated front end
 extern "C" void emu_set_verify(int mode) { g_verify_mode = mode; }
+static int g_exact_payload = 0;                          // emu_set_exact_payload: BTGPU_FLAG_EXACT_PAYLOAD (with symbols)
+extern "C" void emu_set_exact_payload(int on) { g_exact_payload = on; }
+static unsigned int g_long_counts[4] = {0, 0, 0, 0};
+extern "C" void emu_long_counts(unsigned int *out) { std::memcpy(out, g_long_counts, sizeof g_long_counts); }
 extern "C" void emu_set_fuse_m(int on) { g_fuse_m = on; }
 extern "C" int emu_last_fused_m(void) { return g_last_fused_m; }
 extern "C" void emu_verify_counts(unsigned int *out) { std::memcpy(out, g_verify_counts, sizeof g_verify_counts); }
@@ -287,6 +291,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     const int max_hits = 1 << 16;
     std::vector<uint64_t> pcol(des.ac.btbb_pcol, des.ac.btbb_pcol + 24);
     WindowParams p = make_window_params(des, S, nb, 0, max_hits, want_syms, pcol.data());
+    p.exact_payload = (g_exact_payload && want_syms && ve && ve->mode > 0) ? 1 : 0;
     const size_t W = (size_t)S * nch;
     std::vector<double> e_on(W), e_off(W), snr(W);
     std::vector<int> win_len(W, -1), win_fin(W, -1);
@@ -312,6 +317,9 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     // kernel, the DDC of what its hits added, fill, exact window kernel.  EMU_PRESCAN=1 (the runtime's BTGPU_PRESCAN=1; default: the scan inside the window kernel, one DDC launch)
     static const bool prescan_env = getenv("EMU_PRESCAN") && atoi(getenv("EMU_PRESCAN")) == 1;
     const bool prescan = prescan_env && verify && p.verify == 1;
+    std::vector<VerifyTask> ltasks; std::vector<uint32_t> ltiles; std::vector<LongRows> lrows; std::vector<float> dxl;
+    unsigned int lcount[kVerCountWords] = {0};
+    LongView lview{nullptr, nullptr, 0, 0};
     std::vector<int32_t> vinfo(prescan ? W : 1, -1);
     std::vector<unsigned int> vtstart(80, 0u);
     auto launch_window = [&](auto lay) {
@@ -358,6 +366,28 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
                                      fin.data(), &counts[1], &des.le.hdr[0][0], des.le.whiten16, des.le.index_of_channel, win_fin.data(),
                                      want_syms ? symbits.data() : (uint32_t *)nullptr, winbits_v.data());
         });
+        // ---- exact payload: long tasks of the windows that hand symbols over (runtime: tail stream, behind the exact window kernel) ----
+        if (g_exact_payload && want_syms) {
+            const int lcap = 4096, lstride = ((des.d.ddc_out + kVerTile - 1) / kVerTile) * kVerTile + 8;
+            const unsigned int ltcap = 16384;
+            ltasks.assign((size_t)lcap, VerifyTask{}); ltiles.assign((size_t)nch * ltcap, 0u); lrows.assign((size_t)lcap, LongRows{0, 0});
+            dxl.assign((size_t)lcap * lstride, -77.f);
+            std::memset(lcount, 0, sizeof lcount);
+            LongTaskParams lp{};
+            lp.tasks = ltasks.data(); lp.tiles = ltiles.data(); lp.lcount = lcount; lp.tiles_cap = ltcap; lp.rows = lrows.data(); lp.cap = lcap; lp.stride = lstride;
+            emu::launch(dim3((unsigned)(lcap / kLongLanes)), dim3(kLongLanes), [&]() { long_task_kernel(p, fin.data(), &counts[1], lp); });
+            VerifyParams vq = vp;
+            vq.tasks = lp.tasks; vq.vcount = lp.lcount; vq.vcap = lcap; vq.tiles = lp.tiles; vq.tcount = lp.lcount + 4; vq.tiles_cap = ltcap;
+            vq.tstart = nullptr; vq.dx_stride = lstride;
+            if (lcount[1]) {
+                std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
+                emu::launch(dim3((unsigned)(2 * nch + 1)), dim3((unsigned)vl.threads), [&]() { vl.kern(vq, ve->x, (const float2 *)tv.data(), dxl.data()); });
+            }
+            lview.rows = lrows.data(); lview.dxl = dxl.data(); lview.stride = lstride; lview.cap = lcap;
+            std::memcpy(g_long_counts, lcount, sizeof g_long_counts);
+            if (getenv("EMU_DBG_LONG")) for (unsigned f = 0; f < counts[1] && f < (unsigned)lcap; f++)
+                std::fprintf(stderr, "long f %u window slot %d ch %d: start ii %u oo %d rows [%d, %d)\n", f, fin[f].w / nch, fin[f].w % nch, fin[f].ii, fin[f].oo, lrows[f].x, lrows[f].y);
+        }
     };
     if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
     else if (drow == 40) launch_window(WinLayout<6, 40, 10>{});
@@ -377,7 +407,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     {
         const unsigned nblk = (unsigned)((counts[1] + kFinLanes - 1) / kFinLanes + 1);
         emu::launch(dim3(nblk), dim3(kFinLanes), [&]() {
-            if (want_syms) finish_kernel<true>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), symbits.data(), dcol_p);
+            if (want_syms) finish_kernel<true>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), symbits.data(), dcol_p, lview);
             else finish_kernel<false>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), (uint32_t *)nullptr, dcol_p);
         });
         emu::launch(dim3(4), dim3(256), [&]() {
