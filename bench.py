@@ -72,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
     ap.add_argument("--headers", action="store_true", help="also export hit symbols and run the GPU header sweep (BTGPU_FLAG_HEADERS), as the C++ multi_sniffer block does")
+    ap.add_argument("--exact-payload", action="store_true", help="with --headers: BTGPU_FLAG_EXACT_PAYLOAD, as the C++ multi_sniffer block sets it")
     ap.add_argument("--le", action="store_true", help="also run the le_packet::sniff_aa pass (BTGPU_FLAG_LE), as the C++ multi_sniffer block does")
     ap.add_argument("--no-block-config", action="store_true", help="skip the second timed region in the drop-in block's configuration (LE | HEADERS)")
     ap.add_argument("--full-timing", action="store_true", help="HIP events around every kernel in the headline region too (kernel_avg_ms of all kernels)")
@@ -179,7 +180,7 @@ def run_rank(args):
         return pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
                                  channelizer=args.channelizer, squelch=args.squelch_mode,
                                  flags=base_flags | extra | (head_timing if timing is None else timing))
-    head_flags = (pkg.FLAG_HEADERS if args.headers else 0) | (pkg.FLAG_LE if args.le else 0)
+    head_flags = (pkg.FLAG_HEADERS if args.headers else 0) | (pkg.FLAG_LE if args.le else 0) | (pkg.FLAG_EXACT_PAYLOAD if args.exact_payload else 0)
     blk = make_block(head_flags)
     des = blk.design
     H, slot = des.history, des.samples_per_slot
@@ -555,7 +556,7 @@ def run_rank(args):
                        "mode": "multi_sniffer",
                        "partition": "time x%d, halo %d + margin %d samples" % (world, H - 1, margin),
                        "gather": ("one async all_gather_into_tensor per %d batches (%s, own stream), %d rounds" % (args.gather_every, args.backend, gatherer.rounds)) if gathering else "none",
-                       "flags": "ASYNC%s%s%s" % ("|LE" if args.le else "", "|HEADERS" if args.headers else "", "" if args.no_timing else ("|TIMING" if args.full_timing else "|TIMING_BANK")),
+                       "flags": "ASYNC%s%s%s" % ("|LE" if args.le else "", "|HEADERS" if args.headers else "", ("|EXACT_PAYLOAD" if args.exact_payload else "") + "" if args.no_timing else ("|TIMING" if args.full_timing else "|TIMING_BANK")),
                        "channelizer": {1: "direct", 2: "polyphase"}[int(des.channelizer)],
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},
             "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed],

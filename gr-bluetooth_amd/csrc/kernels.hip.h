@@ -48,7 +48,7 @@ struct FinishRec {            // M&M state of a window that reported hits, hande
     int32_t  oo;
     float    mu, omega, last;
     int32_t  done;            // the window already ended inside the window kernel (len known)
-    int32_t  pad_;            // symbol offset of the window's last record (long_task_kernel: where the packet's level is read)
+    int32_t  pad_;            // exact payload: the weakest of the window's packets (W-tile energy inside its access code, float bits)
 };
 
 constexpr int kSymWords = 120;    // packed symbols kept per hit window (3840 >= ~3760 symbols)
@@ -1022,9 +1022,18 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int len1 = oo;                                         // 693, or the whole window if shorter
     int limit = len1 - 68 < 625 ? len1 - 68 : 625;
     int resume = 0, nhits = 0;
-    int last_cpos = -1;                                          // symbol offset of the window's last record (exact payload: where its packet is)
+    // exact payload: the weakest of the window's records' packets, as the W-tile energy ~50 us behind each record's start (inside its
+    // access code) -- long_task_kernel takes the burst as over when the energy has fallen 5 dB under it
+    float min_level = 3.0e38f;
+    auto note_level = [&](int cpos) {
+        if (!p.exact_payload || !p.ptile) return;
+        const int j = (2 * cpos + 100) / p.tile_outs, tb = kq * p.tiles_per_slot;
+        float sw = 0.f;
+        for (int u = 0; u < p.burst_w; u++) { const int t = tb + j - u; sw += (t >= 0 && t < p.ptile_stride) ? fmaxf((float)p.ptile[(size_t)cq * p.ptile_stride + t], 0.f) : 0.f; }
+        min_level = sw < min_level ? sw : min_level;
+    };
     auto emit_classic = [&](int cpos, uint32_t lap, int err) {
-        last_cpos = cpos;
+        note_level(cpos);
         if (!VER && p.verify) {
             // a classic hit of the polyphase path is a claim the exact stage settles: the span that must be exact reaches to
             // the end of this access code (+ header)
@@ -1179,7 +1188,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                         hits[slot_h] = h;
                     }
                     nhits++;
-                    last_cpos = cpos;
+                    note_level(cpos);
                     le_resume = cpos + 40;
                 }
             }
@@ -1195,7 +1204,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             const unsigned int f = atomicAdd(fin_count, 1u);
             FinishRec r;
             r.w = (int32_t)w; r.ii = ii; r.oo = oo; r.mu = mu; r.omega = omega; r.last = last;
-            r.done = ended ? 1 : 0; r.pad_ = last_cpos;
+            r.done = ended ? 1 : 0; r.pad_ = (int32_t)__float_as_uint(min_level < 1.0e38f ? min_level : 0.f);
             if (snap_on && snap_oo >= 0) {                             // the continuation restarts where the exact rows end
                 r.ii = snap_ii; r.oo = snap_oo; r.mu = snap_mu; r.omega = snap_om; r.last = snap_last; r.done = 0;
             }
@@ -1250,8 +1259,8 @@ __global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, c
     const int t0 = k * p.tiles_per_slot;
     const double *pt = p.ptile + (size_t)c * p.ptile_stride;
     const int tmax = p.ptile_stride;
-    // The packet's level: the W-tile energy ~50 us behind the start of the window's last record (inside its access code).  The
-    // burst is on while the W-tile energy stays above 0.3 x that level (-5 dB) and has ended when it has been below for 2 W tiles: a
+    // The packet's level: the W-tile energy ~50 us behind the start of a record (inside its access code), the weakest of the
+    // window's records (FinishRec.pad_).  The burst is on while the W-tile energy stays above 0.3 x that level (-5 dB) and has ended when it has been below for 2 W tiles: a
     // packet >= 6 dB over the noise ends where it ends; a weaker one never "ends" and is taken to the end of the window (cost only).
     // (The span's noise estimate is no help here: a long packet fills the whole span.  A gap inside a packet does not exist; a
     // second packet right behind the first is simply taken along.)
@@ -1264,8 +1273,7 @@ __global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, c
         for (int u = 0; u < W; u++) { const int t = t0 + j - u; sw += (t >= 0 && t < tmax) ? fmaxf((float)pt[t], 0.f) : 0.f; }
         return sw;
     };
-    const int jh = ((r.pad_ > 0 ? r.pad_ : 0) * 2 + 100) / TT;  // (two rows per symbol; + 100 rows: W tiles inside the access code)
-    const float quiet = 0.3f * wsum(jh < jend ? jh : jend - 1);
+    const float quiet = 0.3f * __uint_as_float((uint32_t)r.pad_);      // (0: no level known -- the window is taken to its end)
     int last_on = j0, below = 0;
     float s_cur = wsum(j0);
     for (int j = j0; j < jend && t0 + j < tmax; j++) {
