@@ -556,7 +556,7 @@ def run_rank(args):
                        "mode": "multi_sniffer",
                        "partition": "time x%d, halo %d + margin %d samples" % (world, H - 1, margin),
                        "gather": ("one async all_gather_into_tensor per %d batches (%s, own stream), %d rounds" % (args.gather_every, args.backend, gatherer.rounds)) if gathering else "none",
-                       "flags": "ASYNC%s%s%s" % ("|LE" if args.le else "", "|HEADERS" if args.headers else "", ("|EXACT_PAYLOAD" if args.exact_payload else "") + "" if args.no_timing else ("|TIMING" if args.full_timing else "|TIMING_BANK")),
+                       "flags": "ASYNC%s%s%s" % ("|LE" if args.le else "", "|HEADERS" if args.headers else "", ("|EXACT_PAYLOAD" if args.exact_payload else "") + ("" if args.no_timing else ("|TIMING" if args.full_timing else "|TIMING_BANK"))),
                        "channelizer": {1: "direct", 2: "polyphase"}[int(des.channelizer)],
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},
             "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed],

@@ -645,8 +645,12 @@ int btgpu_handle::stage_batch(const float *head, size_t n_head, const float *bod
     bool direct = false;
     {
         hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, body) == hipSuccess && attr.type == hipMemoryTypeHost) direct = true;
-        else (void)hipGetLastError();                                        // (an unregistered pointer is reported as an error: cleared)
+        // page-locked from its first byte to its last (a buffer registered only in part would be copied as if all of it were: ADVICE r4)
+        if (n_body > 0 && hipPointerGetAttributes(&attr, body) == hipSuccess && attr.type == hipMemoryTypeHost) {
+            hipPointerAttribute_t last;
+            if (hipPointerGetAttributes(&last, (const char *)body + n_body * sizeof(float2) - 1) == hipSuccess && last.type == hipMemoryTypeHost) direct = true;
+            else (void)hipGetLastError();
+        } else (void)hipGetLastError();                                      // (an unregistered pointer is reported as an error: cleared)
         static const bool no_direct = getenv("BTGPU_NO_DIRECT_H2D") != nullptr;
         if (no_direct) direct = false;
     }
@@ -673,7 +677,9 @@ int btgpu_handle::stage_batch(const float *head, size_t n_head, const float *bod
     HIPCHK(this, hipEventRecord(ev_copied[k], copy_stream));
     HIPCHK(this, hipStreamWaitEvent(stream, ev_copied[k], 0));
     const int rc = process_batch(d_buf, n_head + n_body, w0, abs_first_slot, S, stream);
-    if (direct) HIPCHK(this, hipEventSynchronize(ev_copied[k]));                  // (behind the enqueue: the kernels queue up under the copy)
+    // (behind the enqueue: the kernels queue up under the copy; also where process_batch failed -- the buffer is the caller's again
+    // only once the copy has left it)
+    if (direct) { const hipError_t se = hipEventSynchronize(ev_copied[k]); if (rc != BTGPU_OK) return rc; HIPCHK(this, se); }
     HIPCHK(this, hipEventRecord(ev_consumed[k], stream));
     if (verify) HIPCHK(this, hipEventRecord(ev_vdone[k], last_tail));
     stage_used[k] = true;
@@ -693,7 +699,7 @@ int btgpu_handle::harvest(TailCtx &t)
         float ms = 0;
         const bool blk = use_pfb;
         // (deferred squelch: the window kernel starts behind the banks' last mark, not behind stage 2, which runs beside it)
-        hipEvent_t a[7] = {t.ev[0], blk ? t.ev[5] : t.ev[1], t.ev[2], use_staged ? t.ev[6] : t.ev[3], deferred ? t.ev[4] : t.ev[7], t.ev[11], t.ev[9]};
+        hipEvent_t a[7] = {t.ev[0], blk ? t.ev[5] : t.ev[1], t.ev[2], use_staged ? t.ev[6] : t.ev[3], deferred ? t.ev[4] : t.ev[7], t.ev[11], verify ? t.ev[8] : t.ev[9]};   // (the exact stage from the end of the window kernel: its DDC runs in line, before the tail's first mark -- ADVICE r4)
         hipEvent_t e[7] = {t.ev[1], blk ? t.ev[6] : t.ev[2], t.ev[3], use_staged ? t.ev[7] : t.ev[4], t.ev[8], t.ev[10], t.ev[11]};
         for (int i = 0; i < (timing_full ? 7 : 1); i++) {
             HIPCHK(this, hipEventElapsedTime(&ms, a[i], e[i]));
@@ -1049,9 +1055,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             const int off = getenv("BTGPU_TAIL_CU_OFF") ? atoi(getenv("BTGPU_TAIL_CU_OFF")) : 0;
             for (int i = 0; i < tail_cus; i++) { const int b = (i * step + off) & 255; mask[b >> 5] |= 1u << (b & 31); }
             if (hipExtStreamCreateWithCUMask(&h->tail_stream, 8, mask) != hipSuccess) return fail(BTGPU_EDEVICE);
-        } else
-        if (hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
-        for (auto &te : h->tail_extra) if (hipStreamCreateWithPriority(&te, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
+            // (the tails of consecutive batches alternate between these streams: the same mask on all of them -- ADVICE r4)
+            for (auto &te : h->tail_extra) if (hipExtStreamCreateWithCUMask(&te, 8, mask) != hipSuccess) return fail(BTGPU_EDEVICE);
+        } else {
+            if (hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
+            for (auto &te : h->tail_extra) if (hipStreamCreateWithPriority(&te, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
+        }
     }
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
     if (hipStreamCreateWithFlags(&h->sq_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);

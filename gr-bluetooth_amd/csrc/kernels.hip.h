@@ -655,9 +655,17 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                 if (trig && !prev && jx >= 0) {
                     // The run of triggers begins at the tile the packet begins in, or -- where less than ~3 noise tiles' worth of it
                     // lies in that tile -- up to W - 1 tiles later.  An access code is reportable at the offsets below 625
-                    // (lib/multi_sniffer_impl.cc:108), i.e. up to row ~1257 at the loop's slowest clock: a burst that starts later
-                    // is the next window's (in a sniffer window the following slot begins near symbol 635 -- every burst would be
-                    // taken twice, the second time with a full-length span).  Where inside its tile the packet begins is estimated
+                    // (lib/multi_sniffer_impl.cc:108).  Where symbol 625 lies in the window is NOT bounded by the loop's clock limits
+                    // (2 +- 0.005 rows per symbol would give row 1257, rounds 3-4's bound): in the noise in front of a packet the timing
+                    // error term moves mu by up to gain_mu per symbol, a random walk.  Measured on the oracle (3300 packets with their
+                    // onset at rows 1248 .. 1290, profiles/r05_handover_rows.txt): the earlier window still reports the packet in 50 % at
+                    // row 1252, 12 % at 1258, 2 % at 1262, 1 of 156 at 1266, 0 of 3300 behind 1267 -- a Gaussian tail, sigma 4.6 rows.
+                    // A burst is the NEXT window's from row 1270 on: at that row the earlier window reports it in 6e-5 (3.9 sigma), and
+                    // over packets at random instants the loss is the tail's integral / 1250 rows = 5e-8 per packet (round 4's 1261:
+                    // 3 % at the row, 4e-5 per packet -- the ~1e-4 of planted records that rounds 3 and 4 kept losing in unaligned
+                    // traffic).  In a sniffer window the following slot begins at row 1264.5 and its bursts 5 us = 10 rows later: the
+                    // common, slot-aligned case is still taken once, not twice at full length.
+                    // Where inside its tile the packet begins is estimated
                     // from how much of a full tile (the next one) it fills; how far the true onset can lie IN FRONT of that estimate:
                     // with x = (packet tile) / (what was there before, o), a tile sum of ~12.6 independent values has the variance
                     // (o^2 + 2 S o) / 12.6 around a signal part S, so the fill fraction is off by sigma = sqrt((2 / x^2 + 4 / x) / 12.6)
@@ -673,7 +681,7 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                     const float cap_back = (float)(W > 1 ? W - 1 : 1);
                     back = (miss_old > 0 || !(back < cap_back)) ? cap_back : back;
                     const float onset_row = ((float)(jx + 1) - frac - back) * (float)TT - 1.f;
-                    if (onset_row < 1258.f) rise = jx;
+                    if (onset_row < 1270.f) rise = jx;
                 }
                 prev = trig;
             }
