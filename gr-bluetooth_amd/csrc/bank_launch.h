@@ -23,7 +23,9 @@ constexpr int kBankThreadsF = 320;           // pfb100f_kernel: five waves per r
 enum BankVariant { kBankLegacy = 0, kBankLegacyWide = 1, kBankRun256 = 2, kBankRun320 = 3,
                    kBankRun256d = 6,        // run256 as of profiles/r03_j_* (OPT 7: no lean epilogue, no wave priorities)
                    kBankRun256e = 7,        // the default without the wave priorities (OPT 31)
-                   kBankRun256a = 8 };      // ... with the priorities read from BTGPU_PFB_DBG (OPT 31 + 256)
+                   kBankRun256a = 8,        // ... with the priorities read from BTGPU_PFB_DBG (OPT 31 + 256)
+                   kBankRun512 = 9,         // round 5: eight waves per tile, channel and squelch branches on different waves, <= 80 VGPRs
+                   kBankRun512r = 10 };     // ... in <= 128 VGPRs (two workgroups = 16 waves per CU)
 constexpr int kBankNT = 26;                 // channel instants per tile (25 new + 1 halo for the demod)
 constexpr int kNoiseNT = 10;                // instants per tile of the stand-alone noise stage 1
 
@@ -129,6 +131,12 @@ inline int launch_channel_bank(const Design &des, const FastPath &fp, bool fuse_
                 p.b2map = b.b2map_f320;
                 if (bk.real_taps) L(pfb100f_kernel<kBankThreadsF, true, kBankKT>, nruns, kBankThreadsF, lds, p);
                 else L(pfb100f_kernel<kBankThreadsF, false, kBankKT>, nruns, kBankThreadsF, lds, p);
+            } else if (variant == kBankRun512 && bk.real_taps && p.rho_real) {
+                p.b2map = b.b2map_fused_wide;
+                L(pfb100f_kernel<kBankThreadsWide, true, 2 * kBankKT, 239>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreadsWide, lds, p);
+            } else if (variant == kBankRun512r && bk.real_taps && p.rho_real) {
+                p.b2map = b.b2map_fused_wide;
+                L(pfb100f_kernel<kBankThreadsWide, true, 2 * kBankKT, 255 + 512>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreadsWide, lds, p);
             } else if (variant == kBankRun256d && bk.real_taps) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // the default without the lean epilogue
             else if (variant == kBankRun256e && bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 31>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // the default without the wave priorities
             else if (variant == kBankRun256a && bk.real_taps && p.rho_real) L(pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 31 + 256>, (grid + 2 * kBankKT - 1) / (2 * kBankKT), kBankThreads, lds, p);   // priorities from BTGPU_PFB_DBG (scripts/r03_n_prio.sh)

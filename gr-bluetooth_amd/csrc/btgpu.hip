@@ -307,7 +307,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             if (!e) return (int)kBankRun256;
             const std::string v(e);
             return v == "legacy" ? (int)kBankLegacy : v == "wide" ? (int)kBankLegacyWide : v == "run320" ? (int)kBankRun320 :
-                   v == "run256d" ? (int)kBankRun256d :
+                   v == "run512" ? (int)kBankRun512 : v == "run512r" ? (int)kBankRun512r : v == "run256d" ? (int)kBankRun256d :
                    v == "run256e" ? (int)kBankRun256e : v == "run256a" ? (int)kBankRun256a : (int)kBankRun256;
         }();
         ntiles = launch_channel_bank(des, fp, fuse_noise, bb, x_len, w0, S, G, nb, L, variant);

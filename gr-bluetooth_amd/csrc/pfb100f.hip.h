@@ -80,13 +80,16 @@ __device__ __forceinline__ cf chan_mac(const ChanTaps<REAL> &t, int q, cf w, cf 
 // invariants stayed live through all phases and pushed the prefetched input out of the register file.
 // (the two macros live in kernels.hip.h)
 
-template <int R, bool REAL, int OPT>
+// DO_CH / DO_SQ: the eight-wave form (NTH = 512) gives the channel branches and the squelch branches to different waves
+template <int R, bool REAL, int OPT, bool DO_CH = true, bool DO_SQ = true>
 __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &a, const cf (&an)[15], cf *U, int pp)
 {
     constexpr int M = 100, Q = 7, NT = 26, NQ = 15, UST = kPfbUst;
     constexpr int NI = R == 0 ? 3 : 2;                           // noise instants of this parity: 0,2,4 / 1,3
-    constexpr int NN = R == 0 ? 25 : 22;                         // march steps: max(12 + 7, s_last + 15)
-    constexpr int LA = (OPT & 2) ? 8 : 4;                        // LDS reads in flight ahead of the arithmetic
+    // march steps: max(12 + 7, s_last + 15); the channel instants alone end at step 19, the squelch instants start at s_0 = R
+    constexpr int NN = DO_SQ ? (R == 0 ? 25 : 22) : (NT / 2 - 1 + Q);
+    constexpr int N0 = DO_CH ? 0 : (R == 0 ? 0 : 2);
+    constexpr int LA = ((OPT & 2) && DO_CH && DO_SQ) ? 8 : 4;    // LDS reads in flight ahead of the arithmetic (the eight-wave form has 80 registers)
     // Sample-major: a sample is read once and feeds, at once, every sum it belongs to -- up to seven channel instants
     // (tap n - tau of instant tau) and up to three squelch instants (tap n - s_i).  No register window; the live state is
     // the (at most) seven + three accumulators, and neighbouring sums are independent work for the VALU.
@@ -98,19 +101,20 @@ __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &
     int zo = 0;                                                  // always 0: the handle the ordering dependence is hung on
     auto rd = [&](int n) { return z[n * M + zo]; };
 #pragma unroll
-    for (int k = 0; k < LA; k++) zq[k] = rd(k);
+    for (int k = 0; k < LA; k++) zq[k] = rd(N0 + k);
 #pragma unroll
-    for (int n = 0; n < NN; n++) {
-        const cf zn = zq[n % LA];
+    for (int n = N0; n < NN; n++) {
+        const cf zn = zq[(n - N0) % LA];
+        float last = zn.x;
 #pragma unroll
         for (int k = 0; k < NI; k++) {
             const int i = R + 2 * k, s = (5 * i - R) / 2, q = n - s;
-            if (q >= 0 && q < NQ) acc[k] = cmac(acc[k], an[q], zn);
+            if (DO_SQ && q >= 0 && q < NQ) { acc[k] = cmac(acc[k], an[q], zn); last = acc[k].y; }
         }
-        float last = zn.x;
 #pragma unroll
         for (int tau = 0; tau < NT / 2; tau++) {
             const int q = n - tau;
+            if (!DO_CH) continue;
             if (q == 0) u[tau] = mk(0.f, 0.f);
             if (q >= 0 && q < Q) {
                 if (REAL && (OPT & 4)) u[tau] = a.re[q] * zn + u[tau];       // packed form (A/B of the issue rates)
@@ -121,11 +125,13 @@ __device__ __forceinline__ void march_branch(const cf *z, const ChanTaps<REAL> &
         }
         if (n + LA < NN) {
             BTGPU_AFTER(zo, last);                               // read n + LA only once step n has been worked off
-            zq[n % LA] = rd(n + LA);
+            zq[(n - N0) % LA] = rd(n + LA);
         }
     }
+    if (DO_SQ) {
 #pragma unroll
-    for (int k = 0; k < NI; k++) U[(NT + R + 2 * k) * UST + pp] = acc[k];
+        for (int k = 0; k < NI; k++) U[(NT + R + 2 * k) * UST + pp] = acc[k];
+    }
 }
 
 // (exploration, OPT 256: wave priority per phase from p.dbg bits 8..23, one nibble each for staging, march, DFT passes, epilogue)
@@ -137,12 +143,14 @@ __device__ __forceinline__ void setprio_dyn(int v)
     else __builtin_amdgcn_s_setprio(3);
 }
 
+// OPT 512 (NTH = 512 only): four waves per SIMD, i.e. two workgroups per CU in <= 128 registers, instead of six in 80
 // OPT (experiments, A/B on the device): 1 = epilogue not fenced, 2 = march reads 8 steps ahead, 4 = packed channel MACs,
 // 8 = lean epilogue (needs rho = +-1: p.rho_real), 16 = epilogue instants in lockstep pairs on whole tiles, 32 = the DFT passes at raised wave priority, 64 = staging / stores too (2), 128 = epilogue at 1
 template <int NTH, bool REAL, int KT, int OPT = 0>
-__global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbParams p)
+__global__ __launch_bounds__(NTH, NTH == 512 ? ((OPT & 512) ? 4 : 6) : (NTH == 320 ? 4 : 3)) void pfb100f_kernel(PfbParams p)   // (HIP: the second number is waves per SIMD)
 {
-    static_assert(NTH == 256 || NTH == 320, "lane roles are laid out for four or five waves");
+    static_assert(NTH == 256 || NTH == 320 || NTH == 512, "lane roles are laid out for four, five or eight waves");
+    constexpr bool SPLIT = NTH == 512;                           // eight waves: channel branches on waves 0..3, squelch branches on waves 4..7
     constexpr int M = 100, Q = 7, DH = 50, NT = 26, TT = NT - 1, NQ = 15, NR = 250, NU = 5;
     constexpr int NROWS = NT + NU, UST = kPfbUst, YST = kPfbYst;
     constexpr int SPAN = (NR - 1) + NR * (NU - 1) + NQ * M;      // 2749 samples: the noise instants reach furthest
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     constexpr int NSW = NTH == 256 ? 2 : 1;                      // sweeps of a DFT pass
     constexpr int NTASK = NROWS * 10;
     static_assert(NSW * NTH >= NTASK, "a DFT pass must fit its sweeps");
-    constexpr int CH = NTH / 80, RUN = (TT + CH - 1) / CH;
+    constexpr int CH = SPLIT ? 5 : NTH / 80, RUN = (TT + CH - 1) / CH;          // (eight waves: five runs of five instants on 400 lanes)
     constexpr int NZT = (80 * NU + NTH - 1) / NTH;
     HIP_DYNAMIC_SHARED(float4, lds4)
     cf *lds = (cf *)lds4;
@@ -184,9 +192,9 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
     // ---- what a lane FETCHES for its roles, once per workgroup (what it can compute is recomputed per tile) ----
     ChanTaps<REAL> a;
     cf an[NQ];
-    {
+    if (!SPLIT) {
         const int app = l0 & 127;
-        const int pp = (app < M && l0 < 256) ? app : 0;
+        const int pp = (app < M && l0 < (SPLIT ? 512 : 256)) ? app : 0;
         if (REAL) {
             const float4 *tp = (const float4 *)p.taps + pp * 2;                  // [100][8] floats
             const float4 t0 = tp[0], t1 = tp[1];
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         int l = l0;
         BTGPU_OPAQUE(l);                                         // (see the macro: keeps per-phase addresses out of the loop-invariant set)
         const int a_pp = l & 127, a_r = (l >> 7) & 1;
-        const bool a_on = a_pp < M && l < 256;
+        const bool a_on = a_pp < M && l < (SPLIT ? 512 : 256);
         const int e_chunk = l / 80, e_c = l - 80 * e_chunk;
         const bool e_on = e_chunk < CH && e_c < p.nsel;
         // ---- input span -> LDS, FIRST: the only vector-memory operations outstanding at this point are the prefetch loads
@@ -367,8 +375,9 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         if (OPT & 256) setprio_dyn((p.dbg >> 12) & 15);
         else if (OPT & 64) __builtin_amdgcn_s_setprio(0);
         mark(0);
-        // the next tile's input: in flight under this tile's arithmetic
-        if (tu + tstep < ntl && interior(tile + tstep)) load_span(tile + tstep, l);
+        // the next tile's input: in flight under this tile's arithmetic (eight waves: requested behind the march -- the three
+        // registers per lane it lands in are what the march's tap registers need)
+        if (!SPLIT && tu + tstep < ntl && interior(tile + tstep)) load_span(tile + tstep, l);
         // de-rotation factors of this lane's squelch outputs (consumed when the outputs leave, at the top of the next tile)
         {
             const int ph0 = ((nz_u0 % np) + np) % np;            // block-uniform
@@ -386,12 +395,37 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 3 : 4) void pfb100f_kernel(PfbPar
         if (a_on) {
             const cf *z = xs + shift + DH * a_r + a_pp;
             // (pre-tiles, tile < 0: their channel rows are garbage nobody reads -- no branch inside the march)
-            if (a_r == 0) march_branch<0, REAL, OPT>(z, a, an, U, a_pp);      // wave-uniform
-            else march_branch<1, REAL, OPT>(z, a, an, U, a_pp);
+            if (!SPLIT) {
+                if (a_r == 0) march_branch<0, REAL, OPT>(z, a, an, U, a_pp);      // wave-uniform
+                else march_branch<1, REAL, OPT>(z, a, an, U, a_pp);
+            } else if (l < 256) {                                                // waves 0..3: the channel branches
+                // (eight waves, 80 registers: a lane's taps are fetched per tile -- 16 KB of tables that stay in the L1 / L2 -- and
+                // are dead outside the march, instead of 37 registers held through every phase)
+                ChanTaps<REAL> at;
+                cf dummy[NQ];
+                const float4 *tp = (const float4 *)p.taps + a_pp * 2;
+                const float4 t0 = tp[0], t1 = tp[1];
+                at.re[0] = t0.x; at.re[1] = t0.y; at.re[2] = t0.z; at.re[3] = t0.w; at.re[4] = t1.x; at.re[5] = t1.y; at.re[6] = t1.z;
+                if (a_r == 0) march_branch<0, REAL, OPT, true, false>(z, at, dummy, U, a_pp);
+                else march_branch<1, REAL, OPT, true, false>(z, at, dummy, U, a_pp);
+            } else {                                                             // waves 4..7: the squelch branches
+                ChanTaps<REAL> dummy;
+                cf ant[NQ];
+                const float4 *np_ = (const float4 *)p.n_taps + a_pp * 8;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float4 t = np_[k];
+                    ant[2 * k] = mk(t.x, t.y);
+                    if (2 * k + 1 < NQ) ant[2 * k + 1] = mk(t.z, t.w);
+                }
+                if (a_r == 0) march_branch<0, REAL, OPT, false, true>(z, dummy, ant, U, a_pp);
+                else march_branch<1, REAL, OPT, false, true>(z, dummy, ant, U, a_pp);
+            }
         }
         if (PSL > 8) mark(8);
         __syncthreads();
         mark(1);
+        if (SPLIT && tu + tstep < ntl && interior(tile + tstep)) load_span(tile + tstep, l);
 
         // ---- phase B1: DFT over p1 (p = 10 p1 + p2), twiddle e^{-j 2 pi m1 p2 / 100}, in place ----
         // (OPT 32: the two DFT passes -- LDS round trips with little arithmetic between them -- run ahead of the other

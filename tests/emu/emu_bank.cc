@@ -90,7 +90,7 @@ int emu_bank_run(double fs, double fc, int mode, const float *iq, long long x_le
     // forms (five tiles and fenced epilogue / packed channel MACs / ten tiles / five waves); 5 = the round-2 kernel,
     // four waves per tile; 3 = the round-2 kernel, eight waves
     const int variant = fuse == 3 ? kBankLegacyWide : fuse == 5 ? kBankLegacy : fuse == 4 ? kBankRun256a : fuse == 6 ? kBankRun256d :
-                        fuse == 7 ? kBankRun256e : fuse == 8 ? kBankRun320 : kBankRun256;
+                        fuse == 7 ? kBankRun256e : fuse == 8 ? kBankRun320 : fuse == 9 ? kBankRun512 : fuse == 10 ? kBankRun512r : kBankRun256;
     const int ntiles = launch_channel_bank(des, fp, fuse == 1 || fuse >= 3, b, (size_t)x_len, w0, S, G, nb, L, variant);
     if (fuse == 2) launch_noise_bank(des, fp, b, (size_t)x_len, w0, S, L);
     // the tile-blocked copy finish_kernel reads must hold the very same angles: dcol[tile][c][r] == d[25 tile + r][c]

@@ -110,7 +110,7 @@ def c79_capture(synth):
     return fs, fc, S, iq
 
 
-@pytest.mark.parametrize("fuse", [1, 4, 6, 7, 8, 5, 3, 0])
+@pytest.mark.parametrize("fuse", [1, 4, 6, 7, 8, 9, 5, 3, 0])
 def test_channel_bank_vs_oracle_c79(emu, po, c79_capture, fuse):
     """Demodulated stream, window energies and (fused) the squelch energies of the emulated kernels
     against the oracle's direct-form restatement: demod within 1e-4 rad x gain where the channel
