@@ -37,7 +37,7 @@ pmc() { # name slots bench-args...   -> $OUT/<name>_pmc_hbm.json, _pmc_sq.txt, _
 }
 pmc c79 2304
 if [ "$MODE" = "full" ]; then
-pmc block 2304 --le --headers
+pmc block 2304 --le --headers --exact-payload
 pmc c8 16384 --workload c8 --steps 100
 fi
 # the bench line again: picks the PMC summary up when it sits under profiles/ (here: passed explicitly)
@@ -51,6 +51,9 @@ python bench.py --gpus 2 --all-on-device0 --backend gloo --slots 1152 --no-cpu >
 python bench.py --gpus 1 --force-gather --backend nccl --no-cpu --no-block-config --no-ab --no-host-fed 2> "$OUT/one_rank_rccl.err" | head -1 > "$OUT/one_rank_rccl_gather_bench.json"
 fi
 cd $R
+if [ "$MODE" = "full" ]; then
+  timeout 1500 python scripts/gpu_text_parity.py 200 2000 > "$OUT/text_parity_200.txt" 2>&1; tail -2 "$OUT/text_parity_200.txt"
+fi
 if [ "${3:-fuzz}" = "fuzz" ]; then
   timeout 900 python scripts/gpu_fuzz_fast.py 400 32 > "$OUT/fuzz_fast_400_seed32.txt" 2>&1; tail -1 "$OUT/fuzz_fast_400_seed32.txt"
   timeout 1500 python scripts/gpu_fuzz_fast.py 800 77 > "$OUT/fuzz_fast_800_seed77.txt" 2>&1; tail -1 "$OUT/fuzz_fast_800_seed77.txt"
