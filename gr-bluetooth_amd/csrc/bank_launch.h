@@ -259,10 +259,16 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
         const float sigma = 0.28f * std::sqrt(25.0f / (float)(p.tile_outs * p.burst_w));
         const float beta = 1.0f - (0.5f + 0.45f * std::log(nblocks)) * sigma;
         const char *ea = std::getenv("BTGPU_BURST_A");                  // (diagnostics: the scan's threshold in mean noise blocks)
-        p.burst_abs = (ea ? (float)std::atof(ea) : 2.0f) / beta;
+        const float A = ea ? (float)std::atof(ea) : 2.0f;
+        p.burst_abs = A / beta;
+        // the single-tile stand-in (kernels.hip.h): the minimum of the span's tiles lies z(tiles) sigma_tile under the mean; it counts
+        // 1.6 x, so that noise alone never prefers it to the block estimate
+        const float sigma1 = 0.28f * std::sqrt(25.0f / (float)p.tile_outs);
+        const float beta1 = std::max(0.2f, 1.0f - (0.5f + 0.45f * std::log((float)(ntm + kBurstFront))) * sigma1);
+        p.burst_abs1 = A * (float)p.burst_w * 1.6f / beta1;
         const char *eh = std::getenv("BTGPU_BURST_A_HOT");
-        p.burst_abs_hot = std::max(p.burst_abs, (eh ? (float)std::atof(eh) : 3.0f) / beta);
-        p.burst_hot = 100.0f / beta;                     // a neighbour 20 dB over the noise
+        p.burst_abs_hot = std::max(1.0f, (eh ? (float)std::atof(eh) : 3.0f) / A);      // 3.0 x the mean noise beside a hot neighbour
+        p.burst_hot = 100.0f / A;                        // a neighbour 20 dB over the noise
     }
     p.span_extra = headers ? 58 : 0;                     // 54 header symbols + the 4-symbol trailer
 }

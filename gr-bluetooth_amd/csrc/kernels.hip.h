@@ -344,7 +344,8 @@ struct WindowParams {
     int exact_payload;          // BTGPU_FLAG_EXACT_PAYLOAD (with syms): the exact window kernel hands the continuation the state at the end of its exact rows
     int prescan;                // 1: the scan ran in burst_scan_kernel; its verdicts are in vinfo
     const int32_t *vinfo;       // [S * nch] task slot | tiles listed << 16 of an energy-flagged window, -1 otherwise
-    float burst_abs_hot, burst_hot;   // the threshold beside a neighbour channel whose W-tile sum exceeds burst_hot * (that block)
+    float burst_abs1;           // ... or above burst_abs1 * (the quietest single tile), whichever is lower
+    float burst_abs_hot, burst_hot;   // as multiples of that threshold: the threshold beside a neighbour channel whose W-tile sum exceeds burst_hot x it
     int span_extra;             // symbols behind an access code that stay exact as well (the 54-symbol header + margin)
     int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
 };
@@ -609,22 +610,36 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
             for (int u = 0; u < W; u++) { const float e = pe[jb + u]; ok = ok && e > 0.f; some = some || e > 0.f; sb += e; }
             bmin = (ok && sb < bmin) ? sb : bmin;
         }
+        // ... and the span's quietest single tile (with a predecessor that holds signal too: a tile next to silence may be partly
+        // silent itself).  Where a packet follows another within < 50 us -- one quiet tile between them, no quiet BLOCK anywhere in
+        // a span that the second packet then fills -- the block minimum is the packets' own level and (a) could never hold (fuzz
+        // seed 8001 case 2179: a 30 dB packet 25 us behind a 39 dB one, lost).  The single tile's minimum scatters by a factor
+        // of two (0.30 .. 0.64 of the mean over 64 tiles), so it only stands in when the block estimate is more than 1.6 x above
+        // it, which noise alone does not produce; the threshold is then up to 1.6 x higher in noise terms (~5 dB instead of 3).
+        float mn1 = 3.0e38f;
+        {
+            float ep = pe[-NF];
+            for (int jx = -NF + 1; jx < jl; jx++) { const float e = pe[jx]; mn1 = (e > 0.f && ep > 0.f && e < mn1) ? e : mn1; ep = e; }
+        }
         int rise = -1;
         if (bmin > 1.0e38f) {
             // no whole block of the span holds signal (a stream that begins inside the span): nothing to compare with -- exact to the end
             if (some) rise = nt - 1;
         } else {
-            const float thr = p.burst_abs * bmin, thr_n = p.burst_abs_hot * bmin, hot = p.burst_hot * bmin;
+            const float thr_b = p.burst_abs * bmin, thr_1 = p.burst_abs1 * mn1;
+            const float thr = thr_1 < thr_b ? thr_1 : thr_b;
+            const float thr_n = thr * p.burst_abs_hot, hot = thr * p.burst_hot;      // (both as multiples of the threshold)
             // s[j] and s[j-W] by sliding sums; tiles that do not exist (in front of the batch) count as unknown: (b) holds.
             // sl_ / sr_: the same W-tile sum on the two neighbour channels (0 where the capture has none)
             const bool has_l = cq > 0, has_r = cq + 1 < nch;
-            float s_cur = 0.f, s_old = 0.f, sl_ = 0.f, sr_ = 0.f;
+            float s_cur = 0.f, s_old = 0.f, s_old2 = 0.f, sl_ = 0.f, sr_ = 0.f;             // s_old2: the W tiles before s_old's (absent tiles: 0)
             int miss_old = 0;
             for (int u = 0; u < W; u++) {                          // position j = -2
                 const int ic = -2 - u, io = -2 - W - u;
                 const float ec = ic >= -NF ? pe[ic] : -1.f, eo = io >= -NF ? pe[io] : -1.f;
                 s_cur += ec > 0.f ? ec : 0.f;
                 s_old += eo > 0.f ? eo : 0.f; miss_old += eo < 0.f;
+                { const int i2 = -2 - 2 * W - u; const float e2_ = i2 >= -NF ? pe[i2] : 0.f; s_old2 += e2_ > 0.f ? e2_ : 0.f; }
                 const int in_ = ic + kBurstAhead;                  // (the neighbours' sums run kBurstAhead tiles ahead: see below)
                 const float el = (has_l && in_ >= -NF && in_ < ntm) ? pe[in_ - PW] : 0.f, er = (has_r && in_ >= -NF && in_ < ntm) ? pe[in_ + PW] : 0.f;
                 sl_ += el > 0.f ? el : 0.f; sr_ += er > 0.f ? er : 0.f;
@@ -636,6 +651,7 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                 s_cur += (en > 0.f ? en : 0.f) - (eo > 0.f ? eo : 0.f);
                 s_old += (eo > 0.f ? eo : 0.f) - (eq > 0.f ? eq : 0.f);
                 miss_old += (int)(eo < 0.f) - (int)(eq < 0.f);
+                { const int i3 = jx - 3 * W; const float e3 = i3 >= -NF ? pe[i3] : 0.f; s_old2 += (eq > 0.f ? eq : 0.f) - (e3 > 0.f ? e3 : 0.f); }
                 {
                     // (two tiles AHEAD of this channel's sum: a packet that switches on splatters into the neighbour channels
                     // in its first microseconds, when its own W-tile sum has hardly begun to rise)
@@ -652,7 +668,15 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                 // from ~4.5 dB over the noise (alone: from ~2 dB), whatever the neighbour's level.
                 const float thr_j = (sl_ > hot || sr_ > hot) ? thr_n : thr;
                 const bool trig = s_cur > thr_j && (miss_old > 0 || s_cur > 1.5f * s_old);
-                if (trig && !prev && jx >= 0) {
+                // (c) a SHARP edge: this tile four times the quieter of the two in front of it, and itself over the threshold's
+                // per-tile share.  Behind a stronger packet the sum of the 50 us before -- s[j-W] -- still holds that packet's tail
+                // for up to 2 W tiles, and (b) sees a weaker successor only when it has cleared: W .. 2 W - 1 tiles late (fuzz seed
+                // 8001 case 5740: a 36 dB packet 30 us behind a 44 dB one, onset at row 1250, (b) at tile 55 -- taken for the next
+                // window's).  A sharp edge starts a run of its own whatever (b) says.
+                const float e1 = jx - 1 >= -NF ? pe[jx - 1] : -1.f, e2 = jx - 2 >= -NF ? pe[jx - 2] : -1.f;
+                const float floor2 = (e1 >= 0.f && e2 >= 0.f) ? (e1 < e2 ? e1 : e2) : (e1 >= 0.f ? e1 : 3.0e38f);
+                const bool sharp = en > 4.f * floor2 && en * (float)W > 3.f * thr_j;   // (x 3: a neighbour's switch-on click in this channel -- one tile at ~6 x the noise -- is not one)
+                if (((trig && !prev) || sharp) && jx >= 0) {
                     // The run of triggers begins at the tile the packet begins in, or -- where less than ~3 noise tiles' worth of it
                     // lies in that tile -- up to W - 1 tiles later.  An access code is reportable at the offsets below 625
                     // (lib/multi_sniffer_impl.cc:108).  Where symbol 625 lies in the window is NOT bounded by the loop's clock limits
@@ -671,15 +695,19 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                     // (o^2 + 2 S o) / 12.6 around a signal part S, so the fill fraction is off by sigma = sqrt((2 / x^2 + 4 / x) / 12.6)
                     // tiles at most, and a run that began one tile late hides <= 3.2 / x of a tile -- 3.5 sigma + 3.2 / x tiles,
                     // never more than W - 1: 3 rows at 25 dB, 7 at 18 dB, 18 at 12 dB, 46 at 6 dB, the whole 75 below 3 dB.
-                    const float o = miss_old > 0 ? 3.0e38f : s_old / (float)W;
+                    // (What was there before: for a sharp edge the quieter of the two tiles in front; for (b) the mean of the 50 us
+                    // before -- and where the 50 us before THAT held more than twice the present energy, a stronger packet has just
+                    // ended and (b) may be up to 2 W - 1 tiles late.)
+                    const float o = sharp ? floor2 : (miss_old > 0 ? 3.0e38f : s_old / (float)W);
                     const bool nxt = jx + 1 < nt && pe[jx + 1] > en;
                     const float full = nxt ? pe[jx + 1] : en;
                     float frac = (en - o) / (full - o);
                     frac = (full > o && frac > 0.f) ? (frac > 1.f ? 1.f : frac) : 1.f;
                     const float xi = o > 0.f ? o / (full > o ? full - o : 1.0e-30f) : 0.f;          // 1 / x
                     float back = 3.5f * sqrtf((2.f * xi * xi + 4.f * xi) * (1.0f / 12.6f)) + 3.2f * xi;
-                    const float cap_back = (float)(W > 1 ? W - 1 : 1);
-                    back = (miss_old > 0 || !(back < cap_back)) ? cap_back : back;
+                    const bool fell = !sharp && s_old2 > 2.f * s_cur;
+                    const float cap_back = fell ? (float)(2 * W - 1) : (float)(W > 1 ? W - 1 : 1);
+                    back = (fell || (!sharp && miss_old > 0) || !(back < cap_back)) ? cap_back : back;
                     const float onset_row = ((float)(jx + 1) - frac - back) * (float)TT - 1.f;
                     if (onset_row < 1270.f) rise = jx;
                 }

@@ -807,3 +807,39 @@ def test_adversarial_fuzz_slice_emulated(emu):
     assert tot["cases"] == 30 and tot["planted"] > 150, tot
     assert tot["planted_only_product"] == 0 and tot["planted_only_oracle"] == 0 and tot["adverts_differing"] == 0, tot
     assert tot["nsym_dev_max"] <= paritylib.NSYM_BOUND, tot
+
+
+def test_exact_payload_symbols_equal_the_oracles(emu):
+    """BTGPU_FLAG_EXACT_PAYLOAD on the emulator (scripts/emu_symbol_parity.py, 16 adversarial captures at 8 / 20 Msps): every symbol of
+    every record's packet -- access code, header AND payload, to the packet's last bit -- equals the oracle's; long tasks were made and
+    none turned away.  (Without the flag 2 % of the records of the 300-capture run carry a differing payload symbol:
+    profiles/r05_emu_symbol_parity_default_300.txt; with it 0 of 4.1 M symbols: profiles/r05_emu_symbol_parity_exact_payload_800.txt.)"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_symbol_parity.py"), "16", "12", "--rates", "8,20", "--exact-payload"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
+    assert tot["records"] > 60 and tot["symbols"] > 40000, tot
+    assert tot["records_with_a_differing_symbol"] == 0 and tot["differing_symbols"] == 0, tot
+    assert tot["long_tasks"] > 50 and tot["long_turned_away"] == 0, tot
+
+
+@pytest.mark.parametrize("seed,case,what", [
+    (7001, 10079, "hand-over: an isolated 38.7 dB packet whose energy begins at row 1262.7 of window 6, reported there at offset 624 -- round 4's row-1261 rule (and this round's first, 1258) gave it to the next window"),
+    (8001, 2179, "no quiet block: a 30 dB packet 25 us behind a 39 dB one at 20 Msps -- one quiet 25 us tile between them, the span otherwise full: the block-minimum noise estimate was the packets' own level"),
+    (8001, 5740, "behind a stronger packet: 36 dB, 30 us behind a 44 dB one, onset at row 1250 -- the '+50 % over the 50 us before' rule saw it five tiles late and took it for the next window's; the sharp-edge rule sees it at once"),
+])
+def test_adversarial_cases_the_fuzz_found(emu, po, synth, seed, case, what):
+    """The three planted records the 1.2e5-record adversarial runs of round 5 lost on the way, replayed from
+    scripts/emu_fuzz_adversarial.py's generator (rates 8,8,20): each is now identical to the oracle's."""
+    import adversarial
+    rng = np.random.default_rng(seed)
+    for _ in range(case + 1):
+        c = adversarial.draw_case(rng, (8, 8, 20))
+    le = c["le"] and c["sniffer"]
+    iq, truth, meta = adversarial.make_adversarial_capture(c["fs"], c["fc"], c["n_slots"], c["n_packets"], c["seed"], c["laps"],
+                                                          le_channels=c["le_channels"] if le else None, n_adverts=c["n_adverts"],
+                                                          lag_slots=6.4 if c["sniffer"] else 1.5)
+    got, wi, tasks, o = _front_m(emu, po, c["fs"], c["fc"], iq, c["n_slots"], c["squelch"], po.MODE_SNIFFER if c["sniffer"] else po.MODE_LAP, le)
+    d = paritylib.differential(got, wi, truth, lag=6 if c["sniffer"] else 1)
+    assert d["planted_ref"] >= 5 and d["planted_identical"] and d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, (what, d)
