@@ -101,8 +101,8 @@ struct btgpu_handle {
     int vcap = 0, ver_mp = 0, ver_F = 0, ver_grid = kVerGridDdc;
     bool exact_payload = false;            // BTGPU_FLAG_EXACT_PAYLOAD (with symbols and the exact stage)
     int long_stride = 0;
-    static constexpr int kLongCap = 8192;                 // long tasks per batch (windows that hand symbols over); beyond: the polyphase continuation
-    static constexpr unsigned int kLongTilesCap = 65536;  // entries of one channel's list
+    static constexpr int kLongCap = 32768;                // long tasks per batch (windows that hand symbols over; 1 GB of exact rows per batch in flight); a batch with more: the polyphase continuation for all of it
+    static constexpr unsigned int kLongTilesCap = 262144; // entries of one channel's list
     std::vector<const void *> lds_opted;   // bank kernels that have been granted > 48 KiB of dynamic LDS on this handle's device
     DevBuf d_tapsv;                  // class-major taps of the direct-form channel bank (verify_ddc_kernel)
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
@@ -542,11 +542,13 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         LongView lview{nullptr, nullptr, 0, 0};
         if (verify && exact_payload && want_syms) {
             // exact payload: the windows that hand symbols to the host get their rows to the end of the burst from the direct-form DDC
-            HIPCHK(this, hipMemsetAsync(t.d_lcount.p, 0, kVerCountWords * sizeof(unsigned int), tail_stream));
+            HIPCHK(this, hipMemsetAsync(t.d_lcount.p, 0, (kVerCountWords + 80) * sizeof(unsigned int), tail_stream));
             LongTaskParams lp{};
             lp.tasks = (VerifyTask *)t.d_ltasks.p; lp.tiles = (uint32_t *)t.d_ltiles.p; lp.lcount = (unsigned int *)t.d_lcount.p;
             lp.tiles_cap = kLongTilesCap; lp.rows = (LongRows *)t.d_lrows.p; lp.cap = kLongCap; lp.stride = long_stride;
             hipLaunchKernelGGL(long_task_kernel, dim3(kLongCap / kLongLanes), dim3(kLongLanes), 0, tail_stream, p, (const FinishRec *)d_fin.p,
+                               (const unsigned int *)d_hitcount.p + 1, lp);
+            hipLaunchKernelGGL(long_assign_kernel, dim3(kLongCap / kLongLanes), dim3(kLongLanes), 0, tail_stream, p, (const FinishRec *)d_fin.p,
                                (const unsigned int *)d_hitcount.p + 1, lp);
             VerifyParams vl_ = vp;
             vl_.tasks = lp.tasks; vl_.vcount = lp.lcount; vl_.vcap = kLongCap; vl_.tiles = lp.tiles; vl_.tcount = lp.lcount + 4;
@@ -1234,7 +1236,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             if (h->exact_payload) {
                 TRY(h->alloc(t.d_ltasks, (size_t)btgpu_handle::kLongCap * sizeof(VerifyTask)));
                 TRY(h->alloc(t.d_ltiles, (size_t)nch * btgpu_handle::kLongTilesCap * sizeof(uint32_t)));
-                TRY(h->alloc(t.d_lcount, kVerCountWords * sizeof(unsigned int)));
+                TRY(h->alloc(t.d_lcount, (kVerCountWords + 80) * sizeof(unsigned int)));
                 TRY(h->alloc(t.d_lrows, (size_t)btgpu_handle::kLongCap * sizeof(LongRows)));
                 TRY(h->alloc(t.d_dxl, (size_t)btgpu_handle::kLongCap * h->long_stride * sizeof(float)));
             }

@@ -1273,7 +1273,7 @@ struct LongView {
 struct LongTaskParams {
     VerifyTask *tasks;           // [cap]: window, exact rows (end)
     uint32_t *tiles;             // tile lists by channel, like the exact stage's
-    unsigned int *lcount;        // [4 + nch]: 0 long tasks, 1 tiles, 2 turned away; 4 + c: entries of channel c's list
+    unsigned int *lcount;        // [4 + 160]: 0 long tasks, 1 tiles, 2 turned away; 4 + c: entries of channel c's list; 84 + c: entries asked for
     unsigned int tiles_cap;
     LongRows *rows;                  // [cap]
     int cap, stride;
@@ -1286,7 +1286,14 @@ __global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, c
 {
     const unsigned int n = *fin_count;
     const unsigned int f = blockIdx.x * kLongLanes + threadIdx.x;
-    if (f >= n || f >= (unsigned int)lp.cap) { if (f < n) atomicAdd(&lp.lcount[2], 1u); return; }
+    // More record windows than the long-task buffers hold: NONE of this batch gets one.  (Which windows have the low indices is
+    // the order of the window kernels' atomics -- a per-window cut-off would make the records differ from run to run.)
+    if (n > (unsigned int)lp.cap) {
+        if (f < (unsigned int)lp.cap) lp.rows[f] = LongRows{0, 0};
+        if (f == 0) atomicAdd(&lp.lcount[2], n);
+        return;
+    }
+    if (f >= n) return;
     lp.rows[f] = LongRows{0, 0};
     const FinishRec r = fin[f];
     if (r.done) return;
@@ -1325,14 +1332,30 @@ __global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, c
     if (row_hi <= row_lo + 8) return;
     const int jt_hi = (row_hi + kVerTile - 1) / kVerTile;       // DDC tiles [jt_lo, jt_hi)
     const int nt = jt_hi - jt_lo;
-    const unsigned int tp = atomicAdd(&lp.lcount[4 + c], (unsigned int)nt);
-    if (tp + (unsigned int)nt > lp.tiles_cap) { atomicAdd(&lp.lcount[2], 1u); return; }
-    uint32_t *tl = lp.tiles + (size_t)c * lp.tiles_cap;
-    for (int j = 0; j < nt; j++) tl[tp + j] = (uint32_t)f | ((uint32_t)(jt_lo + j) << 24);
+    // first pass: what this window asks of its channel's list (long_assign_kernel hands the entries out)
+    atomicAdd(&lp.lcount[4 + 80 + c], (unsigned int)nt);
     VerifyTask t_;
     t_.w = r.w; t_.n_exact = row_hi; t_.snr = 0.0;
     lp.tasks[f] = t_;
     lp.rows[f] = LongRows{jt_lo * kVerTile + 1, row_hi};      // (row t of a tile's first output is its demod halo: exact from + 1)
+}
+
+// second pass: the tile lists.  A channel whose windows ask for more entries than its list holds gets NO long task in this batch
+// (all of them or none: which of them would still fit is the order of the atomics, and the records must not depend on it).
+__global__ __launch_bounds__(kLongLanes) void long_assign_kernel(WindowParams p, const FinishRec *__restrict__ fin,
+                                                                 const unsigned int *__restrict__ fin_count, LongTaskParams lp)
+{
+    const unsigned int n = *fin_count;
+    const unsigned int f = blockIdx.x * kLongLanes + threadIdx.x;
+    if (n > (unsigned int)lp.cap || f >= n) return;
+    const LongRows lr = lp.rows[f];
+    if (lr.y <= 0) return;
+    const int c = fin[f].w % p.nch;
+    const int jt_lo = (lr.x - 1) / kVerTile, jt_hi = (lr.y + kVerTile - 1) / kVerTile, nt = jt_hi - jt_lo;
+    if (lp.lcount[4 + 80 + c] > lp.tiles_cap) { lp.rows[f] = LongRows{0, 0}; atomicAdd(&lp.lcount[2], 1u); return; }
+    const unsigned int tp = atomicAdd(&lp.lcount[4 + c], (unsigned int)nt);
+    uint32_t *tl = lp.tiles + (size_t)c * lp.tiles_cap;
+    for (int j = 0; j < nt; j++) tl[tp + j] = (uint32_t)f | ((uint32_t)(jt_lo + j) << 24);
     atomicAdd(&lp.lcount[0], 1u); atomicAdd(&lp.lcount[1], (unsigned int)nt);
 }
 

@@ -318,7 +318,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     static const bool prescan_env = getenv("EMU_PRESCAN") && atoi(getenv("EMU_PRESCAN")) == 1;
     const bool prescan = prescan_env && verify && p.verify == 1;
     std::vector<VerifyTask> ltasks; std::vector<uint32_t> ltiles; std::vector<LongRows> lrows; std::vector<float> dxl;
-    unsigned int lcount[kVerCountWords] = {0};
+    unsigned int lcount[kVerCountWords + 80] = {0};
     LongView lview{nullptr, nullptr, 0, 0};
     std::vector<int32_t> vinfo(prescan ? W : 1, -1);
     std::vector<unsigned int> vtstart(80, 0u);
@@ -376,6 +376,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
             LongTaskParams lp{};
             lp.tasks = ltasks.data(); lp.tiles = ltiles.data(); lp.lcount = lcount; lp.tiles_cap = ltcap; lp.rows = lrows.data(); lp.cap = lcap; lp.stride = lstride;
             emu::launch(dim3((unsigned)(lcap / kLongLanes)), dim3(kLongLanes), [&]() { long_task_kernel(p, fin.data(), &counts[1], lp); });
+            emu::launch(dim3((unsigned)(lcap / kLongLanes)), dim3(kLongLanes), [&]() { long_assign_kernel(p, fin.data(), &counts[1], lp); });
             VerifyParams vq = vp;
             vq.tasks = lp.tasks; vq.vcount = lp.lcount; vq.vcap = lcap; vq.tiles = lp.tiles; vq.tcount = lp.lcount + 4; vq.tiles_cap = ltcap;
             vq.tstart = nullptr; vq.dx_stride = lstride;
