@@ -487,7 +487,10 @@ def run_rank(args):
                           "bursts beyond about +-40 kHz of offset are lost by the CPU oracle and the GPU alike "
                           "(tests/test_gpu_parity.py::test_cfo_sweep_gpu_equals_oracle, DESIGN.md section 5)",
                   "truth_detected": found, "truth_expected": expected, "hits": int(len(ints)),
-                  "records_sha256": hashlib.sha256(np.ascontiguousarray(ints, dtype=np.int64).tobytes()).hexdigest()[:16]}
+                  "records_sha256": hashlib.sha256(np.ascontiguousarray(ints, dtype=np.int64).tobytes()).hexdigest()[:16],
+                  # the six key fields (slot, channel, kind, offset, LAP, ac_errors): what the parity contract fixes -- nsym, the seventh
+                  # column, depends on how many rows of a window the exact stage recomputed, which batch and range boundaries move
+                  "records6_sha256": hashlib.sha256(np.ascontiguousarray(np.asarray(ints, dtype=np.int64).reshape(-1, ints.shape[1] if len(ints) else 7)[:, :6]).tobytes()).hexdigest()[:16]}
         if not args.no_cpu:
             import pyoracle as po
             import paritylib

@@ -684,7 +684,9 @@ def test_bench_two_ranks_on_one_device_equal_one_rank(tmp_path):
     assert j2["config"]["gather"].startswith("one async all_gather_into_tensor per 4 batches")
     assert j1["parity"]["hits"] > 40
     assert j1["parity"]["hits"] == j2["parity"]["hits"]
-    assert j1["parity"]["records_sha256"] == j2["parity"]["records_sha256"]
+    # the six key fields of every record; nsym may differ at a range boundary (the burst scan has no tiles in front of a range's
+    # first window: more of it is recomputed exactly -- DESIGN.md section 7, INTEGRATION.md "Batch and range boundaries")
+    assert j1["parity"]["records6_sha256"] == j2["parity"]["records6_sha256"]
     import torch
     if torch.cuda.device_count() < 2:
         bad = subprocess.run(base + ["--gpus", "2", "--slots", "24"], capture_output=True, text=True, env=env, timeout=300)
