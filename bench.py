@@ -72,6 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
     ap.add_argument("--headers", action="store_true", help="also export hit symbols and run the GPU header sweep (BTGPU_FLAG_HEADERS), as the C++ multi_sniffer block does")
+    ap.add_argument("--synth-device", default=None, help="where the synthetic capture is generated (default: the GPU).  'cpu': torch CPU ops + one "
+                    "upload -- for the rocprofv3 --pmc passes of the C8 workload, which crash inside torch's own randn launches")
     ap.add_argument("--exact-payload", action="store_true", help="with --headers: BTGPU_FLAG_EXACT_PAYLOAD, as the C++ multi_sniffer block sets it")
     ap.add_argument("--le", action="store_true", help="also run the le_packet::sniff_aa pass (BTGPU_FLAG_LE), as the C++ multi_sniffer block does")
     ap.add_argument("--no-block-config", action="store_true", help="skip the second timed region in the drop-in block's configuration (LE | HEADERS)")
@@ -189,8 +191,8 @@ def run_rank(args):
     first, _ = bdist.partition_slots(world * S, world, rank)        # rank r owns slots [r S, (r+1) S)
     margin = des.left_margin
     a0, n_need = bdist.segment_bounds(first, S, H, slot, margin)
-    seg, truth = synth.make_segment_torch(fs, fc, first, first + S, device, left_pad=H - 1 + margin, **gen)
-    seg = seg.contiguous()
+    seg, truth = synth.make_segment_torch(fs, fc, first, first + S, args.synth_device or device, left_pad=H - 1 + margin, **gen)
+    seg = seg.to(device).contiguous()
     n_complex = seg.shape[0]
     assert n_complex >= n_need and a0 == first * slot - (H - 1) - margin   # (the generator runs to the end of the last slot)
     torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 evidence in one GPU call, on the build that is committed:  bash scripts/collect_r05.sh r05_a [tests|notests] [fuzz|nofuzz] [full|quick]
-# (quick: GPU suite, bench line, kernel stats + PMC of the headline only)
+# (quick: GPU suite, bench line, kernel stats + PMC of the headline only; c8only: kernel stats + PMC + bench line of the C8 workload)
 # -> gpurun_out/prof_<tag>/: pytest / smoke logs, bench line (exact stage on, A/B without it, block configuration, host-fed leg,
 #    cpu legs), kernel stats + timeline, HBM traffic (PMC, stamped with the build id of libbtgpu.so), SQ / stall counters --
 #    for the headline, the block configuration (LE | HEADERS) and C8 --, two-rank dry run, one-rank RCCL gather, and (fuzz) the
@@ -18,7 +18,7 @@ if [ "${2:-tests}" = "tests" ]; then
   cp gpurun_out/cfo_curve_*.json "$OUT/" 2>/dev/null
 fi
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+[ "$MODE" = "c8only" ] || python $R/bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 KRE='_kernel'   # counters only on the library's kernels (all named *_kernel): rocprofv3 crashed inside torch's randn / mul_ launches of the C8 capture generator
 pmc() { # name slots bench-args...   -> $OUT/<name>_pmc_hbm.json, _pmc_sq.txt, _pmc_stall.txt, _kernel_stats.csv, _timeline.txt
   n=$1; slots=$2; shift; shift
@@ -35,10 +35,15 @@ pmc() { # name slots bench-args...   -> $OUT/<name>_pmc_hbm.json, _pmc_sq.txt, _
   rocprofv3 --kernel-include-regex "$KRE" --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/p4_$n -o p -- $PM > /dev/null 2>> "$OUT/bench.err"
   python $R/scripts/pmc_table.py "$(find /tmp/p4_$n -name '*counter_collection.csv' | head -1)" > "$OUT/${n}_pmc_stall.txt" 2>> "$OUT/bench.err"
 }
-pmc c79 2304
+[ "$MODE" = "c8only" ] || pmc c79 2304
+if [ "$MODE" = "c8only" ]; then
+pmc c8 16384 --workload c8 --steps 100 --synth-device cpu
+python $R/bench.py --workload c8 --steps 100 --no-cpu --no-block-config --no-ab --no-host-fed --pmc-json "$OUT/c8_pmc_hbm.json" > "$OUT/c8_bench_with_traffic.json" 2> "$OUT/c8.err"
+cat "$OUT/c8_pmc_hbm.json" | head -c 1500; tail -1 "$OUT/c8_bench_with_traffic.json" | cut -c1-600; exit 0
+fi
 if [ "$MODE" = "full" ]; then
 pmc block 2304 --le --headers --exact-payload
-pmc c8 16384 --workload c8 --steps 100
+pmc c8 16384 --workload c8 --steps 100 --synth-device cpu      # (the PMC passes crash inside torch's randn launches of the GPU generator)
 fi
 # the bench line again: picks the PMC summary up when it sits under profiles/ (here: passed explicitly)
 python $R/bench.py --no-cpu --no-block-config --no-ab --no-host-fed --pmc-json "$OUT/c79_pmc_hbm.json" > "$OUT/bench_with_traffic.json" 2>> "$OUT/bench.err"
