@@ -478,6 +478,9 @@ def run_rank(args):
                                  % (args.pmc_json, pmc.get("build_id"), pmc.get("slots"), roof["build_id"], S))
             key = {"ddc_channel": "pfb", "window": "window_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
             match = [k for k in pmc["kernels"] if key and k.startswith(key)]
+            # (the small-M banks run the same kernel template twice -- channel bank and squelch stage 1: the channel bank is the one
+            # with the larger traffic, it writes the demodulated stream)
+            match.sort(key=lambda k: -pmc["kernels"][k]["hbm_bytes"])
             if match:
                 roof["traffic"] = pmc["kernels"][match[0]]["hbm_bytes"]
                 roof["traffic_source"] = os.path.basename(args.pmc_json)

@@ -266,6 +266,14 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
         const float sigma1 = 0.28f * std::sqrt(25.0f / (float)p.tile_outs);
         const float beta1 = std::max(0.2f, 1.0f - (0.5f + 0.45f * std::log((float)(ntm + kBurstFront))) * sigma1);
         p.burst_abs1 = A * (float)p.burst_w * 1.6f / beta1;
+        // ... and of the channel's quietest tile of the whole batch (n tiles): the lower tail of a sum of ~12.6 values per 25 outputs --
+        // 0.48 of the mean for the least of 100, 0.40 of 1e3, 0.33 of 1e4, 0.27 of 1e5 (tabulated, log-linear between)
+        {
+            const float lg = std::log10(std::max(100.0f, (float)ntiles) / 100.0f);
+            const float beta2 = std::max(0.2f, 1.0f - (1.0f - (0.48f - 0.065f * lg)) * std::sqrt(std::min(1.0f, 25.0f / (float)p.tile_outs)));
+            p.burst_abs2 = A * (float)p.burst_w * 1.6f / beta2;
+        }
+        p.chan_floor = nullptr;                          // (set by the caller once channel_floor_kernel has run)
         const char *eh = std::getenv("BTGPU_BURST_A_HOT");
         p.burst_abs_hot = std::max(1.0f, (eh ? (float)std::atof(eh) : 3.0f) / A);      // 3.0 x the mean noise beside a hot neighbour
         p.burst_hot = 100.0f / A;                        // a neighbour 20 dB over the noise

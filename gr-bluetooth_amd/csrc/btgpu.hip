@@ -75,6 +75,7 @@ struct btgpu_handle {
         DevBuf d_pfine;                       // small-M F8 bank: |Y|^2 sums per 25 instants (the exact stage's burst scan)
         DevBuf d_Z;                           // staged squelch: stage-1 output (-> noise_stage2_kernel on the post stream)
         DevBuf d_vtasks, d_vtiles, d_vcount, d_dx, d_dxt, d_winbits_v, d_vinfo, d_vtstart;
+        DevBuf d_chanfloor;                                     // the burst scan's last-resort noise reference: each channel's quietest tile of the batch
         DevBuf d_ltasks, d_ltiles, d_lcount, d_lrows, d_dxl;   // BTGPU_FLAG_EXACT_PAYLOAD: the long tasks of the windows that hand symbols to the host
         DevBuf d_eon, d_eoff, d_snr;          // E_on, E_off, SNR per window (window_kernel, or squelch_kernel when the squelch is deferred)   // exact confirmation (verify.hip.h): task list, exact rows, task stream
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
@@ -180,7 +181,7 @@ struct btgpu_handle {
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (TailCtx &t : tc) {
             DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol,
-                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_vinfo, &t.d_vtstart, &t.d_ltasks, &t.d_ltiles, &t.d_lcount, &t.d_lrows, &t.d_dxl, &t.d_eon, &t.d_eoff, &t.d_snr};
+                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_vinfo, &t.d_vtstart, &t.d_chanfloor, &t.d_ltasks, &t.d_ltiles, &t.d_lcount, &t.d_lrows, &t.d_dxl, &t.d_eon, &t.d_eoff, &t.d_snr};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
@@ -400,6 +401,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_pfine.p, ntiles * (pfbm_tile(fp.channel.M) / 25), vb, want_syms, 25);
         else
             set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
+    }
+    if (verify && p.verify == 1) {
+        hipLaunchKernelGGL(channel_floor_kernel, dim3((unsigned)nch), dim3(256), 0, ps, p.ptile, p.ptile_stride, p.ptile_stride, (float *)t.d_chanfloor.p);
+        p.chan_floor = (const float *)t.d_chanfloor.p;
     }
     // BTGPU_PRESCAN=1: the scan as a kernel of its own behind the banks and the energy-selected tasks' DDC on a side stream beside
     // squelch stage 2 and the window kernel.  Built, measured, OFF (profiles/r05_b_*): 2.34-2.38 ms per step against 2.31 in line --
@@ -1233,6 +1238,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             TRY(h->alloc(t.d_vcount, kVerCountWords * sizeof(unsigned int)));
             TRY(h->alloc(t.d_vinfo, (size_t)S * nch * sizeof(int32_t)));
             TRY(h->alloc(t.d_vtstart, 80 * sizeof(unsigned int)));
+            TRY(h->alloc(t.d_chanfloor, 80 * sizeof(float)));
             if (h->exact_payload) {
                 TRY(h->alloc(t.d_ltasks, (size_t)btgpu_handle::kLongCap * sizeof(VerifyTask)));
                 TRY(h->alloc(t.d_ltiles, (size_t)nch * btgpu_handle::kLongTilesCap * sizeof(uint32_t)));

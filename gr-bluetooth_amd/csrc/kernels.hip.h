@@ -345,6 +345,8 @@ struct WindowParams {
     int prescan;                // 1: the scan ran in burst_scan_kernel; its verdicts are in vinfo
     const int32_t *vinfo;       // [S * nch] task slot | tiles listed << 16 of an energy-flagged window, -1 otherwise
     float burst_abs1;           // ... or above burst_abs1 * (the quietest single tile), whichever is lower
+    float burst_abs2;           // ... or above burst_abs2 * chan_floor[channel]: the channel's quietest tile of the whole batch (channel_floor_kernel)
+    const float *chan_floor;    // [nch], nullptr: not computed
     float burst_abs_hot, burst_hot;   // as multiples of that threshold: the threshold beside a neighbour channel whose W-tile sum exceeds burst_hot x it
     int span_extra;             // symbols behind an access code that stay exact as well (the 54-symbol header + margin)
     int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
@@ -626,8 +628,15 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
             // no whole block of the span holds signal (a stream that begins inside the span): nothing to compare with -- exact to the end
             if (some) rise = nt - 1;
         } else {
+            // ... and for rule (d) below, where the span holds no quiet tile at all (a packet straight behind another, the second
+            // filling the span: fuzz seed 9001 case 11029), from the channel's quietest tile of the whole batch (channel_floor_kernel)
             const float thr_b = p.burst_abs * bmin, thr_1 = p.burst_abs1 * mn1;
+            const float thr_2 = p.chan_floor ? p.burst_abs2 * p.chan_floor[cq] : 3.0e38f;
+            // (the batch-wide reference serves rule (d) only: with it in (a), every +50 % step inside a span that collisions keep busy
+            // becomes a task -- 1.6 x the tasks and 2.1 x the rows on the C8 synthetic, eight piconets on eight channels -- where the
+            // span's own quietest block asks for a step to 2.65 x, which the 1.2e5-record runs were clean with)
             const float thr = thr_1 < thr_b ? thr_1 : thr_b;
+            const float thr_d_scale = (thr_2 > 0.f && thr_2 < thr) ? thr_2 / thr : 1.0f;
             const float thr_n = thr * p.burst_abs_hot, hot = thr * p.burst_hot;      // (both as multiples of the threshold)
             // s[j] and s[j-W] by sliding sums; tiles that do not exist (in front of the batch) count as unknown: (b) holds.
             // sl_ / sr_: the same W-tile sum on the two neighbour channels (0 where the capture has none)
@@ -645,6 +654,7 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                 sl_ += el > 0.f ? el : 0.f; sr_ += er > 0.f ? er : 0.f;
             }
             bool prev = true;                                      // (a run that began in front of the window starts nothing)
+            float pre_lvl = -1.f;                                  // what stood on the channel, per tile, before the last rise (-1: no rise seen yet)
             for (int jx = -1; jx < nt; jx++) {
                 const int io = jx - W, iq = jx - 2 * W;
                 const float en = pe[jx], eo = io >= -NF ? pe[io] : -1.f, eq = iq >= -NF ? pe[iq] : -1.f;
@@ -676,6 +686,26 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                 const float e1 = jx - 1 >= -NF ? pe[jx - 1] : -1.f, e2 = jx - 2 >= -NF ? pe[jx - 2] : -1.f;
                 const float floor2 = (e1 >= 0.f && e2 >= 0.f) ? (e1 < e2 ? e1 : e2) : (e1 >= 0.f ? e1 : 3.0e38f);
                 const bool sharp = en > 4.f * floor2 && en * (float)W > 3.f * thr_j;   // (x 3: a neighbour's switch-on click in this channel -- one tile at ~6 x the noise -- is not one)
+                // (d) a FALL onto a plateau: the energy has dropped to a quarter within two tiles -- a packet ended -- and the W tiles
+                // from here on still stand over the threshold: another transmission goes on underneath, and if it began where the first
+                // ended there is no rising edge to see (fuzz seed 9002 case 485: a 10.7 dB packet straight behind a 44 dB one;
+                // seed 9001 case 11029: 39 dB behind 53 dB).  The plateau may be the tail of a packet that began long before -- then
+                // this is a task for nothing, like any other edge that is no packet.
+                bool plateau = false;
+                if (jx >= 0 && (e1 > 4.f * en || e2 > 4.f * en) && jx + W < nt) {
+                    // (... and STAYS down: every one of those W tiles under half of what stood before the fall.  A neighbour's
+                    // leakage swings by 4 x from tile to tile and back; a packet's end does not come back)
+                    const float before = e1 > e2 ? e1 : e2;
+                    float sn = 0.f, mx = 0.f;
+                    // (the W tiles BEHIND this one: it may be the last, partly filled tile of the packet that ends)
+                    for (int u = 1; u <= W; u++) { const float e = pe[jx + u]; sn += e > 0.f ? e : 0.f; mx = e > mx ? e : mx; }
+                    plateau = sn > thr_j * thr_d_scale && mx < 0.5f * before;
+                    // (a plateau at the level the channel had BEFORE the packet that now ends rose is the transmission that was on
+                    // the air then, going on underneath -- its access code is long past; only a new level is a new packet.  In traffic
+                    // that collides all the time -- the C8 synthetic: eight piconets on eight channels -- this halves the tasks)
+                    if (plateau && pre_lvl > 0.f && sn > 0.5f * (float)W * pre_lvl && sn < 2.0f * (float)W * pre_lvl) plateau = false;
+                }
+                if (plateau && !(trig && !prev) && !sharp) { if ((float)((jx - 1) * TT) - 1.f < 1270.f) rise = jx; }
                 if (((trig && !prev) || sharp) && jx >= 0) {
                     // The run of triggers begins at the tile the packet begins in, or -- where less than ~3 noise tiles' worth of it
                     // lies in that tile -- up to W - 1 tiles later.  An access code is reportable at the offsets below 625
@@ -699,6 +729,7 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                     // before -- and where the 50 us before THAT held more than twice the present energy, a stronger packet has just
                     // ended and (b) may be up to 2 W - 1 tiles late.)
                     const float o = sharp ? floor2 : (miss_old > 0 ? 3.0e38f : s_old / (float)W);
+                    pre_lvl = o < 1.0e38f ? o : -1.f;
                     const bool nxt = jx + 1 < nt && pe[jx + 1] > en;
                     const float full = nxt ? pe[jx + 1] : en;
                     float frac = (en - o) / (full - o);
@@ -750,6 +781,26 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
         }
     }
     __syncthreads();                                               // s_live is the chunk loop's flag, the tile is staged over next
+}
+
+// The quietest tile of every channel over the whole batch (with a predecessor that holds signal too, like the scan's own minimum):
+// the burst scan's noise reference of last resort.  One workgroup per channel.
+__global__ __launch_bounds__(256) void channel_floor_kernel(const double *__restrict__ ptile, int stride, int ntiles, float *__restrict__ out)
+{
+    __shared__ float red[256];
+    const double *pt = ptile + (size_t)blockIdx.x * stride;
+    float mn = 3.0e38f;
+    for (int t = 1 + (int)threadIdx.x; t < ntiles; t += 256) {
+        const float e = (float)pt[t], ep = (float)pt[t - 1];
+        mn = (e > 0.f && ep > 0.f && e < mn) ? e : mn;
+    }
+    red[threadIdx.x] = mn;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] = red[threadIdx.x + sft] < red[threadIdx.x] ? red[threadIdx.x + sft] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] < 1.0e38f ? red[0] : 0.f;
 }
 
 // The burst scan as a kernel of its own, right behind the banks (round 5): the energy-selected tasks are then known before squelch

@@ -824,18 +824,20 @@ def test_exact_payload_symbols_equal_the_oracles(emu):
     assert tot["long_tasks"] > 50 and tot["long_turned_away"] == 0, tot
 
 
-@pytest.mark.parametrize("seed,case,what", [
-    (7001, 10079, "hand-over: an isolated 38.7 dB packet whose energy begins at row 1262.7 of window 6, reported there at offset 624 -- round 4's row-1261 rule (and this round's first, 1258) gave it to the next window"),
-    (8001, 2179, "no quiet block: a 30 dB packet 25 us behind a 39 dB one at 20 Msps -- one quiet 25 us tile between them, the span otherwise full: the block-minimum noise estimate was the packets' own level"),
-    (8001, 5740, "behind a stronger packet: 36 dB, 30 us behind a 44 dB one, onset at row 1250 -- the '+50 % over the 50 us before' rule saw it five tiles late and took it for the next window's; the sharp-edge rule sees it at once"),
+@pytest.mark.parametrize("seed,case,rates,what", [
+    (7001, 10079, (8, 8, 20), "hand-over: an isolated 38.7 dB packet whose energy begins at row 1262.7 of window 6, reported there at offset 624 -- round 4's row-1261 rule (and this round's first, 1258) gave it to the next window"),
+    (8001, 2179, (8, 8, 20), "no quiet block: a 30 dB packet 25 us behind a 39 dB one at 20 Msps -- one quiet 25 us tile between them, the span otherwise full: the block-minimum noise estimate was the packets' own level"),
+    (9002, 485, (100,), "fall onto a plateau: a 10.7 dB, 126-bit packet straight behind a 44 dB one at 100 Msps (multi_LAP) -- the energy only falls, onto a level 12 x over the noise that lasts ten tiles"),
+    (9001, 11029, (8, 8, 20), "fall onto a plateau, no quiet tile in the span: a 39 dB packet that begins where a 53 dB one ends and then fills the span (20 Msps) -- no rising edge, and no noise to measure the plateau against but the channel's quietest tile of the whole batch"),
+    (8001, 5740, (8, 8, 20), "behind a stronger packet: 36 dB, 30 us behind a 44 dB one, onset at row 1250 -- the '+50 % over the 50 us before' rule saw it five tiles late and took it for the next window's; the sharp-edge rule sees it at once"),
 ])
-def test_adversarial_cases_the_fuzz_found(emu, po, synth, seed, case, what):
-    """The three planted records the 1.2e5-record adversarial runs of round 5 lost on the way, replayed from
-    scripts/emu_fuzz_adversarial.py's generator (rates 8,8,20): each is now identical to the oracle's."""
+def test_adversarial_cases_the_fuzz_found(emu, po, synth, seed, case, rates, what):
+    """The planted records the 1e5-record adversarial runs of round 5 lost on the way -- one per rule the burst scan gained or changed
+     --, replayed from scripts/emu_fuzz_adversarial.py's generator: each is now identical to the oracle's."""
     import adversarial
     rng = np.random.default_rng(seed)
     for _ in range(case + 1):
-        c = adversarial.draw_case(rng, (8, 8, 20))
+        c = adversarial.draw_case(rng, rates)
     le = c["le"] and c["sniffer"]
     iq, truth, meta = adversarial.make_adversarial_capture(c["fs"], c["fc"], c["n_slots"], c["n_packets"], c["seed"], c["laps"],
                                                           le_channels=c["le_channels"] if le else None, n_adverts=c["n_adverts"],
