@@ -87,7 +87,7 @@ struct btgpu_handle {
         // stage 2, 8 window; tail 9 start, 10 end
         // ... 11 exact stage done (tail)
         hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr, squelch_done = nullptr, scan_done = nullptr, ddc1_done = nullptr;
+        hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr, squelch_done = nullptr, scan_done = nullptr, ddc1_done = nullptr, floor_done = nullptr;
         int S = 0;
         uint64_t abs_first_slot = 0;
         bool pending = false;
@@ -186,7 +186,7 @@ struct btgpu_handle {
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
             for (auto &e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-            for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.scan_done, &t.ddc1_done}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+            for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.scan_done, &t.ddc1_done, &t.floor_done}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
             if (t.h_count) { (void)hipHostFree(t.h_count); t.h_count = nullptr; }
             if (t.h_hits) { (void)hipHostFree(t.h_hits); t.h_hits = nullptr; }
         }
@@ -402,8 +402,16 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         else
             set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
     }
+    bool floor_on_side = false;
     if (verify && p.verify == 1) {
-        hipLaunchKernelGGL(channel_floor_kernel, dim3((unsigned)nch), dim3(256), 0, ps, p.ptile, p.ptile_stride, p.ptile_stride, (float *)t.d_chanfloor.p);
+        // the burst scan's last-resort noise reference: 35 us of streaming over the tile sums -- on the side stream, beside squelch
+        // stage 2 (in line it was 35 us + a launch gap per step); the window kernel waits for it (scan_done)
+        floor_on_side = !deferred && !pipelined;
+        hipStream_t fs_ = floor_on_side ? sq_stream : ps;
+        if (floor_on_side) HIPCHK(this, hipStreamWaitEvent(fs_, t.front_done, 0));
+        HIPCHK(this, hipMemsetAsync(t.d_chanfloor.p, 0x7f, 80 * sizeof(float), fs_));       // (0x7f7f7f7f = 3.4e38: no tile yet)
+        hipLaunchKernelGGL(channel_floor_kernel, dim3((unsigned)std::max(1, std::min(256, p.ptile_stride / 2048)), (unsigned)nch), dim3(256), 0, fs_, p.ptile, p.ptile_stride, p.ptile_stride, (float *)t.d_chanfloor.p);
+        if (floor_on_side) HIPCHK(this, hipEventRecord(t.floor_done, fs_));
         p.chan_floor = (const float *)t.d_chanfloor.p;
     }
     // BTGPU_PRESCAN=1: the scan as a kernel of its own behind the banks and the energy-selected tasks' DDC on a side stream beside
@@ -416,6 +424,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     VerifyParams vp{};
     if (verify) vp = make_verify_params(des, x_len, w0, ver_mp, ver_F, (const float2 *)d_rot_ch.p, (const double *)d_rotstep_ch.p, (const float *)d_atan.p, vb);
     if (prescan) {
+        if (floor_on_side) HIPCHK(this, hipStreamWaitEvent(ps, t.floor_done, 0));
         p.prescan = 1; p.vinfo = (const int32_t *)t.d_vinfo.p;
         auto launch_scan = [&](auto lay) {
             using LAY = decltype(lay);
@@ -468,6 +477,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                (const double *)d_Pt.p, (const double *)d_Q.p, (double *)t.d_eon.p, (double *)t.d_eoff.p, (double *)t.d_snr.p);
             HIPCHK(this, hipEventRecord(t.squelch_done, qs));
         }
+        if (floor_on_side) HIPCHK(this, hipStreamWaitEvent(ps, t.floor_done, 0));
         auto launch_window = [&](auto lay) {
             using LAY = decltype(lay);
             hipLaunchKernelGGL(window_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, ps, p,
@@ -1081,7 +1091,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     for (auto &t : h->tc) {
         for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
-        for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.scan_done, &t.ddc1_done})
+        for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.scan_done, &t.ddc1_done, &t.floor_done})
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     h->async = (cfg->flags & BTGPU_FLAG_ASYNC) != 0;

@@ -631,7 +631,8 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
             // ... and for rule (d) below, where the span holds no quiet tile at all (a packet straight behind another, the second
             // filling the span: fuzz seed 9001 case 11029), from the channel's quietest tile of the whole batch (channel_floor_kernel)
             const float thr_b = p.burst_abs * bmin, thr_1 = p.burst_abs1 * mn1;
-            const float thr_2 = p.chan_floor ? p.burst_abs2 * p.chan_floor[cq] : 3.0e38f;
+            const float cf_ = p.chan_floor ? p.chan_floor[cq] : 3.0e38f;
+            const float thr_2 = cf_ < 1.0e38f ? p.burst_abs2 * cf_ : 3.0e38f;
             // (the batch-wide reference serves rule (d) only: with it in (a), every +50 % step inside a span that collisions keep busy
             // becomes a task -- 1.6 x the tasks and 2.1 x the rows on the C8 synthetic, eight piconets on eight channels -- where the
             // span's own quietest block asks for a step to 2.65 x, which the 1.2e5-record runs were clean with)
@@ -784,13 +785,14 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
 }
 
 // The quietest tile of every channel over the whole batch (with a predecessor that holds signal too, like the scan's own minimum):
-// the burst scan's noise reference of last resort.  One workgroup per channel.
+// the burst scan's noise reference of last resort.  gridDim.y = channels, gridDim.x workgroups share a channel's tiles and meet in
+// an atomic minimum on the float's bits (positive floats order like their bit patterns); out[] preset to 0x7f7fffff by the caller.
 __global__ __launch_bounds__(256) void channel_floor_kernel(const double *__restrict__ ptile, int stride, int ntiles, float *__restrict__ out)
 {
     __shared__ float red[256];
-    const double *pt = ptile + (size_t)blockIdx.x * stride;
+    const double *pt = ptile + (size_t)blockIdx.y * stride;
     float mn = 3.0e38f;
-    for (int t = 1 + (int)threadIdx.x; t < ntiles; t += 256) {
+    for (int t = 1 + (int)(blockIdx.x * 256 + threadIdx.x); t < ntiles; t += 256 * (int)gridDim.x) {
         const float e = (float)pt[t], ep = (float)pt[t - 1];
         mn = (e > 0.f && ep > 0.f && e < mn) ? e : mn;
     }
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(256) void channel_floor_kernel(const double *__rest
         if ((int)threadIdx.x < sft) red[threadIdx.x] = red[threadIdx.x + sft] < red[threadIdx.x] ? red[threadIdx.x + sft] : red[threadIdx.x];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0] < 1.0e38f ? red[0] : 0.f;
+    if (threadIdx.x == 0 && red[0] < 3.0e38f) atomicMin((unsigned int *)out + blockIdx.y, __float_as_uint(red[0]));
 }
 
 // The burst scan as a kernel of its own, right behind the banks (round 5): the energy-selected tasks are then known before squelch

@@ -313,9 +313,9 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         vb.tasks = vtasks.data(); vb.tiles = vtiles.data(); vb.vcount = vcount; vb.dx = dx.data(); vb.dxt = (float *)dxt4.data();
         set_verify_flagging(p, des, *ve->fp, ve->small, ve->mode, ve->ptile, ve->ntiles, vb, want_syms, ve->tile_outs);
     }
-    std::vector<float> chan_floor((size_t)std::max(nch, 1), 0.f);
+    std::vector<float> chan_floor((size_t)std::max(nch, 1), 3.0e38f);
     if (verify && p.verify == 1) {
-        emu::launch(dim3((unsigned)nch), dim3(256), [&]() { channel_floor_kernel(p.ptile, p.ptile_stride, p.ptile_stride, chan_floor.data()); });
+        emu::launch(dim3(2u, (unsigned)nch), dim3(256), [&]() { channel_floor_kernel(p.ptile, p.ptile_stride, p.ptile_stride, chan_floor.data()); });
         p.chan_floor = getenv("EMU_NO_FLOOR") ? nullptr : chan_floor.data();
         if (getenv("EMU_DBG_FLOOR")) for (int c = 0; c < nch; c++) std::fprintf(stderr, "floor ch %d %.4g\n", c, chan_floor[c]);
     }
