@@ -6,6 +6,8 @@ LAP mode, 8 / 20 / 100 Msps (tests/adversarial.py).  A planted record counts as 
 
     python scripts/emu_fuzz_adversarial.py CASES SEED [FIRST STRIDE] [--rates 8,8,20,100] [--only CASE] [--min-snr 3]
       (case index = FIRST + k * STRIDE: run STRIDE processes with FIRST = 0..STRIDE-1; the last line of each is a JSON total)
+(The emulator's fibers and the oracle's scratch are not returned to the system between captures: a process grows by ~5 MB per case --
+keep it under ~1500 cases per process, i.e. use the stride for long runs.)
 Environment: EMU_VERIFY=0 runs the polyphase trajectory alone (what the exact stage is there to repair), EMU_LIB names another
 build of tests/emu/libemu_bank.so.
 """
