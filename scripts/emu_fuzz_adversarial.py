@@ -4,10 +4,8 @@ packets on adjacent channels, back-to-back and overlapping packets on one channe
 LAP mode, 8 / 20 / 100 Msps (tests/adversarial.py).  A planted record counts as identical only with all six key fields equal
 (slot, channel, kind, offset, LAP, ac_errors; tests/paritylib.py).
 
-    python scripts/emu_fuzz_adversarial.py CASES SEED [FIRST STRIDE] [--rates 8,8,20,100] [--only CASE] [--min-snr 3]
+    python scripts/emu_fuzz_adversarial.py CASES SEED [FIRST STRIDE] [--rates 8,8,20,100] [--only CASE] [--min-snr 3] [--wide]
       (case index = FIRST + k * STRIDE: run STRIDE processes with FIRST = 0..STRIDE-1; the last line of each is a JSON total)
-(The emulator's fibers and the oracle's scratch are not returned to the system between captures: a process grows by ~5 MB per case --
-keep it under ~1500 cases per process, i.e. use the stride for long runs.)
 Environment: EMU_VERIFY=0 runs the polyphase trajectory alone (what the exact stage is there to repair), EMU_LIB names another
 build of tests/emu/libemu_bank.so.
 """
@@ -25,6 +23,7 @@ ap.add_argument("cases", type=int); ap.add_argument("seed", type=int)
 ap.add_argument("first", type=int, nargs="?", default=0); ap.add_argument("stride", type=int, nargs="?", default=1)
 ap.add_argument("--rates", default="8,8,20,100"); ap.add_argument("--only", type=int, default=None)
 ap.add_argument("--min-snr", type=float, default=3.0); ap.add_argument("--quiet", action="store_true")
+ap.add_argument("--wide", action="store_true", help="companion packets over the stretched ranges (tests/adversarial.py)")
 a = ap.parse_args()
 L = ctypes.CDLL(os.environ.get("EMU_LIB", os.path.join(ROOT, "tests", "emu", "libemu_bank.so")))
 F, Q, D = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)
@@ -47,7 +46,7 @@ for case in range(a.cases):
     le = c["le"] and c["sniffer"]
     iq, truth, meta = adversarial.make_adversarial_capture(fs, fc, c["n_slots"], c["n_packets"], c["seed"], c["laps"],
                                                           le_channels=c["le_channels"] if le else None, n_adverts=c["n_adverts"],
-                                                          min_snr_db=a.min_snr, lag_slots=6.4 if c["sniffer"] else 1.5)
+                                                          min_snr_db=a.min_snr, lag_slots=6.4 if c["sniffer"] else 1.5, wide=a.wide)
     mode = po.MODE_SNIFFER if c["sniffer"] else po.MODE_LAP
     o = po.Oracle(fs, fc, c["squelch"], mode, le=le)
     want, _ = o.run_stream(iq, threads=1)
@@ -109,5 +108,5 @@ for case in range(a.cases):
               % (case, fs / 1e6, c["sniffer"], le, c["squelch"], len(meta), d["planted_ref"], d["planted_only_gpu"], d["planted_only_ref"],
                  d["planted_nsym_max_abs_dev"], sum(ga.values()), sum(wa.values()), d["other_gpu"], d["other_ref"], d["other_only_gpu"], d["other_only_ref"],
                  int(vc[0]), int(sum(tr[i] for i in range(nt)))), flush=True)
-out = dict(tot); out["nsym_dev_max"] = nsym_dev_max; out["seed"] = a.seed; out["rates"] = a.rates; out["min_snr_db"] = a.min_snr
+out = dict(tot); out["nsym_dev_max"] = nsym_dev_max; out["seed"] = a.seed; out["rates"] = a.rates; out["min_snr_db"] = a.min_snr; out["wide"] = a.wide
 print("TOTAL " + json.dumps(out))

@@ -31,9 +31,12 @@ def _synth():
 
 
 def make_adversarial_capture(fs, fc, n_slots, n_packets, seed, laps, le_channels=None, n_adverts=0, min_snr_db=3.0,
-                             max_payload_bits=2745, cfo_hz=75e3, lag_slots=6.4):
+                             max_payload_bits=2745, cfo_hz=75e3, lag_slots=6.4, wide=False):
     """lag_slots: how far a window's detection span lies behind the newest slot it is given ((history() - 1) / slot: 6.3 for the
-    sniffer, 1.4 for multi_LAP) -- packets are only planted where some window of the capture can report them."""
+    sniffer, 1.4 for multi_LAP) -- packets are only planted where some window of the capture can report them.
+    wide: the companions' ranges stretched past what the selection rules were derived against -- neighbours 8..45 dB up, previous
+    packets -30..+10 dB from the packet and ending -20..+60 us before it, underlays 0..25 dB down (same draws, other ranges: a
+    seed's packets stay where they are)."""
     synth = _synth()
     rng = np.random.default_rng(seed)
     sps = int(round(fs / 1e6)); slot = 625 * sps
@@ -63,16 +66,30 @@ def make_adversarial_capture(fs, fc, n_slots, n_packets, seed, laps, le_channels
             start = int(rng.integers(0, max(reach // slot, 1))) * slot + int(rng.integers(5 * sps, 15 * sps))
         if kind == "near-far" and hi > lo:
             ch2 = ch + (1 if (ch < hi and (ch == lo or rng.random() < 0.5)) else -1)
-            up = float(rng.uniform(8, 34))
+            up = float(rng.uniform(8, 45 if wide else 34))
             put(int(rng.choice(laps)), ch2, start + int(rng.integers(-80 * sps, 80 * sps)), min(level + up, TOP_DB + 10), int(rng.integers(0, 1201)), "neighbour")
         elif kind == "back-to-back":
             nb = int(rng.integers(0, 601)); n_prev = (72 + 54 + nb) * sps       # (access code + header + payload, as packet_bits lays them)
-            gap = int(rng.integers(-20 * sps, 30 * sps))
-            put(int(rng.choice(laps)), ch, start - gap - n_prev, level + float(rng.uniform(-10, 10)), nb, "previous")
+            gap = int(rng.integers(-20 * sps, (60 if wide else 30) * sps))
+            put(int(rng.choice(laps)), ch, start - gap - n_prev, level + float(rng.uniform(-10, 30 if wide else 10)), nb, "previous")
         elif kind == "on-top":
             back = int(rng.integers(100 * sps, 1500 * sps))
-            put(int(rng.choice(laps)), ch, start - back, level - float(rng.uniform(0, 15)), int(rng.integers(2000, 2746)), "underlay")
+            put(int(rng.choice(laps)), ch, start - back, level - float(rng.uniform(0, 25 if wide else 15)), int(rng.integers(2000, 2746)), "underlay")
         put(lap, ch, start, level, payload(), kind)
+    if wide:
+        # interferers that are no packets (a generator of their own: the packets of a seed stay where they are): carriers that
+        # switch on and off inside a channel, and white bursts over the whole band (a WLAN frame seen through every channel filter)
+        ri = np.random.default_rng(seed ^ 0x5EED1)
+        n = len(iq); sigma1 = 10 ** (-TOP_DB / 20)                      # amplitude of a carrier at the noise-in-1-MHz level
+        for _ in range(int(ri.integers(0, 4))):
+            ch = int(ri.integers(lo, hi + 1)); a0 = int(ri.integers(0, n)); dur = int(ri.integers(50 * sps, max(51 * sps, n)))
+            f = (synth.BASE_FREQUENCY + ch * 1e6 - fc) + float(ri.uniform(-400e3, 400e3)); amp = sigma1 * 10 ** (float(ri.uniform(0, 30)) / 20)
+            m = np.arange(a0, min(a0 + dur, n))
+            iq[a0:a0 + len(m)] += (amp * np.exp(1j * (2 * np.pi * f / fs * m + float(ri.uniform(0, 2 * np.pi))))).astype(np.complex64)
+        for _ in range(int(ri.integers(0, 4))):
+            a0 = int(ri.integers(0, n)); dur = int(ri.integers(50 * sps, 2000 * sps)); m = min(a0 + dur, n) - a0
+            s1 = sigma1 * np.sqrt(sps / 2.0) * 10 ** (float(ri.uniform(0, 20)) / 20)      # per-component sigma: `level` dB over the noise floor
+            iq[a0:a0 + m] += (ri.standard_normal(m) * s1 + 1j * ri.standard_normal(m) * s1).astype(np.complex64)
     if le_channels:
         for _ in range(n_adverts):
             ch = int(rng.choice(list(le_channels)))

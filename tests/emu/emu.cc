@@ -31,7 +31,7 @@ void barrier()
 void launch(dim3 grid, dim3 block, const std::function<void()> &body)
 {
     const unsigned nt = block.x * block.y * block.z;
-    fibers.resize(nt);
+    if (fibers.size() < nt) fibers.resize(nt);          // (never shrunk: a Fiber dropped from the vector would take its stack's pointer with it)
     for (auto &f : fibers) if (!f.stack) f.stack = (char *)std::malloc(kStack);
     cur_body = &body;
     g_dim = grid; b_dim = block;
@@ -54,10 +54,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body)
                 cur = (int)t; t_idx = f.tid; b_idx = dim3(bx, by, bz);
                 swapcontext(&sched_ctx, &f.ctx);
             }
-            for (auto &f : fibers) if (!f.done) alive++;
+            for (unsigned t = 0; t < nt; t++) if (!fibers[t].done) alive++;
             if (!alive) break;
             // every live fiber sits at the barrier: release them (exited threads do not take part)
-            for (auto &f : fibers) f.waiting = false;
+            for (unsigned t = 0; t < nt; t++) fibers[t].waiting = false;
         }
     }
 }
