@@ -1,8 +1,8 @@
 """The adversarial record differential of scripts/emu_fuzz_adversarial.py (tests/adversarial.py's generator) on the DEVICE, through the
 C ABI, against the all-core oracle.  Run on the GPU box:
-    python scripts/gpu_fuzz_adversarial.py CASES SEED [--rates 8,8,20,100]
+    python scripts/gpu_fuzz_adversarial.py CASES SEED [--rates 8,8,20,100] [--wide] [--seconds S]   (S: stop after S seconds of cases)
 Planted records identical on the six key fields (tests/paritylib.py), LE adverts identical; the last line is a JSON total."""
-import argparse, collections, importlib, json, os, sys
+import argparse, collections, importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import numpy as np
@@ -12,15 +12,19 @@ from tests.conftest import load_pkg
 pkg = load_pkg()
 bdist = importlib.import_module("gr_bluetooth_amd.dist")
 ap = argparse.ArgumentParser(); ap.add_argument("cases", type=int); ap.add_argument("seed", type=int); ap.add_argument("--rates", default="8,8,20,100")
+ap.add_argument("--wide", action="store_true"); ap.add_argument("--seconds", type=float, default=0.0)
 a = ap.parse_args()
+t0 = time.time()
 rates = tuple(int(x) for x in a.rates.split(","))
 rng = np.random.default_rng(a.seed)
 tot = collections.Counter(); nsym_dev = 0
 for case in range(a.cases):
+    if a.seconds and time.time() - t0 > a.seconds:
+        break
     c = adversarial.draw_case(rng, rates)
     fs, fc = c["fs"], c["fc"]; le = c["le"] and c["sniffer"]
     iq, truth, meta = adversarial.make_adversarial_capture(fs, fc, c["n_slots"], c["n_packets"], c["seed"], c["laps"], le_channels=c["le_channels"] if le else None,
-                                                          n_adverts=c["n_adverts"], lag_slots=6.4 if c["sniffer"] else 1.5)
+                                                          n_adverts=c["n_adverts"], lag_slots=6.4 if c["sniffer"] else 1.5, wide=a.wide)
     want, _ = po.Oracle(fs, fc, c["squelch"], po.MODE_SNIFFER if c["sniffer"] else po.MODE_LAP, le=le).run_stream(iq, threads=os.cpu_count() or 1)
     blk = pkg.multi_sniffer(fs, fc, c["squelch"], False, le=le) if c["sniffer"] else pkg.multi_LAP(fs, fc, c["squelch"])
     blk.push(iq); got = blk.poll(); tm = blk.timing(); blk.close()
@@ -40,5 +44,5 @@ for case in range(a.cases):
     if bad:
         gs = collections.Counter(map(tuple, gi[:, :6].tolist())); ws = collections.Counter(map(tuple, wi[:, :6].tolist()))
         print("FAIL case %d (seed %d, rates %s): only product %s only oracle %s" % (case, a.seed, a.rates, sorted((gs - ws).elements()), sorted((ws - gs).elements())), flush=True)
-out = dict(tot); out["nsym_dev_max"] = nsym_dev; out["seed"] = a.seed; out["rates"] = a.rates
+out = dict(tot); out["nsym_dev_max"] = nsym_dev; out["seed"] = a.seed; out["rates"] = a.rates; out["wide"] = a.wide
 print("TOTAL " + json.dumps(out))

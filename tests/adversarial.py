@@ -101,7 +101,9 @@ def make_adversarial_capture(fs, fc, n_slots, n_packets, seed, laps, le_channels
     return iq, truth, meta
 
 
-RATES = {8: (8e6, 2476.5e6, {78: 39}), 20: (20e6, 2441e6, {}), 100: (100e6, 2441e6, {0: 37, 24: 38, 78: 39})}
+RATES = {8: (8e6, 2476.5e6, {78: 39}), 20: (20e6, 2441e6, {}), 100: (100e6, 2441e6, {0: 37, 24: 38, 78: 39}),
+         # further rates of the polyphase path (any even number of samples per symbol), other tile geometries of the burst scan
+         4: (4e6, 2427e6, {24: 38}), 10: (10e6, 2450e6, {}), 16: (16e6, 2405e6, {0: 37}), 40: (40e6, 2461e6, {78: 39}), 50: (50e6, 2426e6, {24: 38})}
 
 
 def draw_case(rng, rates=(8, 8, 20, 100)):
@@ -110,7 +112,7 @@ def draw_case(rng, rates=(8, 8, 20, 100)):
     fs, fc, lech = RATES[r]
     sniffer = bool(rng.random() < 0.8)
     return dict(fs=fs, fc=fc, le_channels=lech, n_slots=int(rng.integers(11, 16)) if sniffer else int(rng.integers(5, 9)),
-                n_packets=int(rng.integers(30, 90)) if r == 100 else int(rng.integers(8, 30)),
+                n_packets=int(rng.integers(30, 90)) if r == 100 else int(rng.integers(15, 50)) if r >= 40 else int(rng.integers(8, 30)),
                 squelch=float(rng.choice([5.0, 10.0, 14.0])), sniffer=sniffer, le=bool(rng.integers(0, 2)),
                 laps=tuple(int(x) for x in rng.integers(0, 1 << 24, 5)), seed=int(rng.integers(0, 1 << 30)),
                 n_adverts=int(rng.integers(0, 6)))
