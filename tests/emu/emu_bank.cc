@@ -255,6 +255,7 @@ int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
 struct StudyCapture { std::vector<float> d; std::vector<double> snr; long long G = 0; int drow = 0, nch = 0, S = 0;
                       std::vector<VerifyTask> tasks; std::vector<float> dx; };
 static uint32_t *g_sym_out = nullptr; static uint8_t *g_hdr_out = nullptr;     // set by emu_front_direct_headers_run
+static bool g_rows_only = false;                        // emu_verify_check: the demodulated rows are all it reads -- the exact noise bank is left out (E_off = 0: every window passes)
 static StudyCapture *g_study = nullptr;                 // emu_margin_study: keep the demodulated stream and the squelch SNRs
 
 // exact confirmation in the emulated front end: what the runtime's tail stream does (btgpu.hip process_batch)
@@ -548,7 +549,7 @@ extern "C" int emu_front_direct_run(double fs, double fc, int mode, int le, doub
         });
     };
     ddc(sc, des.channel, d.first_channel_sample, st, Y.data(), G, ystride, seg_ch);
-    ddc(sn, des.noise, d.first_noise_sample, sno, Yn.data(), Gn, ystride_n, seg_n);
+    if (!g_rows_only) ddc(sn, des.noise, d.first_noise_sample, sno, Yn.data(), Gn, ystride_n, seg_n);   // (20 001 taps per output: most of this function's time)
     std::vector<double> P((size_t)nch * nb), Pt((size_t)nch * nb), Qn((size_t)nch * S);
     emu::launch(dim3((unsigned)nb, (unsigned)nch), dim3(256), [&]() {
         energy_kernel(Y.data(), G, ystride, ops, des.tail, P.data(), Pt.data(), nb, nch, ops);
@@ -722,9 +723,9 @@ extern "C" long emu_verify_check(double fs, double fc, int mode, double squelch_
     std::vector<long long> rec((size_t)8 * 65536); std::vector<double> sn(65536);
     g_study = &fast;
     int rc = emu_front_m_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
-    g_study = &exact;
+    g_study = &exact; g_rows_only = true;
     if (rc >= 0) rc = emu_front_direct_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
-    g_study = nullptr;
+    g_study = nullptr; g_rows_only = false;
     if (rc < 0) return rc;
     btgpu_config cfg{};
     cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = squelch_db; cfg.mode = mode;

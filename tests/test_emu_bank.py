@@ -539,11 +539,14 @@ def test_false_alarm_behind_the_exact_span_is_what_still_differs(emu, po, synth)
     assert any(t["slot"] == 8 and t["channel"] == 77 for t in truth) and lap not in laps   # ... of a planted packet; no planted LAP
 
 
-@pytest.mark.parametrize("fs,fc,sniff,nsl", [(8e6, 2476.5e6, True, 14), (20e6, 2441e6, False, 10), (100e6, 2441e6, True, 9)])
+@pytest.mark.parametrize("fs,fc,sniff,nsl", [(8e6, 2476.5e6, True, 14), (20e6, 2441e6, False, 10), (100e6, 2441e6, True, 9), (100e6, 2441e6, False, 5),
+                                                 (4e6, 2427e6, True, 14), (10e6, 2450e6, True, 12), (16e6, 2405e6, False, 8), (40e6, 2461e6, True, 9),
+                                                 (50e6, 2426e6, False, 5)])
 def test_exact_stage_rows_equal_the_direct_path_bit_for_bit(emu, synth, fs, fc, sniff, nsl):
     """verify_ddc_kernel (the product's source under the emulator) against ddc_direct_kernel + demod_rows_kernel: every
     demodulated row the exact stage recomputes -- rows [1, n_exact) of every window it takes -- is bit-identical to the
-    bit-exact path's (which the other tests pin to the oracle), at the three bank geometries (D = 4, 10, 50)."""
+    bit-exact path's (which the other tests pin to the oracle), at the three bank geometries of the BASELINE configs and the
+    fuzz (D = 4, 10, 50) and at D = 2, 5, 8, 20, 25."""
     import pyoracle as po_
     iq, _ = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=11, snr_db=22, occupancy=0.6,
                                cfo_hz=60e3, max_payload_bits=1200)
@@ -558,6 +561,7 @@ def test_exact_stage_rows_equal_the_direct_path_bit_for_bit(emu, synth, fs, fc, 
     vc = (ctypes.c_uint * 4)()
     emu.emu_verify_counts(vc)
     assert bad == 0, "rows differ: %d, first at window %d row %d of %d" % (bad, fb[0], fb[1], fb[2])
+    assert vc[0] >= 10 and vc[2] == 0, list(vc)             # (windows the exact stage took; none turned away)
 
 
 @pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (4e6, 2476e6, False, False), (5e6, 2470e6, True, False),
@@ -805,6 +809,21 @@ def test_adversarial_fuzz_slice_emulated(emu):
     assert r.returncode == 0, r.stderr[-2000:]
     tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
     assert tot["cases"] == 30 and tot["planted"] > 150, tot
+    assert tot["planted_only_product"] == 0 and tot["planted_only_oracle"] == 0 and tot["adverts_differing"] == 0, tot
+    assert tot["nsym_dev_max"] <= paritylib.NSYM_BOUND, tot
+
+
+def test_adversarial_fuzz_slice_wide_generator_other_rates(emu):
+    """Sixteen captures of the same script with --wide (companions over the stretched ranges -- neighbours to 45 dB up, previous packets
+    30 dB stronger and up to 60 us ahead, underlays 25 dB down -- plus carriers and white bursts that are no packets) at 4 / 10 / 16 /
+    40 / 50 Msps: the burst scan's other tile geometries.  (The long runs: profiles/r05_emu_fuzz_adversarial_more.txt; on the device
+    profiles/r05_p_*.)"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_fuzz_adversarial.py"), "16", "906", "--rates", "4,10,16,40,50", "--quiet", "--wide"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
+    assert tot["cases"] == 16 and tot["planted"] > 60 and tot["wide"], tot
     assert tot["planted_only_product"] == 0 and tot["planted_only_oracle"] == 0 and tot["adverts_differing"] == 0, tot
     assert tot["nsym_dev_max"] <= paritylib.NSYM_BOUND, tot
 
