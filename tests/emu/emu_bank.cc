@@ -723,9 +723,11 @@ extern "C" long emu_verify_check(double fs, double fc, int mode, double squelch_
     std::vector<long long> rec((size_t)8 * 65536); std::vector<double> sn(65536);
     g_study = &fast;
     int rc = emu_front_m_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
+    unsigned int fast_counts[4]; std::memcpy(fast_counts, g_verify_counts, sizeof fast_counts);   // (emu_verify_counts after this call: the polyphase run's)
     g_study = &exact; g_rows_only = true;
     if (rc >= 0) rc = emu_front_direct_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
     g_study = nullptr; g_rows_only = false;
+    std::memcpy(g_verify_counts, fast_counts, sizeof fast_counts);
     if (rc < 0) return rc;
     btgpu_config cfg{};
     cfg.sample_rate = fs; cfg.center_freq = fc; cfg.squelch_db = squelch_db; cfg.mode = mode;

@@ -561,7 +561,7 @@ def test_exact_stage_rows_equal_the_direct_path_bit_for_bit(emu, synth, fs, fc, 
     vc = (ctypes.c_uint * 4)()
     emu.emu_verify_counts(vc)
     assert bad == 0, "rows differ: %d, first at window %d row %d of %d" % (bad, fb[0], fb[1], fb[2])
-    assert vc[0] >= 10 and vc[2] == 0, list(vc)             # (windows the exact stage took; none turned away)
+    assert vc[0] >= 3 and vc[2] == 0, list(vc)              # (windows the exact stage took; none turned away)
 
 
 @pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (4e6, 2476e6, False, False), (5e6, 2470e6, True, False),
