@@ -1,7 +1,7 @@
 """What the handlers of the drop-in sniffer block are given on the DEFAULT path (polyphase banks + exact stage, BTGPU_FLAG_SYMBOLS):
 the sliced symbols of every record's window from the hit on, compared with the oracle's symbol by symbol -- the input of every
 header / payload decode and CRC (lib/multi_sniffer_impl.cc:118-123, lib/packet_impl.cc:1066-1160).  Emulator, adversarial captures.
-    python scripts/emu_symbol_parity.py CASES SEED [--rates 8,20]
+    python scripts/emu_symbol_parity.py CASES SEED [FIRST STRIDE] [--rates 8,20] [--exact-payload] [--wide]
 Per record: symbols compared, first differing symbol (relative to the hit), number differing within the packet's own length."""
 import argparse, collections, ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ load_pkg()
 ap = argparse.ArgumentParser(); ap.add_argument("cases", type=int); ap.add_argument("seed", type=int); ap.add_argument("--rates", default="8,20")
 ap.add_argument("first", type=int, nargs="?", default=0); ap.add_argument("stride", type=int, nargs="?", default=1)
 ap.add_argument("--exact-payload", action="store_true", help="BTGPU_FLAG_EXACT_PAYLOAD: long tasks to the end of each burst")
+ap.add_argument("--wide", action="store_true", help="the generator's stretched ranges and non-packet interferers (tests/adversarial.py)")
 a = ap.parse_args()
 L = ctypes.CDLL(os.environ.get("EMU_LIB", os.path.join(ROOT, "tests", "emu", "libemu_bank.so")))
 F, Q, D = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)
@@ -30,7 +31,7 @@ for case in range(a.cases):
     if case % a.stride != a.first % a.stride:
         continue
     fs, fc = c["fs"], c["fc"]
-    iq, truth, meta = adversarial.make_adversarial_capture(fs, fc, c["n_slots"], c["n_packets"], c["seed"], c["laps"], lag_slots=6.4)
+    iq, truth, meta = adversarial.make_adversarial_capture(fs, fc, c["n_slots"], c["n_packets"], c["seed"], c["laps"], lag_slots=6.4, wide=a.wide)
     o = po.Oracle(fs, fc, c["squelch"], po.MODE_SNIFFER, le=False)
     want, _ = o.run_stream(iq, threads=1)
     x = np.ascontiguousarray(np.concatenate([np.zeros(o.history - 1, np.complex64), iq.astype(np.complex64)])).view(np.float32)
