@@ -1,10 +1,12 @@
 """The adversarial record differential of scripts/emu_fuzz_adversarial.py (tests/adversarial.py's generator) on the DEVICE, through the
 C ABI, against the all-core oracle.  Run on the GPU box:
-    python scripts/gpu_fuzz_adversarial.py CASES SEED [--rates 8,8,20,100] [--wide] [--seconds S]   (S: stop after S seconds of cases)
+    python scripts/gpu_fuzz_adversarial.py CASES SEED [--rates 8,8,20,100] [--wide] [--seconds S] [--no-torch]   (S: stop after S seconds of cases)
 Planted records identical on the six key fields (tests/paritylib.py), LE adverts identical; the last line is a JSON total."""
 import argparse, collections, importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+if "--no-torch" in sys.argv:                  # libbtgpu.so then binds /opt/rocm's HIP runtime itself; saves torch's minute-long first import on a fresh box
+    sys.argv.remove("--no-torch"); sys.modules["torch"] = None
 import numpy as np
 import pyoracle as po
 import paritylib, adversarial
