@@ -98,6 +98,32 @@ def build_id():
     return hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
 
 
+def traffic_by_device_code(key, S):
+    """roofline.traffic when profiles/ holds no PMC summary of THIS build of libbtgpu.so.  A summary collected on ANOTHER build still
+    measures the dominant kernel if that kernel's instructions are the same in both (a change elsewhere in the library does not
+    un-measure the bank kernel; a change to it does): the summaries carry a per-kernel id of the device code they ran
+    (scripts/device_code_ids.py: sha256 of the normalised gfx950 disassembly, stamped from a bit-identical rebuild of the measured
+    build).  Returns the roofline fields on an equal id, else None.  key: the kernel-name prefix, S: slots per launch."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import device_code_ids as dci
+    ids = dci.kernel_code_ids(os.path.join(ROOT, "gr-bluetooth_amd", "libbtgpu.so"))
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm.json")), reverse=True):
+        try:
+            pj = json.load(open(cand))
+        except (OSError, ValueError):
+            continue
+        if pj.get("slots") != S or not isinstance(pj.get("kernel_code_sha"), dict):
+            continue
+        match = sorted([k for k in pj["kernels"] if key and k.startswith(key)], key=lambda k: -pj["kernels"][k]["hbm_bytes"])
+        want_id = pj["kernel_code_sha"].get(match[0]) if match else None
+        if want_id and want_id == dci.lookup(ids, match[0]):
+            return {"traffic": pj["kernels"][match[0]]["hbm_bytes"], "traffic_source": os.path.basename(cand),
+                    "traffic_basis": "PMC passes ran on build %s; %s is instruction-identical in this build (device code id %s, "
+                                     "scripts/device_code_ids.py)" % (pj.get("build_id"), match[0], want_id)}
+    return None
+
+
 def _spawn_entry(rank, args, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -487,6 +513,13 @@ def run_rank(args):
             if match:
                 roof["traffic"] = pmc["kernels"][match[0]]["hbm_bytes"]
                 roof["traffic_source"] = os.path.basename(args.pmc_json)
+        else:
+            # no summary of this very build: one of another build counts for the dominant kernel on an equal device-code id
+            key = {"ddc_channel": "pfb", "window": "window_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
+            try:
+                roof.update(traffic_by_device_code(key, S) or {})
+            except Exception as e:                      # (no disassembler on the box, ...: traffic stays null)
+                roof["traffic_note"] = "no PMC summary of this build; device-code match not possible: %r" % (e,)
 
         # ---- cpu_baseline + parity: the oracle (a port, NOT the upstream binary) ----
         cpu = None

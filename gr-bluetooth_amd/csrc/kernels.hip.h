@@ -1112,14 +1112,20 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     int limit = len1 - 68 < 625 ? len1 - 68 : 625;
     int resume = 0, nhits = 0;
     // exact payload: the weakest of the window's records' packets, as the W-tile energy ~50 us behind each record's start (inside its
-    // access code) -- long_task_kernel takes the burst as over when the energy has fallen 5 dB under it
+    // access code) -- long_task_kernel takes the burst as over when the energy has fallen 5 dB under it.  The smaller of the sums that
+    // end 50 and 75 us behind the start: the first still holds the tail of whatever ended under the access code's first symbols (a
+    // predecessor 30 dB stronger, a neighbour's switch-off splatter: level 6 x too high, the packet "over" at once); too LOW a level
+    // (a 68-us ID packet: the second sum is 1/7 noise) only makes the long task longer.
     float min_level = 3.0e38f;
     auto note_level = [&](int cpos) {
         if (!p.exact_payload || !p.ptile) return;
-        const int j = (2 * cpos + 100) / p.tile_outs, tb = kq * p.tiles_per_slot;
-        float sw = 0.f;
-        for (int u = 0; u < p.burst_w; u++) { const int t = tb + j - u; sw += (t >= 0 && t < p.ptile_stride) ? fmaxf((float)p.ptile[(size_t)cq * p.ptile_stride + t], 0.f) : 0.f; }
-        min_level = sw < min_level ? sw : min_level;
+        const int tb = kq * p.tiles_per_slot;
+        for (int behind = 100; behind <= 150; behind += 50) {
+            const int j = (2 * cpos + behind) / p.tile_outs;
+            float sw = 0.f;
+            for (int u = 0; u < p.burst_w; u++) { const int t = tb + j - u; sw += (t >= 0 && t < p.ptile_stride) ? fmaxf((float)p.ptile[(size_t)cq * p.ptile_stride + t], 0.f) : 0.f; }
+            min_level = sw < min_level ? sw : min_level;
+        }
     };
     auto emit_classic = [&](int cpos, uint32_t lap, int err) {
         note_level(cpos);
@@ -1388,8 +1394,15 @@ __global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, c
             }
             bmin = (ok && sb < bmin) ? sb : bmin;
         }
+        // ... or, where a transmission fills all of those tiles (the record's own long packet with nothing in front of it at the start
+        // of a stream, or a stronger one that reaches back over the seven tiles in front: the local "noise" is a packet, and a real
+        // record's level lies under twice it), the channel's quietest tile of the whole batch (channel_floor_kernel).  Whichever is
+        // lowest: a record is left out only when every reference calls it noise.
         const float thr_b = p.burst_abs * bmin, thr_1 = p.burst_abs1 * mn1;
-        const float thr = thr_1 < thr_b ? thr_1 : thr_b;
+        const float cf_ = p.chan_floor ? p.chan_floor[c] : 3.0e38f;
+        const float thr_2 = cf_ < 1.0e38f ? p.burst_abs2 * cf_ : 3.0e38f;
+        float thr = thr_1 < thr_b ? thr_1 : thr_b;
+        thr = thr_2 < thr ? thr_2 : thr;
         if (level > 0.f && thr < 1.0e38f && level < thr) return;
     }
     int last_on = j0, below = 0;

@@ -51,7 +51,7 @@ for case in range(a.cases):
         cand = [m for m in meta if m["channel"] == h.channel and m["lap"] == h.lap and abs(m["start"] - est) < 12 * sps]
         if not cand:
             continue
-        pk = min(cand, key=lambda m: abs(m["start"] - est))
+        pk = min(cand, key=lambda m: (abs(m["start"] - est), -m["snr_db"]))      # (two of one LAP at one instant: the record is the stronger one's)
         win = o.window(iq, h.slot)
         osym, _ = o.channel_symbols(o.channel_samples(win, h.channel)[0] if isinstance(o.channel_samples(win, h.channel), tuple) else o.channel_samples(win, h.channel))
         bits = np.unpackbits(sym[got[key]].view(np.uint8), bitorder="little")

@@ -843,6 +843,25 @@ def test_exact_payload_symbols_equal_the_oracles(emu):
     assert tot["long_tasks"] > 50 and tot["long_turned_away"] == 0, tot
 
 
+@pytest.mark.parametrize("seed,case,rates,wide,what", [
+    (41, 76, "4,10,16,40,50", False, "a 2294-bit packet that begins with the stream (no tile in front of it) and fills the first 64 tiles of its window at 40 Msps: "
+                                     "every local noise reference was the packet itself, the record's level lay under 2 x it and was taken for noise-born -- no long "
+                                     "task; now the channel's quietest tile of the batch is a reference too"),
+    (42, 503, "8,20", True, "a 14 dB, 2328-bit packet whose access code begins 16 us before a 49 dB neighbour switches off: the level read 50 us behind the "
+                            "record's start held the neighbour's splatter (6 x too high), the burst was 'over' after 70 us; now the smaller of the sums 50 and 75 us behind"),
+])
+def test_exact_payload_cases_the_wide_fuzz_found(emu, seed, case, rates, wide, what):
+    """BTGPU_FLAG_EXACT_PAYLOAD: the two ways a long task came out too short (or not at all) in the stretched generator's runs
+    (scripts/emu_symbol_parity.py --exact-payload: 19 of 11 200 records carried a differing payload symbol; the committed rules: 0)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_symbol_parity.py"), str(case + 1), str(seed), str(case), "1000000", "--rates", rates,
+                        "--exact-payload"] + (["--wide"] if wide else []), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
+    assert tot["records"] >= 5 and tot["long_tasks"] >= 5 and tot["long_turned_away"] == 0, tot
+    assert tot["records_with_a_differing_symbol"] == 0 and tot["differing_symbols"] == 0, (what, tot)
+
+
 @pytest.mark.parametrize("seed,case,rates,what", [
     (7001, 10079, (8, 8, 20), "hand-over: an isolated 38.7 dB packet whose energy begins at row 1262.7 of window 6, reported there at offset 624 -- round 4's row-1261 rule (and this round's first, 1258) gave it to the next window"),
     (8001, 2179, (8, 8, 20), "no quiet block: a 30 dB packet 25 us behind a 39 dB one at 20 Msps -- one quiet 25 us tile between them, the span otherwise full: the block-minimum noise estimate was the packets' own level"),
