@@ -48,7 +48,7 @@ struct FinishRec {            // M&M state of a window that reported hits, hande
     int32_t  oo;
     float    mu, omega, last;
     int32_t  done;            // the window already ended inside the window kernel (len known)
-    int32_t  pad_;            // exact payload: the weakest of the window's packets (W-tile energy inside its access code, float bits)
+    int32_t  pad_;            // exact payload: the weakest of the window's packets (W-tile energy inside its access code, float bits; sign bit: a record on a rise)
 };
 
 constexpr int kSymWords = 120;    // packed symbols kept per hit window (3840 >= ~3760 symbols)
@@ -1112,20 +1112,29 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     int limit = len1 - 68 < 625 ? len1 - 68 : 625;
     int resume = 0, nhits = 0;
     // exact payload: the weakest of the window's records' packets, as the W-tile energy ~50 us behind each record's start (inside its
-    // access code) -- long_task_kernel takes the burst as over when the energy has fallen 5 dB under it.  The smaller of the sums that
-    // end 50 and 75 us behind the start: the first still holds the tail of whatever ended under the access code's first symbols (a
-    // predecessor 30 dB stronger, a neighbour's switch-off splatter: level 6 x too high, the packet "over" at once); too LOW a level
-    // (a 68-us ID packet: the second sum is 1/7 noise) only makes the long task longer.
+    // access code) -- long_task_kernel takes the burst as over when the energy has fallen 5 dB under it.  The smallest of the sums that
+    // end 50 and 75 us behind the start (and, where a tile is longer than 25 us, one tile further): the first still holds the tail of
+    // whatever ended under the access code's first symbols (a predecessor 30 dB stronger, a neighbour's switch-off splatter: level
+    // 6 x too high, the packet "over" at once; in a 125-us tile of the 4 Msps bank both sums are that tile); too LOW a level (a 68-us
+    // ID packet: the later sums are part noise) only makes the long task longer.
+    // level_rise: one of the records begins on a RISE -- the level is more than 1.5 x the W tiles that end in front of the record's
+    // tile (the burst scan's rule (b)): such a record stands on a packet whatever the noise references say (long_task_kernel's
+    // noise-born test; a packet as strong as the carrier it sits on is 2 x "the noise" at most).
     float min_level = 3.0e38f;
+    bool level_rise = false;
     auto note_level = [&](int cpos) {
         if (!p.exact_payload || !p.ptile) return;
         const int tb = kq * p.tiles_per_slot;
-        for (int behind = 100; behind <= 150; behind += 50) {
-            const int j = (2 * cpos + behind) / p.tile_outs;
+        auto wsum = [&](int j) {
             float sw = 0.f;
             for (int u = 0; u < p.burst_w; u++) { const int t = tb + j - u; sw += (t >= 0 && t < p.ptile_stride) ? fmaxf((float)p.ptile[(size_t)cq * p.ptile_stride + t], 0.f) : 0.f; }
-            min_level = sw < min_level ? sw : min_level;
-        }
+            return sw;
+        };
+        const int j50 = (2 * cpos + 100) / p.tile_outs, j75 = (2 * cpos + 150) / p.tile_outs;
+        float lv = fminf(wsum(j50), wsum(j75));
+        if (p.tile_outs > 50) lv = fminf(lv, wsum(j75 + 1));
+        min_level = lv < min_level ? lv : min_level;
+        level_rise = level_rise || lv > 1.5f * wsum((2 * cpos) / p.tile_outs - 1);
     };
     auto emit_classic = [&](int cpos, uint32_t lap, int err) {
         note_level(cpos);
@@ -1299,7 +1308,8 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             const unsigned int f = atomicAdd(fin_count, 1u);
             FinishRec r;
             r.w = (int32_t)w; r.ii = ii; r.oo = oo; r.mu = mu; r.omega = omega; r.last = last;
-            r.done = ended ? 1 : 0; r.pad_ = (int32_t)__float_as_uint(min_level < 1.0e38f ? min_level : 0.f);
+            r.done = ended ? 1 : 0;
+            r.pad_ = (int32_t)(__float_as_uint(min_level < 1.0e38f ? min_level : 0.f) | (level_rise ? 0x80000000u : 0u));   // (a level is >= 0: the sign bit carries level_rise)
             if (snap_on && snap_oo >= 0) {                             // the continuation restarts where the exact rows end
                 r.ii = snap_ii; r.oo = snap_oo; r.mu = snap_mu; r.omega = snap_om; r.last = snap_last; r.done = 0;
             }
@@ -1375,12 +1385,14 @@ __global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, c
         for (int u = 0; u < W; u++) { const int t = t0 + j - u; sw += (t >= 0 && t < tmax) ? fmaxf((float)pt[t], 0.f) : 0.f; }
         return sw;
     };
-    const float level = __uint_as_float((uint32_t)r.pad_);
+    const float level = __uint_as_float((uint32_t)r.pad_ & 0x7fffffffu);
+    const bool on_a_rise = ((uint32_t)r.pad_ >> 31) != 0;              // (window_kernel's level_rise)
     const float quiet = 0.3f * level;                                  // (0: no level known -- the window is taken to its end)
     // A record that does not stand on a burst -- an access address or a six-error access code found in NOISE -- has no payload
     // to be exact about, and its "level" never falls 5 dB: it would be taken to the end of its window (1500 of the 4500 long
     // tasks of a bench batch, 60 % of their rows).  Not on a burst = its level is under the burst scan's own absolute threshold
-    // (2 x the mean noise, from the quietest block or tile of the window's first ~64 tiles and the seven in front).
+    // (2 x the mean noise, from the quietest block or tile of the window's first ~64 tiles and the seven in front) AND none of the
+    // window's records begins on a rise of the energy (window_kernel's level_rise).
     {
         const int NFl = kBurstFront;
         float bmin = 3.0e38f, mn1 = 3.0e38f, ep = -1.f;
@@ -1403,7 +1415,7 @@ __global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, c
         const float thr_2 = cf_ < 1.0e38f ? p.burst_abs2 * cf_ : 3.0e38f;
         float thr = thr_1 < thr_b ? thr_1 : thr_b;
         thr = thr_2 < thr ? thr_2 : thr;
-        if (level > 0.f && thr < 1.0e38f && level < thr) return;
+        if (level > 0.f && thr < 1.0e38f && level < thr && !on_a_rise) return;
     }
     int last_on = j0, below = 0;
     float s_cur = wsum(j0);

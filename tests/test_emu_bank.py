@@ -849,16 +849,21 @@ def test_exact_payload_symbols_equal_the_oracles(emu):
                                      "task; now the channel's quietest tile of the batch is a reference too"),
     (42, 503, "8,20", True, "a 14 dB, 2328-bit packet whose access code begins 16 us before a 49 dB neighbour switches off: the level read 50 us behind the "
                             "record's start held the neighbour's splatter (6 x too high), the burst was 'over' after 70 us; now the smaller of the sums 50 and 75 us behind"),
+    (53, 460, "4,10,16,40,50", True, "4 Msps, 125-us tiles: a 15 dB packet beginning 6 us before a 36 dB predecessor ends -- both sums lay in the predecessor's tile; "
+                                     "where a tile is longer than 25 us the level now looks one tile further as well"),
+    (52, 524, "8,20", True, "a 16 dB packet on a carrier of its own strength that lasts the whole batch: every noise reference is the carrier, the record's level "
+                            "under 2 x it -- taken for noise-born; a record that begins on a RISE of the energy (1.5 x the tiles in front) now always gets its long task"),
 ])
 def test_exact_payload_cases_the_wide_fuzz_found(emu, seed, case, rates, wide, what):
-    """BTGPU_FLAG_EXACT_PAYLOAD: the two ways a long task came out too short (or not at all) in the stretched generator's runs
-    (scripts/emu_symbol_parity.py --exact-payload: 19 of 11 200 records carried a differing payload symbol; the committed rules: 0)."""
+    """BTGPU_FLAG_EXACT_PAYLOAD: the ways a long task came out too short (or not at all) in the stretched generator's runs
+    (scripts/emu_symbol_parity.py --exact-payload: 28 of 31 521 records carried a differing payload symbol; the committed rules: 0,
+    profiles/r05_emu_symbol_parity_wide.txt)."""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_symbol_parity.py"), str(case + 1), str(seed), str(case), "1000000", "--rates", rates,
                         "--exact-payload"] + (["--wide"] if wide else []), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
-    assert tot["records"] >= 5 and tot["long_tasks"] >= 5 and tot["long_turned_away"] == 0, tot
+    assert tot["records"] >= 4 and tot["long_tasks"] >= 3 and tot["long_turned_away"] == 0, tot
     assert tot["records_with_a_differing_symbol"] == 0 and tot["differing_symbols"] == 0, (what, tot)
 
 
