@@ -529,6 +529,11 @@ __device__ __forceinline__ int ver_rows_of(const WindowParams &p, int span)
 {
     int rows = (int)((float)span * (p.omega_mid + p.omega_relative_limit)) + 12;
     const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
+    // Where the banks' tiles are longer than 25 us (<= 10 Msps apart from the C8 geometry: 125-us tiles, W = 1) the scan places an
+    // edge that coarsely, and a second packet of the window can lie behind the span of the first: the exact pass would run over
+    // polyphase rows from there and may decode what neither the reference nor the polyphase path does (seed 19001 case 3376,
+    // tests/test_emu_bank.py).  At those rates a task is the whole detection span -- a few MB/s of input, the rows cost nothing.
+    if (p.tile_outs > 50) return cap_rows;
     return rows > cap_rows ? cap_rows : rows;
 }
 

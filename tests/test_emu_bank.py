@@ -890,16 +890,15 @@ def test_adversarial_cases_the_fuzz_found(emu, po, synth, seed, case, rates, wha
     assert d["planted_ref"] >= 5 and d["planted_identical"] and d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, (what, d)
 
 
-@pytest.mark.xfail(strict=True, reason="KNOWN DEVIATION, found in the round's last run and not fixed (DESIGN.md section 5, profiles/r05_emu_fuzz_adversarial_more.txt): "
-                                       "the exact pass decodes an access code 770 rows behind its own 423 exact rows, over polyphase rows from the exact state")
-def test_known_deviation_a_hit_of_the_exact_pass_behind_its_exact_span(emu, po, synth):
-    """Case 3376 of `scripts/emu_fuzz_adversarial.py 9000 19001 --rates 8,8,20,10,16,4,40 --wide` (10 Msps, multi_LAP): a 41 dB packet
-    begins 5 us before a 67 dB one of the same LAP ends.  The oracle -- its clock recovery still locked to the 67 dB packet -- decodes no
-    access code there, nor does the DIRECT path, nor the polyphase trajectory alone; the product reports (2, 51, offset 596, 1 error):
-    window (2, 51) is a task with 423 exact rows (the 67 dB packet's rise), behind them the exact pass runs over the polyphase rows
-    from the exact state, a third trajectory, and that one locks.  The burst scan (125-us tiles at this rate) gave the fall onto the new
-    packet's plateau to the NEXT window only.  What closes it: a second, longer task for a hit behind the exact span, and 25-output
-    sums at <= 10 Msps.  The assertion below is the contract; it fails today (1 of 446 728 planted records of the committed selection)."""
+def test_a_hit_of_the_exact_pass_behind_its_exact_span_coarse_tiles(emu, po, synth):
+    """Case 3376 of `scripts/emu_fuzz_adversarial.py 9000 19001 --rates 8,8,20,10,16,4,40 --wide` (10 Msps, multi_LAP), the one planted
+    record the round's fuzz of the committed selection found on the product's side only: a 41 dB packet begins 5 us before a 67 dB one
+    of the same LAP ends.  The oracle -- its clock recovery still locked to the 67 dB packet -- decodes no access code there, nor does
+    the DIRECT path, nor the polyphase trajectory alone; the product reported (2, 51, offset 596, 1 error): window (2, 51) was a task
+    with 423 exact rows (the 67 dB packet's rise), behind them the exact pass ran over the polyphase rows from the exact state, a third
+    trajectory, and that one locked.  The burst scan, on 125-us tiles at this rate, gave the fall onto the new packet's plateau to the
+    NEXT window only.  Since then a task at the coarse-tile rates is the whole detection span (ver_rows_of); the general form -- a
+    second, longer task for any hit of the exact pass behind its exact rows -- is DESIGN.md section 8 item 0."""
     import adversarial
     rng = np.random.default_rng(19001)
     for _ in range(3376 + 1):
