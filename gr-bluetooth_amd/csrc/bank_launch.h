@@ -13,6 +13,7 @@
 #include "pfb100f.hip.h"
 #include "pfbm.hip.h"
 #include "verify.hip.h"
+#include "exact.hip.h"
 
 namespace btgpu {
 
@@ -219,13 +220,12 @@ inline WindowParams make_window_params(const Design &des, int S, int nb, long lo
 
 // ---- exact confirmation (verify.hip.h): geometry and parameters shared by the runtime and the emulator ----
 struct VerifyBuffers {                                   // device (or emulated) memory of one in-flight batch
-    VerifyTask *tasks = nullptr; uint32_t *tiles = nullptr; unsigned int *vcount = nullptr;   // vcount[4 + c]: tiles listed for channel c
-    float *dx = nullptr, *dxt = nullptr;
+    VerifyTask *tasks = nullptr; unsigned int *vcount = nullptr;
+    float *dxt = nullptr;
     int vcap = 0;
-    unsigned int tiles_cap = 0;                           // entries per CHANNEL's list: verify_tiles_capacity(S)
+    uint32_t *bm1 = nullptr, *bm2 = nullptr; int bm_tiles = 0;   // exact rows' bitmaps [bm_tiles][kExBmWords] (presence / the first run's uncovered hits)
 };
-inline size_t verify_tiles_capacity(int S) { return (size_t)S * kVerMaxTiles; }
-constexpr int kVerCountWords = 4 + 80;                  // vcount: 4 counters + one tile count per channel
+constexpr int kVerCountWords = 8;                       // vcount: 0 tasks, 1 pairs marked, 2 turned away, 3 busy windows, 4 / 5 pairs computed by the first / second launch of exact_rows_kernel
 inline int verify_capacity(int S, int nch) { return (int)std::min<long long>((long long)S * nch, 32768); }
 // the small-M bank in its F8 form (C8) also leaves 25-instant sums: finer than its 250-instant tiles
 inline bool verify_has_fine(const Design &des, const FastPath &fp, int drow)
@@ -234,22 +234,21 @@ inline bool verify_has_fine(const Design &des, const FastPath &fp, int drow)
     return fp.channel.natural && fp.channel.M == 8 && nch == 8 && drow == 8 && pfbm_tile(8) + 1 <= kPfbmThreads && pfbm_tile(8) % 25 == 0;
 }
 inline int verify_rows(const Design &des) { return des.d.ddc_out < kVerRows ? des.d.ddc_out : kVerRows; }
-constexpr int kVerGridDdc = 2048, kVerGridFill = 1024;  // workgroups of verify_ddc_kernel (they stride over the tiles; two fit a CU at 100 Msps: 2048 balanced the
-                                                         // uneven tile counts better than 512 persistent ones, 0.42 against 0.49 ms)
+constexpr int kVerGridFill = 1024;
 // tile length (outputs) of the |Y|^2 tile sums the polyphase banks leave behind
 inline int verify_tile_outs(const FastPath &fp, bool small) { return small ? pfbm_tile(fp.channel.M) : kBankNT - 1; }
 
-// first run (the polyphase path's window_kernel): which windows go to the exact stage
-// (ptile / ntiles / tile_outs: the tile sums the scan reads -- the bank's own tiles, or the F8 bank's 25-instant sums)
-inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPath &fp, bool small, int mode /*1 hits + energy, 2 hits only*/,
+// presence_kernel's and the first run's parameters (mode 1: presence + uncovered hits, 2: uncovered hits only)
+// (ptile / ntiles / tile_outs: the tile sums presence reads -- the bank's own tiles, or the F8 bank's 25-instant sums)
+inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPath &fp, bool small, int mode,
                                 const double *ptile, int ntiles, const VerifyBuffers &vb, bool headers, int tile_outs = 0)
 {
     p.verify = mode;
     p.ptile = ptile; p.ptile_stride = ntiles; p.tile_outs = tile_outs > 0 ? tile_outs : verify_tile_outs(fp, small);
     p.tiles_per_slot = des.outs_per_slot / p.tile_outs;
-    p.vtasks = vb.tasks; p.vtiles = vb.tiles; p.vcount = vb.vcount; p.vcap = vb.vcap; p.vtcount = vb.vcount + 4; p.vtcap = vb.tiles_cap;
+    p.vtasks = vb.tasks; p.vcount = vb.vcount; p.vcap = vb.vcap; p.bm1 = vb.bm1; p.bm2 = vb.bm2; p.bm_tiles = vb.bm_tiles;
     const int ntm = (2 * kDetectSyms + 16 + p.tile_outs - 1) / p.tile_outs;
-    if (ntm + kBurstFront > 64) p.verify = 2;            // (the scan stages <= 64 tiles per channel)
+    if (ntm + kBurstFront > 64) p.verify = 2;            // (presence stages <= 64 tiles per channel)
     // The scan's statistic is the energy of W tiles, ~50 us.  Its threshold is 2.0 x the MEAN noise block; the scan knows the
     // span's QUIETEST aligned block, which lies z sigma under the mean: sigma of a 25-output tile sum is 0.28 of its mean (the
     // 2 Msps stream of a ~1 MHz filter holds ~12.6 independent values per 25), z the expected minimum of n normal draws.
@@ -280,27 +279,23 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
     }
     p.span_extra = headers ? 58 : 0;                     // 54 header symbols + the 4-symbol trailer
 }
-inline VerifyParams make_verify_params(const Design &des, size_t x_len, long long w0, int mp, int F, const float2 *rot,
-                                       const double *rot_step_turns, const float *atan_tab, const VerifyBuffers &vb)
+// exact_rows_kernel's parameters for one bitmap of the batch (tapsA: exact_pack_taps of the direct-form channel bank)
+inline ExactParams make_exact_params(const Design &des, size_t x_len, long long w0, long long G, const float *tapsA, const float2 *rot,
+                                     const float *atan_tab, const uint32_t *bitmap, int bm_tiles, float *d, int drow, float *dcol, unsigned int *stat)
 {
-    const btgpu_design &d = des.d;
-    VerifyParams v{};
-    v.x_len = (long long)x_len; v.first0 = w0 + d.first_channel_sample;
-    v.D = d.decimation; v.ntp = des.channel.ntp; v.slot = d.samples_per_slot;
-    v.inv2d = (uint32_t)((1ull << 32) / (unsigned long long)(2 * d.decimation) + 1ull);
-    v.mp = mp; v.F = F;
-    v.rot = rot; v.Q = des.channel.rot_period; v.rot_step_turns = rot_step_turns;
-    v.atan_tab = atan_tab; v.gain = des.demod_gain;
-    v.tasks = vb.tasks; v.tiles = vb.tiles; v.vcount = vb.vcount; v.vcap = vb.vcap; v.tiles_cap = vb.tiles_cap; v.tcount = vb.vcount + 4;
-    v.nch = d.high_channel - d.low_channel + 1;
-    v.tstart = nullptr; v.dx_stride = kVerRows;
-    return v;
+    const btgpu_design &dd = des.d;
+    ExactParams e{};
+    e.x_len = (long long)x_len; e.first0 = w0 + dd.first_channel_sample; e.G = G;
+    e.tapsA = tapsA; e.rot = rot; e.Qr = des.channel.rot_period; e.atan_tab = atan_tab; e.gain = des.demod_gain;
+    e.bitmap = bitmap; e.ntiles = bm_tiles; e.stat = stat; e.d = d; e.drow = drow; e.dcol = dcol;
+    e.ydbg = nullptr; e.ystride = 0; e.nch = dd.high_channel - dd.low_channel + 1;
+    return e;
 }
 inline VerifyFillParams make_verify_fill_params(const Design &des, const float *d_stream, const float *dcol, int drow, long long G,
                                                 const VerifyBuffers &vb)
 {
     VerifyFillParams f{};
-    f.tasks = vb.tasks; f.vcount = vb.vcount; f.vcap = vb.vcap; f.dx = vb.dx;
+    f.tasks = vb.tasks; f.vcount = vb.vcount; f.vcap = vb.vcap;
     f.d = d_stream; f.dcol = dcol; f.drow = drow; f.d_rows = G;
     f.nch = des.d.high_channel - des.d.low_channel + 1; f.outs_per_slot = des.outs_per_slot; f.rows = verify_rows(des);
     f.dxt = vb.dxt;

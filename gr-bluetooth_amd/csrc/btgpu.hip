@@ -74,9 +74,9 @@ struct btgpu_handle {
         DevBuf d_ptile, d_phead;              // polyphase banks: |Y|^2 tile sums (-> block_sum_kernel on the post stream)
         DevBuf d_pfine;                       // small-M F8 bank: |Y|^2 sums per 25 instants (the exact stage's burst scan)
         DevBuf d_Z;                           // staged squelch: stage-1 output (-> noise_stage2_kernel on the post stream)
-        DevBuf d_vtasks, d_vtiles, d_vcount, d_dx, d_dxt, d_winbits_v, d_vinfo, d_vtstart;
-        DevBuf d_chanfloor;                                     // the burst scan's last-resort noise reference: each channel's quietest tile of the batch
-        DevBuf d_ltasks, d_ltiles, d_lcount, d_lrows, d_dxl;   // BTGPU_FLAG_EXACT_PAYLOAD: the long tasks of the windows that hand symbols to the host
+        DevBuf d_vtasks, d_vcount, d_dxt, d_winbits_v;
+        DevBuf d_bm;                                            // exact rows' bitmaps bm1 | bm2, [2][bm_tiles][kExBmWords] (presence / the first run's uncovered hits)
+        DevBuf d_chanfloor;                                     // presence's last-resort noise reference: each channel's quietest tile of the batch, [80] the quietest of all
         DevBuf d_eon, d_eoff, d_snr;          // E_on, E_off, SNR per window (window_kernel, or squelch_kernel when the squelch is deferred)   // exact confirmation (verify.hip.h): task list, exact rows, task stream
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
@@ -86,8 +86,9 @@ struct btgpu_handle {
         // form), 3 noise stage 1 / direct noise bank, 4 direct noise energy; post 5 start, 6 block sums, 7 squelch
         // stage 2, 8 window; tail 9 start, 10 end
         // ... 11 exact stage done (tail)
-        hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr, squelch_done = nullptr, scan_done = nullptr, ddc1_done = nullptr, floor_done = nullptr;
+        // ... 12 / 13 around presence + the exact rows in line (post)
+        hipEvent_t ev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr, squelch_done = nullptr, exact_done = nullptr, floor_done = nullptr;
         int S = 0;
         uint64_t abs_first_slot = 0;
         bool pending = false;
@@ -98,14 +99,11 @@ struct btgpu_handle {
     bool timing_on = false;          // BTGPU_FLAG_TIMING / _BANK: bracket the kernels with events (btgpu_last_timing)
     bool timing_full = false;        // every kernel (BTGPU_FLAG_TIMING), not just the channel bank
     bool no_nsym = false;            // BTGPU_FLAG_NO_NSYM: skip the M&M continuation that produces hit.nsym
-    int verify = 0;                  // exact confirmation of the polyphase path's records: 0 off, 1 hits + burst energy, 2 hits only
-    int vcap = 0, ver_mp = 0, ver_F = 0, ver_grid = kVerGridDdc;
-    bool exact_payload = false;            // BTGPU_FLAG_EXACT_PAYLOAD (with symbols and the exact stage)
-    int long_stride = 0;
-    static constexpr int kLongCap = 32768;                // long tasks per batch (windows that hand symbols over; 1 GB of exact rows per batch in flight); a batch with more: the polyphase continuation for all of it
-    static constexpr unsigned int kLongTilesCap = 262144; // entries of one channel's list
+    int verify = 0;                  // exact rows under the polyphase path's records (exact.hip.h): 0 off, 1 presence + uncovered hits, 2 uncovered hits only
+    int vcap = 0, bm_tiles = 0;
+    ExactRowsKernel ex_kern = nullptr; size_t ex_lds = 0;
     std::vector<const void *> lds_opted;   // bank kernels that have been granted > 48 KiB of dynamic LDS on this handle's device
-    DevBuf d_tapsv;                  // class-major taps of the direct-form channel bank (verify_ddc_kernel)
+    DevBuf d_tapsA;                  // the direct-form channel bank's taps as exact_rows_kernel's A operand (exact_pack_taps)
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
     hipStream_t copy_stream = nullptr;
     hipStream_t spill_stream = nullptr;          // harvest: records beyond the eager copies (never behind an input copy)
@@ -177,16 +175,16 @@ struct btgpu_handle {
                          &d_Y, &d_Yn, &d_P, &d_Pt, &d_Q, &d_mmse, &d_atan, &d_aclo, &d_achi,
                          &d_le_hdr, &d_le_whiten, &d_le_index, &d_winbits,
                          &d_pfb_taps_ch, &d_pfb_tw, &d_binpos_ch, &d_binnat_ch, &d_rho_ch, &d_krot_ch, &d_b2map_fused, &d_b2map_fused_wide, &d_b2map_ch, &d_b2map_noise, &d_b2map_f320, &d_dftw_ch, &d_dftw_n,
-                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18, &d_tapsv};
+                         &d_pfb_taps_n, &d_binpos_n, &d_krot_n, &d_h3, &d_w, &d_taps_s1, &d_rot_s1, &d_rotstep_s1, &d_prof, &d_pcol, &d_wh18, &d_tapsA};
         for (DevBuf *b : all) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
         for (TailCtx &t : tc) {
             DevBuf *tb[] = {&t.d_winlen, &t.d_hits, &t.d_hitcount, &t.d_fin, &t.d_winfin, &t.d_symbits, &t.d_hdr, &t.d_d, &t.d_dcol,
-                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vtiles, &t.d_vcount, &t.d_dx, &t.d_dxt, &t.d_winbits_v, &t.d_vinfo, &t.d_vtstart, &t.d_chanfloor, &t.d_ltasks, &t.d_ltiles, &t.d_lcount, &t.d_lrows, &t.d_dxl, &t.d_eon, &t.d_eoff, &t.d_snr};
+                            &t.d_ptile, &t.d_phead, &t.d_pfine, &t.d_Z, &t.d_vtasks, &t.d_vcount, &t.d_dxt, &t.d_winbits_v, &t.d_bm, &t.d_chanfloor, &t.d_eon, &t.d_eoff, &t.d_snr};
             if (t.h_hdr) { (void)hipHostFree(t.h_hdr); t.h_hdr = nullptr; }
             if (t.h_sym) { (void)hipHostFree(t.h_sym); t.h_sym = nullptr; }
             for (DevBuf *b : tb) if (b->p) { (void)hipFree(b->p); b->p = nullptr; }
             for (auto &e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-            for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.scan_done, &t.ddc1_done, &t.floor_done}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+            for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.exact_done, &t.floor_done}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
             if (t.h_count) { (void)hipHostFree(t.h_count); t.h_count = nullptr; }
             if (t.h_hits) { (void)hipHostFree(t.h_hits); t.h_hits = nullptr; }
         }
@@ -390,62 +388,44 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     p.want_len = no_nsym ? 0 : 1;
     p.deferred = deferred ? 1 : 0;
     p.snr_arr = (const double *)t.d_snr.p;
-    p.exact_payload = (exact_payload && want_syms && verify) ? 1 : 0;
-    // exact confirmation (verify.hip.h): the window kernel hands the windows that can carry a packet's record to the exact
-    // stage, which runs on the tail stream below (beside the next batch's banks)
+    // exact rows (exact.hip.h): presence marks the busy windows' rows (bm1), exact_rows_kernel recomputes them IN PLACE in the
+    // demodulated stream, in line, before the window kernel reads it
     VerifyBuffers vb;
     if (verify) {
-        vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.tiles = (uint32_t *)t.d_vtiles.p; vb.vcount = (unsigned int *)t.d_vcount.p;
-        vb.dx = (float *)t.d_dx.p; vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap; vb.tiles_cap = (unsigned int)verify_tiles_capacity(max_slots);
+        vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.vcount = (unsigned int *)t.d_vcount.p;
+        vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap;
+        vb.bm_tiles = exact_ntiles(G); vb.bm1 = (uint32_t *)t.d_bm.p; vb.bm2 = vb.bm1 + (size_t)bm_tiles * kExBmWords;
         if (pfb_small && t.d_pfine.p && verify_has_fine(des, fp, drow))
             set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_pfine.p, ntiles * (pfbm_tile(fp.channel.M) / 25), vb, want_syms, 25);
         else
             set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_ptile.p, ntiles, vb, want_syms);
+        HIPCHK(this, hipMemsetAsync(t.d_bm.p, 0, (size_t)2 * bm_tiles * kExBmWords * sizeof(uint32_t), ps));
     }
-    bool floor_on_side = false;
+    auto launch_exact_rows = [&](const uint32_t *bitmap, unsigned int *stat, hipStream_t s_) {
+        const ExactParams ep = make_exact_params(des, x_len, w0, G, (const float *)d_tapsA.p, (const float2 *)d_rot_ch.p, (const float *)d_atan.p,
+                                                 bitmap, vb.bm_tiles, (float *)d_d.p, drow, (float *)(use_dcol ? t.d_dcol.p : nullptr), stat);
+        hipLaunchKernelGGL(ex_kern, dim3((unsigned)vb.bm_tiles), dim3(kExThreads), ex_lds, s_, ep, d_x);
+    };
+    HIPCHK(this, mark(12, ps));
     if (verify && p.verify == 1) {
-        // the burst scan's last-resort noise reference: 35 us of streaming over the tile sums -- on the side stream, beside squelch
-        // stage 2 (in line it was 35 us + a launch gap per step); the window kernel waits for it (scan_done)
-        floor_on_side = !deferred && !pipelined;
-        hipStream_t fs_ = floor_on_side ? sq_stream : ps;
-        if (floor_on_side) HIPCHK(this, hipStreamWaitEvent(fs_, t.front_done, 0));
-        HIPCHK(this, hipMemsetAsync(t.d_chanfloor.p, 0x7f, 80 * sizeof(float), fs_));       // (0x7f7f7f7f = 3.4e38: no tile yet)
-        hipLaunchKernelGGL(channel_floor_kernel, dim3((unsigned)std::max(1, std::min(256, p.ptile_stride / 2048)), (unsigned)nch), dim3(256), 0, fs_, p.ptile, p.ptile_stride, p.ptile_stride, (float *)t.d_chanfloor.p);
-        if (floor_on_side) HIPCHK(this, hipEventRecord(t.floor_done, fs_));
+        // presence's last-resort noise reference: each channel's quietest full tile of the batch
+        HIPCHK(this, hipMemsetAsync(t.d_chanfloor.p, 0x7f, 81 * sizeof(float), ps));       // (0x7f7f7f7f = 3.4e38: no tile yet)
+        const int full_tiles = (G % p.tile_outs) ? p.ptile_stride - 1 : p.ptile_stride;    // (the batch's last tile may be a partial one: ADVICE r5)
+        hipLaunchKernelGGL(channel_floor_kernel, dim3((unsigned)std::max(1, std::min(256, p.ptile_stride / 2048)), (unsigned)nch), dim3(256), 0, ps, p.ptile, p.ptile_stride,
+                           std::max(1, full_tiles), (float *)t.d_chanfloor.p);
         p.chan_floor = (const float *)t.d_chanfloor.p;
-    }
-    // BTGPU_PRESCAN=1: the scan as a kernel of its own behind the banks and the energy-selected tasks' DDC on a side stream beside
-    // squelch stage 2 and the window kernel.  Built, measured, OFF (profiles/r05_b_*): 2.34-2.38 ms per step against 2.31 in line --
-    // beside three 51 KB window workgroups per CU the DDC's 59 KB workgroups wait (0.9-1.9 ms instead of 0.30), and the window
-    // kernel beside them takes 0.48-0.6 instead of 0.42 ms.  Every front kernel holds its CUs by LDS; nothing overlaps for free.
-    static const bool prescan_env = getenv("BTGPU_PRESCAN") && atoi(getenv("BTGPU_PRESCAN")) == 1;
-    static const bool ddc_on_tail = getenv("BTGPU_VERIFY_TAIL") && atoi(getenv("BTGPU_VERIFY_TAIL")) == 1;
-    const bool prescan = prescan_env && verify == 1 && p.verify == 1 && !deferred && !ddc_on_tail && !pipelined;
-    VerifyParams vp{};
-    if (verify) vp = make_verify_params(des, x_len, w0, ver_mp, ver_F, (const float2 *)d_rot_ch.p, (const double *)d_rotstep_ch.p, (const float *)d_atan.p, vb);
-    if (prescan) {
-        if (floor_on_side) HIPCHK(this, hipStreamWaitEvent(ps, t.floor_done, 0));
-        p.prescan = 1; p.vinfo = (const int32_t *)t.d_vinfo.p;
-        auto launch_scan = [&](auto lay) {
+        auto launch_presence = [&](auto lay) {
             using LAY = decltype(lay);
-            hipLaunchKernelGGL(burst_scan_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, ps, p, (int32_t *)t.d_vinfo.p);
+            hipLaunchKernelGGL(presence_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, ps, p);
         };
-        if (drow == 80) launch_scan(WinLayout<3, 96, 20>{});
-        else if (drow == 40) launch_scan(WinLayout<6, 40, 10>{});
-        else if (drow == 20) launch_scan(WinLayout<12, 20, 5>{});
-        else if (drow == 8) launch_scan(WinLayout<32, 8, 2>{});
-        else launch_scan(WinLayout<64, 4, 1>{});
-        // the lists as the scan leaves them: the second DDC launch (below, on the tail) starts behind these entries
-        HIPCHK(this, hipMemcpyAsync(t.d_vtstart.p, (const unsigned int *)t.d_vcount.p + 4, (size_t)nch * sizeof(unsigned int), hipMemcpyDeviceToDevice, ps));
-        HIPCHK(this, hipEventRecord(t.scan_done, ps));
-        // the energy-selected tasks' DDC: on the side stream, beside squelch stage 2 (24 KB of LDS per workgroup) and the window kernel
-        HIPCHK(this, hipStreamWaitEvent(sq_stream, t.scan_done, 0));
-        {
-            const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
-            hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, sq_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
-        }
-        HIPCHK(this, hipEventRecord(t.ddc1_done, sq_stream));
+        if (drow == 80) launch_presence(WinLayout<3, 96, 20>{});
+        else if (drow == 40) launch_presence(WinLayout<6, 40, 10>{});
+        else if (drow == 20) launch_presence(WinLayout<12, 20, 5>{});
+        else if (drow == 8) launch_presence(WinLayout<32, 8, 2>{});
+        else launch_presence(WinLayout<64, 4, 1>{});
+        launch_exact_rows(vb.bm1, vb.vcount + 4, ps);
     }
+    HIPCHK(this, mark(13, ps));
     HIPCHK(this, mark(5, qs));
     // tile sums -> block sums: as extra rows of the squelch stage-2 launch where both exist (a kernel of its own costs 0.05 ms
     // of launch ramp and tail for microseconds of work; on a side stream it saved those and cost 0.4 ms per step in
@@ -477,7 +457,6 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                (const double *)d_Pt.p, (const double *)d_Q.p, (double *)t.d_eon.p, (double *)t.d_eoff.p, (double *)t.d_snr.p);
             HIPCHK(this, hipEventRecord(t.squelch_done, qs));
         }
-        if (floor_on_side) HIPCHK(this, hipStreamWaitEvent(ps, t.floor_done, 0));
         auto launch_window = [&](auto lay) {
             using LAY = decltype(lay);
             hipLaunchKernelGGL(window_kernel<LAY>, dim3((S + LAY::kSlots - 1) / LAY::kSlots), dim3(kWinThreads), 0, ps, p,
@@ -501,36 +480,14 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         else if (drow == 8) launch_window(WinLayout<32, 8, 2>{});
         else launch_window(WinLayout<64, 4, 1>{});
         HIPCHK(this, mark(8, ps));
-        // exact stage, first kernel: the direct-form DDC of the handed-over windows.  It runs HERE, in line behind the window
-        // kernel, not on the tail stream: it fills the device by itself (0.42 ms for 9 G multiply-adds at C79) and 62 KB of LDS
-        // per workgroup fit beside neither the banks' tiles nor the window kernel's -- beside the next batch's front it took
-        // 1.4 ms and stretched the bank from 1.24 to 1.6 and the window kernel from 0.32 to 0.6 ms (profiles/r04_b_*).
-        // BTGPU_VERIFY_TAIL=1 puts it back on the tail stream (A/B).
-        if (verify) {
-            if (!ddc_on_tail && !prescan) {
-                const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
-                hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, ps, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
-            }
-        }
         // =========================== TAIL (tail_stream): finish + nsym + record copies ===========================
         HIPCHK(this, hipEventRecord(t.detect_done, ps));
         HIPCHK(this, hipStreamWaitEvent(tail_stream, t.detect_done, 0));
         if (deferred) HIPCHK(this, hipStreamWaitEvent(tail_stream, t.squelch_done, 0));
         HIPCHK(this, mark(9, tail_stream));
         if (verify) {
-            if (prescan) {
-                // the tiles the window kernel's hits have added since the scan (a window that only a hit flags; a header behind an
-                // access code): a second, short launch over the lists' new entries, once the first one has left the side stream
-                HIPCHK(this, hipStreamWaitEvent(tail_stream, t.ddc1_done, 0));
-                VerifyParams vp2 = vp;
-                vp2.tstart = (const unsigned int *)t.d_vtstart.p;
-                const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
-                hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, tail_stream, vp2, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
-            }
-            if (ddc_on_tail) {
-                const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
-                hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, tail_stream, vp, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dx.p);
-            }
+            // the second run: the rows under the first run's uncovered hits (bm2), then those windows again
+            launch_exact_rows(vb.bm2, vb.vcount + 5, tail_stream);
             const VerifyFillParams fz = make_verify_fill_params(des, (const float *)d_d.p, (const float *)(use_dcol ? t.d_dcol.p : nullptr),
                                                                 drow, G, vb);
             hipLaunchKernelGGL(verify_fill_kernel, dim3(kVerGridFill), dim3(256), 0, tail_stream, fz);
@@ -552,26 +509,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             else if (drow == 20) launch_exact(WinLayout<12, 20, 5>{});
             else if (drow == 8) launch_exact(WinLayout<32, 8, 2>{});
             else launch_exact(WinLayout<64, 4, 1>{});
-            HIPCHK(this, hipMemcpyAsync(t.h_count + 4, t.d_vcount.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
-        }
-        LongView lview{nullptr, nullptr, 0, 0};
-        if (verify && exact_payload && want_syms) {
-            // exact payload: the windows that hand symbols to the host get their rows to the end of the burst from the direct-form DDC
-            HIPCHK(this, hipMemsetAsync(t.d_lcount.p, 0, (kVerCountWords + 80) * sizeof(unsigned int), tail_stream));
-            LongTaskParams lp{};
-            lp.tasks = (VerifyTask *)t.d_ltasks.p; lp.tiles = (uint32_t *)t.d_ltiles.p; lp.lcount = (unsigned int *)t.d_lcount.p;
-            lp.tiles_cap = kLongTilesCap; lp.rows = (LongRows *)t.d_lrows.p; lp.cap = kLongCap; lp.stride = long_stride;
-            hipLaunchKernelGGL(long_task_kernel, dim3(kLongCap / kLongLanes), dim3(kLongLanes), 0, tail_stream, p, (const FinishRec *)d_fin.p,
-                               (const unsigned int *)d_hitcount.p + 1, lp);
-            hipLaunchKernelGGL(long_assign_kernel, dim3(kLongCap / kLongLanes), dim3(kLongLanes), 0, tail_stream, p, (const FinishRec *)d_fin.p,
-                               (const unsigned int *)d_hitcount.p + 1, lp);
-            VerifyParams vl_ = vp;
-            vl_.tasks = lp.tasks; vl_.vcount = lp.lcount; vl_.vcap = kLongCap; vl_.tiles = lp.tiles; vl_.tcount = lp.lcount + 4;
-            vl_.tiles_cap = kLongTilesCap; vl_.tstart = nullptr; vl_.dx_stride = long_stride;
-            const VerifyDdcLaunch vl = verify_ddc_pick(d.decimation, des.channel.ntp);
-            hipLaunchKernelGGL(vl.kern, dim3(ver_grid), dim3(vl.threads), vl.lds, tail_stream, vl_, d_x, (const float2 *)d_tapsv.p, (float *)t.d_dxl.p);
-            HIPCHK(this, hipMemcpyAsync(t.h_count + 8, t.d_lcount.p, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
-            lview.rows = (const LongRows *)t.d_lrows.p; lview.dxl = (const float *)t.d_dxl.p; lview.stride = long_stride; lview.cap = kLongCap;
+            HIPCHK(this, hipMemcpyAsync(t.h_count + 4, t.d_vcount.p, kVerCountWords * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
         }
         if (timing_on && timing_full) HIPCHK(this, hipEventRecord(ev[11], tail_stream));
         {
@@ -585,7 +523,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                 hipLaunchKernelGGL(finish_kernel<true>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
                                    (const unsigned int *)d_hitcount.p + 1, (int *)d_winlen.p, (uint32_t *)d_symbits.p,
-                                   (const float *)(use_dcol ? t.d_dcol.p : nullptr), lview);
+                                   (const float *)(use_dcol ? t.d_dcol.p : nullptr));
             else
                 hipLaunchKernelGGL(finish_kernel<false>, dim3(nblk), dim3(kFinLanes), 0, tail_stream, p, (const float *)d_d.p,
                                    drow, G, (const float *)d_mmse.p, (const FinishRec *)d_fin.p,
@@ -723,14 +661,17 @@ int btgpu_handle::harvest(TailCtx &t)
             timing.kernel_ms[i] += ms;
             timing.kernel_launches[i] += 1;
         }
+        if (timing_full && verify) { HIPCHK(this, hipEventElapsedTime(&ms, t.ev[12], t.ev[13])); timing.kernel_ms[6] += ms; }   // (+ presence and the exact rows in line)
         if (timing_full) { HIPCHK(this, hipEventElapsedTime(&ms, t.ev[0], t.ev[10])); timing.total_ms += ms; }
     }
     timing.batches += 1;
     if (verify) {
-        timing.verify_windows += std::min<unsigned>(t.h_count[4], (unsigned)vcap);
-        timing.verify_rows += (uint64_t)t.h_count[5] * kVerTile;
+        // h_count[4..]: vcount -- tasks of the second run, pairs marked, turned away, busy windows, pairs computed by the two launches
+        timing.verify_windows += t.h_count[7] + std::min<unsigned>(t.h_count[4], (unsigned)vcap);
+        timing.verify_rows += (uint64_t)(t.h_count[8] + t.h_count[9]) * kExTile;
         timing.verify_turned_away += t.h_count[6];
-        if (exact_payload) { timing.long_tasks += t.h_count[8]; timing.long_rows += (uint64_t)t.h_count[9] * kVerTile; timing.long_turned_away += t.h_count[10]; }
+        timing.long_tasks += std::min<unsigned>(t.h_count[4], (unsigned)vcap);      // (reused: the second run's windows and rows)
+        timing.long_rows += (uint64_t)t.h_count[9] * kExTile;
     }
     timing.slots += (uint64_t)t.S;
     timing.samples += (uint64_t)t.S * (uint64_t)d.samples_per_slot;
@@ -1091,7 +1032,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     for (auto &t : h->tc) {
         for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
-        for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.scan_done, &t.ddc1_done, &t.floor_done})
+        for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.exact_done, &t.floor_done})
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
     h->async = (cfg->flags & BTGPU_FLAG_ASYNC) != 0;
@@ -1103,7 +1044,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     // exact confirmation: on wherever the channelizer is the polyphase one (BTGPU_VERIFY=0 | 1 | 2: A/B timing and tests)
     h->verify = (h->use_pfb && !(cfg->flags & BTGPU_FLAG_NO_VERIFY)) ? 1 : 0;
     if (h->use_pfb && getenv("BTGPU_VERIFY")) h->verify = std::max(0, std::min(2, atoi(getenv("BTGPU_VERIFY"))));
-    if (verify_span(h->des.d.decimation, h->des.channel.ntp) > kVerPre * kVerThreads) h->verify = 0;   // (span of a tile beyond the kernel's prefetch registers: no such rate today; after the override: it cannot be asked for)
+    // (exact rows on the shared grid need every window's rotator to start at exactly +-1 there -- true wherever the polyphase banks
+    // exist: their channels sit on bins of fs / M, multiples of 0.5 MHz, i.e. of the 800 Hz a slot's rotation is periodic in)
+    if (h->verify && !(exact_rows_available(h->des) && exact_rows_pick(h->des.d.decimation))) {
+        if (cfg->channelizer == BTGPU_CHANNELIZER_POLYPHASE && !(cfg->flags & BTGPU_FLAG_NO_VERIFY)) return fail(BTGPU_EUNSUPPORTED);
+        h->verify = 0;
+    }
     h->ntail = h->verify ? h->nctx : 1;
     if (getenv("BTGPU_TAILS")) h->ntail = std::max(1, std::min(h->nctx, atoi(getenv("BTGPU_TAILS"))));   // A/B timing
     // front(n+1) beside post(n) (BTGPU_PIPE=1; possible only where the front writes nothing but per-context buffers).
@@ -1123,9 +1069,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
                   getenv("BTGPU_DEFER") && atoi(getenv("BTGPU_DEFER")) == 1;
     h->want_hdrs = (cfg->flags & BTGPU_FLAG_HEADERS) != 0;
     h->want_syms = (cfg->flags & BTGPU_FLAG_SYMBOLS) != 0 || h->want_hdrs;
-    h->exact_payload = (cfg->flags & BTGPU_FLAG_EXACT_PAYLOAD) != 0 && h->want_syms && h->verify == 1;
-    if (getenv("BTGPU_EXACT_PAYLOAD")) h->exact_payload = atoi(getenv("BTGPU_EXACT_PAYLOAD")) != 0 && h->want_syms && h->verify == 1;   // (A/B)
-    h->long_stride = ((h->des.d.ddc_out + kVerTile - 1) / kVerTile) * kVerTile + 8;
+    // (BTGPU_FLAG_EXACT_PAYLOAD: accepted, and always on since round 6 -- a packet's air time is busy, so its rows are exact to its end)
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != BTGPU_OK) { int c__ = rc__; std::string m__ = h->err; \
         if (getenv("BTGPU_VERBOSE")) fprintf(stderr, "btgpu_create: %s\n", m__.c_str()); return fail(c__); } } while (0)
@@ -1222,8 +1166,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     TRY(h->alloc(h->d_winbits, (size_t)((S + 2) / 3) * kBitWords * kWinThreads * sizeof(uint32_t)));   // most workgroups: 3 slots each
     if (h->verify) {
         h->vcap = verify_capacity(S, nch);
-        const std::vector<float> tv = pack_class_major(des.channel, d.decimation, h->ver_mp, h->ver_F);
-        TRY(h->upload(h->d_tapsv, tv.data(), tv.size() * sizeof(float)));
+        std::vector<float> ta((size_t)nch * d.decimation * 64);
+        exact_pack_taps(des.channel.taps.data(), nch, des.channel.ntp, d.decimation, ta.data());
+        TRY(h->upload(h->d_tapsA, ta.data(), ta.size() * sizeof(float)));
+        h->ex_kern = exact_rows_pick(d.decimation); h->ex_lds = exact_lds_bytes(d.decimation);
+        h->bm_tiles = exact_ntiles(h->ystride + 64);
+        (void)hipFuncSetAttribute((const void *)h->ex_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(h->ex_lds, 64 * 1024));
     }
     for (int i = 0; i < h->nctx; i++) {
         auto &t = h->tc[i];
@@ -1244,19 +1192,9 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (h->verify) {
             const int vcap = h->vcap, nps = (vcap + nch - 1) / nch;
             TRY(h->alloc(t.d_vtasks, (size_t)vcap * sizeof(VerifyTask)));
-            TRY(h->alloc(t.d_vtiles, verify_tiles_capacity(S) * nch * sizeof(uint32_t)));
             TRY(h->alloc(t.d_vcount, kVerCountWords * sizeof(unsigned int)));
-            TRY(h->alloc(t.d_vinfo, (size_t)S * nch * sizeof(int32_t)));
-            TRY(h->alloc(t.d_vtstart, 80 * sizeof(unsigned int)));
-            TRY(h->alloc(t.d_chanfloor, 80 * sizeof(float)));
-            if (h->exact_payload) {
-                TRY(h->alloc(t.d_ltasks, (size_t)btgpu_handle::kLongCap * sizeof(VerifyTask)));
-                TRY(h->alloc(t.d_ltiles, (size_t)nch * btgpu_handle::kLongTilesCap * sizeof(uint32_t)));
-                TRY(h->alloc(t.d_lcount, (kVerCountWords + 80) * sizeof(unsigned int)));
-                TRY(h->alloc(t.d_lrows, (size_t)btgpu_handle::kLongCap * sizeof(LongRows)));
-                TRY(h->alloc(t.d_dxl, (size_t)btgpu_handle::kLongCap * h->long_stride * sizeof(float)));
-            }
-            TRY(h->alloc(t.d_dx, (size_t)vcap * kVerRows * sizeof(float)));
+            TRY(h->alloc(t.d_bm, (size_t)2 * h->bm_tiles * kExBmWords * sizeof(uint32_t)));
+            TRY(h->alloc(t.d_chanfloor, 81 * sizeof(float)));
             TRY(h->alloc(t.d_dxt, ((size_t)nps * kVerRows + 64) * h->drow * sizeof(float)));
             TRY(h->alloc(t.d_winbits_v, (size_t)(nps + 1) * kBitWords * kWinThreads * sizeof(uint32_t)));
         }
@@ -1280,10 +1218,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
     (void)hipFuncSetAttribute((const void *)ddc_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void *)verify_ddc_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void *)verify_ddc_kernel<50, 672>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void *)verify_ddc_small_kernel<4, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void *)verify_ddc_small_kernel<10, 136>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<7, 1, 26, false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100_kernel<15, 5, 10, false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1311,11 +1245,6 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, true, 2 * kBankKT, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute((const void *)pfb100f_kernel<kBankThreads, false, 2 * kBankKT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    {
-        // (verify_ddc_kernel gives every channel gridDim.x / nch workgroups: fewer than nch would leave all of them without work)
-        const int nch_ = h->des.d.high_channel - h->des.d.low_channel + 1;
-        if (getenv("BTGPU_VERIFY_GRID")) h->ver_grid = std::max(nch_, atoi(getenv("BTGPU_VERIFY_GRID")));
-    }
     h->pre.assign((size_t)h->margin * 2, 0.f);
     if (getenv("BTGPU_VERBOSE"))
         fprintf(stderr, "btgpu_create: %d contexts, d=%p Z=%p ptile=%p\n", h->nctx, h->tc[0].d_d.p, h->tc[0].d_Z.p, h->tc[0].d_ptile.p);
@@ -1554,9 +1483,9 @@ long btgpu_debug_fetch(btgpu_handle *h, int what, int channel, size_t first, siz
         case 10:                                             // exact stage: the tasks of the last batch (VerifyTask: w, n_exact, snr)
             if (!h->verify) return BTGPU_EINVAL;
             src = h->tc[h->last_ctx].d_vtasks.p; elem = sizeof(VerifyTask); avail = std::min<size_t>(h->tc[h->last_ctx].h_count[4], (size_t)h->vcap); break;
-        case 11:                                             // ... and their exact demodulated rows, [task][kVerRows] float
+        case 11:                                             // exact rows: the two bitmaps of the last batch, [2][bm_tiles][kExBmWords] uint32
             if (!h->verify) return BTGPU_EINVAL;
-            src = h->tc[h->last_ctx].d_dx.p; elem = sizeof(float); avail = std::min<size_t>(h->tc[h->last_ctx].h_count[4], (size_t)h->vcap) * kVerRows; break;
+            src = h->tc[h->last_ctx].d_bm.p; elem = sizeof(uint32_t); avail = (size_t)2 * h->bm_tiles * kExBmWords; break;
         case 2: src = h->tc[h->last_ctx].d_eon.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 3: src = h->tc[h->last_ctx].d_eoff.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;
         case 4: src = h->tc[h->last_ctx].d_snr.p; elem = sizeof(double); avail = (size_t)h->last_S * nch; break;

@@ -75,7 +75,8 @@ void build_bank_impl(FilterBank &b, const std::vector<float> &h, int low_ch, int
                      double center_freq, double fs, int decim)
 {
     b.ntaps = (int)h.size();
-    b.ntp = (b.ntaps + kFirLanes - 1) / kFirLanes * kFirLanes;
+    b.blk = decim > 0 ? decim : 1;                               // summation order: blocks of `decim` taps (kernels.hip.h ddc_direct_kernel)
+    b.ntp = (b.ntaps + b.blk - 1) / b.blk * b.blk;
     b.nch = nch;
     b.taps.assign((size_t)nch * b.ntp * 2, 0.f);
     b.foff.resize(nch);

@@ -9,7 +9,6 @@
 
 namespace btgpu {
 
-constexpr int kFirLanes = 8;             // FIR summation order: 8 strided partial sums
 constexpr int kMmseTaps = 8;
 constexpr int kMmseSteps = 128;
 constexpr int kSymbolsPerSlot = 625;
@@ -19,7 +18,8 @@ constexpr int kSymbolsHistorySniffer = 3125;
 
 struct FilterBank {
     int ntaps = 0;                       // true filter length
-    int ntp = 0;                         // padded to a multiple of kFirLanes
+    int blk = 1;                         // block length of the summation order: the bank's decimation (hop)
+    int ntp = 0;                         // padded with exact zeros to whole blocks: ceil(ntaps / blk) * blk
     int nch = 0;
     std::vector<float> taps;             // [nch][ntp][2] (re, im), time-reversed, zero padded
     std::vector<double> foff;            // [nch] centre offset in Hz
@@ -140,9 +140,12 @@ struct FastPath {
 
 int make_fast_path(const Design &des, FastPath &fp);
 
-// Exact confirmation (verify.hip.h): the direct-form bank's reversed taps class by class -- out[((c * 8 + l) * mp + F + m) * 2 ..]
-// = taps[c][l + 8 m] -- with F = ceil(D / 8) exact zeros in front of and behind each row (mp = ntp / 8 + 2 F + 16: the kernel marches in double blocks of four steps with one block of look-ahead).
-std::vector<float> pack_class_major(const FilterBank &b, int D, int &mp, int &F);
+// Exact rows (exact.hip.h): can the demodulated rows of the direct-form channel bank be computed ONCE on the shared output grid and
+// serve every window that overlaps them?  The reference restarts its rotator per window (lib/multi_block.cc:180-205 through
+// freq_xlating_fir_filter_ccf [EXT]); the grid's rotator differs from a window's own by the factor rot[window start], and the
+// quadrature demodulator y[t] conj(y[t-1]) is bit for bit indifferent to a common factor of exactly +-1.  True when the bank is
+// periodic, the windows share one grid, D is one the kernel is built for and every window start of every channel meets +-1.
+bool exact_rows_available(const Design &des);
 
 // direct-form bank builder shared by the reference-filter banks and the staged squelch
 void build_direct_bank(FilterBank &b, const std::vector<float> &h, int low_ch, int nch, double extra_hz,

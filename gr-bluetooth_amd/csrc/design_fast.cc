@@ -248,18 +248,18 @@ bool solve_dense(std::vector<double> &A, std::vector<double> &b, int n)
 
 }  // namespace
 
-std::vector<float> pack_class_major(const FilterBank &b, int D, int &mp, int &F)
+bool exact_rows_available(const Design &des)
 {
-    F = (D + 7) / 8;
-    mp = b.ntp / 8 + 2 * F + 16;
-    std::vector<float> out((size_t)b.nch * 8 * mp * 2, 0.f);
+    const FilterBank &b = des.channel;
+    const int D = des.d.decimation;
+    if (des.segmented || b.rot_period <= 0 || D < 2 || D > 50 || b.ntp / b.blk > 14 || b.blk != D) return false;
+    if (D > 25 && D != 50) return false;                                   // (instantiated: 2 .. 25 and 50)
     for (int c = 0; c < b.nch; c++)
-        for (int j = 0; j < b.ntp; j++) {
-            const size_t o = (((size_t)c * 8 + (j & 7)) * mp + F + (j >> 3)) * 2;
-            out[o] = b.taps[((size_t)c * b.ntp + j) * 2];
-            out[o + 1] = b.taps[((size_t)c * b.ntp + j) * 2 + 1];
+        for (int k = 0; k < b.rot_period; k++) {                           // window k starts at grid row k * outs_per_slot
+            const size_t i = ((size_t)c * b.rot_period + (size_t)(((long long)k * des.outs_per_slot) % b.rot_period)) * 2;
+            if (!(std::fabs(b.rot[i]) == 1.0f && b.rot[i + 1] == 0.0f)) return false;
         }
-    return out;
+    return true;
 }
 
 int make_fast_path(const Design &des, FastPath &fp)

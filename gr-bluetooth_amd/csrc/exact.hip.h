@@ -1,0 +1,202 @@
+// exact.hip.h -- the reference's per-channel DDC + quadrature demod on the fp32 MATRIX pipe (gfx950, wave = 64 lanes).
+//
+// What it replaces: freq_xlating_fir_filter_ccf [EXT] as multi_block::channel_samples calls it (lib/multi_block.cc:180-205)
+// followed by multi_block::demod (:158-168), for the (channel, time tile) pairs a bitmap names; the rows are written over the
+// polyphase banks' demodulated stream in place, so that every consumer behind (window_kernel, finish_kernel) reads the
+// reference's own arithmetic wherever a channel is busy.
+//
+// The decimating FIR as a dense contraction.  With the reversed taps t[j] and D = the decimation,
+//     y[n] = sum_j t[j] x[nD + j]  =  sum_q G[q][n + q],      G[q][m] = sum_{r < D} t[qD + r] x[mD + r]
+// -- a GEMM  G = T [2 QB x 2 D] * X [2 D x columns]  over the input reshaped into columns of D samples (no copy: column m is
+// x[mD .. mD + D)), followed by a QB-term diagonal sum.  Rows of T: (q, re) = (tr, -ti) interleaved along K, (q, im) = (ti, tr);
+// K runs over (r, re/im) = the interleaved floats of the input as they lie in memory.
+//
+// SUMMATION ORDER (the bit-exact contract with oracle/bt_oracle.c ddc_run and ddc_direct_kernel):
+//     G[q] = fmaf chain over r ascending, from +0:  re: fmaf(tr, xr, .) then fmaf(-ti, xi, .);  im: fmaf(ti, xr, .) then fmaf(tr, xi, .)
+//     y    = ((G[0] + G[1]) + G[2]) + ... ascending q
+// v_mfma_f32_32x32x2_f32 is bit for bit that chain (k = 0 then k = 1, one rounding per product, no wider accumulator:
+// scripts/ubench/exact_mfma.hip checks it on the device against per-lane fmaf).  VOLK's order in the reference is unspecified
+// and GNU Radio is not in the image (parity of the float half is unpinned upstream): the order is this repository's to fix.
+//
+// One workgroup = one time tile of 160 columns = 147 outputs (the first is the demodulator's halo): five waves, wave w owns
+// columns [32 w, 32 w + 32) -- its 32 D input samples go through LDS once and stay in D registers per lane as the B operand for
+// EVERY channel the bitmap names for the tile; the channel's T (2 QB x 2 D floats, lane-major, 12.8 KB at D = 50) is streamed
+// through LDS as the A operand.  Per channel and wave: D MFMAs (64 cycles each) and nothing else on the critical path.
+#pragma once
+#include "kernels.hip.h"
+
+namespace btgpu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kExWaves = 5, kExThreads = 64 * kExWaves;
+constexpr int kExCols = 32 * kExWaves;          // polyphase columns per tile
+constexpr int kExQB = 14;                       // tap blocks: ceil(ntaps / D) (firdes: ntaps = 44 fs / (22 * 300 kHz) | 1 = 13.33 D + 1 with D = fs / 2 MHz)
+constexpr int kExOuts = kExCols - (kExQB - 1);  // 147 outputs per tile; output 0 is the halo of the demodulator
+constexpr int kExTile = kExOuts - 1;            // 146 new demodulated rows per tile
+static_assert(kExTile == kExTileRows, "kernels.hip.h marks the bitmap in tiles of kExTileRows rows");
+constexpr int kExGStride = 168;                 // floats per row of G in LDS: 4 rows further = 32 banks further (the two half-waves of a C/D register)
+constexpr int kExWords = kExBmWords;            // bitmap words per tile (<= 96 channels)
+
+struct ExactParams {
+    long long x_len;
+    long long first0;             // x index of (grid row 0, tap 0): w0 + first_channel_sample
+    long long G;                  // rows of the shared output grid
+    const float *tapsA;           // [nch][D][64]: the A operand of step r for lane l -- row l & 31 = 2 q + (re: 0, im: 1), k = l >> 5
+    const float2 *rot; int Qr;    // de-rotation table [nch][Qr] by grid row (the windows' own rotators differ from it by an exact +-1: the demodulated rows are the same bits)
+    const float *atan_tab; float gain;
+    const uint32_t *bitmap;       // [ntiles][kExWords]: bit c of tile j = rows [kExTile j, kExTile (j + 1)) of channel c are recomputed
+    int ntiles;
+    unsigned int *stat;           // nullptr, or a counter of the (channel, tile) pairs computed
+    float *d; int drow;           // time-major stream [G][drow]
+    float *dcol;                  // nullptr, or the tile-blocked copy [G / 25][80][25]
+    float2 *ydbg; long long ystride;   // diagnostics: nullptr, or the de-rotated y [nch][ystride]
+    int nch;
+};
+
+// LDS: the staged span (32 D samples per wave), reused for A, G and the outputs once the B operands are in registers; + the arctangent table
+constexpr size_t exact_lds_main(int D)
+{
+    const size_t stage = (size_t)kExWaves * 32 * D * 8, ops = (size_t)(D * 64 + 2 * kExQB * kExGStride) * 4 + (size_t)kExOuts * 8;
+    return ((stage > ops ? stage : ops) + 15) / 16 * 16;
+}
+inline size_t exact_lds_bytes(int D) { return exact_lds_main(D) + 260 * sizeof(float); }
+inline int exact_ntiles(long long G) { return (int)((G + kExTile - 1) / kExTile); }
+
+// tapsA from a direct-form bank's reversed taps [nch][ntp][2] (design.h FilterBank): zero beyond the filter and in rows 2 QB .. 31
+inline void exact_pack_taps(const float *taps, int nch, int ntp, int D, float *out /* [nch][D][64] */)
+{
+    for (int c = 0; c < nch; c++)
+        for (int r = 0; r < D; r++)
+            for (int l = 0; l < 64; l++) {
+                const int row = l & 31, kh = l >> 5, q = row >> 1, im = row & 1, j = q * D + r;
+                float tr = 0.f, ti = 0.f;
+                if (q < kExQB && j < ntp) { tr = taps[((size_t)c * ntp + j) * 2]; ti = taps[((size_t)c * ntp + j) * 2 + 1]; }
+                out[((size_t)c * D + r) * 64 + l] = im ? (kh ? tr : ti) : (kh ? -ti : tr);
+            }
+}
+
+template <int D>
+__global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
+{
+    HIP_DYNAMIC_SHARED(float2, lds)
+    constexpr int NS = 32 * D;                                     // samples per wave
+    float *atab = (float *)((char *)lds + exact_lds_main(D));
+    // the staged span is dead once the B operands are in registers: A, G and the outputs live over it
+    float *As = (float *)lds;                                      // [D][64]
+    float *Gs = As + D * 64;                                       // [2 QB][kExGStride]
+    float2 *ys = (float2 *)(Gs + 2 * kExQB * kExGStride);          // [kExOuts]
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    const int wave = tid >> 6;
+#endif
+    for (int i = tid; i < 257; i += kExThreads) atab[i] = p.atan_tab[i];
+    for (int tile = (int)blockIdx.x; tile < p.ntiles; tile += (int)gridDim.x) {
+        uint32_t bm[kExWords];
+        uint32_t any = 0;
+#pragma unroll
+        for (int i = 0; i < kExWords; i++) { bm[i] = p.bitmap[(size_t)tile * kExWords + i]; any |= bm[i]; }
+        if (!any) continue;                                        // uniform
+        if (p.stat && tid == 0) { unsigned int n = 0; for (int i = 0; i < kExWords; i++) n += (unsigned int)__popc(bm[i]); atomicAdd(p.stat, n); }
+        const long long g0 = (long long)tile * kExTile - 1;        // grid row of output 0
+        const long long sb = p.first0 + g0 * D + (long long)wave * NS;
+        __syncthreads();                                           // the previous tile's buffers are consumed
+        // ---- the wave's 32 columns: coalesced loads, LDS, then one column half per lane ----
+        {
+            float2 *xs = lds + wave * NS;
+            constexpr int NL = (NS + 63) / 64;
+            float2 v[NL];
+            if (sb >= 0 && sb + NS <= p.x_len) {
+                const float2 *xb = x + sb;
+#pragma unroll
+                for (int i = 0; i < NL; i++) { const int n = lane + 64 * i; v[i] = xb[n < NS ? n : NS - 1]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    const long long a = sb + lane + 64 * i;
+                    const float2 t = x[a < 0 ? 0 : (a < p.x_len ? a : p.x_len - 1)];
+                    v[i] = (a >= 0 && a < p.x_len) ? t : make_float2(0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NL; i++) { const int n = lane + 64 * i; if (n < NS) xs[n] = v[i]; }
+        }
+        __syncthreads();
+        float B[D];
+        {
+            const float *xf = (const float *)(lds + wave * NS) + 2 * D * (lane & 31) + (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < D; r++) B[r] = xf[2 * r];
+        }
+        __syncthreads();                                           // every wave has its operands: the span is free
+        for (int wi = 0; wi < kExWords; wi++) {
+            uint32_t m = bm[wi];
+            while (m) {                                            // uniform
+                const int c = 32 * wi + __ffs(m) - 1;
+                m &= m - 1;
+                {
+                    const float2 *ta = (const float2 *)(p.tapsA + (size_t)c * D * 64);
+                    for (int i = tid; i < D * 32; i += kExThreads) ((float2 *)As)[i] = ta[i];
+                }
+                __syncthreads();
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+                for (int r = 0; r < D; r++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[r * 64 + lane], B[r], acc, 0, 0, 0);
+                {
+                    const int col = 32 * wave + (lane & 31), rb = 4 * (lane >> 5);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int row = (i & 3) + 8 * (i >> 2) + rb;
+                        if (row < 2 * kExQB) Gs[row * kExGStride + col] = acc[i];
+                    }
+                }
+                __syncthreads();
+                if (tid < kExOuts) {
+                    float yr = Gs[tid], yi = Gs[kExGStride + tid];
+#pragma unroll
+                    for (int q = 1; q < kExQB; q++) {
+                        yr = yr + Gs[(2 * q) * kExGStride + tid + q];
+                        yi = yi + Gs[(2 * q + 1) * kExGStride + tid + q];
+                    }
+                    const long long g = g0 + tid;
+                    float rr = 1.f, ri = 0.f;
+                    if (g >= 0) { const float2 r = p.rot[(size_t)c * p.Qr + (int)(g % p.Qr)]; rr = r.x; ri = r.y; }
+                    float2 out;
+                    out.x = fmaf(-yi, ri, yr * rr);
+                    out.y = fmaf(yi, rr, yr * ri);
+                    ys[tid] = out;
+                    if (p.ydbg && g >= 0 && g < p.G) p.ydbg[(size_t)c * p.ystride + g] = out;
+                }
+                __syncthreads();
+                if (tid >= 1 && tid < kExOuts) {
+                    const long long g = g0 + tid;
+                    if (g >= 1 && g < p.G) {
+                        const float dv = demod_one(atab, p.gain, ys[tid], ys[tid - 1]);
+                        p.d[(size_t)g * p.drow + c] = dv;
+                        if (p.dcol) { const unsigned int gq = (unsigned int)g, tq = gq / 25u; p.dcol[(size_t)(gq + 25u * (79u * tq + (unsigned int)c))] = dv; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+typedef void (*ExactRowsKernel)(ExactParams, const float2 *);
+// the instantiations: D = fs / 2 MHz for the rates the polyphase banks serve (4 .. 50 Msps: D = 2 .. 25; 100 Msps: D = 50)
+inline ExactRowsKernel exact_rows_pick(int D)
+{
+    switch (D) {
+#define BTGPU_EX(n) case n: return exact_rows_kernel<n>;
+        BTGPU_EX(2) BTGPU_EX(3) BTGPU_EX(4) BTGPU_EX(5) BTGPU_EX(6) BTGPU_EX(7) BTGPU_EX(8) BTGPU_EX(9) BTGPU_EX(10) BTGPU_EX(11) BTGPU_EX(12) BTGPU_EX(13)
+        BTGPU_EX(14) BTGPU_EX(15) BTGPU_EX(16) BTGPU_EX(17) BTGPU_EX(18) BTGPU_EX(19) BTGPU_EX(20) BTGPU_EX(21) BTGPU_EX(22) BTGPU_EX(23) BTGPU_EX(24) BTGPU_EX(25)
+        BTGPU_EX(50)
+#undef BTGPU_EX
+    }
+    return nullptr;
+}
+
+}  // namespace btgpu

@@ -48,7 +48,7 @@ struct FinishRec {            // M&M state of a window that reported hits, hande
     int32_t  oo;
     float    mu, omega, last;
     int32_t  done;            // the window already ended inside the window kernel (len known)
-    int32_t  pad_;            // exact payload: the weakest of the window's packets (W-tile energy inside its access code, float bits; sign bit: a record on a rise)
+    int32_t  pad_;
 };
 
 constexpr int kSymWords = 120;    // packed symbols kept per hit window (3840 >= ~3760 symbols)
@@ -58,8 +58,10 @@ constexpr int kSymWords = 120;    // packed symbols kept per hit window (3840 >=
 // direct-form (bit-exact) arithmetic over the first n_exact demodulated rows of the window.
 struct VerifyTask {
     int32_t w;                // window index k * nch + c
-    int32_t n_exact;          // demodulated rows [0, n_exact) of the window are recomputed exactly
-    double  snr;              // the window's squelch figure (the exact stage runs beside the next batch, whose sums reuse P / Qn)
+    int32_t n_exact;          // demodulated rows [0, n_exact) of the window are exact by the time the second run reads them
+    double  snr;              // the window's squelch figure (the second run goes beside the next batch, whose sums reuse P / Qn)
+    int32_t emit_from;        // the first run has already emitted this window's classic records at offsets below this one (from exact rows)
+    int32_t pad_;
 };
 constexpr int kVerRows = 1416;    // rows of a window the exact stage's clock recovery can reach in 693 symbols (693 * 2.01 + 8), rounded up
 constexpr int kVerTile = 127;     // new demodulated rows per tile of verify_ddc_kernel (128 outputs, the first is the demod halo)
@@ -67,9 +69,10 @@ constexpr int kVerTile = 127;     // new demodulated rows per tile of verify_ddc
 // ------------------------------------------------------------------------------------
 // K1: direct-form decimating complex band-pass FIR bank (channel bank and noise bank).
 //   y[c][g] = ( sum_j taps[c][j] * x[first + g*D + j] ) * rot[c][g]
-// Summation order (bit-exact contract with the oracle): 8 partial sums, partial l takes
-// j = l, l+8, l+16, ... ascending, four fmaf per complex MAC; combined as
-// ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)).
+// Summation order (bit-exact contract with the oracle's ddc_run and with exact.hip.h, which runs the same order on the matrix
+// pipe): the taps in BLOCKS of D (the hop), each block an fmaf chain from +0 over r ascending -- re: fmaf(tr, xr, .) then
+// fmaf(-ti, xi, .); im: fmaf(ti, xr, .) then fmaf(tr, xi, .) -- and the block sums added in ascending order; ntp is a whole
+// number of blocks (zero taps behind the filter).
 // One lane = one output instant, CPB channels per workgroup; the input span of the
 // workgroup's tile is staged through LDS once per tap chunk and shared by the CPB
 // channels; taps are wave-uniform (scalar loads).
@@ -94,11 +97,9 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
     const int c0 = blockIdx.y * CPB;
     const int o = threadIdx.x;
 
-    float ar[CPB][8], ai[CPB][8];
+    float gr[CPB], gi[CPB], yr[CPB], yi[CPB];      // the running block and the sum of the finished ones
 #pragma unroll
-    for (int cc = 0; cc < CPB; cc++)
-#pragma unroll
-        for (int l = 0; l < 8; l++) { ar[cc][l] = 0.f; ai[cc][l] = 0.f; }
+    for (int cc = 0; cc < CPB; cc++) { gr[cc] = 0.f; gi[cc] = 0.f; yr[cc] = 0.f; yi[cc] = 0.f; }
 
     const float2 *tp[CPB];
 #pragma unroll
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
         tp[cc] = taps + (size_t)c * ntp;
     }
 
+    int r = 0;                                     // position inside the block (uniform)
+    bool first_blk = true;
     for (int j0 = 0; j0 < ntp; j0 += JC) {
         const int jc = (ntp - j0) < JC ? (ntp - j0) : JC;
         const int need = (T - 1) * D + jc;
@@ -131,18 +134,24 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
         }
         __syncthreads();
         const float2 *px = tile + o * D;
-        for (int j = 0; j < jc; j += 8) {
+        for (int j = 0; j < jc; j++) {
+            const float2 v = px[j];
 #pragma unroll
-            for (int l = 0; l < 8; l++) {
-                const float2 v = px[j + l];
+            for (int cc = 0; cc < CPB; cc++) {
+                const float2 t = tp[cc][j0 + j];
+                gr[cc] = fmaf(t.x, v.x, gr[cc]);
+                gr[cc] = fmaf(-t.y, v.y, gr[cc]);
+                gi[cc] = fmaf(t.y, v.x, gi[cc]);
+                gi[cc] = fmaf(t.x, v.y, gi[cc]);
+            }
+            if (++r == D) {                        // uniform: the block is complete
 #pragma unroll
                 for (int cc = 0; cc < CPB; cc++) {
-                    const float2 t = tp[cc][j0 + j + l];
-                    ar[cc][l] = fmaf(t.x, v.x, ar[cc][l]);
-                    ar[cc][l] = fmaf(-t.y, v.y, ar[cc][l]);
-                    ai[cc][l] = fmaf(t.x, v.y, ai[cc][l]);
-                    ai[cc][l] = fmaf(t.y, v.x, ai[cc][l]);
+                    yr[cc] = first_blk ? gr[cc] : yr[cc] + gr[cc];
+                    yi[cc] = first_blk ? gi[cc] : yi[cc] + gi[cc];
+                    gr[cc] = 0.f; gi[cc] = 0.f;
                 }
+                r = 0; first_blk = false;
             }
         }
     }
@@ -154,14 +163,10 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
     for (int cc = 0; cc < CPB; cc++) {
         const int c = c0 + cc;
         if (c >= nch) break;
-        float yr = ((ar[cc][0] + ar[cc][1]) + (ar[cc][2] + ar[cc][3])) +
-                   ((ar[cc][4] + ar[cc][5]) + (ar[cc][6] + ar[cc][7]));
-        float yi = ((ai[cc][0] + ai[cc][1]) + (ai[cc][2] + ai[cc][3])) +
-                   ((ai[cc][4] + ai[cc][5]) + (ai[cc][6] + ai[cc][7]));
         float rr, ri;
         if (Q > 0) {
-            const float2 r = rot[(size_t)c * Q + (int)(g % Q)];
-            rr = r.x; ri = r.y;
+            const float2 rt = rot[(size_t)c * Q + (int)(g % Q)];
+            rr = rt.x; ri = rt.y;
         } else {
             double t = rot_step_turns[c] * (double)g;
             t -= floor(t);
@@ -170,8 +175,8 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
             rr = (float)co; ri = (float)s;
         }
         float2 out;
-        out.x = fmaf(-yi, ri, yr * rr);
-        out.y = fmaf(yi, rr, yr * ri);
+        out.x = fmaf(-yi[cc], ri, yr[cc] * rr);
+        out.y = fmaf(yi[cc], rr, yr[cc] * ri);
         Y[(size_t)c * ystride + gout] = out;
     }
 }
@@ -331,22 +336,20 @@ struct WindowParams {
     int deferred;
     const double *snr_arr;      // [S * nch] 10 log10(E_on / E_off) per window, from squelch_kernel (deferred mode)
     // exact confirmation of the polyphase path's records (verify.hip.h)
-    int verify;                 // 1: this launch hands windows with a classic hit or burst energy to the exact stage and emits no
-                                //    record for them (2: without the energy scan); the exact stage's own launch is window_kernel<LAY, true>
-    int rows_per_slot;          // stream rows from one slot's first row to the next slot's (outs_per_slot; exact stage: kVerRows)
+    int verify;                 // 1, 2: a classic hit whose rows are not exact yet (exact.hip.h has not covered them: bm1) is not emitted; the window
+                                //    is listed for the second run, window_kernel<LAY, true>, behind a second launch of exact.hip.h (bm2).  1: presence_kernel has marked bm1
+    int rows_per_slot;          // stream rows from one slot's first row to the next slot's (outs_per_slot; second run: kVerRows)
     const double *ptile;        // [nch][ptile_stride] |Y|^2 sums per tile of tile_outs outputs (the polyphase banks' by-product)
     int ptile_stride, tile_outs, tiles_per_slot;
-    VerifyTask *vtasks; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 tiles listed (statistics), 2 windows turned away (list full)
-    uint32_t *vtiles; unsigned int *vtcount; unsigned int vtcap;     // tile lists BY CHANNEL: entries task | tile << 24 at vtiles[c * vtcap ..], vtcount[c] of them
+    VerifyTask *vtasks; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 (channel, tile) pairs marked, 2 windows turned away (list full), 3 busy windows (presence)
     int vcap;                   // capacity of vtasks
-    float burst_abs;            // new energy: a W-tile sum above burst_abs * (the quietest aligned W-tile block of the span) ...
+    uint32_t *bm1, *bm2;        // exact rows' bitmaps [bm_tiles][kExBmWords]: marked by presence_kernel / by the first run's uncovered hits
+    int bm_tiles;
+    float burst_abs;            // presence: a W-tile sum above burst_abs * (the quietest aligned W-tile block of the span) ...
     int burst_w;                // ... W = tiles per ~50 us (set_verify_flagging, bank_launch.h)
-    int exact_payload;          // BTGPU_FLAG_EXACT_PAYLOAD (with syms): the exact window kernel hands the continuation the state at the end of its exact rows
-    int prescan;                // 1: the scan ran in burst_scan_kernel; its verdicts are in vinfo
-    const int32_t *vinfo;       // [S * nch] task slot | tiles listed << 16 of an energy-flagged window, -1 otherwise
     float burst_abs1;           // ... or above burst_abs1 * (the quietest single tile), whichever is lower
     float burst_abs2;           // ... or above burst_abs2 * chan_floor[channel]: the channel's quietest tile of the whole batch (channel_floor_kernel)
-    const float *chan_floor;    // [nch], nullptr: not computed
+    const float *chan_floor;    // [81], nullptr: not computed
     float burst_abs_hot, burst_hot;   // as multiples of that threshold: the threshold beside a neighbour channel whose W-tile sum exceeds burst_hot x it
     int span_extra;             // symbols behind an access code that stay exact as well (the 54-symbol header + margin)
     int dbg_stop;               // diagnostics (BTGPU_WIN_STOP): 1 = stop before phase 1, 2 = after it, 3 = after the classic search
@@ -386,6 +389,7 @@ constexpr int kMmseStride = 12;      // floats per interpolator row in LDS: 16-b
                                      // 2 imu mod 16 (eight classes for the sixteen lanes of a 16-byte read group)
 constexpr int kDetectSyms = 693;     // 625 search offsets + 68-symbol access code
 constexpr int kBurstAhead = 2;       // the neighbour channels' energy sums run this many tiles ahead of the channel's own
+constexpr int kChanFloorAll = 80;     // channel_floor_kernel: out[80] = the quietest tile of ANY channel
 constexpr int kBurstFront = 7;       // tiles in front of a window that the burst scan reads (57 tiles of the span + 7 = one wave's 64 lanes)
 constexpr int kBitWords = 24;        // 32-bit words of sliced symbols kept per lane (>= 693 + 99 bits)
 
@@ -529,43 +533,66 @@ __device__ __forceinline__ int ver_rows_of(const WindowParams &p, int span)
 {
     int rows = (int)((float)span * (p.omega_mid + p.omega_relative_limit)) + 12;
     const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
-    // Where the banks' tiles are longer than 25 us (<= 10 Msps apart from the C8 geometry: 125-us tiles, W = 1) the scan places an
-    // edge that coarsely, and a second packet of the window can lie behind the span of the first: the exact pass would run over
-    // polyphase rows from there and may decode what neither the reference nor the polyphase path does (seed 19001 case 3376,
-    // tests/test_emu_bank.py).  At those rates a task is the whole detection span -- a few MB/s of input, the rows cost nothing.
-    if (p.tile_outs > 50) return cap_rows;
     return rows > cap_rows ? cap_rows : rows;
 }
 
-// The exact stage's window selection by burst energy, for the lanes of one workgroup laid out like the
-// window kernel's: lane = (slot sl of the workgroup, channel cq), window (kq, cq); `tile`: kWinSlots * kTileFloats floats of LDS,
-// s_live: two ints of LDS.  Lanes with scan_on take part; a lane whose window shows new energy leaves with its task reserved
-// (vslot), the energy's span (vspan, symbols) and the tiles already listed for it (vtiles0).  Called by every lane of the
-// workgroup (barriers inside).  Shared by window_kernel (scan in line, round 4's choreography) and burst_scan_kernel (round 5:
-// the scan right behind the banks, so that the exact stage's DDC can run beside squelch stage 2).
+// ---- exact rows: which (channel, time tile) pairs are recomputed through the reference's own arithmetic (exact.hip.h) ----
+// bitmap[tile][kExWords]: bit c of tile j = grid rows [kExTile j, kExTile (j + 1)) of channel c.
+constexpr int kExTileRows = 146;     // = exact.hip.h kExTile (160 polyphase columns - 13 - the demodulator's halo)
+constexpr int kExBmWords = 3;        // bitmap words per tile (<= 96 channels)
+__device__ __forceinline__ void exact_mark(uint32_t *bm, const uint32_t *skip, int ntiles, long long g_lo, long long g_hi, int c, unsigned int *stat)
+{
+    int t0 = (int)(g_lo / kExTileRows), t1 = (int)((g_hi - 1) / kExTileRows);
+    if (t1 >= ntiles) t1 = ntiles - 1;
+    const uint32_t bit = 1u << (c & 31);
+    int n = 0;
+    for (int t = t0; t <= t1; t++) {
+        const size_t i = (size_t)t * kExBmWords + (c >> 5);
+        if (skip && (skip[i] & bit)) continue;
+        if (!(atomicOr(&bm[i], bit) & bit)) n++;
+    }
+    if (stat && n) atomicAdd(stat, (unsigned int)n);
+}
+// rows of window (k, c), from its first row on, that the bitmap covers without a gap
+__device__ __forceinline__ int exact_covered_rows(const uint32_t *bm, int ntiles, long long g_lo, int c)
+{
+    int t = (int)(g_lo / kExTileRows);
+    const uint32_t bit = 1u << (c & 31);
+    while (t < ntiles && (bm[(size_t)t * kExBmWords + (c >> 5)] & bit)) t++;
+    const long long cov = (long long)t * kExTileRows - g_lo;
+    return cov > 0 ? (cov > 0x3fffffff ? 0x3fffffff : (int)cov) : 0;
+}
+
+// PRESENCE (round 6).  The reference runs one arithmetic over every window and needs no edge, no gap and no
+// step in level to find an access code (lib/multi_sniffer_impl.cc:87-127).  The product's default front end is a tolerance path
+// (polyphase banks), so every window whose detection span holds ENERGY -- the channel's 50-us sum over 2.0 x the mean noise,
+// anywhere in the span: a packet that begins there, one that began before the window and is still on the air, one that
+// continues another with neither gap nor step -- gets its rows, from the window's first row to 80 symbols past the last busy
+// tile, recomputed by exact.hip.h before the window kernel reads them.  Rounds 4-5 selected on RISING energy (a dozen tuned
+// constants; each round's generator found the next class of packet that shows no rise): gone.  What presence does not see is a
+// packet under the threshold itself (~2-3 dB over the noise; beside a neighbour channel >= 20 dB over the noise: 3.0 x, ~4.5 dB)
+// -- sensitivity, the one statement left.
+// Launched like the window kernel (lane = (slot, channel)); the tile sums of a slot's channels cross LDS.
 template <class LAY>
-__device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, int *s_live, int nch, int sl, int kq, int cq, bool scan_on,
-                                           int &vslot, int &vspan, int &vtiles0, bool &vtried)
+__global__ __launch_bounds__(kWinThreads) void presence_kernel(WindowParams p)
 {
     constexpr int kWinSlots = LAY::kSlots, kTileFloats = LAY::kTileFloats;
-    const int nmax = scan_on ? 1 : 0;
-    auto ver_rows = [&](int span) { return ver_rows_of(p, span); };
-    // The tile sums of a slot's channels cross LDS (the dead demod tile): read straight from ptile[channel][tile] the 79
-    // lanes of a slot touch 79 cache lines per load -- 2 x 57 such loads per lane doubled the kernel's time.
+    __shared__ __attribute__((aligned(16))) float tile[kWinSlots * kTileFloats];
+    __shared__ unsigned int s_cnt[2];
+    const int nch = p.nch;
+    const int sl = (int)threadIdx.x / nch, cq = (int)threadIdx.x - sl * nch, kq = blockIdx.x * kWinSlots + sl;
+    const bool lane_ok = sl < kWinSlots && kq < p.S;
+    if (threadIdx.x == 0) { s_cnt[0] = 0u; s_cnt[1] = 0u; }
     const int TT = p.tile_outs;
     const int ntm = (2 * kDetectSyms + 16 + TT - 1) / TT;          // tiles of the detection span
-    constexpr int NF = kBurstFront;                                // tiles in front of the window that the scan looks at
+    constexpr int NF = kBurstFront;                                // tiles in front of the window that the noise estimate and the first sums read
     const int NTW = ntm + NF, PW = NTW | 1;                        // odd pitch: no bank conflicts
-    // as many slots per pass as the tile holds (all three at C79 do not fit; the narrow layouts -- 32 slots of 8 channels --
-    // take 19 at a time: one pass per slot was 32 x two barriers)
     int spp = (kWinSlots * kTileFloats) / (nch * PW);
     spp = spp < 1 ? 1 : (spp > kWinSlots ? kWinSlots : spp);
     float *et = tile;                                              // [spp][nch][PW]: tile t0 - NF + jj of (slot, channel) at et[(sp * nch + cc) * PW + jj]; -1 = no such tile
     for (int s0 = 0; s0 < kWinSlots; s0 += spp) {
         if (blockIdx.x * kWinSlots + s0 >= p.S) break;             // uniform
         __syncthreads();
-        // (NTW <= 64: a wave takes the tiles of one (slot, channel) -- contiguous doubles --, the four waves every fourth pair; four
-        // pairs per wave in flight: one load per trip was 40 dependent memory round trips per pass, most of the scan's time)
         for (int pr0 = (int)threadIdx.x >> 6; pr0 < spp * nch; pr0 += 4 * (kWinThreads / 64)) {
             float v[4];
 #pragma unroll
@@ -588,27 +615,17 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
             }
         }
         __syncthreads();
-        if (sl < s0 || sl >= s0 + spp || nmax == 0) continue;      // this lane's slot is not in this pass
+        if (sl < s0 || sl >= s0 + spp || !lane_ok) continue;       // this lane's slot is not in this pass
         const int t0 = kq * p.tiles_per_slot;
         const float *pe = et + ((sl - s0) * nch + cq) * PW + NF;   // pe[j]: tile j of this window's span, j = -NF .. nt - 1
         int nt = ntm;
         if (nt > p.ptile_stride - t0) nt = p.ptile_stride - t0;
-        // ---- where does NEW energy appear in the span?  (round 5) ----
-        // The statistic is the energy of W tiles (~50 us: two thirds of an access code), s[j] = e[j-W+1] + .. + e[j].  New energy
-        // shows at j when (a) s[j] > burst_abs * (the span's quietest aligned W-tile block): the block minimum underestimates the
-        // mean noise by a known factor, folded into burst_abs by the host, which is calibrated to 2.0 x the mean noise -- a
-        // packet 3 dB over the noise triggers in 400 of 400 trials, one at 1.5 dB in 97 %, at 0 dB in 68 %, noise in 0 of 2700 windows
-        // (1.8 x: 99.5 % / 88 % and 0.1 % of the windows, each of them a task of ~700 rows); and (b)
-        // s[j] > 1.5 s[j-W]: half as much again as in the 50 us before -- a packet that begins in noise, in a neighbour's leakage
-        // or ON TOP of one already on the air with C/I >= -3 dB (below that the demodulator follows the stronger one).
-        // No rule says "this edge cannot be a packet" any more: round 4's dismissal of edges that a 17 dB stronger neighbour
-        // "explains" lost a packet the reference receives (the filter's leakage is -36 .. -20 dB per tile: 18 dB under a
-        // neighbour is 2 .. 18 dB OVER its leakage), and its absolute 4 x threshold left packets under 5 dB to the polyphase
-        // trajectory.  A packet that continues another one on the same channel with no gap and no step in level shows
-        // nothing in the energy; it is reached through the task its predecessor opens (exact rows up to there) and the
-        // polyphase path's own hit.
         const int W = p.burst_w;
         const int jl = t0 + nt == p.ptile_stride ? nt - 1 : nt;    // the batch's last tile may be a partial one
+        // ---- the noise references: the span's quietest aligned W-tile block (the host folds its known shortfall under the mean into
+        // burst_abs), the span's quietest single tile (1.6 x: noise alone never prefers it), the channel's quietest tile of the whole
+        // batch and 1.5 x the quietest of any channel's (channel_floor_kernel) -- a span that a packet fills from end to end holds no
+        // quiet tile of its own.  The LOWEST threshold decides: a false "busy" costs rows, a false "quiet" a record.
         float bmin = 3.0e38f;
         bool some = false;                                         // any tile with signal at all (GNU Radio's leading zeros are none)
         for (int jb = -NF; jb + W <= jl; jb += W) {
@@ -617,59 +634,38 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
             for (int u = 0; u < W; u++) { const float e = pe[jb + u]; ok = ok && e > 0.f; some = some || e > 0.f; sb += e; }
             bmin = (ok && sb < bmin) ? sb : bmin;
         }
-        // ... and the span's quietest single tile (with a predecessor that holds signal too: a tile next to silence may be partly
-        // silent itself).  Where a packet follows another within < 50 us -- one quiet tile between them, no quiet BLOCK anywhere in
-        // a span that the second packet then fills -- the block minimum is the packets' own level and (a) could never hold (fuzz
-        // seed 8001 case 2179: a 30 dB packet 25 us behind a 39 dB one, lost).  The single tile's minimum scatters by a factor
-        // of two (0.30 .. 0.64 of the mean over 64 tiles), so it only stands in when the block estimate is more than 1.6 x above
-        // it, which noise alone does not produce; the threshold is then up to 1.6 x higher in noise terms (~5 dB instead of 3).
         float mn1 = 3.0e38f;
         {
             float ep = pe[-NF];
             for (int jx = -NF + 1; jx < jl; jx++) { const float e = pe[jx]; mn1 = (e > 0.f && ep > 0.f && e < mn1) ? e : mn1; ep = e; }
         }
-        int rise = -1;
+        int last_busy = -1;
         if (bmin > 1.0e38f) {
             // no whole block of the span holds signal (a stream that begins inside the span): nothing to compare with -- exact to the end
-            if (some) rise = nt - 1;
+            if (some) last_busy = nt - 1;
         } else {
-            // ... and for rule (d) below, where the span holds no quiet tile at all (a packet straight behind another, the second
-            // filling the span: fuzz seed 9001 case 11029), from the channel's quietest tile of the whole batch (channel_floor_kernel)
             const float thr_b = p.burst_abs * bmin, thr_1 = p.burst_abs1 * mn1;
-            const float cf_ = p.chan_floor ? p.chan_floor[cq] : 3.0e38f;
+            const float cf_ = p.chan_floor ? fminf(p.chan_floor[cq], 1.5f * p.chan_floor[kChanFloorAll]) : 3.0e38f;
             const float thr_2 = cf_ < 1.0e38f ? p.burst_abs2 * cf_ : 3.0e38f;
-            // (the batch-wide reference serves rule (d) only: with it in (a), every +50 % step inside a span that collisions keep busy
-            // becomes a task -- 1.6 x the tasks and 2.1 x the rows on the C8 synthetic, eight piconets on eight channels -- where the
-            // span's own quietest block asks for a step to 2.65 x, which the 1.2e5-record runs were clean with)
-            const float thr = thr_1 < thr_b ? thr_1 : thr_b;
-            const float thr_d_scale = (thr_2 > 0.f && thr_2 < thr) ? thr_2 / thr : 1.0f;
+            float thr = thr_1 < thr_b ? thr_1 : thr_b;
+            thr = thr_2 < thr ? thr_2 : thr;
             const float thr_n = thr * p.burst_abs_hot, hot = thr * p.burst_hot;      // (both as multiples of the threshold)
-            // s[j] and s[j-W] by sliding sums; tiles that do not exist (in front of the batch) count as unknown: (b) holds.
-            // sl_ / sr_: the same W-tile sum on the two neighbour channels (0 where the capture has none)
             const bool has_l = cq > 0, has_r = cq + 1 < nch;
-            float s_cur = 0.f, s_old = 0.f, s_old2 = 0.f, sl_ = 0.f, sr_ = 0.f;             // s_old2: the W tiles before s_old's (absent tiles: 0)
-            int miss_old = 0;
-            for (int u = 0; u < W; u++) {                          // position j = -2
-                const int ic = -2 - u, io = -2 - W - u;
-                const float ec = ic >= -NF ? pe[ic] : -1.f, eo = io >= -NF ? pe[io] : -1.f;
+            float s_cur = 0.f, sl_ = 0.f, sr_ = 0.f;               // the W-tile sums of the channel and of its two neighbours (those kBurstAhead tiles ahead)
+            for (int u = 0; u < W; u++) {                          // position j = -1
+                const int ic = -1 - u;
+                const float ec = ic >= -NF ? pe[ic] : -1.f;
                 s_cur += ec > 0.f ? ec : 0.f;
-                s_old += eo > 0.f ? eo : 0.f; miss_old += eo < 0.f;
-                { const int i2 = -2 - 2 * W - u; const float e2_ = i2 >= -NF ? pe[i2] : 0.f; s_old2 += e2_ > 0.f ? e2_ : 0.f; }
-                const int in_ = ic + kBurstAhead;                  // (the neighbours' sums run kBurstAhead tiles ahead: see below)
+                const int in_ = ic + kBurstAhead;
                 const float el = (has_l && in_ >= -NF && in_ < ntm) ? pe[in_ - PW] : 0.f, er = (has_r && in_ >= -NF && in_ < ntm) ? pe[in_ + PW] : 0.f;
                 sl_ += el > 0.f ? el : 0.f; sr_ += er > 0.f ? er : 0.f;
             }
-            bool prev = true;                                      // (a run that began in front of the window starts nothing)
-            float pre_lvl = -1.f;                                  // what stood on the channel, per tile, before the last rise (-1: no rise seen yet)
-            for (int jx = -1; jx < nt; jx++) {
-                const int io = jx - W, iq = jx - 2 * W;
-                const float en = pe[jx], eo = io >= -NF ? pe[io] : -1.f, eq = iq >= -NF ? pe[iq] : -1.f;
+            for (int jx = 0; jx < nt; jx++) {
+                const int io = jx - W;
+                const float en = pe[jx], eo = io >= -NF ? pe[io] : -1.f;
                 s_cur += (en > 0.f ? en : 0.f) - (eo > 0.f ? eo : 0.f);
-                s_old += (eo > 0.f ? eo : 0.f) - (eq > 0.f ? eq : 0.f);
-                miss_old += (int)(eo < 0.f) - (int)(eq < 0.f);
-                { const int i3 = jx - 3 * W; const float e3 = i3 >= -NF ? pe[i3] : 0.f; s_old2 += (eq > 0.f ? eq : 0.f) - (e3 > 0.f ? e3 : 0.f); }
                 {
-                    // (two tiles AHEAD of this channel's sum: a packet that switches on splatters into the neighbour channels
+                    // (two tiles AHEAD of this channel's sum: a transmitter that switches on splatters into the neighbour channels
                     // in its first microseconds, when its own W-tile sum has hardly begun to rise)
                     const int jn = jx + kBurstAhead, jo = io + kBurstAhead;
                     const float ln = (has_l && jn < ntm) ? pe[jn - PW] : 0.f, lo = (has_l && jo >= -NF && jo < ntm) ? pe[jo - PW] : 0.f;
@@ -679,119 +675,28 @@ __device__ __forceinline__ void burst_scan(const WindowParams &p, float *tile, i
                 }
                 // Beside a neighbour channel that carries a packet >= 20 dB over the noise the threshold is 3 x the mean noise
                 // instead of 2 x: the channel filter passes -36 .. -20 dB of that packet per tile, i.e. about the noise level
-                // and up, and with the low threshold every strong packet would make full-length tasks of its two neighbour
-                // windows.  This is a statement about SENSITIVITY, not a dismissal: beside such a neighbour a packet is taken
-                // from ~4.5 dB over the noise (alone: from ~2 dB), whatever the neighbour's level.
+                // and up, and with the low threshold every strong packet would make busy windows of its two neighbour channels.
+                // A statement about SENSITIVITY: beside such a neighbour a packet is taken from ~4.5 dB over the noise.
                 const float thr_j = (sl_ > hot || sr_ > hot) ? thr_n : thr;
-                const bool trig = s_cur > thr_j && (miss_old > 0 || s_cur > 1.5f * s_old);
-                // (c) a SHARP edge: this tile four times the quieter of the two in front of it, and itself over the threshold's
-                // per-tile share.  Behind a stronger packet the sum of the 50 us before -- s[j-W] -- still holds that packet's tail
-                // for up to 2 W tiles, and (b) sees a weaker successor only when it has cleared: W .. 2 W - 1 tiles late (fuzz seed
-                // 8001 case 5740: a 36 dB packet 30 us behind a 44 dB one, onset at row 1250, (b) at tile 55 -- taken for the next
-                // window's).  A sharp edge starts a run of its own whatever (b) says.
-                const float e1 = jx - 1 >= -NF ? pe[jx - 1] : -1.f, e2 = jx - 2 >= -NF ? pe[jx - 2] : -1.f;
-                const float floor2 = (e1 >= 0.f && e2 >= 0.f) ? (e1 < e2 ? e1 : e2) : (e1 >= 0.f ? e1 : 3.0e38f);
-                const bool sharp = en > 4.f * floor2 && en * (float)W > 3.f * thr_j;   // (x 3: a neighbour's switch-on click in this channel -- one tile at ~6 x the noise -- is not one)
-                // (d) a FALL onto a plateau: the energy has dropped to a quarter within two tiles -- a packet ended -- and the W tiles
-                // from here on still stand over the threshold: another transmission goes on underneath, and if it began where the first
-                // ended there is no rising edge to see (fuzz seed 9002 case 485: a 10.7 dB packet straight behind a 44 dB one;
-                // seed 9001 case 11029: 39 dB behind 53 dB).  The plateau may be the tail of a packet that began long before -- then
-                // this is a task for nothing, like any other edge that is no packet.
-                bool plateau = false;
-                if (jx >= 0 && (e1 > 4.f * en || e2 > 4.f * en) && jx + W < nt) {
-                    // (... and STAYS down: every one of those W tiles under half of what stood before the fall.  A neighbour's
-                    // leakage swings by 4 x from tile to tile and back; a packet's end does not come back)
-                    const float before = e1 > e2 ? e1 : e2;
-                    float sn = 0.f, mx = 0.f;
-                    // (the W tiles BEHIND this one: it may be the last, partly filled tile of the packet that ends)
-                    for (int u = 1; u <= W; u++) { const float e = pe[jx + u]; sn += e > 0.f ? e : 0.f; mx = e > mx ? e : mx; }
-                    plateau = sn > thr_j * thr_d_scale && mx < 0.5f * before;
-                    // (a plateau at the level the channel had BEFORE the packet that now ends rose is the transmission that was on
-                    // the air then, going on underneath -- its access code is long past; only a new level is a new packet.  In traffic
-                    // that collides all the time -- the C8 synthetic: eight piconets on eight channels -- this halves the tasks)
-                    if (plateau && pre_lvl > 0.f && sn > 0.5f * (float)W * pre_lvl && sn < 2.0f * (float)W * pre_lvl) plateau = false;
-                }
-                if (plateau && !(trig && !prev) && !sharp) { if ((float)((jx - 1) * TT) - 1.f < 1270.f) rise = jx; }
-                if (((trig && !prev) || sharp) && jx >= 0) {
-                    // The run of triggers begins at the tile the packet begins in, or -- where less than ~3 noise tiles' worth of it
-                    // lies in that tile -- up to W - 1 tiles later.  An access code is reportable at the offsets below 625
-                    // (lib/multi_sniffer_impl.cc:108).  Where symbol 625 lies in the window is NOT bounded by the loop's clock limits
-                    // (2 +- 0.005 rows per symbol would give row 1257, rounds 3-4's bound): in the noise in front of a packet the timing
-                    // error term moves mu by up to gain_mu per symbol, a random walk.  Measured on the oracle (3300 packets with their
-                    // onset at rows 1248 .. 1290, profiles/r05_handover_rows.txt): the earlier window still reports the packet in 50 % at
-                    // row 1252, 12 % at 1258, 2 % at 1262, 1 of 156 at 1266, 0 of 3300 behind 1267 -- a Gaussian tail, sigma 4.6 rows.
-                    // A burst is the NEXT window's from row 1270 on: at that row the earlier window reports it in 6e-5 (3.9 sigma), and
-                    // over packets at random instants the loss is the tail's integral / 1250 rows = 5e-8 per packet (round 4's 1261:
-                    // 3 % at the row, 4e-5 per packet -- the ~1e-4 of planted records that rounds 3 and 4 kept losing in unaligned
-                    // traffic).  In a sniffer window the following slot begins at row 1264.5 and its bursts 5 us = 10 rows later: the
-                    // common, slot-aligned case is still taken once, not twice at full length.
-                    // Where inside its tile the packet begins is estimated
-                    // from how much of a full tile (the next one) it fills; how far the true onset can lie IN FRONT of that estimate:
-                    // with x = (packet tile) / (what was there before, o), a tile sum of ~12.6 independent values has the variance
-                    // (o^2 + 2 S o) / 12.6 around a signal part S, so the fill fraction is off by sigma = sqrt((2 / x^2 + 4 / x) / 12.6)
-                    // tiles at most, and a run that began one tile late hides <= 3.2 / x of a tile -- 3.5 sigma + 3.2 / x tiles,
-                    // never more than W - 1: 3 rows at 25 dB, 7 at 18 dB, 18 at 12 dB, 46 at 6 dB, the whole 75 below 3 dB.
-                    // (What was there before: for a sharp edge the quieter of the two tiles in front; for (b) the mean of the 50 us
-                    // before -- and where the 50 us before THAT held more than twice the present energy, a stronger packet has just
-                    // ended and (b) may be up to 2 W - 1 tiles late.)
-                    const float o = sharp ? floor2 : (miss_old > 0 ? 3.0e38f : s_old / (float)W);
-                    pre_lvl = o < 1.0e38f ? o : -1.f;
-                    const bool nxt = jx + 1 < nt && pe[jx + 1] > en;
-                    const float full = nxt ? pe[jx + 1] : en;
-                    float frac = (en - o) / (full - o);
-                    frac = (full > o && frac > 0.f) ? (frac > 1.f ? 1.f : frac) : 1.f;
-                    const float xi = o > 0.f ? o / (full > o ? full - o : 1.0e-30f) : 0.f;          // 1 / x
-                    float back = 3.5f * sqrtf((2.f * xi * xi + 4.f * xi) * (1.0f / 12.6f)) + 3.2f * xi;
-                    const bool fell = !sharp && s_old2 > 2.f * s_cur;
-                    const float cap_back = fell ? (float)(2 * W - 1) : (float)(W > 1 ? W - 1 : 1);
-                    back = (fell || (!sharp && miss_old > 0) || !(back < cap_back)) ? cap_back : back;
-                    const float onset_row = ((float)(jx + 1) - frac - back) * (float)TT - 1.f;
-                    if (onset_row < 1270.f) rise = jx;
-                }
-                prev = trig;
+                if (s_cur > thr_j) last_busy = jx;
             }
         }
-        // (to the end of the access code that may start there: whether one does is what the exact stage settles; the header
-        // behind it is added to the span by the hit that finds it, emit_classic)
-        if (rise >= 0) vspan = ((rise + 1) * TT) / 2 + 72 + 8;
-    }
-    // one task-list reservation per workgroup: thousands of lanes asking the same counter at the same moment queued up
-    // at the L2 for ~80 us (a quarter of this kernel's time, profiles/r04_c_*)
-    // (the tiles of the span the energy asks for are listed here as well; a later hit that reaches further appends the rest)
-    __syncthreads();                                               // (also: the tile is staged over next)
-    int *s_tl = (int *)tile;                                       // [0] tiles asked for by this workgroup, [1] their base in the list
-    if (threadIdx.x == 0) { s_live[0] = 0; s_tl[0] = 0; }
-    __syncthreads();
-    vtiles0 = vspan > 0 ? (ver_rows(vspan) + kVerTile - 1) / kVerTile : 0;
-    const int mine = vspan > 0 ? atomicAdd(&s_live[0], 1) : -1;
-    if (vspan > 0) atomicAdd(&s_tl[0], vtiles0);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_live[0] > 0) {
-        s_live[1] = (int)atomicAdd(&p.vcount[0], (unsigned int)s_live[0]);
-        atomicAdd(&p.vcount[1], (unsigned int)s_tl[0]);            // (statistics)
-    }
-    __syncthreads();
-    if (mine >= 0) {
-        vtried = true;
-        const unsigned int s_ = (unsigned int)s_live[1] + (unsigned int)mine;
-        if (s_ < (unsigned int)p.vcap) {
-            vslot = (int)s_;
-            // the tiles go to the list of this lane's CHANNEL (one counter per channel: ~70 lanes each, not 5000 on one): a
-            // workgroup of verify_ddc_kernel stays with one channel, whose taps then stay in its CU's scalar cache
-            const unsigned int tp = atomicAdd(&p.vtcount[cq], (unsigned int)vtiles0);
-            uint32_t *tl = p.vtiles + (size_t)cq * p.vtcap;
-            for (int j = 0; j < vtiles0; j++) if (tp + j < p.vtcap) tl[tp + j] = (uint32_t)vslot | ((uint32_t)j << 24);
-        } else {
-            atomicAdd(&p.vcount[2], 1u);
-            vtiles0 = 0;
+        if (last_busy >= 0) {
+            // to 80 symbols behind the last busy tile: the end of an access code that starts in it, its header (54 + 4 symbols)
+            const int rows = ver_rows_of(p, ((last_busy + 1) * TT) / 2 + 80);
+            const long long g_lo = (long long)kq * p.outs_per_slot;
+            exact_mark(p.bm1, nullptr, p.bm_tiles, g_lo, g_lo + rows, cq, &s_cnt[1]);
+            atomicAdd(&s_cnt[0], 1u);
         }
     }
-    __syncthreads();                                               // s_live is the chunk loop's flag, the tile is staged over next
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt[0]) { atomicAdd(&p.vcount[3], s_cnt[0]); atomicAdd(&p.vcount[1], s_cnt[1]); }   // (statistics: busy windows, pairs marked)
 }
 
-// The quietest tile of every channel over the whole batch (with a predecessor that holds signal too, like the scan's own minimum):
-// the burst scan's noise reference of last resort.  gridDim.y = channels, gridDim.x workgroups share a channel's tiles and meet in
-// an atomic minimum on the float's bits (positive floats order like their bit patterns); out[] preset to 0x7f7fffff by the caller.
+// The quietest tile of every channel over the whole batch (with a predecessor that holds signal too, like the scan's own minimum),
+// and in out[kChanFloorAll] the quietest of all channels: presence's noise reference of last resort.  gridDim.y = channels,
+// gridDim.x workgroups share a channel's tiles and meet in an atomic minimum on the float's bits (positive floats order like their
+// bit patterns); out[] preset to 0x7f7f7f7f (3.4e38) by the caller.  ntiles: the FULL tiles (a batch's last tile may be a partial one).
 __global__ __launch_bounds__(256) void channel_floor_kernel(const double *__restrict__ ptile, int stride, int ntiles, float *__restrict__ out)
 {
     __shared__ float red[256];
@@ -807,38 +712,10 @@ __global__ __launch_bounds__(256) void channel_floor_kernel(const double *__rest
         if ((int)threadIdx.x < sft) red[threadIdx.x] = red[threadIdx.x + sft] < red[threadIdx.x] ? red[threadIdx.x + sft] : red[threadIdx.x];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && red[0] < 3.0e38f) atomicMin((unsigned int *)out + blockIdx.y, __float_as_uint(red[0]));
-}
-
-// The burst scan as a kernel of its own, right behind the banks (round 5): the energy-selected tasks are then known before squelch
-// stage 2 and the window kernel have run, and the exact stage's DDC for them runs BESIDE those two instead of behind them.  The
-// squelch verdict is not known here: a task is listed for every window with new energy, its snr preset to "failed"; the window
-// kernel writes the real figure (and whatever its hits add to the span) when it comes by.  Exact rows are whole tiles of the
-// DDC kernel here -- what that launch computes anyway --, so that a hit which reaches a few rows further inside the last tile
-// finds them exact.
-template <class LAY>
-__global__ __launch_bounds__(kWinThreads) void burst_scan_kernel(WindowParams p, int32_t *__restrict__ vinfo_out)
-{
-    constexpr int kWinSlots = LAY::kSlots, kTileFloats = LAY::kTileFloats;
-    __shared__ __attribute__((aligned(16))) float tile[kWinSlots * kTileFloats];
-    __shared__ int s_live[2];
-    const int nch = p.nch;
-    const int sl = (int)threadIdx.x / nch, c = (int)threadIdx.x - sl * nch, k = blockIdx.x * kWinSlots + sl;
-    const bool lane_ok = sl < kWinSlots && k < p.S;
-    int vslot = -1, vspan = 0, vtiles0 = 0;
-    bool vtried = false;
-    burst_scan<LAY>(p, tile, s_live, nch, sl, k, c, lane_ok, vslot, vspan, vtiles0, vtried);
-    if (!lane_ok) return;
-    const long long w = (long long)k * nch + c;
-    if (vslot >= 0) {
-        const int cap_rows = p.ddc_out < kVerRows ? p.ddc_out : kVerRows;
-        int rows = vtiles0 * kVerTile;
-        rows = rows > cap_rows ? cap_rows : rows;
-        VerifyTask t_;
-        t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = -1.0e300;
-        p.vtasks[vslot] = t_;
-        vinfo_out[w] = vslot | (vtiles0 << 16);
-    } else vinfo_out[w] = -1;
+    if (threadIdx.x == 0 && red[0] < 3.0e38f) {
+        atomicMin((unsigned int *)out + blockIdx.y, __float_as_uint(red[0]));
+        atomicMin((unsigned int *)out + kChanFloorAll, __float_as_uint(red[0]));
+    }
 }
 
 // VER = true: the exact stage's run (verify.hip.h).  Lanes are the tasks of p.vtasks, 79 (nch) per pseudo-slot, and the stream
@@ -883,7 +760,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int k = blockIdx.x * kWinSlots + sl;                   // slot (VER: pseudo-slot) whose rows this lane reads
     // the window the lane stands for: (k, c) itself, or the task's
     int kq = k, cq = c;
-    unsigned int n_ex = 0u;                          // VER: rows [0, n_ex) of this task's stream are the exact ones
+    int emit_from = 0;                               // VER: classic records below this offset left in the first run
     bool lane_ok = sl < kWinSlots && k < p.S;
     if (VER) {
         unsigned int ntask = p.vcount[0];
@@ -893,7 +770,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         lane_ok = sl < kWinSlots && q < ntask;
         const int wr = lane_ok ? p.vtasks[q].w : 0;
         kq = wr / nch; cq = wr - kq * nch;
-        n_ex = lane_ok ? (unsigned int)p.vtasks[q].n_exact : 0u;
+        emit_from = lane_ok ? p.vtasks[q].emit_from : 0;
     }
     const long long w = (long long)kq * nch + cq;
     int nmax = 0;                                    // symbols this lane will produce in phase 1
@@ -901,8 +778,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     if (VER && lane_ok) {                            // a task passed the squelch in the first run -- or, deferred, is judged here
         snr = p.deferred ? p.snr_arr[w] : p.vtasks[k * nch + c].snr;
         win_len[w] = -1;
-        // (prescan: tasks are listed before the squelch is known; a window that failed it keeps the scan's snr = -1e300)
-        if ((!p.deferred && !p.prescan) || snr >= p.target_snr) nmax = kDetectSyms;
+        if (!p.deferred || snr >= p.target_snr) nmax = kDetectSyms;
     }
     if (!VER && lane_ok && p.deferred) {             // deferred squelch: every window runs, the decision comes with the records
         win_len[w] = -1;
@@ -922,28 +798,18 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         if (snr >= p.target_snr) nmax = kDetectSyms;
     }
 
-    // ---- exact confirmation, first half: which windows go to the exact stage ----
-    // A window is handed over (and emits no record here) when its classic search finds a hit (below) or when the channel's
-    // |Y|^2 tile sums show burst energy inside the detection span: the clock-recovery loop quantises its phase to 1/128
-    // sample, so a 1e-6 difference of the polyphase stream parts the two trajectories in ~10 % of the windows within 150
-    // symbols; in noise that is invisible, across a burst it can move the access code by a symbol, change an error count
-    // or -- where a carrier offset puts one symbol level near zero -- lose the packet on one side.
-    int vslot = -1, vspan = 0, vtiles0 = 0;                                // vtiles0: entries of the tile list this window already owns
-    bool vtried = false;
+    // ---- exact rows (exact.hip.h) ----
+    // The clock-recovery loop quantises its phase to 1/128 sample, so a 1e-6 difference of the polyphase stream parts the two
+    // trajectories in ~10 % of the windows within 150 symbols; in noise that is invisible, across a burst it can move the access
+    // code by a symbol, change an error count or lose the packet on one side.  So the rows of every BUSY window have been
+    // recomputed by the reference's own arithmetic before this kernel runs (presence_kernel -> bm1 -> exact_rows_kernel, in place):
+    // cov_rows of this window, from its first row on.  A classic hit inside them is final.  One that reaches beyond them (a
+    // packet under the presence threshold, a hit born from noise) is a claim: the window is listed, its rows are marked (bm2) and
+    // recomputed, and the second run -- this kernel with VER = true -- emits what the first has not.
+    int vslot = -1, vspan = 0;
+    int cov_rows = 0, first_uncov = -1;
+    if (!VER && p.verify && lane_ok && nmax != 0) cov_rows = exact_covered_rows(p.bm1, p.bm_tiles, (long long)kq * p.outs_per_slot, cq);
     auto ver_rows = [&](int span) { return ver_rows_of(p, span); };
-    if (!VER && p.verify == 1 && !p.prescan)
-        burst_scan<LAY>(p, tile, s_live, nch, sl, kq, cq, nmax != 0, vslot, vspan, vtiles0, vtried);
-    if (!VER && p.verify == 1 && p.prescan && lane_ok) {
-        // the scan ran in burst_scan_kernel, right behind the banks: its verdict for this window
-        const int vi = p.vinfo[w];
-        if (vi >= 0) { vslot = vi & 0xffff; vtiles0 = vi >> 16; vtried = true; }
-    }
-    auto vreserve = [&]() {
-        vtried = true;
-        const unsigned int s_ = atomicAdd(&p.vcount[0], 1u);
-        if (s_ < (unsigned int)p.vcap) vslot = (int)s_;
-        else atomicAdd(&p.vcount[2], 1u);                         // list full: this window keeps the polyphase path's records
-    };
 
     if (p.dbg_stop == 1) return;
     // ---- phase 1: M&M ----
@@ -998,10 +864,6 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             v[j] = *(const float4 *)(wgb + (o < max_off ? o : max_off));
         }
     };
-    // exact payload (VER): the loop's state at the last symbol that lies wholly inside the task's exact rows -- where the
-    // continuation over the long task's rows (finish_kernel) takes over
-    unsigned int snap_ii = 0u; int snap_oo = -1; float snap_mu = 0.f, snap_om = 0.f, snap_last = 0.f;
-    const bool snap_on = VER && p.exact_payload != 0;
     int base = 0;
     fetch(0);
     for (int it = 0;; it++) {
@@ -1020,7 +882,6 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         // byte offset of this lane's column in row `base` of the tile (24-bit arithmetic: one v_mad_u32_u24 per symbol)
         const uint32_t colb = (uint32_t)(((int)(mytile - tile) + c - base * kWinRowStride) * 4);
         while (ii <= lim && oo < nmax) {
-            if (snap_on && snap_oo < 0 && ii + 8u > n_ex) { snap_ii = ii; snap_oo = oo; snap_mu = mu; snap_om = omega; snap_last = last; }
             // interpolate: sum_q T[imu][7-q] * in[ii+q], q ascending
             // mu = x - floor(x) lies in [0, 1] (1.0 when x is a tiny negative number): imu in 0..128, no clamp needed
             // rintf(mu * 128) through the mantissa: mu * 128 + 1.5 * 2^23 is rounded to the nearest integer (ties to even, as
@@ -1116,43 +977,20 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int len1 = oo;                                         // 693, or the whole window if shorter
     int limit = len1 - 68 < 625 ? len1 - 68 : 625;
     int resume = 0, nhits = 0;
-    // exact payload: the weakest of the window's records' packets, as the W-tile energy ~50 us behind each record's start (inside its
-    // access code) -- long_task_kernel takes the burst as over when the energy has fallen 5 dB under it.  The smallest of the sums that
-    // end 50 and 75 us behind the start (and, where a tile is longer than 25 us, one tile further): the first still holds the tail of
-    // whatever ended under the access code's first symbols (a predecessor 30 dB stronger, a neighbour's switch-off splatter: level
-    // 6 x too high, the packet "over" at once; in a 125-us tile of the 4 Msps bank both sums are that tile); too LOW a level (a 68-us
-    // ID packet: the later sums are part noise) only makes the long task longer.
-    // level_rise: one of the records begins on a RISE -- the level is more than 1.5 x the W tiles that end in front of the record's
-    // tile (the burst scan's rule (b)): such a record stands on a packet whatever the noise references say (long_task_kernel's
-    // noise-born test; a packet as strong as the carrier it sits on is 2 x "the noise" at most).
-    float min_level = 3.0e38f;
-    bool level_rise = false;
-    auto note_level = [&](int cpos) {
-        if (!p.exact_payload || !p.ptile) return;
-        const int tb = kq * p.tiles_per_slot;
-        auto wsum = [&](int j) {
-            float sw = 0.f;
-            for (int u = 0; u < p.burst_w; u++) { const int t = tb + j - u; sw += (t >= 0 && t < p.ptile_stride) ? fmaxf((float)p.ptile[(size_t)cq * p.ptile_stride + t], 0.f) : 0.f; }
-            return sw;
-        };
-        const int j50 = (2 * cpos + 100) / p.tile_outs, j75 = (2 * cpos + 150) / p.tile_outs;
-        float lv = fminf(wsum(j50), wsum(j75));
-        if (p.tile_outs > 50) lv = fminf(lv, wsum(j75 + 1));
-        min_level = lv < min_level ? lv : min_level;
-        level_rise = level_rise || lv > 1.5f * wsum((2 * cpos) / p.tile_outs - 1);
-    };
     auto emit_classic = [&](int cpos, uint32_t lap, int err) {
-        note_level(cpos);
         if (!VER && p.verify) {
-            // a classic hit of the polyphase path is a claim the exact stage settles: the span that must be exact reaches to
-            // the end of this access code (+ header)
-            if (!vtried) vreserve();
-            if (vslot >= 0) {
-                const int e_ = cpos + 72 + p.span_extra + 8;
-                vspan = e_ > vspan ? e_ : vspan;
-                return;
+            // the rows this record stands on: to the end of its access code (+ the header the host will read)
+            const int span_ = cpos + 72 + p.span_extra + 8;
+            if (first_uncov >= 0 || ver_rows(span_) > cov_rows) {
+                if (first_uncov < 0) {
+                    const unsigned int s_ = atomicAdd(&p.vcount[0], 1u);
+                    if (s_ < (unsigned int)p.vcap) { vslot = (int)s_; first_uncov = cpos; }
+                    else atomicAdd(&p.vcount[2], 1u);             // list full: this window keeps the polyphase path's records
+                }
+                if (vslot >= 0) { vspan = span_ > vspan ? span_ : vspan; return; }
             }
         }
+        if (VER && cpos < emit_from) return;                      // (the first run emitted it, from the same exact rows)
         const unsigned int slot_h = atomicAdd(hit_count, 1u);
         if (slot_h < (unsigned int)p.max_hits) {
             DeviceHit h;
@@ -1218,18 +1056,12 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     search_classic(mybits, limit, kSymbolsShortAcDev, p.mode == 0, p.a0_lo, p.a0_hi, ac_lo, ac_hi, resume, nhits, emit_classic);
     if (p.dbg_stop == 3) return;
     if (vslot >= 0) {
-        // exact confirmation: this window's records come from the exact stage
-        int rows = ver_rows(vspan);
-        if (p.prescan && vtiles0 > 0) { const int r0 = p.vtasks[vslot].n_exact; rows = rows > r0 ? rows : r0; }   // the energy's span: whole tiles, computed by now
-        const int ntl = (rows + kVerTile - 1) / kVerTile;
-        if (ntl > vtiles0) {                                          // a hit reaches further than the energy's span (or there was no such span)
-            atomicAdd(&p.vcount[1], (unsigned int)(ntl - vtiles0));
-            const unsigned int tp = atomicAdd(&p.vtcount[cq], (unsigned int)(ntl - vtiles0));
-            uint32_t *tl = p.vtiles + (size_t)cq * p.vtcap;
-            for (int j = vtiles0; j < ntl; j++) if (tp + (j - vtiles0) < p.vtcap) tl[tp + (j - vtiles0)] = (uint32_t)vslot | ((uint32_t)j << 24);
-        }
+        // the rest of this window's records come from the second run: mark the rows they stand on (what presence has not marked)
+        const int rows = ver_rows(vspan);
+        const long long g_lo = (long long)kq * p.outs_per_slot;
+        exact_mark(p.bm2, p.bm1, p.bm_tiles, g_lo, g_lo + rows, cq, &p.vcount[1]);
         VerifyTask t_;
-        t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr;
+        t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr; t_.emit_from = first_uncov; t_.pad_ = 0;
         p.vtasks[vslot] = t_;
         return;
     }
@@ -1297,7 +1129,6 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                         hits[slot_h] = h;
                     }
                     nhits++;
-                    note_level(cpos);
                     le_resume = cpos + 40;
                 }
             }
@@ -1314,10 +1145,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
             FinishRec r;
             r.w = (int32_t)w; r.ii = ii; r.oo = oo; r.mu = mu; r.omega = omega; r.last = last;
             r.done = ended ? 1 : 0;
-            r.pad_ = (int32_t)(__float_as_uint(min_level < 1.0e38f ? min_level : 0.f) | (level_rise ? 0x80000000u : 0u));   // (a level is >= 0: the sign bit carries level_rise)
-            if (snap_on && snap_oo >= 0) {                             // the continuation restarts where the exact rows end
-                r.ii = snap_ii; r.oo = snap_oo; r.mu = snap_mu; r.omega = snap_om; r.last = snap_last; r.done = 0;
-            }
+            r.pad_ = 0;
             fin[f] = r;
             if (p.syms) {
                 win_fin[w] = (int)f;
@@ -1329,150 +1157,6 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Exact payload (BTGPU_FLAG_EXACT_PAYLOAD; round 5).  The exact stage makes a record's access code and header the reference's
-// own arithmetic; the symbols BEHIND them -- the payload every header-announced decode and CRC of the host layer reads
-// (lib/packet_impl.cc:1066-1160) -- came from the continuation over the polyphase stream, and in 2.3 % of the records of an
-// adversarial run (all of them multi-slot packets, the first differing symbol >= 478 symbols behind the hit) one or more of them
-// differed from the oracle's (scripts/emu_symbol_parity.py).  With the flag every window that hands symbols to the host gets a
-// LONG TASK: the direct-form DDC (verify_ddc_kernel, the same arithmetic) over the rows from where the window kernel stopped to the
-// END OF THE BURST -- read off the tile energies: until the 50-us energy has fallen to 1.5 x the noise and stays there --, and
-// finish_kernel continues over those rows.  Behind the burst the continuation is back on the polyphase stream (noise symbols; nsym).
-struct LongRows { int x, y; };
-struct LongView {
-    const LongRows *rows;            // [cap] exact rows [x, y) of the window of FinishRec f in dxl (y = 0: none)
-    const float *dxl;            // [cap][stride]
-    int stride, cap;
-};
-struct LongTaskParams {
-    VerifyTask *tasks;           // [cap]: window, exact rows (end)
-    uint32_t *tiles;             // tile lists by channel, like the exact stage's
-    unsigned int *lcount;        // [4 + 160]: 0 long tasks, 1 tiles, 2 turned away; 4 + c: entries of channel c's list; 84 + c: entries asked for
-    unsigned int tiles_cap;
-    LongRows *rows;                  // [cap]
-    int cap, stride;
-};
-constexpr int kLongLanes = 64;
-
-// one lane per FinishRec
-__global__ __launch_bounds__(kLongLanes) void long_task_kernel(WindowParams p, const FinishRec *__restrict__ fin,
-                                                               const unsigned int *__restrict__ fin_count, LongTaskParams lp)
-{
-    const unsigned int n = *fin_count;
-    const unsigned int f = blockIdx.x * kLongLanes + threadIdx.x;
-    // More record windows than the long-task buffers hold: NONE of this batch gets one.  (Which windows have the low indices is
-    // the order of the window kernels' atomics -- a per-window cut-off would make the records differ from run to run.)
-    if (n > (unsigned int)lp.cap) {
-        if (f < (unsigned int)lp.cap) lp.rows[f] = LongRows{0, 0};
-        if (f == 0) atomicAdd(&lp.lcount[2], n);
-        return;
-    }
-    if (f >= n) return;
-    lp.rows[f] = LongRows{0, 0};
-    const FinishRec r = fin[f];
-    if (r.done) return;
-    const int k = r.w / p.nch, c = r.w - k * p.nch;
-    const int TT = p.tile_outs, W = p.burst_w;
-    const int t0 = k * p.tiles_per_slot;
-    const double *pt = p.ptile + (size_t)c * p.ptile_stride;
-    const int tmax = p.ptile_stride;
-    // The packet's level: the W-tile energy ~50 us behind the start of a record (inside its access code), the weakest of the
-    // window's records (FinishRec.pad_).  The burst is on while the W-tile energy stays above 0.3 x that level (-5 dB) and has ended when it has been below for 2 W tiles: a
-    // packet >= 6 dB over the noise ends where it ends; a weaker one never "ends" and is taken to the end of the window (cost only).
-    // (The span's noise estimate is no help here: a long packet fills the whole span.  A gap inside a packet does not exist; a
-    // second packet right behind the first is simply taken along.)
-    const int row_lo = (int)r.ii > 8 ? (int)r.ii - 8 : 0;
-    const int jt_lo = row_lo / kVerTile;                        // first DDC tile
-    const int j0 = row_lo / TT;
-    const int jend = (p.ddc_out + TT - 1) / TT;
-    auto wsum = [&](int j) {
-        float sw = 0.f;
-        for (int u = 0; u < W; u++) { const int t = t0 + j - u; sw += (t >= 0 && t < tmax) ? fmaxf((float)pt[t], 0.f) : 0.f; }
-        return sw;
-    };
-    const float level = __uint_as_float((uint32_t)r.pad_ & 0x7fffffffu);
-    const bool on_a_rise = ((uint32_t)r.pad_ >> 31) != 0;              // (window_kernel's level_rise)
-    const float quiet = 0.3f * level;                                  // (0: no level known -- the window is taken to its end)
-    // A record that does not stand on a burst -- an access address or a six-error access code found in NOISE -- has no payload
-    // to be exact about, and its "level" never falls 5 dB: it would be taken to the end of its window (1500 of the 4500 long
-    // tasks of a bench batch, 60 % of their rows).  Not on a burst = its level is under the burst scan's own absolute threshold
-    // (2 x the mean noise, from the quietest block or tile of the window's first ~64 tiles and the seven in front) AND none of the
-    // window's records begins on a rise of the energy (window_kernel's level_rise).
-    {
-        const int NFl = kBurstFront;
-        float bmin = 3.0e38f, mn1 = 3.0e38f, ep = -1.f;
-        for (int jb = -NFl; jb + W <= 64; jb += W) {
-            float sb = 0.f; bool ok = true;
-            for (int u = 0; u < W; u++) {
-                const int t = t0 + jb + u;
-                const float e = (t >= 0 && t < tmax) ? (float)pt[t] : -1.f;
-                ok = ok && e > 0.f; sb += e;
-                mn1 = (e > 0.f && ep > 0.f && e < mn1) ? e : mn1; ep = e;
-            }
-            bmin = (ok && sb < bmin) ? sb : bmin;
-        }
-        // ... or, where a transmission fills all of those tiles (the record's own long packet with nothing in front of it at the start
-        // of a stream, or a stronger one that reaches back over the seven tiles in front: the local "noise" is a packet, and a real
-        // record's level lies under twice it), the channel's quietest tile of the whole batch (channel_floor_kernel).  Whichever is
-        // lowest: a record is left out only when every reference calls it noise.
-        const float thr_b = p.burst_abs * bmin, thr_1 = p.burst_abs1 * mn1;
-        const float cf_ = p.chan_floor ? p.chan_floor[c] : 3.0e38f;
-        const float thr_2 = cf_ < 1.0e38f ? p.burst_abs2 * cf_ : 3.0e38f;
-        float thr = thr_1 < thr_b ? thr_1 : thr_b;
-        thr = thr_2 < thr ? thr_2 : thr;
-        if (level > 0.f && thr < 1.0e38f && level < thr && !on_a_rise) return;
-    }
-    int last_on = j0, below = 0;
-    float s_cur = wsum(j0);
-    for (int j = j0; j < jend && t0 + j < tmax; j++) {
-        if (j > j0) {
-            const int tn = t0 + j, to = t0 + j - W;
-            s_cur += fmaxf((float)pt[tn], 0.f) - ((to >= 0) ? fmaxf((float)pt[to], 0.f) : 0.f);
-        }
-        if (s_cur > quiet) { last_on = j; below = 0; }
-        else if (++below >= 2 * W) break;
-    }
-    int row_hi = (last_on + 2) * TT;                            // (+ a tile: the filter's tail and the 8-tap interpolator)
-    row_hi = row_hi > p.ddc_out ? p.ddc_out : row_hi;
-    if (row_hi <= row_lo + 8) return;
-    const int jt_hi = (row_hi + kVerTile - 1) / kVerTile;       // DDC tiles [jt_lo, jt_hi)
-    const int nt = jt_hi - jt_lo;
-    // first pass: what this window asks of its channel's list (long_assign_kernel hands the entries out)
-    atomicAdd(&lp.lcount[4 + 80 + c], (unsigned int)nt);
-    VerifyTask t_;
-    t_.w = r.w; t_.n_exact = row_hi; t_.snr = 0.0;
-    lp.tasks[f] = t_;
-    lp.rows[f] = LongRows{jt_lo * kVerTile + 1, row_hi};      // (row t of a tile's first output is its demod halo: exact from + 1)
-}
-
-// second pass: the tile lists.  A channel whose windows ask for more entries than its list holds gets NO long task in this batch
-// (all of them or none: which of them would still fit is the order of the atomics, and the records must not depend on it).
-__global__ __launch_bounds__(kLongLanes) void long_assign_kernel(WindowParams p, const FinishRec *__restrict__ fin,
-                                                                 const unsigned int *__restrict__ fin_count, LongTaskParams lp)
-{
-    const unsigned int n = *fin_count;
-    const unsigned int f = blockIdx.x * kLongLanes + threadIdx.x;
-    if (n > (unsigned int)lp.cap || f >= n) return;
-    const LongRows lr = lp.rows[f];
-    if (lr.y <= 0) return;
-    const int c = fin[f].w % p.nch;
-    const int jt_lo = (lr.x - 1) / kVerTile, jt_hi = (lr.y + kVerTile - 1) / kVerTile, nt = jt_hi - jt_lo;
-    if (lp.lcount[4 + 80 + c] > lp.tiles_cap) { lp.rows[f] = LongRows{0, 0}; atomicAdd(&lp.lcount[2], 1u); return; }
-    const unsigned int tp = atomicAdd(&lp.lcount[4 + c], (unsigned int)nt);
-    uint32_t *tl = lp.tiles + (size_t)c * lp.tiles_cap;
-    for (int j = 0; j < nt; j++) tl[tp + j] = (uint32_t)f | ((uint32_t)(jt_lo + j) << 24);
-    atomicAdd(&lp.lcount[0], 1u); atomicAdd(&lp.lcount[1], (unsigned int)nt);
-}
-
-// Continue the M&M recursion of the windows that reported hits (a few per cent) to the end of their
-// window and store len.  One lane per window; each lane stages its own channel into a private LDS slab,
-// kFinRows samples at a time, all loads of a refill in flight together.  Source: the 100-bin bank's
-// tile-blocked copy dcol[tile][80][25] (a channel's 25 consecutive instants are 100 contiguous bytes) or,
-// where no such copy exists (small-M and direct-form banks: rows of 4..40 floats), the strided column of the
-// time-major stream d[g][drow].  The strided column of the 80-float rows cost a cache line per sample
-// (2.0 GB of HBM reads per 2304-slot batch for 90 MB of samples, and 0.08 ms on the bank kernel running
-// beside it); a throughput-style gather of the hit columns in front of this kernel was no better (its burst
-// slowed the next batch's bank kernel by as much as it saved here).  No cross-lane data => no barriers.
 constexpr int kFinRows = 16;       // rows per refill
 constexpr int kFinRing = 32;       // rows resident per lane
 constexpr int kFinSlab = kFinRing + 8 + 1;   // + the first eight slots again behind the ring (the 8-tap window never wraps),
@@ -1484,7 +1168,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     WindowParams p, const float *__restrict__ d, int drow, long long d_rows,
     const float *__restrict__ mmse_g, const FinishRec *__restrict__ fin,
     const unsigned int *__restrict__ fin_count, int *__restrict__ win_len, uint32_t *__restrict__ symbits,
-    const float *__restrict__ dcol = nullptr, LongView lv = LongView{nullptr, nullptr, 0, 0})
+    const float *__restrict__ dcol = nullptr)
 {
     constexpr unsigned int RING = kFinRing, MASK = RING - 1;
     __shared__ __attribute__((aligned(16))) float mmse[129 * 8];
@@ -1520,10 +1204,7 @@ __global__ __launch_bounds__(64) void finish_kernel(
     // rows [hi - RING, hi) are resident, row q in slot q & 31 (slots 0..7 also at 32..39); refills are whole
     // 16-row blocks, so a block is either slots 0..15 (guard copy of its first half) or 16..31
     unsigned int hi = ii & ~(unsigned int)(kFinRows - 1);
-    // exact payload: rows [lrow.x, lrow.y) of this window come from the long task's exact rows
-    const LongRows lrow = (SYMS && lv.rows && f < (unsigned int)lv.cap) ? lv.rows[f] : LongRows{0, 0};
-    const float *lx = lv.dxl + (size_t)(f < (unsigned int)lv.cap ? f : 0) * (size_t)lv.stride;
-    auto fetch_poly = [&](float *v) {                            // rows [hi, hi + 16): unconditional loads, values selected later
+    auto fetch = [&](float *v) {                            // rows [hi, hi + 16): unconditional loads, values selected later
         if (p.dbg_stop == 9) {                                   // timing experiment (BTGPU_WIN_STOP=9): no stream traffic
 #pragma unroll
             for (int j = 0; j < kFinRows; j++) v[j] = 0.01f * (float)((hi + j) & 7) - 0.03f;
@@ -1543,18 +1224,6 @@ __global__ __launch_bounds__(64) void finish_kernel(
         }
 #pragma unroll
         for (int j = 0; j < kFinRows; j++) { const unsigned int idx = hi + j; v[j] = col[(size_t)(idx < nvalid ? idx : nvalid - 1) * drow]; }
-    };
-    auto fetch = [&](float *v) {
-        if (SYMS && lrow.y > 0 && (int)hi >= lrow.x && (int)hi + kFinRows <= lrow.y) {            // the whole block is exact
-#pragma unroll
-            for (int j = 0; j < kFinRows; j++) v[j] = lx[hi + j];
-            return;
-        }
-        fetch_poly(v);
-        if (SYMS && lrow.y > 0 && (int)hi + kFinRows > lrow.x && (int)hi < lrow.y) {              // a block across either end
-#pragma unroll
-            for (int j = 0; j < kFinRows; j++) { const int idx = (int)hi + j; if (idx >= lrow.x && idx < lrow.y) v[j] = lx[idx]; }
-        }
     };
     auto put = [&](const float *v) {                             // rows [hi, hi + 16) -> ring; rows past the stream read as 0
         const unsigned int s0 = hi & MASK;                       // 0 or 16

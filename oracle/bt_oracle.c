@@ -25,12 +25,12 @@
 #define CHANNEL_WIDTH               1000000.0
 #define MMSE_NTAPS                  8
 #define MMSE_NSTEPS                 128
-#define LANES                       BTO_FIR_LANES
 
 typedef struct fir_bank {
     int    ntaps;        /* true length                                  */
-    int    ntp;          /* padded to a multiple of LANES                */
-    float *tr, *ti;      /* [nch][ntp] reversed complex taps, zero padded */
+    int    blk;          /* block length of the summation order = the decimation (ddc_run) */
+    int    ntp;          /* padded to whole blocks: ceil(ntaps / blk) * blk */
+    float *tr, *ti;      /* [nch][blk][ntp / blk]: reversed complex taps, zero padded, tap q blk + r at [r][q] */
     double *foff;        /* [nch] frequency offset of each channel (Hz)  */
 } fir_bank;
 
@@ -235,10 +235,12 @@ float bto_mmse_interpolate(const bto_ctx *c, const float *in, float mu)
 static double channel_abs_freq(int ch) { return BASE_FREQUENCY + ch * CHANNEL_WIDTH; }
 
 static void build_bank(fir_bank *b, const float *h, int ntaps, int nch, int low_ch,
-                       double center, double fs, double extra)
+                       double center, double fs, double extra, int blk)
 {
     b->ntaps = ntaps;
-    b->ntp = (ntaps + LANES - 1) / LANES * LANES;
+    b->blk = blk;
+    b->ntp = (ntaps + blk - 1) / blk * blk;
+    const int nq = b->ntp / blk;
     b->tr = (float *)calloc((size_t)nch * b->ntp, sizeof(float));
     b->ti = (float *)calloc((size_t)nch * b->ntp, sizeof(float));
     b->foff = (double *)calloc(nch, sizeof(double));
@@ -250,8 +252,8 @@ static void build_bank(fir_bank *b, const float *h, int ntaps, int nch, int low_
             float wr, wi;
             phase_factor(foff, fs, k, &wr, &wi);
             int j = ntaps - 1 - k;               /* stored reversed: y = sum_j t[j] x[base+j] */
-            b->tr[(size_t)c * b->ntp + j] = h[k] * wr;
-            b->ti[(size_t)c * b->ntp + j] = h[k] * wi;
+            b->tr[(size_t)c * b->ntp + (size_t)(j % blk) * nq + j / blk] = h[k] * wr;
+            b->ti[(size_t)c * b->ntp + (size_t)(j % blk) * nq + j / blk] = h[k] * wi;
         }
     }
 }
@@ -300,9 +302,9 @@ bto_ctx *bto_create(double sample_rate, double center_freq, double squelch_db, i
     if (hi > 78) hi = 78;
     c->low_ch = lo; c->high_ch = hi;
     c->nch = hi >= lo ? hi - lo + 1 : 0;
-    build_bank(&c->ch_bank, c->h_ch, c->ntaps_ch, c->nch, lo, center_freq, sample_rate, 0.0);
+    build_bank(&c->ch_bank, c->h_ch, c->ntaps_ch, c->nch, lo, center_freq, sample_rate, 0.0, c->decim);
     build_bank(&c->noise_bank, c->h_noise, c->ntaps_noise, c->nch, lo, center_freq, sample_rate,
-               790000.0);
+               790000.0, c->decim);
 
     c->demod_gain = (float)(channel_sps / M_PI_2);
     c->gain_mu = 0.175f;
@@ -382,43 +384,62 @@ int bto_noise_out(const bto_ctx *c)                                    /* :269 *
 /* [EXT] freq_xlating_fir_filter_ccf::work restated, fixed summation order     */
 /* ------------------------------------------------------------------------- */
 
-/* xr/xi: de-interleaved window with >= LANES zeros of slack after the end. */
+/* SUMMATION ORDER (this repository's to define: VOLK's in the reference is unspecified and GNU Radio is not in the image,
+ * bt_oracle.h).  With the reversed taps t[j] and D = the decimation, the filter is taken in BLOCKS of D taps:
+ *     G[q] = fmaf chain over r = 0 .. D-1 from +0, j = q D + r:
+ *                re: fmaf(tr[j], xr, .) then fmaf(-ti[j], xi, .)     im: fmaf(ti[j], xr, .) then fmaf(tr[j], xi, .)
+ *     y    = ((G[0] + G[1]) + G[2]) + ...      (q ascending; taps beyond the filter are exact zeros)
+ * -- the polyphase-GEMM form of the decimating FIR: G[q][m] = sum_r t[qD + r] x[mD + r] is a matrix product over the input
+ * reshaped into columns of D samples, and y[n] = sum_q G[q][n + q].  The product's exact stage computes it on the fp32 matrix
+ * pipe (v_mfma_f32_32x32x2_f32 is bit for bit this fmaf chain, scripts/ubench/exact_mfma.hip), the generic kernels on the VALU.
+ * xt: the window transposed into those columns, xt[(r * 2 + part) * ncol + m] = part of x[m D + r], so that the loop over q
+ * (the one the compiler vectorises) reads consecutive floats. */
 static void ddc_run(const fir_bank *b, int chan_idx, double fs, int decim,
-                    const float *xr, const float *xi, int first, int nout, float *out_iq)
+                    const float *xt, int ncol, int first, int nout, float *out_iq)
 {
-    const float *tr = b->tr + (size_t)chan_idx * b->ntp;
+    const int D = b->blk, nq = b->ntp / b->blk;
+    const float *tr = b->tr + (size_t)chan_idx * b->ntp;      /* transposed: tr[r * nq + q] = tap q D + r */
     const float *ti = b->ti + (size_t)chan_idx * b->ntp;
-    const int ntp = b->ntp;
     const double foff = b->foff[chan_idx];
+    float *gr = (float *)malloc(sizeof(float) * 2 * (size_t)nq), *gi = gr + nq;
+    (void)decim;
     for (int i = 0; i < nout; i++) {
-        float ar[LANES], ai[LANES];
-        for (int l = 0; l < LANES; l++) { ar[l] = 0.0f; ai[l] = 0.0f; }
-        const float *pr = xr + first + (size_t)i * decim;
-        const float *pi = xi + first + (size_t)i * decim;
-        for (int j = 0; j < ntp; j += LANES) {
-            for (int l = 0; l < LANES; l++) {
-                float a = tr[j + l], bq = ti[j + l], vr = pr[j + l], vi = pi[j + l];
-                ar[l] = fmaf(a, vr, ar[l]);
-                ar[l] = fmaf(-bq, vi, ar[l]);
-                ai[l] = fmaf(a, vi, ai[l]);
-                ai[l] = fmaf(bq, vr, ai[l]);
+        for (int q = 0; q < nq; q++) { gr[q] = 0.0f; gi[q] = 0.0f; }
+        for (int r = 0; r < D; r++) {
+            /* sample first + i D + q D + r = column (i + q + a), row rho */
+            const int s0 = first + r, a = s0 / D, rho = s0 - a * D;
+            const float *pr = xt + (size_t)(2 * rho) * ncol + i + a, *pi = xt + (size_t)(2 * rho + 1) * ncol + i + a;
+            const float *ar = tr + (size_t)r * nq, *ai = ti + (size_t)r * nq;
+            for (int q = 0; q < nq; q++) {
+                const float ta = ar[q], tb = ai[q], vr = pr[q], vi = pi[q];
+                gr[q] = fmaf(ta, vr, gr[q]);
+                gr[q] = fmaf(-tb, vi, gr[q]);
+                gi[q] = fmaf(tb, vr, gi[q]);
+                gi[q] = fmaf(ta, vi, gi[q]);
             }
         }
-        float yr = ((ar[0] + ar[1]) + (ar[2] + ar[3])) + ((ar[4] + ar[5]) + (ar[6] + ar[7]));
-        float yi = ((ai[0] + ai[1]) + (ai[2] + ai[3])) + ((ai[4] + ai[5]) + (ai[6] + ai[7]));
+        float yr = gr[0], yi = gi[0];
+        for (int q = 1; q < nq; q++) { yr = yr + gr[q]; yi = yi + gi[q]; }
         /* rotator: out[i] = y[i] * exp(-j theta D i), restarted per window (Q3) */
         float rr, ri;
         phase_factor(-foff, fs, (long long)decim * i, &rr, &ri);
         out_iq[2 * i]     = fmaf(-yi, ri, yr * rr);
         out_iq[2 * i + 1] = fmaf(yi, rr, yr * ri);
     }
+    free(gr);
 }
 
-static void deinterleave(const float *win, int n, float **xr, float **xi)
+/* the window in columns of D samples (see ddc_run); zero columns behind the end */
+static int transpose_cols(const float *win, int n, int D, int extra_cols, float **xt)
 {
-    *xr = (float *)calloc((size_t)n + 2 * LANES, sizeof(float));
-    *xi = (float *)calloc((size_t)n + 2 * LANES, sizeof(float));
-    for (int i = 0; i < n; i++) { (*xr)[i] = win[2 * i]; (*xi)[i] = win[2 * i + 1]; }
+    const int ncol = (n + D - 1) / D + extra_cols;
+    *xt = (float *)calloc((size_t)2 * D * ncol, sizeof(float));
+    for (int i = 0; i < n; i++) {
+        const int m = i / D, r = i - m * D;
+        (*xt)[(size_t)(2 * r) * ncol + m] = win[2 * i];
+        (*xt)[(size_t)(2 * r + 1) * ncol + m] = win[2 * i + 1];
+    }
+    return ncol;
 }
 
 static double mean_mag2(const float *iq, int n)
@@ -432,18 +453,18 @@ static double mean_mag2(const float *iq, int n)
     return e / n;
 }
 
-static int channel_samples_d(bto_ctx *c, int channel, const float *xr, const float *xi,
+static int channel_samples_d(bto_ctx *c, int channel, const float *xt, int ncol,
                              float *out_iq, double *energy)
 {
     int idx = channel - c->low_ch;
     if (idx < 0 || idx >= c->nch) { *energy = 1.0; return 0; }      /* multi_block.cc:223-225 */
     int nout = bto_ddc_out(c);
-    ddc_run(&c->ch_bank, idx, c->sample_rate, c->decim, xr, xi, c->first_ch, nout, out_iq);
+    ddc_run(&c->ch_bank, idx, c->sample_rate, c->decim, xt, ncol, c->first_ch, nout, out_iq);
     *energy = mean_mag2(out_iq, nout);
     return nout;
 }
 
-static int check_snr_d(bto_ctx *c, int channel, double on_energy, const float *xr, const float *xi,
+static int check_snr_d(bto_ctx *c, int channel, double on_energy, const float *xt, int ncol,
                        double *snr, double *off_energy)
 {
     int idx = channel - c->low_ch;
@@ -452,7 +473,7 @@ static int check_snr_d(bto_ctx *c, int channel, double on_energy, const float *x
     else {
         int nout = bto_noise_out(c);
         float *tmp = (float *)malloc(sizeof(float) * 2 * (size_t)nout);
-        ddc_run(&c->noise_bank, idx, c->sample_rate, c->decim, xr, xi, c->first_noise, nout, tmp);
+        ddc_run(&c->noise_bank, idx, c->sample_rate, c->decim, xt, ncol, c->first_noise, nout, tmp);
         off = mean_mag2(tmp, nout);
         free(tmp);
     }
@@ -463,20 +484,20 @@ static int check_snr_d(bto_ctx *c, int channel, double on_energy, const float *x
 
 int bto_channel_samples(bto_ctx *c, int channel, const float *win, float *out_iq, double *energy)
 {
-    float *xr, *xi;
-    deinterleave(win, c->history, &xr, &xi);
-    int n = channel_samples_d(c, channel, xr, xi, out_iq, energy);
-    free(xr); free(xi);
+    float *xt;
+    int ncol = transpose_cols(win, c->history, c->decim, 2, &xt);
+    int n = channel_samples_d(c, channel, xt, ncol, out_iq, energy);
+    free(xt);
     return n;
 }
 
 int bto_check_snr(bto_ctx *c, int channel, double on_energy, const float *win, double *snr,
                   double *off_energy)
 {
-    float *xr, *xi;
-    deinterleave(win, c->history, &xr, &xi);
-    int r = check_snr_d(c, channel, on_energy, xr, xi, snr, off_energy);
-    free(xr); free(xi);
+    float *xt;
+    int ncol = transpose_cols(win, c->history, c->decim, 2, &xt);
+    int r = check_snr_d(c, channel, on_energy, xt, ncol, snr, off_energy);
+    free(xt);
     return r;
 }
 
@@ -1003,27 +1024,27 @@ static int search_symbols(const bto_ctx *c, char *symbols, int len, int channel,
     return nh;
 }
 
-static int work_channel(bto_ctx *c, int ch, const float *xr, const float *xi, uint32_t slot,
+static int work_channel(bto_ctx *c, int ch, const float *xt, int ncol, uint32_t slot,
                         bto_hit *hits, int max_hits, float *chbuf, char *symbols)
 {
     double e_on, snr;
-    int n = channel_samples_d(c, ch, xr, xi, chbuf, &e_on);
-    if (!check_snr_d(c, ch, e_on, xr, xi, &snr, NULL)) return 0;
+    int n = channel_samples_d(c, ch, xt, ncol, chbuf, &e_on);
+    if (!check_snr_d(c, ch, e_on, xt, ncol, &snr, NULL)) return 0;
     int len = bto_channel_symbols(c, chbuf, n, symbols, NULL);
     return search_symbols(c, symbols, len, ch, slot, snr, hits, max_hits);
 }
 
 int bto_work(bto_ctx *c, const float *win, uint32_t slot, bto_hit *hits, int max_hits)
 {
-    float *xr, *xi;
-    deinterleave(win, c->history, &xr, &xi);
+    float *xt;
+    int ncol = transpose_cols(win, c->history, c->decim, 2, &xt);
     int nout = bto_ddc_out(c);
     float *chbuf = (float *)malloc(sizeof(float) * 2 * (size_t)(nout + 1));
     char *symbols = (char *)calloc((size_t)c->history + 64, 1);
     int nh = 0;
     for (int ch = c->low_ch; ch <= c->high_ch; ch++)
-        nh += work_channel(c, ch, xr, xi, slot, hits + nh, max_hits - nh, chbuf, symbols);
-    free(chbuf); free(symbols); free(xr); free(xi);
+        nh += work_channel(c, ch, xt, ncol, slot, hits + nh, max_hits - nh, chbuf, symbols);
+    free(chbuf); free(symbols); free(xt);
     return nh;
 }
 
@@ -1074,8 +1095,8 @@ int bto_run_stream_mt(bto_ctx *c, const float *iq, size_t n_complex, bto_hit *hi
     {
         bto_ctx local = *c;                        /* private M&M state (windowed reset) */
         local.mm_policy = BTO_MM_WINDOWED_RESET;
-        float *xr = (float *)calloc((size_t)H + 2 * LANES, sizeof(float));
-        float *xi = (float *)calloc((size_t)H + 2 * LANES, sizeof(float));
+        const int D = local.decim, ncol = (H + D - 1) / D + 2;
+        float *xt = (float *)calloc((size_t)2 * D * ncol, sizeof(float));
         float *chbuf = (float *)malloc(sizeof(float) * 2 * (size_t)(nout + 1));
         char *symbols = (char *)calloc((size_t)H + 64, 1);
         bto_hit tmp[64];
@@ -1084,11 +1105,13 @@ int bto_run_stream_mt(bto_ctx *c, const float *iq, size_t n_complex, bto_hit *hi
             long long a0 = k * slot - (H - 1);
             for (int i = 0; i < H; i++) {
                 long long a = a0 + i;
-                if (a < 0 || (size_t)a >= n_complex) { xr[i] = 0.f; xi[i] = 0.f; }
-                else { xr[i] = iq[2 * a]; xi[i] = iq[2 * a + 1]; }
+                const int m = i / D, r = i - m * D;
+                const int in = !(a < 0 || (size_t)a >= n_complex);
+                xt[(size_t)(2 * r) * ncol + m] = in ? iq[2 * a] : 0.f;
+                xt[(size_t)(2 * r + 1) * ncol + m] = in ? iq[2 * a + 1] : 0.f;
             }
             for (int ch = local.low_ch; ch <= local.high_ch; ch++) {
-                int n = work_channel(&local, ch, xr, xi, (uint32_t)k, tmp, 64, chbuf, symbols);
+                int n = work_channel(&local, ch, xt, ncol, (uint32_t)k, tmp, 64, chbuf, symbols);
                 if (n > 0) {
 #pragma omp critical
                     {
@@ -1097,7 +1120,7 @@ int bto_run_stream_mt(bto_ctx *c, const float *iq, size_t n_complex, bto_hit *hi
                 }
             }
         }
-        free(xr); free(xi); free(chbuf); free(symbols);
+        free(xt); free(chbuf); free(symbols);
     }
     qsort(hits, nh, sizeof(bto_hit), hit_cmp);
     if (slots_done) *slots_done = (int)S;

@@ -63,7 +63,7 @@ extern "C" {
 #define BTO_KIND_AC 0
 #define BTO_KIND_AA 1
 
-#define BTO_FIR_LANES 8       /* summation order: 8 strided partial sums */
+/* FIR summation order: blocks of D = decimation taps, each an fmaf chain from +0, block sums added ascending (bt_oracle.c ddc_run) */
 
 typedef struct bto_hit {
     uint32_t slot;        /* work() call index k == d_cumulative_count / samples_per_slot */
