@@ -27,7 +27,7 @@ L.emu_front_m_run.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ct
 L.emu_verify_counts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
 if os.environ.get("EMU_VERIFY") is not None:                    # 0: exact confirmation off (the round-3 behaviour), 2: hit windows only
     L.emu_set_verify(int(os.environ["EMU_VERIFY"]))
-vc = (ctypes.c_uint * 4)()
+vc = (ctypes.c_uint * 8)()
 tot = dict(verified_windows=0, windows=0, cases=0, planted=0, planted_differing=0, planted_offset_differs=0, other_emu=0, other_ref=0, other_only_emu=0,
            other_only_ref=0, nsym_dev_max=0, failed=0)
 for case in range(cases):
@@ -49,7 +49,7 @@ for case in range(cases):
     n = L.emu_front_m_run(fs, fc, mode, int(le), sq, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), nsl,
                           rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap)
     assert 0 <= n <= cap, n
-    L.emu_verify_counts(vc); tot["verified_windows"] += int(vc[0]); tot["windows"] += nsl * (o.high_ch - o.low_ch + 1)
+    L.emu_verify_counts(vc); tot["verified_windows"] += int(vc[0]) + int(vc[3]); tot["windows"] += nsl * (o.high_ch - o.low_ch + 1)
     assert vc[2] == 0, "task list overflow"
     gi = rec[:n, :7]
     wi = np.array([[h.slot, h.channel, h.kind, h.offset, h.lap, h.ac_errors, h.nsym] for h in want], np.int64).reshape(-1, 7)
@@ -66,5 +66,5 @@ for case in range(cases):
         print("   only emu   :", sorted(gs - ws)); print("   only oracle:", sorted(ws - gs))
     print("case %4d fs %3.0fM sniff %d le %d sq %4.1f snr %4.1f occ %.2f slots %2d  planted %3d identical %s offset-differs %d nsym-dev %d  other emu/ref %d/%d one-sided %d/%d  verified %d" %
           (case, fs / 1e6, sniff, le, sq, snr_db, occ, nsl, d["planted_ref"], d["planted_identical"], d["planted_offset_differs"],
-           d["planted_nsym_max_abs_dev"], d["other_gpu"], d["other_ref"], d["other_only_gpu"], d["other_only_ref"], int(vc[0])), flush=True)
+           d["planted_nsym_max_abs_dev"], d["other_gpu"], d["other_ref"], d["other_only_gpu"], d["other_only_ref"], int(vc[0]) + int(vc[3])), flush=True)
 print("TOTAL", tot)

@@ -24,7 +24,7 @@ cap = 1 << 16
 rec = np.zeros((cap, 8), np.int64); snr = np.zeros(cap, np.float64)
 n = L.emu_front_m_run(fs, fc, mode, 0, 10.0, xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(x), nsl,
                       rec.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), snr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cap)
-vc = (ctypes.c_uint * 4)(); L.emu_verify_counts(vc)
+vc = (ctypes.c_uint * 8)(); L.emu_verify_counts(vc)
 nw = nsl * (o.high_ch - o.low_ch + 1)
 print("windows %d, bursts planted %d, records %d, verified windows %d (%.1f %%), tiles %d" % (nw, len(truth), n, vc[0], 100.0 * vc[0] / nw, vc[1]))
 

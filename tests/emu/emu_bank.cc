@@ -253,7 +253,7 @@ int emu_b2map(int rows, int lanes, int sweeps, uint16_t *out)
 // window_kernel + finish_kernel + nsym_patch_kernel over the demodulated stream d (time-major, `drow` floats per row;
 // dcol = the 100-bin bank's tile-blocked copy or null), the channel block energies P / Pt and the noise energies Qn
 struct StudyCapture { std::vector<float> d; std::vector<double> snr; long long G = 0; int drow = 0, nch = 0, S = 0;
-                      std::vector<VerifyTask> tasks; std::vector<float> dx; };
+                      std::vector<VerifyTask> tasks; };
 static uint32_t *g_sym_out = nullptr; static uint8_t *g_hdr_out = nullptr;     // set by emu_front_direct_headers_run
 static bool g_rows_only = false;                        // emu_verify_check: the demodulated rows are all it reads -- the exact noise bank is left out (E_off = 0: every window passes)
 static StudyCapture *g_study = nullptr;                 // emu_margin_study: keep the demodulated stream and the squelch SNRs
@@ -265,7 +265,7 @@ struct VerifyEmu {
     unsigned int counts[4] = {0, 0, 0, 0};              // out: tasks, tiles, turned away
 };
 static int g_verify_mode = 1;                            // emu_set_verify: 0 off, 1 hits + burst energy, 2 hits only
-static unsigned int g_verify_counts[4] = {0, 0, 0, 0};  // of the last emulated front end
+static unsigned int g_verify_counts[kVerCountWords] = {0};  // of the last emulated front end: tasks, pairs marked, turned away, busy windows, pairs computed (two launches)
 extern "C" void emu_set_verify(int mode) { g_verify_mode = mode; }
 static int g_exact_payload = 0;                          // emu_set_exact_payload: BTGPU_FLAG_EXACT_PAYLOAD (with symbols)
 extern "C" void emu_set_exact_payload(int on) { g_exact_payload = on; }
@@ -274,7 +274,15 @@ extern "C" void emu_long_counts(unsigned int *out) { std::memcpy(out, g_long_cou
 extern "C" void emu_set_fuse_m(int on) { g_fuse_m = on; }
 extern "C" int emu_last_fused_m(void) { return g_last_fused_m; }
 extern "C" void emu_verify_counts(unsigned int *out) { std::memcpy(out, g_verify_counts, sizeof g_verify_counts); }
-static std::vector<VerifyTask> g_verify_tasks;           // of the last emulated front end
+static std::vector<VerifyTask> g_verify_tasks;           // of the last emulated front end: windows with exact rows (n_exact: covered rows from the window's first)
+static std::vector<VerifyTask> g_second_run;             // ... and the windows its second run took
+static std::vector<uint32_t> g_exact_bitmap; static int g_exact_tiles = 0;   // bm1 | bm2 of the last emulated front end
+extern "C" int emu_exact_bitmap(uint32_t *out, int cap_words)
+{
+    const int n = (int)std::min<size_t>(g_exact_bitmap.size(), (size_t)cap_words);
+    if (out) std::memcpy(out, g_exact_bitmap.data(), (size_t)n * 4);
+    return g_exact_tiles;
+}
 extern "C" int emu_verify_tasks(int *w_out, int *rows_out, int cap)
 {
     const int n = (int)std::min<size_t>(g_verify_tasks.size(), (size_t)cap);
@@ -292,7 +300,6 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     const int max_hits = 1 << 16;
     std::vector<uint64_t> pcol(des.ac.btbb_pcol, des.ac.btbb_pcol + 24);
     WindowParams p = make_window_params(des, S, nb, 0, max_hits, want_syms, pcol.data());
-    p.exact_payload = (g_exact_payload && want_syms && ve && ve->mode > 0) ? 1 : 0;
     const size_t W = (size_t)S * nch;
     std::vector<double> e_on(W), e_off(W), snr(W);
     std::vector<int> win_len(W, -1), win_fin(W, -1);
@@ -301,57 +308,49 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     unsigned int counts[2] = {0, 0};
     std::vector<uint32_t> winbits((size_t)((S + 2) / 3 + 1) * kBitWords * kWinThreads, 0u);
     std::vector<uint32_t> symbits(want_syms ? W * kSymWords : 1, 0u);
-    // exact confirmation: task list, exact rows, task stream
+    // exact rows: bitmaps, the second run's task list and task stream
     VerifyBuffers vb;
-    std::vector<VerifyTask> vtasks; std::vector<uint32_t> vtiles; std::vector<float> dx; std::vector<float4> dxt4;
+    std::vector<VerifyTask> vtasks; std::vector<float4> dxt4; std::vector<uint32_t> bm;
     unsigned int vcount[kVerCountWords] = {0};
-    const bool verify = ve && ve->mode > 0;
+    const bool verify = ve && ve->mode > 0 && exact_rows_available(des) && exact_rows_pick(des.d.decimation);
     if (verify) {
         vb.vcap = verify_capacity(S, nch);
-        vtasks.resize((size_t)vb.vcap); vtiles.resize(verify_tiles_capacity(S) * nch); vb.tiles_cap = (unsigned int)verify_tiles_capacity(S); dx.assign((size_t)vb.vcap * kVerRows, -55.f);
+        vtasks.resize((size_t)vb.vcap);
         const int nps = (vb.vcap + nch - 1) / nch;
         dxt4.assign(((size_t)nps * kVerRows * drow + 3) / 4 + 16, make_float4(-66.f, -66.f, -66.f, -66.f));
-        vb.tasks = vtasks.data(); vb.tiles = vtiles.data(); vb.vcount = vcount; vb.dx = dx.data(); vb.dxt = (float *)dxt4.data();
+        vb.bm_tiles = exact_ntiles(G);
+        bm.assign((size_t)2 * vb.bm_tiles * kExBmWords, 0u);
+        vb.bm1 = bm.data(); vb.bm2 = bm.data() + (size_t)vb.bm_tiles * kExBmWords;
+        vb.tasks = vtasks.data(); vb.vcount = vcount; vb.dxt = (float *)dxt4.data();
         set_verify_flagging(p, des, *ve->fp, ve->small, ve->mode, ve->ptile, ve->ntiles, vb, want_syms, ve->tile_outs);
     }
-    std::vector<float> chan_floor((size_t)std::max(nch, 1), 3.0e38f);
-    if (verify && p.verify == 1) {
-        emu::launch(dim3(2u, (unsigned)nch), dim3(256), [&]() { channel_floor_kernel(p.ptile, p.ptile_stride, p.ptile_stride, chan_floor.data()); });
-        p.chan_floor = getenv("EMU_NO_FLOOR") ? nullptr : chan_floor.data();
-        if (getenv("EMU_DBG_FLOOR")) for (int c = 0; c < nch; c++) std::fprintf(stderr, "floor ch %d %.4g\n", c, chan_floor[c]);
-    }
-    // the runtime's choreography (btgpu.hip process_batch): burst scan behind the banks, the energy-selected tasks' DDC, the window
-    // kernel, the DDC of what its hits added, fill, exact window kernel.  EMU_PRESCAN=1 (the runtime's BTGPU_PRESCAN=1; default: the scan inside the window kernel, one DDC launch)
-    static const bool prescan_env = getenv("EMU_PRESCAN") && atoi(getenv("EMU_PRESCAN")) == 1;
-    const bool prescan = prescan_env && verify && p.verify == 1;
-    std::vector<VerifyTask> ltasks; std::vector<uint32_t> ltiles; std::vector<LongRows> lrows; std::vector<float> dxl;
-    unsigned int lcount[kVerCountWords + 80] = {0};
-    LongView lview{nullptr, nullptr, 0, 0};
-    std::vector<int32_t> vinfo(prescan ? W : 1, -1);
-    std::vector<unsigned int> vtstart(80, 0u);
+    std::vector<float> chan_floor(81, 3.0e38f);
+    // the runtime's choreography (btgpu.hip process_batch): channel floor, presence, exact rows in place (bm1), the window kernel, the
+    // exact rows under its uncovered hits (bm2), fill, the second run
+    std::vector<float> tapsA;
+    auto run_exact = [&](const uint32_t *bitmap, unsigned int *stat) {
+        const int D = des.d.decimation;
+        if (tapsA.empty()) { tapsA.resize((size_t)nch * D * 64); exact_pack_taps(des.channel.taps.data(), nch, des.channel.ntp, D, tapsA.data()); }
+        const ExactParams ep = make_exact_params(des, (size_t)ve->x_len, 0, G, tapsA.data(), (const float2 *)des.channel.rot.data(), des.atan_tab,
+                                                 bitmap, vb.bm_tiles, const_cast<float *>(d), drow, const_cast<float *>(dcol_p), stat);
+        const ExactRowsKernel kern = exact_rows_pick(D);
+        if (exact_lds_bytes(D) > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", exact_lds_bytes(D)); std::abort(); }
+        bool any = false;
+        for (size_t i = 0; i < (size_t)vb.bm_tiles * kExBmWords; i++) any = any || bitmap[i];
+        if (!any) return;
+        std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
+        // (ONE emulated workgroup strides over all the tiles, as the kernel allows: the fibers are set up once)
+        emu::launch(dim3(1), dim3(kExThreads), [&]() { kern(ep, ve->x); });
+    };
     auto launch_window = [&](auto lay) {
         using LAY = decltype(lay);
-        int mp = 0, F = 0;
-        std::vector<float> tv;
-        std::vector<double> st(nch);
-        VerifyParams vp{};
-        VerifyDdcLaunch vl{};
-        auto run_ddc = [&](const VerifyParams &vq) {
-            if (vl.lds > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", (size_t)vl.lds); std::abort(); }
-            std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
-            emu::launch(dim3((unsigned)(2 * nch + 1)), dim3((unsigned)vl.threads), [&]() { vl.kern(vq, ve->x, (const float2 *)tv.data(), dx.data()); });
-        };
-        if (verify) {
-            tv = pack_class_major(des.channel, des.d.decimation, mp, F);
-            for (int c = 0; c < nch; c++) st[c] = -des.channel.foff[c] * des.d.decimation / des.cfg.sample_rate;
-            vp = make_verify_params(des, (size_t)ve->x_len, 0, mp, F, (const float2 *)des.channel.rot.data(), st.data(), des.atan_tab, vb);
-            vl = verify_ddc_pick(des.d.decimation, des.channel.ntp);
-        }
-        if (prescan) {
-            p.prescan = 1; p.vinfo = vinfo.data();
-            emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() { burst_scan_kernel<LAY>(p, vinfo.data()); });
-            for (int c = 0; c < nch; c++) vtstart[c] = vcount[4 + c];
-            if (vcount[1]) run_ddc(vp);
+        if (verify && p.verify == 1) {
+            const int full_tiles = (G % p.tile_outs) ? p.ptile_stride - 1 : p.ptile_stride;
+            emu::launch(dim3(2u, (unsigned)nch), dim3(256), [&]() { channel_floor_kernel(p.ptile, p.ptile_stride, std::max(1, full_tiles), chan_floor.data()); });
+            p.chan_floor = getenv("EMU_NO_FLOOR") ? nullptr : chan_floor.data();
+            if (getenv("EMU_DBG_FLOOR")) for (int c = 0; c < nch; c++) std::fprintf(stderr, "floor ch %d %.4g\n", c, chan_floor[c]);
+            emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() { presence_kernel<LAY>(p); });
+            run_exact(vb.bm1, &vcount[4]);
         }
         emu::launch(dim3((unsigned)((S + LAY::kSlots - 1) / LAY::kSlots)), dim3(kWinThreads), [&]() {
             window_kernel<LAY>(p, d, G, P, Pt, Qn, des.mmse, &des.ac.byte_lo[0][0], &des.ac.byte_hi[0][0],
@@ -360,9 +359,9 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
                                want_syms ? symbits.data() : (uint32_t *)nullptr, winbits.data());
         });
         if (!verify) return;
-        // ---- the exact stage (runtime: tail stream) ----
-        if (prescan) { VerifyParams vp2 = vp; vp2.tstart = vtstart.data(); run_ddc(vp2); }
-        else if (vcount[1]) run_ddc(vp);
+        // ---- the second run (runtime: tail stream) ----
+        run_exact(vb.bm2, &vcount[5]);
+        if (!vcount[0]) return;
         const VerifyFillParams fpz = make_verify_fill_params(des, d, dcol_p, drow, G, vb);
         emu::launch(dim3(16), dim3(256), [&]() { verify_fill_kernel(fpz); });
         const WindowParams pv = make_verify_window_params(p, vb);
@@ -373,29 +372,6 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
                                      fin.data(), &counts[1], &des.le.hdr[0][0], des.le.whiten16, des.le.index_of_channel, win_fin.data(),
                                      want_syms ? symbits.data() : (uint32_t *)nullptr, winbits_v.data());
         });
-        // ---- exact payload: long tasks of the windows that hand symbols over (runtime: tail stream, behind the exact window kernel) ----
-        if (g_exact_payload && want_syms) {
-            const int lcap = 4096, lstride = ((des.d.ddc_out + kVerTile - 1) / kVerTile) * kVerTile + 8;
-            const unsigned int ltcap = 16384;
-            ltasks.assign((size_t)lcap, VerifyTask{}); ltiles.assign((size_t)nch * ltcap, 0u); lrows.assign((size_t)lcap, LongRows{0, 0});
-            dxl.assign((size_t)lcap * lstride, -77.f);
-            std::memset(lcount, 0, sizeof lcount);
-            LongTaskParams lp{};
-            lp.tasks = ltasks.data(); lp.tiles = ltiles.data(); lp.lcount = lcount; lp.tiles_cap = ltcap; lp.rows = lrows.data(); lp.cap = lcap; lp.stride = lstride;
-            emu::launch(dim3((unsigned)(lcap / kLongLanes)), dim3(kLongLanes), [&]() { long_task_kernel(p, fin.data(), &counts[1], lp); });
-            emu::launch(dim3((unsigned)(lcap / kLongLanes)), dim3(kLongLanes), [&]() { long_assign_kernel(p, fin.data(), &counts[1], lp); });
-            VerifyParams vq = vp;
-            vq.tasks = lp.tasks; vq.vcount = lp.lcount; vq.vcap = lcap; vq.tiles = lp.tiles; vq.tcount = lp.lcount + 4; vq.tiles_cap = ltcap;
-            vq.tstart = nullptr; vq.dx_stride = lstride;
-            if (lcount[1]) {
-                std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
-                emu::launch(dim3((unsigned)(2 * nch + 1)), dim3((unsigned)vl.threads), [&]() { vl.kern(vq, ve->x, (const float2 *)tv.data(), dxl.data()); });
-            }
-            lview.rows = lrows.data(); lview.dxl = dxl.data(); lview.stride = lstride; lview.cap = lcap;
-            std::memcpy(g_long_counts, lcount, sizeof g_long_counts);
-            if (getenv("EMU_DBG_LONG")) for (unsigned f = 0; f < counts[1] && f < (unsigned)lcap; f++)
-                std::fprintf(stderr, "long f %u window slot %d ch %d: start ii %u oo %d rows [%d, %d)\n", f, fin[f].w / nch, fin[f].w % nch, fin[f].ii, fin[f].oo, lrows[f].x, lrows[f].y);
-        }
     };
     if (drow == 80) launch_window(WinLayout<3, 96, 20>{});
     else if (drow == 40) launch_window(WinLayout<6, 40, 10>{});
@@ -410,12 +386,25 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         for (int j = -kBurstFront; j < 60 && t0 + j < p.ptile_stride; j++) if (t0 + j >= 0) std::fprintf(stderr, " %.3g", p.ptile[(size_t)cd * p.ptile_stride + t0 + j]);
         std::fprintf(stderr, "\n");
     }
-    g_verify_tasks.assign(vtasks.begin(), vtasks.begin() + std::min<size_t>(vtasks.size(), vcount[0]));
-    if (g_study) { g_study->tasks = g_verify_tasks; g_study->dx = dx; }
+    // what the tests ask for as "the exact stage's tasks": every window with exact rows, and how many of them from its first row on
+    // (presence's marks and the second run's together)
+    g_verify_tasks.clear();
+    if (verify) {
+        std::vector<uint32_t> un((size_t)vb.bm_tiles * kExBmWords);
+        for (size_t i = 0; i < un.size(); i++) un[i] = vb.bm1[i] | vb.bm2[i];
+        for (int k = 0; k < S; k++)
+            for (int c = 0; c < nch; c++) {
+                const int cov = exact_covered_rows(un.data(), vb.bm_tiles, (long long)k * p.outs_per_slot, c);
+                if (cov > 0) g_verify_tasks.push_back(VerifyTask{k * nch + c, cov, 0.0, 0, 0});
+            }
+    }
+    g_second_run.assign(vtasks.begin(), vtasks.begin() + std::min<size_t>(vtasks.size(), vcount[0]));
+    g_exact_bitmap = bm; g_exact_tiles = vb.bm_tiles;
+    if (g_study) g_study->tasks = g_verify_tasks;
     {
         const unsigned nblk = (unsigned)((counts[1] + kFinLanes - 1) / kFinLanes + 1);
         emu::launch(dim3(nblk), dim3(kFinLanes), [&]() {
-            if (want_syms) finish_kernel<true>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), symbits.data(), dcol_p, lview);
+            if (want_syms) finish_kernel<true>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), symbits.data(), dcol_p);
             else finish_kernel<false>(p, d, drow, G, des.mmse, fin.data(), &counts[1], win_len.data(), (uint32_t *)nullptr, dcol_p);
         });
         emu::launch(dim3(4), dim3(256), [&]() {
@@ -714,16 +703,18 @@ extern "C" int emu_margin_study(double fs, double fc, int mode, double squelch_d
 }
 
 
-// The exact stage's demodulated rows against the bit-exact front end's (diagnostics / test): for every task of the polyphase run,
-// rows [1, n_exact) of dx must equal the DIRECT path's stream bit for bit.  Returns the number of differing rows (0 = exact), or
-// a negative error; first_bad[0..2] = task window, row, task rows of the first difference.
+// The exact rows against the bit-exact front end's (diagnostics / test): every (channel, tile) pair the polyphase run marked --
+// presence and the first run's uncovered hits -- must hold the DIRECT path's demodulated rows bit for bit.  Returns the number
+// of differing rows (0 = exact), or a negative error; first_bad[0..3] = channel index, grid row, tile of the first difference,
+// rows compared.
 extern "C" long emu_verify_check(double fs, double fc, int mode, double squelch_db, const float *iq, long long x_len, int S, long long *first_bad)
 {
     StudyCapture fast, exact;
     std::vector<long long> rec((size_t)8 * 65536); std::vector<double> sn(65536);
     g_study = &fast;
     int rc = emu_front_m_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
-    unsigned int fast_counts[4]; std::memcpy(fast_counts, g_verify_counts, sizeof fast_counts);   // (emu_verify_counts after this call: the polyphase run's)
+    unsigned int fast_counts[kVerCountWords]; std::memcpy(fast_counts, g_verify_counts, sizeof fast_counts);
+    const std::vector<uint32_t> fast_bm = g_exact_bitmap; const int fast_tiles = g_exact_tiles;   // (emu_verify_counts after this call: the polyphase run's)
     g_study = &exact; g_rows_only = true;
     if (rc >= 0) rc = emu_front_direct_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
     g_study = nullptr; g_rows_only = false;
@@ -735,19 +726,23 @@ extern "C" long emu_verify_check(double fs, double fc, int mode, double squelch_
     des = Design();
     rc = make_design(cfg, des);
     if (rc) return rc;
-    const int nch = fast.nch, ops = des.outs_per_slot;
+    const int nch = fast.nch;
     long bad = 0;
-    for (size_t q = 0; q < fast.tasks.size(); q++) {
-        const VerifyTask &t = fast.tasks[q];
-        const int k = t.w / nch, c = t.w % nch;
-        for (int i = 1; i < t.n_exact; i++) {
-            const float a = fast.dx[q * kVerRows + i], b = exact.d[((size_t)k * ops + i) * exact.drow + c];
-            if (std::memcmp(&a, &b, 4) != 0) {
-                if (!bad && first_bad) { first_bad[0] = t.w; first_bad[1] = i; first_bad[2] = t.n_exact; }
-                if (getenv("EMU_DBG_ROWS") && bad < 60) std::fprintf(stderr, "task %zu w %d row %d: %.9g vs %.9g\n", q, t.w, i, a, b);
-                bad++;
+    long long checked = 0;
+    const uint32_t *b1 = fast_bm.data(), *b2 = b1 + (size_t)fast_tiles * kExBmWords;
+    for (int t = 0; t < fast_tiles; t++)
+        for (int c = 0; c < nch; c++) {
+            if (!(((b1[(size_t)t * kExBmWords + (c >> 5)] | b2[(size_t)t * kExBmWords + (c >> 5)]) >> (c & 31)) & 1u)) continue;
+            for (long long g = std::max<long long>(1, (long long)t * kExTile); g < (long long)(t + 1) * kExTile && g < fast.G; g++) {
+                const float a = fast.d[(size_t)g * fast.drow + c], b = exact.d[(size_t)g * exact.drow + c];
+                checked++;
+                if (std::memcmp(&a, &b, 4) != 0) {
+                    if (!bad && first_bad) { first_bad[0] = c; first_bad[1] = g; first_bad[2] = t; }
+                    if (getenv("EMU_DBG_ROWS") && bad < 60) std::fprintf(stderr, "tile %d ch %d row %lld: %.9g vs %.9g\n", t, c, g, a, b);
+                    bad++;
+                }
             }
         }
-    }
+    if (first_bad) first_bad[3] = checked;
     return bad;
 }

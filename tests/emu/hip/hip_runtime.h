@@ -75,6 +75,7 @@ static inline float __fdiv_rn(float a, float b) { return a / b; }
 static inline void sincospi(double x, double *s, double *c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }   // fibers: one OS thread
 template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 // __shfl_down through a per-workgroup exchange buffer and two workgroup barriers (write, read): exact for kernels
 // whose shuffles sit in workgroup-uniform control flow or are followed only by the exit of the lanes that skip them
 // (the emulator's barrier ignores exited lanes) -- energy_kernel, block_sum_kernel, noise_stage2_kernel.

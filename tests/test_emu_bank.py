@@ -441,9 +441,10 @@ def test_fuzz_seed77_case_312_offset_one_symbol_apart(emu, po, synth):
             assert n == len(want) == 13
             d = paritylib.differential(rec[:n, :7], wi, truth, lag=1)
             # (six-field contract: a record with its offset a symbol apart is one record on either side)
-            assert d["planted_ref"] == 13 and d["planted_identical"] == (offsets_apart == 0), d
-            assert d["planted_only_gpu"] == offsets_apart and d["planted_only_ref"] == offsets_apart, (verify, d)
-            assert d["planted_offset_differs"] == offsets_apart and d["planted_offset_max_abs_dev"] == offsets_apart, (verify, d)
+            assert d["planted_ref"] == 13, d
+            if verify == 0: continue        # (round 3's order of summation had the offsets one apart here; which windows part without the exact rows depends on the last bit of the oracle's order -- round 6 redefined it)
+            assert d["planted_identical"] and d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, (verify, d)
+            assert d["planted_offset_differs"] == 0 and d["planted_offset_max_abs_dev"] == 0, (verify, d)
     finally:
         L.emu_set_verify(1)
 
@@ -497,16 +498,16 @@ def test_exact_stage_settles_the_deviating_fuzz_cases(emu, po, synth, seed, case
         L.emu_set_verify(1)
     d = out[1]
     assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= paritylib.NSYM_BOUND, d
-    d0 = out[0]
-    assert (not d0["planted_identical"]) or d0["planted_offset_differs"] > 0, d0       # the case is one of those that deviated
+    # (out[0], the run without the exact rows: these were the cases that deviated under round 3's order of summation; which windows
+    # part without them depends on the oracle's last bit, and round 6 redefined the order -- nothing is asserted about it)
 
 
-def test_false_alarm_behind_the_exact_span_is_what_still_differs(emu, po, synth):
-    """What the exact stage does NOT settle, pinned: case 1471 of seed 31337 (100 Msps, sniffer, LE on).  A
-    planted packet in (slot 8, channel 77) is found by both sides with identical fields; the sniffer goes on searching behind
-    it, and the oracle meets a six-error access code at offset 196 -- in the packet's payload, behind the rows the exact stage
-    recomputes for that window -- which the polyphase stream's symbols do not show.  No packet is there: every planted record
-    of the capture is identical."""
+def test_false_alarm_in_a_payload_is_the_same_on_both_sides(emu, po, synth):
+    """What rounds 4-5 could NOT settle, pinned then as the one thing that still differed: case 1471 of seed 31337 (100 Msps, sniffer,
+    LE on).  A planted packet in (slot 8, channel 77) is found by both sides; the sniffer goes on searching behind it, and the
+    oracle met a six-error access code in the packet's PAYLOAD -- behind the rows the exact stage recomputed for that window, where
+    the polyphase stream's symbols did not show it.  With presence (round 6) a packet's whole air time is exact rows: every
+    record of the capture, planted or not, is identical on the six key fields."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import paritylib
@@ -531,22 +532,18 @@ def test_false_alarm_behind_the_exact_span_is_what_still_differs(emu, po, synth)
     d = paritylib.differential(rec[:n, :7], wi, truth, lag=6)
     assert d["planted_identical"] and d["planted_offset_differs"] == 0 and d["planted_nsym_max_abs_dev"] <= paritylib.NSYM_BOUND, d
     gs, ws = set(map(tuple, rec[:n, :6].tolist())), set(map(tuple, wi[:, :6].tolist()))
-    assert gs - ws == set()
-    only_ref = sorted(ws - gs)
-    assert len(only_ref) == 1, only_ref
-    slot, ch, kind, off, lap, err = only_ref[0]
-    assert (slot, ch, kind, err) == (8, 77, 0, 6) and off > 150                     # a classic six-error code deep in a payload
-    assert any(t["slot"] == 8 and t["channel"] == 77 for t in truth) and lap not in laps   # ... of a planted packet; no planted LAP
+    assert gs == ws, (sorted(gs - ws), sorted(ws - gs))
 
 
 @pytest.mark.parametrize("fs,fc,sniff,nsl", [(8e6, 2476.5e6, True, 14), (20e6, 2441e6, False, 10), (100e6, 2441e6, True, 9), (100e6, 2441e6, False, 5),
                                                  (4e6, 2427e6, True, 14), (10e6, 2450e6, True, 12), (16e6, 2405e6, False, 8), (40e6, 2461e6, True, 9),
                                                  (50e6, 2426e6, False, 5)])
 def test_exact_stage_rows_equal_the_direct_path_bit_for_bit(emu, synth, fs, fc, sniff, nsl):
-    """verify_ddc_kernel (the product's source under the emulator) against ddc_direct_kernel + demod_rows_kernel: every
-    demodulated row the exact stage recomputes -- rows [1, n_exact) of every window it takes -- is bit-identical to the
-    bit-exact path's (which the other tests pin to the oracle), at the three bank geometries of the BASELINE configs and the
-    fuzz (D = 4, 10, 50) and at D = 2, 5, 8, 20, 25."""
+    """exact_rows_kernel (the product's source under the emulator, its MFMA as the k-ordered fmaf chain the hardware's is) against
+    ddc_direct_kernel + demod_rows_kernel: every demodulated row it writes over the polyphase stream -- all rows of every
+    (channel, tile) pair that presence or an uncovered hit marked -- is bit-identical to the bit-exact path's (which the other
+    tests pin to the oracle), at the three bank geometries of the BASELINE configs and the fuzz (D = 4, 10, 50) and at
+    D = 2, 5, 8, 20, 25."""
     import pyoracle as po_
     iq, _ = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=11, snr_db=22, occupancy=0.6,
                                cfo_hz=60e3, max_payload_bits=1200)
@@ -555,13 +552,13 @@ def test_exact_stage_rows_equal_the_direct_path_bit_for_bit(emu, synth, fs, fc, 
     x = np.concatenate([np.zeros(o.history - 1, np.complex64), iq.astype(np.complex64)])
     xf = np.ascontiguousarray(x).view(np.float32)
     emu.emu_verify_check.restype = ctypes.c_long
-    fb = (ctypes.c_longlong * 3)()
+    fb = (ctypes.c_longlong * 4)()
     bad = emu.emu_verify_check(ctypes.c_double(fs), ctypes.c_double(fc), mode, ctypes.c_double(10.0),
                                xf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.c_longlong(len(x)), nsl, fb)
-    vc = (ctypes.c_uint * 4)()
+    vc = (ctypes.c_uint * 8)()
     emu.emu_verify_counts(vc)
-    assert bad == 0, "rows differ: %d, first at window %d row %d of %d" % (bad, fb[0], fb[1], fb[2])
-    assert vc[0] >= 3 and vc[2] == 0, list(vc)              # (windows the exact stage took; none turned away)
+    assert bad == 0, "rows differ: %d of %d, first at channel %d row %d (tile %d)" % (bad, fb[3], fb[0], fb[1], fb[2])
+    assert vc[3] >= 3 and vc[2] == 0 and fb[3] >= 3 * 146, (list(vc), fb[3])      # (busy windows; none turned away; rows compared)
 
 
 @pytest.mark.parametrize("fs,fc,sniff,le", [(8e6, 2476.5e6, True, True), (4e6, 2476e6, False, False), (5e6, 2470e6, True, False),
@@ -739,8 +736,8 @@ def test_judge_r04_nearfar_case_35_is_found(emu, po, synth):     # (synth: the f
 
 
 @pytest.mark.parametrize("name", ["weak-3dB", "on-top-5dB", "under-a-neighbour-coincident", "late-but-reportable", "next-windows-burst"])
-def test_burst_scan_on_its_thresholds(emu, po, synth, name):
-    """One constellation per rule of the burst scan, each sitting on the rule (8 Msps, window 7 of 9, every trial another noise / phase /
+def test_presence_on_its_thresholds(emu, po, synth, name):
+    """One constellation per rule of rounds 4-5's burst scan (presence replaced it in round 6: one threshold), each sitting on the rule (8 Msps, window 7 of 9, every trial another noise / phase /
     carrier-offset draw).  What is asserted is the SELECTION -- the window of the packet is a task of the exact stage whose exact rows
     reach past the access code -- because that is what makes the record the reference's own arithmetic; the records themselves are
     compared as well.
@@ -791,8 +788,10 @@ def test_burst_scan_on_its_thresholds(emu, po, synth, name):
         w = k * nch + (ch - lo)
         need = int(row + 2 * 72 + 16)                                   # rows up to the end of the access code
         if name == "next-windows-burst":
-            assert tasks.get(w, 0) < 1000, (t, tasks.get(w))            # not taken at full length here ...
-            assert tasks.get(w + nch, 0) >= int(row - 1250 + 160), (t, tasks.get(w + nch))   # ... and taken by the next window
+            # (rounds 4-5 had to DECIDE whose burst it is -- F10, the hand-over row; with presence both windows stand on exact rows,
+            # which they share on the grid: no decision, no hand-over to get wrong)
+            assert tasks.get(w, 0) >= 1416, (t, tasks.get(w))
+            assert tasks.get(w + nch, 0) >= int(row - 1250 + 160), (t, tasks.get(w + nch))
         else:
             assert tasks.get(w, 0) >= min(need, 1416), (name, t, row, tasks.get(w))
         d = paritylib.differential(got, wi, truth, lag=6)
@@ -830,8 +829,7 @@ def test_adversarial_fuzz_slice_wide_generator_other_rates(emu):
 
 def test_exact_payload_symbols_equal_the_oracles(emu):
     """BTGPU_FLAG_EXACT_PAYLOAD on the emulator (scripts/emu_symbol_parity.py, 16 adversarial captures at 8 / 20 Msps): every symbol of
-    every record's packet -- access code, header AND payload, to the packet's last bit -- equals the oracle's; long tasks were made and
-    none turned away.  (Without the flag 2 % of the records of the 300-capture run carry a differing payload symbol:
+    every record's packet -- access code, header AND payload, to the packet's last bit -- equals the oracle's.  (Round 5, without the flag: 2 % of the records of the 300-capture run carry a differing payload symbol:
     profiles/r05_emu_symbol_parity_default_300.txt; with it 0 of 4.1 M symbols: profiles/r05_emu_symbol_parity_exact_payload_800.txt.)"""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_symbol_parity.py"), "16", "12", "--rates", "8,20", "--exact-payload"],
@@ -840,7 +838,7 @@ def test_exact_payload_symbols_equal_the_oracles(emu):
     tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
     assert tot["records"] > 60 and tot["symbols"] > 40000, tot
     assert tot["records_with_a_differing_symbol"] == 0 and tot["differing_symbols"] == 0, tot
-    assert tot["long_tasks"] > 50 and tot["long_turned_away"] == 0, tot
+    # (round 5 paid for this with LONG TASKS, 10 x the exact stage's rows; with presence a packet's air time is busy: its rows are exact anyway)
 
 
 @pytest.mark.parametrize("seed,case,rates,wide,what", [
@@ -863,7 +861,7 @@ def test_exact_payload_cases_the_wide_fuzz_found(emu, seed, case, rates, wide, w
                         "--exact-payload"] + (["--wide"] if wide else []), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
-    assert tot["records"] >= 4 and tot["long_tasks"] >= 3 and tot["long_turned_away"] == 0, tot
+    assert tot["records"] >= 4, tot
     assert tot["records_with_a_differing_symbol"] == 0 and tot["differing_symbols"] == 0, (what, tot)
 
 
@@ -911,17 +909,12 @@ def test_a_hit_of_the_exact_pass_behind_its_exact_span_coarse_tiles(emu, po, syn
     assert d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, d
 
 
-@pytest.mark.xfail(strict=True, reason="KNOWN DEVIATION at the coarse-tile rates, found 50 minutes before the round's end: a 131-us gap is invisible in 125-us tiles "
-                                       "(profiles/r05_emu_fuzz_adversarial_more.txt): 1 of 49 051 planted records of the 4 / 10 Msps run of the stretched generator")
-def test_known_deviation_coarse_tiles_a_53_db_packet_in_mid_window(emu, po, synth):
-    """Case 4983 of `scripts/emu_fuzz_adversarial.py N 21001 --rates 4,10,10 --wide` (10 Msps, multi_LAP, squelch 14 dB): the oracle
-    reports (3, 52, offset 440, 0 errors) -- a 53 dB packet (10 dB over full scale: the stretched generator) that begins in mid-window,
-    131 us after ANOTHER 53 dB packet on the same channel ended; the product has no task for window (3, 52) and no record.  A 131-us
-    gap between two packets of one level does not empty a 125-us tile (W = 1 at this rate): no +50 % step, no sharp edge, no fall
-    onto a plateau -- the scan's resolution, not a rule; and the polyphase path's own search, the second trigger, does not find the
-    access code.  The same with the build of commit 448ee3c: not a consequence of the full-span tasks.  The 8 / 16 / 20 / 40 / 50 /
-    100 Msps runs of the same generator (25- and 12.5-us tiles): none.  Wants the 25-output sums at <= 10 Msps (DESIGN.md section 8
-    item 0).  The assertion below is the contract; it fails today."""
+def test_round5s_known_deviation_a_53_db_packet_131_us_behind_another_of_its_level(emu, po, synth):
+    """Round 5's strict-xfail, now a plain test.  Case 4983 of `scripts/emu_fuzz_adversarial.py N 21001 --rates 4,10,10 --wide` (10 Msps,
+    multi_LAP, squelch 14 dB): the oracle reports (3, 52, offset 440, 0 errors) -- a 53 dB packet that begins in mid-window, 131 us after
+    ANOTHER 53 dB packet on the same channel ended.  A 131-us gap between two packets of one level does not empty a 125-us tile: no
+    step, no edge, no fall onto a plateau -- round 5's burst scan had no task for window (3, 52) and lost the record.  Presence asks
+    for no edge: the channel is busy, the rows are exact, the record is the oracle's."""
     import adversarial
     rng = np.random.default_rng(21001)
     for _ in range(4983 + 1):
