@@ -434,8 +434,8 @@ class _MultiBlock:
 
     def debug_fetch(self, what, channel=0, first=0, count=0):
         dt = {0: np.complex64, 1: np.float32, 2: np.float64, 3: np.float64, 4: np.float64, 5: np.complex64,
-              6: np.float32, 7: np.int32, 9: np.uint64, 11: np.float32,
-              10: np.dtype([('w', '<i4'), ('rows', '<i4'), ('snr', '<f8')]),
+              6: np.float32, 7: np.int32, 9: np.uint64, 11: np.uint32,
+              10: np.dtype([('w', '<i4'), ('rows', '<i4'), ('snr', '<f8'), ('emit_from', '<i4'), ('pad', '<i4')]),
               8: np.dtype([('w', '<i4'), ('ii', '<u4'), ('oo', '<i4'), ('mu', '<f4'), ('omega', '<f4'), ('last', '<f4')])}[what]
         out = np.zeros(count, dt)
         n = self._L.btgpu_debug_fetch(self._h, what, channel, first, count, out.ctypes.data_as(ctypes.c_void_p))

@@ -42,11 +42,11 @@ struct ExactParams {
     long long x_len;
     long long first0;             // x index of (grid row 0, tap 0): w0 + first_channel_sample
     long long G;                  // rows of the shared output grid
-    const float *tapsA;           // [nch][D][64]: the A operand of step r for lane l -- row l & 31 = 2 q + (re: 0, im: 1), k = l >> 5
+    const float *tapsA;           // [nch][64][exact_dpad(D)]: the A operand of lane l, step r -- row l & 31 = 2 q + (re: 0, im: 1), k = l >> 5 (exact_pack_taps)
     const float2 *rot; int Qr;    // de-rotation table [nch][Qr] by grid row (the windows' own rotators differ from it by an exact +-1: the demodulated rows are the same bits)
     const float *atan_tab; float gain;
-    const uint32_t *bitmap;       // [ntiles][kExWords]: bit c of tile j = rows [kExTile j, kExTile (j + 1)) of channel c are recomputed
-    int ntiles;
+    const uint32_t *bitmap;       // [ntiles][kExWords]: bit c of tile j = rows [kExTile j - shift, kExTile (j + 1) - shift) of channel c are recomputed
+    int ntiles, shift;
     unsigned int *stat;           // nullptr, or a counter of the (channel, tile) pairs computed
     float *d; int drow;           // time-major stream [G][drow]
     float *dcol;                  // nullptr, or the tile-blocked copy [G / 25][80][25]
@@ -54,38 +54,50 @@ struct ExactParams {
     int nch;
 };
 
-// LDS: the staged span (32 D samples per wave), reused for A, G and the outputs once the B operands are in registers; + the arctangent table
+constexpr int exact_dpad(int D) { return (D + 3) / 4 * 4; }      // floats per lane of a channel's A operand (16-byte reads)
+// LDS: the staged span (32 D samples per wave), reused once the B operands are in registers for A (two buffers) and G (two buffers); + the arctangent table
 constexpr size_t exact_lds_main(int D)
 {
-    const size_t stage = (size_t)kExWaves * 32 * D * 8, ops = (size_t)(D * 64 + 2 * kExQB * kExGStride) * 4 + (size_t)kExOuts * 8;
+    const size_t stage = (size_t)kExWaves * 32 * D * 8, ops = (size_t)2 * (64 * exact_dpad(D) + 2 * kExQB * kExGStride) * 4;
     return ((stage > ops ? stage : ops) + 15) / 16 * 16;
 }
 inline size_t exact_lds_bytes(int D) { return exact_lds_main(D) + 260 * sizeof(float); }
-inline int exact_ntiles(long long G) { return (int)((G + kExTile - 1) / kExTile); }
+inline int exact_ntiles(long long G) { return (int)((G + kExTile - 1) / kExTile) + 1; }   // (+ 1: the tiles are anchored to the absolute grid)
 
-// tapsA from a direct-form bank's reversed taps [nch][ntp][2] (design.h FilterBank): zero beyond the filter and in rows 2 QB .. 31
-inline void exact_pack_taps(const float *taps, int nch, int ntp, int D, float *out /* [nch][D][64] */)
+// tapsA from a direct-form bank's reversed taps [nch][ntp][2] (design.h FilterBank): out[(c * 64 + l) * dpad + r] = the A operand of
+// step r for lane l -- row l & 31 = 2 q + (re: 0, im: 1), k = l >> 5: (tr, -ti) for a re row, (ti, tr) for an im row; zero beyond the
+// filter, in rows 2 QB .. 31 and in the pad
+inline void exact_pack_taps(const float *taps, int nch, int ntp, int D, float *out /* [nch][64][exact_dpad(D)] */)
 {
+    const int DP = exact_dpad(D);
     for (int c = 0; c < nch; c++)
-        for (int r = 0; r < D; r++)
-            for (int l = 0; l < 64; l++) {
+        for (int l = 0; l < 64; l++)
+            for (int r = 0; r < DP; r++) {
                 const int row = l & 31, kh = l >> 5, q = row >> 1, im = row & 1, j = q * D + r;
                 float tr = 0.f, ti = 0.f;
-                if (q < kExQB && j < ntp) { tr = taps[((size_t)c * ntp + j) * 2]; ti = taps[((size_t)c * ntp + j) * 2 + 1]; }
-                out[((size_t)c * D + r) * 64 + l] = im ? (kh ? tr : ti) : (kh ? -ti : tr);
+                if (r < D && q < kExQB && j < ntp) { tr = taps[((size_t)c * ntp + j) * 2]; ti = taps[((size_t)c * ntp + j) * 2 + 1]; }
+                out[((size_t)c * 64 + l) * DP + r] = im ? (kh ? tr : ti) : (kh ? -ti : tr);
             }
 }
+inline size_t exact_taps_floats(int nch, int D) { return (size_t)nch * 64 * exact_dpad(D); }
 
+// Choreography of one tile: the five waves stage their 32 columns each (coalesced loads -> LDS -> D registers per lane: the B
+// operand for every channel of the tile), then per channel ONE barrier:
+//     [loads of the NEXT channel's A in flight]  D MFMAs over As[n & 1]  ->  G to Gs[n & 1]  ->  next A to As[~n & 1]  ->  barrier
+//     ->  epilogue of channel n: diagonal sums, de-rotation, demodulator, stores  (while other waves are already in channel n + 1's MFMAs)
+// Epilogue lanes: wave w takes outputs 30 w - 1 .. 30 w + 29 on its lanes 0 .. 30 (lane 0 only supplies its right neighbour's
+// predecessor), so that y[t - 1] is one shuffle away and all five waves share the work.
 template <int D>
 __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
 {
     HIP_DYNAMIC_SHARED(float2, lds)
     constexpr int NS = 32 * D;                                     // samples per wave
+    constexpr int DP = exact_dpad(D), NA4 = 64 * DP / 4;           // float4 of one channel's A
+    constexpr int NPF = (NA4 + kExThreads - 1) / kExThreads;       // ... per thread
+    constexpr int GSZ = 2 * kExQB * kExGStride;
     float *atab = (float *)((char *)lds + exact_lds_main(D));
-    // the staged span is dead once the B operands are in registers: A, G and the outputs live over it
-    float *As = (float *)lds;                                      // [D][64]
-    float *Gs = As + D * 64;                                       // [2 QB][kExGStride]
-    float2 *ys = (float2 *)(Gs + 2 * kExQB * kExGStride);          // [kExOuts]
+    float4 *As4 = (float4 *)lds;                                   // [2][NA4]
+    float *Gs = (float *)lds + 2 * 64 * DP;                        // [2][GSZ]
     const int tid = (int)threadIdx.x, lane = tid & 63;
 #if defined(__HIP_DEVICE_COMPILE__)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,7 +112,27 @@ __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p
         for (int i = 0; i < kExWords; i++) { bm[i] = p.bitmap[(size_t)tile * kExWords + i]; any |= bm[i]; }
         if (!any) continue;                                        // uniform
         if (p.stat && tid == 0) { unsigned int n = 0; for (int i = 0; i < kExWords; i++) n += (unsigned int)__popc(bm[i]); atomicAdd(p.stat, n); }
-        const long long g0 = (long long)tile * kExTile - 1;        // grid row of output 0
+        auto next_channel = [&]() {                                // uniform: the lowest channel left in bm, -1 when none
+            int c = -1;
+#pragma unroll
+            for (int wi = kExWords - 1; wi >= 0; wi--) if (bm[wi]) c = 32 * wi + __ffs(bm[wi]) - 1;
+#pragma unroll
+            for (int wi = 0; wi < kExWords; wi++) if (c >= 0 && (c >> 5) == wi) bm[wi] &= bm[wi] - 1;   // (static indices: a run-time one put bm in scratch memory)
+            return c;
+        };
+        float4 apf[NPF];
+        auto load_a = [&](int c) {
+            const float4 *ta = (const float4 *)p.tapsA + (size_t)c * NA4;
+#pragma unroll
+            for (int i = 0; i < NPF; i++) { const int j = tid + i * kExThreads; apf[i] = ta[j < NA4 ? j : NA4 - 1]; }
+        };
+        auto store_a = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < NPF; i++) { const int j = tid + i * kExThreads; if (j < NA4) As4[buf * NA4 + j] = apf[i]; }
+        };
+        int c_cur = next_channel();
+        load_a(c_cur);                                             // (in flight under the staging)
+        const long long g0 = (long long)tile * kExTile - p.shift - 1;   // grid row of output 0
         const long long sb = p.first0 + g0 * D + (long long)wave * NS;
         __syncthreads();                                           // the previous tile's buffers are consumed
         // ---- the wave's 32 columns: coalesced loads, LDS, then one column half per lane ----
@@ -131,56 +163,65 @@ __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p
             for (int r = 0; r < D; r++) B[r] = xf[2 * r];
         }
         __syncthreads();                                           // every wave has its operands: the span is free
-        for (int wi = 0; wi < kExWords; wi++) {
-            uint32_t m = bm[wi];
-            while (m) {                                            // uniform
-                const int c = 32 * wi + __ffs(m) - 1;
-                m &= m - 1;
-                {
-                    const float2 *ta = (const float2 *)(p.tapsA + (size_t)c * D * 64);
-                    for (int i = tid; i < D * 32; i += kExThreads) ((float2 *)As)[i] = ta[i];
-                }
-                __syncthreads();
-                f32x16 acc;
+        store_a(0);
+        __syncthreads();
+        // the epilogue's lane: output u of the tile (u = 0: the halo), -1 where the lane has none
+        const int u = (lane <= 30) ? 30 * wave + lane - 1 : -1;
+        const bool u_ok = u >= 0 && u < kExOuts;
+        const long long g = g0 + (u_ok ? u : 0);
+        for (int n = 0; c_cur >= 0; n++) {
+            const int c_nxt = next_channel();
+            if (c_nxt >= 0) load_a(c_nxt);
+            float2 rt = make_float2(1.f, 0.f);
+            if (u_ok && g >= 0) rt = p.rot[(size_t)c_cur * p.Qr + (int)(g % p.Qr)];
+            f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 16; i++) acc[i] = 0.f;
+            for (int i = 0; i < 16; i++) acc[i] = 0.f;
+            {
+                const float4 *ap = As4 + (n & 1) * NA4 + lane * (DP / 4);
+                float4 a = ap[0];
 #pragma unroll
-                for (int r = 0; r < D; r++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[r * 64 + lane], B[r], acc, 0, 0, 0);
-                {
-                    const int col = 32 * wave + (lane & 31), rb = 4 * (lane >> 5);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int row = (i & 3) + 8 * (i >> 2) + rb;
-                        if (row < 2 * kExQB) Gs[row * kExGStride + col] = acc[i];
-                    }
-                }
-                __syncthreads();
-                if (tid < kExOuts) {
-                    float yr = Gs[tid], yi = Gs[kExGStride + tid];
-#pragma unroll
-                    for (int q = 1; q < kExQB; q++) {
-                        yr = yr + Gs[(2 * q) * kExGStride + tid + q];
-                        yi = yi + Gs[(2 * q + 1) * kExGStride + tid + q];
-                    }
-                    const long long g = g0 + tid;
-                    float rr = 1.f, ri = 0.f;
-                    if (g >= 0) { const float2 r = p.rot[(size_t)c * p.Qr + (int)(g % p.Qr)]; rr = r.x; ri = r.y; }
-                    float2 out;
-                    out.x = fmaf(-yi, ri, yr * rr);
-                    out.y = fmaf(yi, rr, yr * ri);
-                    ys[tid] = out;
-                    if (p.ydbg && g >= 0 && g < p.G) p.ydbg[(size_t)c * p.ystride + g] = out;
-                }
-                __syncthreads();
-                if (tid >= 1 && tid < kExOuts) {
-                    const long long g = g0 + tid;
-                    if (g >= 1 && g < p.G) {
-                        const float dv = demod_one(atab, p.gain, ys[tid], ys[tid - 1]);
-                        p.d[(size_t)g * p.drow + c] = dv;
-                        if (p.dcol) { const unsigned int gq = (unsigned int)g, tq = gq / 25u; p.dcol[(size_t)(gq + 25u * (79u * tq + (unsigned int)c))] = dv; }
-                    }
+                for (int i = 0; i < DP / 4; i++) {
+                    const float4 an = ap[i + 1 < DP / 4 ? i + 1 : i];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, B[4 * i], acc, 0, 0, 0);
+                    if (4 * i + 1 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, B[4 * i + 1 < D ? 4 * i + 1 : 0], acc, 0, 0, 0);
+                    if (4 * i + 2 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, B[4 * i + 2 < D ? 4 * i + 2 : 0], acc, 0, 0, 0);
+                    if (4 * i + 3 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, B[4 * i + 3 < D ? 4 * i + 3 : 0], acc, 0, 0, 0);
+                    a = an;
                 }
             }
+            float *Gn = Gs + (n & 1) * GSZ;
+            {
+                const int col = 32 * wave + (lane & 31), rb = 4 * (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int row = (i & 3) + 8 * (i >> 2) + rb;
+                    if (row < 2 * kExQB) Gn[row * kExGStride + col] = acc[i];
+                }
+            }
+            if (c_nxt >= 0) store_a((n + 1) & 1);
+            __syncthreads();
+            // ---- epilogue of channel c_cur ----
+            float2 y = make_float2(0.f, 0.f);
+            if (u_ok) {
+                float yr = Gn[u], yi = Gn[kExGStride + u];
+#pragma unroll
+                for (int q = 1; q < kExQB; q++) {
+                    yr = yr + Gn[(2 * q) * kExGStride + u + q];
+                    yi = yi + Gn[(2 * q + 1) * kExGStride + u + q];
+                }
+                y.x = fmaf(-yi, rt.y, yr * rt.x);
+                y.y = fmaf(yi, rt.x, yr * rt.y);
+                if (p.ydbg && g >= 0 && g < p.G) p.ydbg[(size_t)c_cur * p.ystride + g] = y;
+            }
+            float2 yp;                                             // y[u - 1]: the left neighbour's
+            yp.x = __shfl_up(y.x, 1, 64); yp.y = __shfl_up(y.y, 1, 64);
+            if (u_ok && lane >= 1 && u >= 1 && g >= 1 && g < p.G) {
+                const float dv = demod_one(atab, p.gain, y, yp);
+                p.d[(size_t)g * p.drow + c_cur] = dv;
+                if (p.dcol) { const unsigned int gq = (unsigned int)g, tq = gq / 25u; p.dcol[(size_t)(gq + 25u * (79u * tq + (unsigned int)c_cur))] = dv; }
+            }
+            c_cur = c_nxt;
         }
     }
 }

@@ -93,7 +93,7 @@ int main(int argc, char **argv)
         taps[((size_t)c * ntp + j) * 2] = 1e-3f * (float)((int)(mix(7, c, j) % 2001u) - 1000);
         taps[((size_t)c * ntp + j) * 2 + 1] = 1e-3f * (float)((int)(mix(8, c, j) % 2001u) - 1000);
     }
-    std::vector<float> tapsA((size_t)nch * D * 64);
+    std::vector<float> tapsA(exact_taps_floats(nch, D));
     exact_pack_taps(taps.data(), nch, ntp, D, tapsA.data());
     std::vector<float> rot((size_t)nch * Qr * 2);
     for (int c = 0; c < nch; c++) { rot[(c * Qr) * 2] = 1.f; rot[(c * Qr) * 2 + 1] = 0.f; rot[(c * Qr + 1) * 2] = (c & 1) ? -1.f : 1.f; rot[(c * Qr + 1) * 2 + 1] = 0.f; }
@@ -108,7 +108,7 @@ int main(int argc, char **argv)
         CK(hipMalloc(&d_bm, bitmap.size() * 4)); CK(hipMemcpy(d_bm, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice));
         ExactParams p{};
         p.x_len = (long long)x_len; p.first0 = 0; p.G = G; p.tapsA = d_tapsA; p.rot = d_rot; p.Qr = Qr; p.atan_tab = d_atab; p.gain = 1.0f;
-        p.bitmap = d_bm; p.ntiles = exact_ntiles(G); p.d = d_d; p.drow = 80; p.dcol = d_dcol; p.ydbg = d_y; p.ystride = G; p.nch = nch;
+        p.bitmap = d_bm; p.ntiles = exact_ntiles(G); p.shift = 0; p.d = d_d; p.drow = 80; p.dcol = d_dcol; p.ydbg = d_y; p.ystride = G; p.nch = nch;
         const size_t lds = exact_lds_bytes(D);
         CK(hipFuncSetAttribute((const void *)exact_rows_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -92,6 +92,18 @@ template <class T> static inline T __shfl_down(T v, int off, int width = 64)
     emu::barrier();
     return r;
 }
+template <class T> static inline T __shfl_up(T v, int off, int width = 64)
+{
+    static_assert(sizeof(T) <= 16, "exchange slot");
+    const unsigned tid = threadIdx.x;
+    std::memcpy(emu::xchg[tid], &v, sizeof(T));
+    emu::barrier();
+    T r = v;
+    const unsigned lane = tid % (unsigned)width;
+    if (lane >= (unsigned)off) std::memcpy(&r, emu::xchg[tid - off], sizeof(T));
+    emu::barrier();
+    return r;
+}
 static inline unsigned long long __ballot(int pred)
 {
     const unsigned tid = threadIdx.x, w0 = tid & ~63u;

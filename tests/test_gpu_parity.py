@@ -834,32 +834,35 @@ def test_randomised_differential_direct_path(pkg, po, synth):
 
 @pytest.mark.parametrize("fs,fc,nsl", [(100e6, 2441e6, 14), (8e6, 2476.5e6, 24), (20e6, 2441e6, 12)])
 def test_exact_stage_rows_equal_the_direct_path(pkg, synth, fs, fc, nsl):
-    """verify_ddc_kernel on the MI355X against the DIRECT path's ddc_direct_kernel + demod_rows_kernel (which
-    test_intermediates_bit_exact pins to the oracle): every demodulated row the exact stage recomputed for the windows it took
-    is bit-identical to the bit-exact path's stream."""
+    """exact_rows_kernel (the fp32 matrix pipe) on the MI355X against the DIRECT path's ddc_direct_kernel + demod_rows_kernel (which
+    test_intermediates_bit_exact pins to the oracle): every demodulated row it wrote over the polyphase stream -- all rows of
+    every (channel, tile) pair that presence or an uncovered hit marked -- is bit-identical to the bit-exact path's stream."""
     iq, _ = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=11, snr_db=22, occupancy=0.6,
                                cfo_hz=60e3, max_payload_bits=1200)
     fast = pkg.multi_sniffer(fs, fc, 10.0, False, max_batch_slots=nsl)
     assert fast.design.channelizer == pkg.CHANNELIZER_POLYPHASE
     fast.push(iq); fast.poll()
-    tasks = fast.debug_fetch(10, 0, 0, 1 << 16)
-    assert len(tasks) >= 8
-    dx = fast.debug_fetch(11, 0, 0, len(tasks) * 1416).reshape(len(tasks), 1416)
     exact, _ = _run_gpu(pkg, pkg.multi_sniffer, fs, fc, iq, max_batch_slots=nsl)
     d = exact.design
     nch = d.high_channel - d.low_channel + 1
     ops = d.samples_per_slot // d.decimation
-    cols = {}
-    rows_checked = 0
-    for t, row in zip(tasks, dx):
-        k, c = int(t["w"]) // nch, int(t["w"]) % nch
-        if c not in cols:
-            cols[c] = exact.debug_fetch(1, d.low_channel + c, 0, 1 << 24)
-        n = int(t["rows"])
-        assert 100 < n <= 1416
-        assert np.array_equal(row[1:n], cols[c][k * ops + 1: k * ops + n]), (k, c, n)
-        rows_checked += n - 1
-    print("exact stage: %d windows, %d rows bit-identical to the direct path" % (len(tasks), rows_checked))
+    G = ops * (nsl - 1) + d.ddc_out
+    bm = fast.debug_fetch(11, 0, 0, 1 << 22)
+    tiles = len(bm) // 6
+    bm = (bm[:tiles * 3] | bm[tiles * 3:]).reshape(tiles, 3)             # presence's marks | the second run's
+    rows_checked = pairs = 0
+    for c in range(nch):
+        marked = [t for t in range(min(tiles, (G + 145) // 146)) if (int(bm[t, c >> 5]) >> (c & 31)) & 1]
+        if not marked:
+            continue
+        a = fast.debug_fetch(1, d.low_channel + c, 0, 1 << 24)
+        b = exact.debug_fetch(1, d.low_channel + c, 0, 1 << 24)
+        for t in marked:
+            lo, hi = max(1, 146 * t), min(146 * (t + 1), G)
+            assert np.array_equal(a[lo:hi], b[lo:hi]), (c, t)
+            rows_checked += hi - lo; pairs += 1
+    assert pairs >= 8
+    print("exact rows: %d (channel, tile) pairs, %d rows bit-identical to the direct path" % (pairs, rows_checked))
     fast.close(); exact.close()
 
 
