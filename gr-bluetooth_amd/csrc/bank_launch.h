@@ -223,7 +223,7 @@ struct VerifyBuffers {                                   // device (or emulated)
     VerifyTask *tasks = nullptr; unsigned int *vcount = nullptr;
     float *dxt = nullptr;
     int vcap = 0;
-    uint32_t *bm1 = nullptr, *bm2 = nullptr; int bm_tiles = 0, bm_shift = 0;   // exact rows' bitmaps [bm_tiles][kExBmWords] (presence / the first run's uncovered hits)
+    uint32_t *bm1 = nullptr, *bm2 = nullptr; int bm_tiles = 0;   // exact rows' bitmaps [bm_tiles][kExBmWords] (presence / the first run's uncovered hits)
 };
 constexpr int kVerCountWords = 8;                       // vcount: 0 tasks, 1 pairs marked, 2 turned away, 3 busy windows, 4 / 5 pairs computed by the first / second launch of exact_rows_kernel
 inline int verify_capacity(int S, int nch) { return (int)std::min<long long>((long long)S * nch, 32768); }
@@ -246,7 +246,7 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
     p.verify = mode;
     p.ptile = ptile; p.ptile_stride = ntiles; p.tile_outs = tile_outs > 0 ? tile_outs : verify_tile_outs(fp, small);
     p.tiles_per_slot = des.outs_per_slot / p.tile_outs;
-    p.vtasks = vb.tasks; p.vcount = vb.vcount; p.vcap = vb.vcap; p.bm1 = vb.bm1; p.bm2 = vb.bm2; p.bm_tiles = vb.bm_tiles; p.bm_shift = vb.bm_shift;
+    p.vtasks = vb.tasks; p.vcount = vb.vcount; p.vcap = vb.vcap; p.bm1 = vb.bm1; p.bm2 = vb.bm2; p.bm_tiles = vb.bm_tiles;
     const int ntm = (2 * kDetectSyms + 16 + p.tile_outs - 1) / p.tile_outs;
     if (ntm + kBurstFront > 64) p.verify = 2;            // (presence stages <= 64 tiles per channel)
     // The scan's statistic is the energy of W tiles, ~50 us.  Its threshold is 2.0 x the MEAN noise block; the scan knows the
@@ -279,15 +279,16 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
     }
     p.span_extra = headers ? 58 : 0;                     // 54 header symbols + the 4-symbol trailer
 }
+static_assert(kExactTileRows == kExTile, "design.h and exact.hip.h agree on the tile");
 // exact_rows_kernel's parameters for one bitmap of the batch (tapsA: exact_pack_taps of the direct-form channel bank)
 inline ExactParams make_exact_params(const Design &des, size_t x_len, long long w0, long long G, const float *tapsA, const float2 *rot,
-                                     const float *atan_tab, const uint32_t *bitmap, int bm_tiles, int bm_shift, float *d, int drow, float *dcol, unsigned int *stat)
+                                     const float *atan_tab, const uint32_t *bitmap, int bm_tiles, float *d, int drow, float *dcol, unsigned int *stat)
 {
     const btgpu_design &dd = des.d;
     ExactParams e{};
     e.x_len = (long long)x_len; e.first0 = w0 + dd.first_channel_sample; e.G = G;
     e.tapsA = tapsA; e.rot = rot; e.Qr = des.channel.rot_period; e.atan_tab = atan_tab; e.gain = des.demod_gain;
-    e.bitmap = bitmap; e.ntiles = bm_tiles; e.shift = bm_shift; e.stat = stat; e.d = d; e.drow = drow; e.dcol = dcol;
+    e.bitmap = bitmap; e.ntiles = bm_tiles; e.stat = stat; e.d = d; e.drow = drow; e.dcol = dcol;
     e.ydbg = nullptr; e.ystride = 0; e.nch = dd.high_channel - dd.low_channel + 1;
     return e;
 }

@@ -394,7 +394,6 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     if (verify) {
         vb.tasks = (VerifyTask *)t.d_vtasks.p; vb.vcount = (unsigned int *)t.d_vcount.p;
         vb.dxt = (float *)t.d_dxt.p; vb.vcap = vcap;
-        vb.bm_shift = (int)((abs_first_slot * (uint64_t)ops) % (uint64_t)kExTile);
         vb.bm_tiles = exact_ntiles(G); vb.bm1 = (uint32_t *)t.d_bm.p; vb.bm2 = vb.bm1 + (size_t)bm_tiles * kExBmWords;
         if (pfb_small && t.d_pfine.p && verify_has_fine(des, fp, drow))
             set_verify_flagging(p, des, fp, pfb_small, verify, (const double *)t.d_pfine.p, ntiles * (pfbm_tile(fp.channel.M) / 25), vb, want_syms, 25);
@@ -404,7 +403,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     }
     auto launch_exact_rows = [&](const uint32_t *bitmap, unsigned int *stat, hipStream_t s_) {
         const ExactParams ep = make_exact_params(des, x_len, w0, G, (const float *)d_tapsA.p, (const float2 *)d_rot_ch.p, (const float *)d_atan.p,
-                                                 bitmap, vb.bm_tiles, vb.bm_shift, (float *)d_d.p, drow, (float *)(use_dcol ? t.d_dcol.p : nullptr), stat);
+                                                 bitmap, vb.bm_tiles, (float *)d_d.p, drow, (float *)(use_dcol ? t.d_dcol.p : nullptr), stat);
         hipLaunchKernelGGL(ex_kern, dim3((unsigned)vb.bm_tiles), dim3(kExThreads), ex_lds, s_, ep, d_x);
     };
     HIPCHK(this, mark(12, ps));

@@ -18,7 +18,7 @@
 // scripts/ubench/exact_mfma.hip checks it on the device against per-lane fmaf).  VOLK's order in the reference is unspecified
 // and GNU Radio is not in the image (parity of the float half is unpinned upstream): the order is this repository's to fix.
 //
-// One workgroup = one time tile of 160 columns = 147 outputs (the first is the demodulator's halo): five waves, wave w owns
+// One workgroup = one time tile of 160 columns, of which 139 carry its 126 outputs (the first is the demodulator's halo): five waves, wave w owns
 // columns [32 w, 32 w + 32) -- its 32 D input samples go through LDS once and stay in D registers per lane as the B operand for
 // EVERY channel the bitmap names for the tile; the channel's T (2 QB x 2 D floats, lane-major, 12.8 KB at D = 50) is streamed
 // through LDS as the A operand.  Per channel and wave: D MFMAs (64 cycles each) and nothing else on the critical path.
@@ -32,8 +32,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kExWaves = 5, kExThreads = 64 * kExWaves;
 constexpr int kExCols = 32 * kExWaves;          // polyphase columns per tile
 constexpr int kExQB = 14;                       // tap blocks: ceil(ntaps / D) (firdes: ntaps = 44 fs / (22 * 300 kHz) | 1 = 13.33 D + 1 with D = fs / 2 MHz)
-constexpr int kExOuts = kExCols - (kExQB - 1);  // 147 outputs per tile; output 0 is the halo of the demodulator
-constexpr int kExTile = kExOuts - 1;            // 146 new demodulated rows per tile
+constexpr int kExTile = 125;                    // new demodulated rows per tile: a SLOT is ten tiles (1250 rows), so tiles never straddle a batch's or a rank's first row
+constexpr int kExOuts = kExTile + 1;            // outputs per tile; output 0 is the halo of the demodulator
+static_assert(kExOuts + kExQB - 1 <= kExCols, "the tile's outputs and the diagonal sum's overhang fit the columns");   // 139 of 160
+constexpr int kExEpw = (kExOuts + kExWaves - 1) / kExWaves + 1;   // epilogue lanes per wave: its share of the outputs + its left neighbour's last
 static_assert(kExTile == kExTileRows, "kernels.hip.h marks the bitmap in tiles of kExTileRows rows");
 constexpr int kExGStride = 168;                 // floats per row of G in LDS: 4 rows further = 32 banks further (the two half-waves of a C/D register)
 constexpr int kExWords = kExBmWords;            // bitmap words per tile (<= 96 channels)
@@ -45,8 +47,8 @@ struct ExactParams {
     const float *tapsA;           // [nch][64][exact_dpad(D)]: the A operand of lane l, step r -- row l & 31 = 2 q + (re: 0, im: 1), k = l >> 5 (exact_pack_taps)
     const float2 *rot; int Qr;    // de-rotation table [nch][Qr] by grid row (the windows' own rotators differ from it by an exact +-1: the demodulated rows are the same bits)
     const float *atan_tab; float gain;
-    const uint32_t *bitmap;       // [ntiles][kExWords]: bit c of tile j = rows [kExTile j - shift, kExTile (j + 1) - shift) of channel c are recomputed
-    int ntiles, shift;
+    const uint32_t *bitmap;       // [ntiles][kExWords]: bit c of tile j = rows [kExTile j, kExTile (j + 1)) of channel c are recomputed
+    int ntiles;
     unsigned int *stat;           // nullptr, or a counter of the (channel, tile) pairs computed
     float *d; int drow;           // time-major stream [G][drow]
     float *dcol;                  // nullptr, or the tile-blocked copy [G / 25][80][25]
@@ -62,7 +64,7 @@ constexpr size_t exact_lds_main(int D)
     return ((stage > ops ? stage : ops) + 15) / 16 * 16;
 }
 inline size_t exact_lds_bytes(int D) { return exact_lds_main(D) + 260 * sizeof(float); }
-inline int exact_ntiles(long long G) { return (int)((G + kExTile - 1) / kExTile) + 1; }   // (+ 1: the tiles are anchored to the absolute grid)
+inline int exact_ntiles(long long G) { return (int)((G + kExTile - 1) / kExTile); }
 
 // tapsA from a direct-form bank's reversed taps [nch][ntp][2] (design.h FilterBank): out[(c * 64 + l) * dpad + r] = the A operand of
 // step r for lane l -- row l & 31 = 2 q + (re: 0, im: 1), k = l >> 5: (tr, -ti) for a re row, (ti, tr) for an im row; zero beyond the
@@ -85,7 +87,7 @@ inline size_t exact_taps_floats(int nch, int D) { return (size_t)nch * 64 * exac
 // operand for every channel of the tile), then per channel ONE barrier:
 //     [loads of the NEXT channel's A in flight]  D MFMAs over As[n & 1]  ->  G to Gs[n & 1]  ->  next A to As[~n & 1]  ->  barrier
 //     ->  epilogue of channel n: diagonal sums, de-rotation, demodulator, stores  (while other waves are already in channel n + 1's MFMAs)
-// Epilogue lanes: wave w takes outputs 30 w - 1 .. 30 w + 29 on its lanes 0 .. 30 (lane 0 only supplies its right neighbour's
+// Epilogue lanes: wave w takes outputs 26 w - 1 .. 26 w + 25 on its lanes 0 .. 26 (lane 0 only supplies its right neighbour's
 // predecessor), so that y[t - 1] is one shuffle away and all five waves share the work.
 template <int D>
 __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p
         };
         int c_cur = next_channel();
         load_a(c_cur);                                             // (in flight under the staging)
-        const long long g0 = (long long)tile * kExTile - p.shift - 1;   // grid row of output 0
+        const long long g0 = (long long)tile * kExTile - 1;        // grid row of output 0
         const long long sb = p.first0 + g0 * D + (long long)wave * NS;
         __syncthreads();                                           // the previous tile's buffers are consumed
         // ---- the wave's 32 columns: coalesced loads, LDS, then one column half per lane ----
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p
         store_a(0);
         __syncthreads();
         // the epilogue's lane: output u of the tile (u = 0: the halo), -1 where the lane has none
-        const int u = (lane <= 30) ? 30 * wave + lane - 1 : -1;
+        const int u = (lane < kExEpw) ? (kExEpw - 1) * wave + lane - 1 : -1;
         const bool u_ok = u >= 0 && u < kExOuts;
         const long long g = g0 + (u_ok ? u : 0);
         for (int n = 0; c_cur >= 0; n++) {

@@ -344,7 +344,7 @@ struct WindowParams {
     VerifyTask *vtasks; unsigned int *vcount;   // vcount: 0 tasks reserved, 1 (channel, tile) pairs marked, 2 windows turned away (list full), 3 busy windows (presence)
     int vcap;                   // capacity of vtasks
     uint32_t *bm1, *bm2;        // exact rows' bitmaps [bm_tiles][kExBmWords]: marked by presence_kernel / by the first run's uncovered hits
-    int bm_tiles, bm_shift;     // bm_shift: (absolute grid row of the batch's first row) mod kExTileRows
+    int bm_tiles;
     float burst_abs;            // presence: a W-tile sum above burst_abs * (the quietest aligned W-tile block of the span) ...
     int burst_w;                // ... W = tiles per ~50 us (set_verify_flagging, bank_launch.h)
     float burst_abs1;           // ... or above burst_abs1 * (the quietest single tile), whichever is lower
@@ -537,14 +537,14 @@ __device__ __forceinline__ int ver_rows_of(const WindowParams &p, int span)
 }
 
 // ---- exact rows: which (channel, time tile) pairs are recomputed through the reference's own arithmetic (exact.hip.h) ----
-// bitmap[tile][kExWords]: bit c of tile j = grid rows [kExTile j - shift, kExTile (j + 1) - shift) of channel c.  `shift` anchors the
-// tiles to the ABSOLUTE output grid (the batch's first row modulo the tile length): the same rows are exact however the stream is
-// cut into batches or ranks.
-constexpr int kExTileRows = 146;     // = exact.hip.h kExTile (160 polyphase columns - 13 - the demodulator's halo)
+// bitmap[tile][kExWords]: bit c of tile j = grid rows [kExTile j, kExTile (j + 1)) of channel c.  A slot is a whole number of tiles
+// (1250 rows = 10 tiles at every rate with a shared grid), a batch begins with a slot: which rows are exact does not depend on how
+// the stream is cut into batches or ranks, nor on what the first slot is called.
+constexpr int kExTileRows = 125;     // = exact.hip.h kExTile
 constexpr int kExBmWords = 3;        // bitmap words per tile (<= 96 channels)
-__device__ __forceinline__ void exact_mark(uint32_t *bm, const uint32_t *skip, int ntiles, int shift, long long g_lo, long long g_hi, int c, unsigned int *stat)
+__device__ __forceinline__ void exact_mark(uint32_t *bm, const uint32_t *skip, int ntiles, long long g_lo, long long g_hi, int c, unsigned int *stat)
 {
-    int t0 = (int)((g_lo + shift) / kExTileRows), t1 = (int)((g_hi - 1 + shift) / kExTileRows);
+    int t0 = (int)(g_lo / kExTileRows), t1 = (int)((g_hi - 1) / kExTileRows);
     if (t1 >= ntiles) t1 = ntiles - 1;
     const uint32_t bit = 1u << (c & 31);
     int n = 0;
@@ -556,12 +556,12 @@ __device__ __forceinline__ void exact_mark(uint32_t *bm, const uint32_t *skip, i
     if (stat && n) atomicAdd(stat, (unsigned int)n);
 }
 // rows of window (k, c), from its first row on, that the bitmap covers without a gap
-__device__ __forceinline__ int exact_covered_rows(const uint32_t *bm, int ntiles, int shift, long long g_lo, int c)
+__device__ __forceinline__ int exact_covered_rows(const uint32_t *bm, int ntiles, long long g_lo, int c)
 {
-    int t = (int)((g_lo + shift) / kExTileRows);
+    int t = (int)(g_lo / kExTileRows);
     const uint32_t bit = 1u << (c & 31);
     while (t < ntiles && (bm[(size_t)t * kExBmWords + (c >> 5)] & bit)) t++;
-    const long long cov = (long long)t * kExTileRows - shift - g_lo;
+    const long long cov = (long long)t * kExTileRows - g_lo;
     return cov > 0 ? (cov > 0x3fffffff ? 0x3fffffff : (int)cov) : 0;
 }
 
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(kWinThreads) void presence_kernel(WindowParams p)
             // to 80 symbols behind the last busy tile: the end of an access code that starts in it, its header (54 + 4 symbols)
             const int rows = ver_rows_of(p, ((last_busy + 1) * TT) / 2 + 80);
             const long long g_lo = (long long)kq * p.outs_per_slot;
-            exact_mark(p.bm1, nullptr, p.bm_tiles, p.bm_shift, g_lo, g_lo + rows, cq, &s_cnt[1]);
+            exact_mark(p.bm1, nullptr, p.bm_tiles, g_lo, g_lo + rows, cq, &s_cnt[1]);
             atomicAdd(&s_cnt[0], 1u);
         }
     }
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     // recomputed, and the second run -- this kernel with VER = true -- emits what the first has not.
     int vslot = -1, vspan = 0;
     int cov_rows = 0, first_uncov = -1;
-    if (!VER && p.verify && lane_ok && nmax != 0) cov_rows = exact_covered_rows(p.bm1, p.bm_tiles, p.bm_shift, (long long)kq * p.outs_per_slot, cq);
+    if (!VER && p.verify && lane_ok && nmax != 0) cov_rows = exact_covered_rows(p.bm1, p.bm_tiles, (long long)kq * p.outs_per_slot, cq);
     auto ver_rows = [&](int span) { return ver_rows_of(p, span); };
 
     if (p.dbg_stop == 1) return;
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         // the rest of this window's records come from the second run: mark the rows they stand on (what presence has not marked)
         const int rows = ver_rows(vspan);
         const long long g_lo = (long long)kq * p.outs_per_slot;
-        exact_mark(p.bm2, p.bm1, p.bm_tiles, p.bm_shift, g_lo, g_lo + rows, cq, &p.vcount[1]);
+        exact_mark(p.bm2, p.bm1, p.bm_tiles, g_lo, g_lo + rows, cq, &p.vcount[1]);
         VerifyTask t_;
         t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr; t_.emit_from = first_uncov; t_.pad_ = 0;
         p.vtasks[vslot] = t_;

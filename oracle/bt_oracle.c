@@ -30,7 +30,7 @@ typedef struct fir_bank {
     int    ntaps;        /* true length                                  */
     int    blk;          /* block length of the summation order = the decimation (ddc_run) */
     int    ntp;          /* padded to whole blocks: ceil(ntaps / blk) * blk */
-    float *tr, *ti;      /* [nch][blk][ntp / blk]: reversed complex taps, zero padded, tap q blk + r at [r][q] */
+    float *tr, *ti;      /* [nch][ntp] reversed complex taps, zero padded */
     double *foff;        /* [nch] frequency offset of each channel (Hz)  */
 } fir_bank;
 
@@ -240,7 +240,6 @@ static void build_bank(fir_bank *b, const float *h, int ntaps, int nch, int low_
     b->ntaps = ntaps;
     b->blk = blk;
     b->ntp = (ntaps + blk - 1) / blk * blk;
-    const int nq = b->ntp / blk;
     b->tr = (float *)calloc((size_t)nch * b->ntp, sizeof(float));
     b->ti = (float *)calloc((size_t)nch * b->ntp, sizeof(float));
     b->foff = (double *)calloc(nch, sizeof(double));
@@ -252,8 +251,8 @@ static void build_bank(fir_bank *b, const float *h, int ntaps, int nch, int low_
             float wr, wi;
             phase_factor(foff, fs, k, &wr, &wi);
             int j = ntaps - 1 - k;               /* stored reversed: y = sum_j t[j] x[base+j] */
-            b->tr[(size_t)c * b->ntp + (size_t)(j % blk) * nq + j / blk] = h[k] * wr;
-            b->ti[(size_t)c * b->ntp + (size_t)(j % blk) * nq + j / blk] = h[k] * wi;
+            b->tr[(size_t)c * b->ntp + j] = h[k] * wr;
+            b->ti[(size_t)c * b->ntp + j] = h[k] * wi;
         }
     }
 }
@@ -392,41 +391,50 @@ int bto_noise_out(const bto_ctx *c)                                    /* :269 *
  * -- the polyphase-GEMM form of the decimating FIR: G[q][m] = sum_r t[qD + r] x[mD + r] is a matrix product over the input
  * reshaped into columns of D samples, and y[n] = sum_q G[q][n + q].  The product's exact stage computes it on the fp32 matrix
  * pipe (v_mfma_f32_32x32x2_f32 is bit for bit this fmaf chain, scripts/ubench/exact_mfma.hip), the generic kernels on the VALU.
- * xt: the window transposed into those columns, xt[(r * 2 + part) * ncol + m] = part of x[m D + r], so that the loop over q
- * (the one the compiler vectorises) reads consecutive floats. */
+ * xt: the window transposed into those columns, xt[(r * 2 + part) * ncol + m] = part of x[m D + r]: sixteen consecutive OUTPUTS then
+ * read consecutive floats at every (q, r), and the loop over them is the one the compiler vectorises (each output its own chain). */
+#define DDC_V 16
 static void ddc_run(const fir_bank *b, int chan_idx, double fs, int decim,
                     const float *xt, int ncol, int first, int nout, float *out_iq)
 {
     const int D = b->blk, nq = b->ntp / b->blk;
-    const float *tr = b->tr + (size_t)chan_idx * b->ntp;      /* transposed: tr[r * nq + q] = tap q D + r */
+    const float *tr = b->tr + (size_t)chan_idx * b->ntp;
     const float *ti = b->ti + (size_t)chan_idx * b->ntp;
     const double foff = b->foff[chan_idx];
-    float *gr = (float *)malloc(sizeof(float) * 2 * (size_t)nq), *gi = gr + nq;
+    /* sample first + i D + q D + r = column (i + q + a[r]), row rho[r] */
+    int *ra = (int *)malloc(sizeof(int) * 2 * (size_t)D), *rho = ra + D;
+    for (int r = 0; r < D; r++) { const int s0 = first + r; ra[r] = s0 / D; rho[r] = s0 - ra[r] * D; }
     (void)decim;
-    for (int i = 0; i < nout; i++) {
-        for (int q = 0; q < nq; q++) { gr[q] = 0.0f; gi[q] = 0.0f; }
-        for (int r = 0; r < D; r++) {
-            /* sample first + i D + q D + r = column (i + q + a), row rho */
-            const int s0 = first + r, a = s0 / D, rho = s0 - a * D;
-            const float *pr = xt + (size_t)(2 * rho) * ncol + i + a, *pi = xt + (size_t)(2 * rho + 1) * ncol + i + a;
-            const float *ar = tr + (size_t)r * nq, *ai = ti + (size_t)r * nq;
-            for (int q = 0; q < nq; q++) {
-                const float ta = ar[q], tb = ai[q], vr = pr[q], vi = pi[q];
-                gr[q] = fmaf(ta, vr, gr[q]);
-                gr[q] = fmaf(-tb, vi, gr[q]);
-                gi[q] = fmaf(tb, vr, gi[q]);
-                gi[q] = fmaf(ta, vi, gi[q]);
+    for (int i0 = 0; i0 < nout; i0 += DDC_V) {
+        float yr[DDC_V], yi[DDC_V];
+        for (int q = 0; q < nq; q++) {
+            float gr[DDC_V], gi[DDC_V];
+            for (int l = 0; l < DDC_V; l++) { gr[l] = 0.0f; gi[l] = 0.0f; }
+            for (int r = 0; r < D; r++) {
+                const float ta = tr[q * D + r], tb = ti[q * D + r];
+                const float *pr = xt + (size_t)(2 * rho[r]) * ncol + i0 + ra[r] + q;
+                const float *pi = xt + (size_t)(2 * rho[r] + 1) * ncol + i0 + ra[r] + q;
+                for (int l = 0; l < DDC_V; l++) {
+                    const float vr = pr[l], vi = pi[l];
+                    gr[l] = fmaf(ta, vr, gr[l]);
+                    gr[l] = fmaf(-tb, vi, gr[l]);
+                    gi[l] = fmaf(tb, vr, gi[l]);
+                    gi[l] = fmaf(ta, vi, gi[l]);
+                }
             }
+            if (q == 0) for (int l = 0; l < DDC_V; l++) { yr[l] = gr[l]; yi[l] = gi[l]; }
+            else for (int l = 0; l < DDC_V; l++) { yr[l] = yr[l] + gr[l]; yi[l] = yi[l] + gi[l]; }
         }
-        float yr = gr[0], yi = gi[0];
-        for (int q = 1; q < nq; q++) { yr = yr + gr[q]; yi = yi + gi[q]; }
-        /* rotator: out[i] = y[i] * exp(-j theta D i), restarted per window (Q3) */
-        float rr, ri;
-        phase_factor(-foff, fs, (long long)decim * i, &rr, &ri);
-        out_iq[2 * i]     = fmaf(-yi, ri, yr * rr);
-        out_iq[2 * i + 1] = fmaf(yi, rr, yr * ri);
+        for (int l = 0; l < DDC_V && i0 + l < nout; l++) {
+            const int i = i0 + l;
+            /* rotator: out[i] = y[i] * exp(-j theta D i), restarted per window (Q3) */
+            float rr, ri;
+            phase_factor(-foff, fs, (long long)decim * i, &rr, &ri);
+            out_iq[2 * i]     = fmaf(-yi[l], ri, yr[l] * rr);
+            out_iq[2 * i + 1] = fmaf(yi[l], rr, yr[l] * ri);
+        }
     }
-    free(gr);
+    free(ra);
 }
 
 /* the window in columns of D samples (see ddc_run); zero columns behind the end */
@@ -485,7 +493,7 @@ static int check_snr_d(bto_ctx *c, int channel, double on_energy, const float *x
 int bto_channel_samples(bto_ctx *c, int channel, const float *win, float *out_iq, double *energy)
 {
     float *xt;
-    int ncol = transpose_cols(win, c->history, c->decim, 2, &xt);
+    int ncol = transpose_cols(win, c->history, c->decim, DDC_V + 2, &xt);
     int n = channel_samples_d(c, channel, xt, ncol, out_iq, energy);
     free(xt);
     return n;
@@ -495,7 +503,7 @@ int bto_check_snr(bto_ctx *c, int channel, double on_energy, const float *win, d
                   double *off_energy)
 {
     float *xt;
-    int ncol = transpose_cols(win, c->history, c->decim, 2, &xt);
+    int ncol = transpose_cols(win, c->history, c->decim, DDC_V + 2, &xt);
     int r = check_snr_d(c, channel, on_energy, xt, ncol, snr, off_energy);
     free(xt);
     return r;
@@ -1037,7 +1045,7 @@ static int work_channel(bto_ctx *c, int ch, const float *xt, int ncol, uint32_t 
 int bto_work(bto_ctx *c, const float *win, uint32_t slot, bto_hit *hits, int max_hits)
 {
     float *xt;
-    int ncol = transpose_cols(win, c->history, c->decim, 2, &xt);
+    int ncol = transpose_cols(win, c->history, c->decim, DDC_V + 2, &xt);
     int nout = bto_ddc_out(c);
     float *chbuf = (float *)malloc(sizeof(float) * 2 * (size_t)(nout + 1));
     char *symbols = (char *)calloc((size_t)c->history + 64, 1);
@@ -1095,7 +1103,7 @@ int bto_run_stream_mt(bto_ctx *c, const float *iq, size_t n_complex, bto_hit *hi
     {
         bto_ctx local = *c;                        /* private M&M state (windowed reset) */
         local.mm_policy = BTO_MM_WINDOWED_RESET;
-        const int D = local.decim, ncol = (H + D - 1) / D + 2;
+        const int D = local.decim, ncol = (H + D - 1) / D + DDC_V + 2;
         float *xt = (float *)calloc((size_t)2 * D * ncol, sizeof(float));
         float *chbuf = (float *)malloc(sizeof(float) * 2 * (size_t)(nout + 1));
         char *symbols = (char *)calloc((size_t)H + 64, 1);

@@ -276,7 +276,7 @@ extern "C" int emu_last_fused_m(void) { return g_last_fused_m; }
 extern "C" void emu_verify_counts(unsigned int *out) { std::memcpy(out, g_verify_counts, sizeof g_verify_counts); }
 static std::vector<VerifyTask> g_verify_tasks;           // of the last emulated front end: windows with exact rows (n_exact: covered rows from the window's first)
 static std::vector<VerifyTask> g_second_run;             // ... and the windows its second run took
-static std::vector<uint32_t> g_exact_bitmap; static int g_exact_tiles = 0, g_exact_shift = 0;   // bm1 | bm2 of the last emulated front end
+static std::vector<uint32_t> g_exact_bitmap; static int g_exact_tiles = 0;   // bm1 | bm2 of the last emulated front end
 extern "C" int emu_exact_bitmap(uint32_t *out, int cap_words)
 {
     const int n = (int)std::min<size_t>(g_exact_bitmap.size(), (size_t)cap_words);
@@ -319,7 +319,6 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         const int nps = (vb.vcap + nch - 1) / nch;
         dxt4.assign(((size_t)nps * kVerRows * drow + 3) / 4 + 16, make_float4(-66.f, -66.f, -66.f, -66.f));
         vb.bm_tiles = exact_ntiles(G);
-        vb.bm_shift = getenv("EMU_BM_SHIFT") ? atoi(getenv("EMU_BM_SHIFT")) % kExTile : 0;   // (the runtime: the batch's absolute first grid row mod the tile length)
         bm.assign((size_t)2 * vb.bm_tiles * kExBmWords, 0u);
         vb.bm1 = bm.data(); vb.bm2 = bm.data() + (size_t)vb.bm_tiles * kExBmWords;
         vb.tasks = vtasks.data(); vb.vcount = vcount; vb.dxt = (float *)dxt4.data();
@@ -333,7 +332,7 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         const int D = des.d.decimation;
         if (tapsA.empty()) { tapsA.resize(exact_taps_floats(nch, D)); exact_pack_taps(des.channel.taps.data(), nch, des.channel.ntp, D, tapsA.data()); }
         const ExactParams ep = make_exact_params(des, (size_t)ve->x_len, 0, G, tapsA.data(), (const float2 *)des.channel.rot.data(), des.atan_tab,
-                                                 bitmap, vb.bm_tiles, vb.bm_shift, const_cast<float *>(d), drow, const_cast<float *>(dcol_p), stat);
+                                                 bitmap, vb.bm_tiles, const_cast<float *>(d), drow, const_cast<float *>(dcol_p), stat);
         const ExactRowsKernel kern = exact_rows_pick(D);
         if (exact_lds_bytes(D) > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", exact_lds_bytes(D)); std::abort(); }
         bool any = false;
@@ -395,12 +394,12 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         for (size_t i = 0; i < un.size(); i++) un[i] = vb.bm1[i] | vb.bm2[i];
         for (int k = 0; k < S; k++)
             for (int c = 0; c < nch; c++) {
-                const int cov = exact_covered_rows(un.data(), vb.bm_tiles, vb.bm_shift, (long long)k * p.outs_per_slot, c);
+                const int cov = exact_covered_rows(un.data(), vb.bm_tiles, (long long)k * p.outs_per_slot, c);
                 if (cov > 0) g_verify_tasks.push_back(VerifyTask{k * nch + c, cov, 0.0, 0, 0});
             }
     }
     g_second_run.assign(vtasks.begin(), vtasks.begin() + std::min<size_t>(vtasks.size(), vcount[0]));
-    g_exact_bitmap = bm; g_exact_tiles = vb.bm_tiles; g_exact_shift = vb.bm_shift;
+    g_exact_bitmap = bm; g_exact_tiles = vb.bm_tiles;
     if (g_study) g_study->tasks = g_verify_tasks;
     {
         const unsigned nblk = (unsigned)((counts[1] + kFinLanes - 1) / kFinLanes + 1);
@@ -715,7 +714,7 @@ extern "C" long emu_verify_check(double fs, double fc, int mode, double squelch_
     g_study = &fast;
     int rc = emu_front_m_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
     unsigned int fast_counts[kVerCountWords]; std::memcpy(fast_counts, g_verify_counts, sizeof fast_counts);
-    const std::vector<uint32_t> fast_bm = g_exact_bitmap; const int fast_tiles = g_exact_tiles, fast_shift = g_exact_shift;   // (emu_verify_counts after this call: the polyphase run's)
+    const std::vector<uint32_t> fast_bm = g_exact_bitmap; const int fast_tiles = g_exact_tiles;   // (emu_verify_counts after this call: the polyphase run's)
     g_study = &exact; g_rows_only = true;
     if (rc >= 0) rc = emu_front_direct_run(fs, fc, mode, 0, squelch_db, iq, x_len, S, rec.data(), sn.data(), 65536);
     g_study = nullptr; g_rows_only = false;
@@ -734,7 +733,7 @@ extern "C" long emu_verify_check(double fs, double fc, int mode, double squelch_
     for (int t = 0; t < fast_tiles; t++)
         for (int c = 0; c < nch; c++) {
             if (!(((b1[(size_t)t * kExBmWords + (c >> 5)] | b2[(size_t)t * kExBmWords + (c >> 5)]) >> (c & 31)) & 1u)) continue;
-            for (long long g = std::max<long long>(1, (long long)t * kExTile - fast_shift); g < (long long)(t + 1) * kExTile - fast_shift && g < fast.G; g++) {
+            for (long long g = std::max<long long>(1, (long long)t * kExTile); g < (long long)(t + 1) * kExTile && g < fast.G; g++) {
                 const float a = fast.d[(size_t)g * fast.drow + c], b = exact.d[(size_t)g * exact.drow + c];
                 checked++;
                 if (std::memcmp(&a, &b, 4) != 0) {
