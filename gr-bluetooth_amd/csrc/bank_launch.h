@@ -279,7 +279,7 @@ inline void set_verify_flagging(WindowParams &p, const Design &des, const FastPa
     }
     p.span_extra = headers ? 58 : 0;                     // 54 header symbols + the 4-symbol trailer
 }
-static_assert(kExactTileRows == kExTile, "design.h and exact.hip.h agree on the tile");
+static_assert(kExactSlotRows == kExSlotRows, "design.h and kernels.hip.h agree on the slot");
 // exact_rows_kernel's parameters for one bitmap of the batch (tapsA: exact_pack_taps of the direct-form channel bank)
 inline ExactParams make_exact_params(const Design &des, size_t x_len, long long w0, long long G, const float *tapsA, const float2 *rot,
                                      const float *atan_tab, const uint32_t *bitmap, int bm_tiles, float *d, int drow, float *dcol, unsigned int *stat)

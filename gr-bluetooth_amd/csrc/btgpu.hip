@@ -668,10 +668,10 @@ int btgpu_handle::harvest(TailCtx &t)
     if (verify) {
         // h_count[4..]: vcount -- tasks of the second run, pairs marked, turned away, busy windows, pairs computed by the two launches
         timing.verify_windows += t.h_count[7] + std::min<unsigned>(t.h_count[4], (unsigned)vcap);
-        timing.verify_rows += (uint64_t)(t.h_count[8] + t.h_count[9]) * kExTile;
+        timing.verify_rows += (uint64_t)(t.h_count[8] + t.h_count[9]) * kExSlotRows / kExSlotTiles;   // (eleven tiles per 1250-row slot)
         timing.verify_turned_away += t.h_count[6];
         timing.long_tasks += std::min<unsigned>(t.h_count[4], (unsigned)vcap);      // (reused: the second run's windows and rows)
-        timing.long_rows += (uint64_t)t.h_count[9] * kExTile;
+        timing.long_rows += (uint64_t)t.h_count[9] * kExSlotRows / kExSlotTiles;
     }
     timing.slots += (uint64_t)t.S;
     timing.samples += (uint64_t)t.S * (uint64_t)d.samples_per_slot;

@@ -145,7 +145,7 @@ int make_fast_path(const Design &des, FastPath &fp);
 // freq_xlating_fir_filter_ccf [EXT]); the grid's rotator differs from a window's own by the factor rot[window start], and the
 // quadrature demodulator y[t] conj(y[t-1]) is bit for bit indifferent to a common factor of exactly +-1.  True when the bank is
 // periodic, the windows share one grid, D is one the kernel is built for and every window start of every channel meets +-1.
-constexpr int kExactTileRows = 125;     // rows per tile of exact_rows_kernel (kernels.hip.h kExTileRows): a slot must be a whole number of them
+constexpr int kExactSlotRows = 1250;    // rows per slot that exact_rows_kernel's tiling is laid out for (kernels.hip.h kExSlotRows: eleven tiles per slot)
 bool exact_rows_available(const Design &des);
 
 // direct-form bank builder shared by the reference-filter banks and the staged squelch

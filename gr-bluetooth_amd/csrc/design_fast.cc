@@ -254,7 +254,7 @@ bool exact_rows_available(const Design &des)
     const int D = des.d.decimation;
     if (des.segmented || b.rot_period <= 0 || D < 2 || D > 50 || b.ntp / b.blk > 14 || b.blk != D) return false;
     if (D > 25 && D != 50) return false;                                   // (instantiated: 2 .. 25 and 50)
-    if (des.outs_per_slot % kExactTileRows != 0) return false;             // (tiles never straddle a slot: 1250 rows = 10 tiles wherever the grid is shared)
+    if (des.outs_per_slot != kExactSlotRows) return false;                 // (tiles never straddle a slot: 1250 rows = 11 tiles wherever the grid is shared)
     for (int c = 0; c < b.nch; c++)
         for (int k = 0; k < b.rot_period; k++) {                           // window k starts at grid row k * outs_per_slot
             const size_t i = ((size_t)c * b.rot_period + (size_t)(((long long)k * des.outs_per_slot) % b.rot_period)) * 2;

@@ -18,7 +18,7 @@
 // scripts/ubench/exact_mfma.hip checks it on the device against per-lane fmaf).  VOLK's order in the reference is unspecified
 // and GNU Radio is not in the image (parity of the float half is unpinned upstream): the order is this repository's to fix.
 //
-// One workgroup = one time tile of 160 columns, of which 139 carry its 126 outputs (the first is the demodulator's halo): five waves, wave w owns
+// One workgroup = one time tile of 128 columns = 115 outputs (the first is the demodulator's halo) + the diagonal sum's 13: four waves, wave w owns
 // columns [32 w, 32 w + 32) -- its 32 D input samples go through LDS once and stay in D registers per lane as the B operand for
 // EVERY channel the bitmap names for the tile; the channel's T (2 QB x 2 D floats, lane-major, 12.8 KB at D = 50) is streamed
 // through LDS as the A operand.  Per channel and wave: D MFMAs (64 cycles each) and nothing else on the critical path.
@@ -29,15 +29,16 @@ namespace btgpu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kExWaves = 5, kExThreads = 64 * kExWaves;
+constexpr int kExWaves = 4, kExThreads = 64 * kExWaves;         // one wave per SIMD: a five-wave form ran at 45 % of the matrix pipe's rate -- the SIMD that
+                                                                 // held two waves of every workgroup set the pace, whatever the occupancy (profiles/r06_e_*)
 constexpr int kExCols = 32 * kExWaves;          // polyphase columns per tile
 constexpr int kExQB = 14;                       // tap blocks: ceil(ntaps / D) (firdes: ntaps = 44 fs / (22 * 300 kHz) | 1 = 13.33 D + 1 with D = fs / 2 MHz)
-constexpr int kExTile = 125;                    // new demodulated rows per tile: a SLOT is ten tiles (1250 rows), so tiles never straddle a batch's or a rank's first row
+constexpr int kExTile = 114;                    // new demodulated rows per full tile; a SLOT (1250 rows) is ten of those and one of 110 (kernels.hip.h exact_tile_of)
 constexpr int kExOuts = kExTile + 1;            // outputs per tile; output 0 is the halo of the demodulator
-static_assert(kExOuts + kExQB - 1 <= kExCols, "the tile's outputs and the diagonal sum's overhang fit the columns");   // 139 of 160
+static_assert(kExOuts + kExQB - 1 <= kExCols, "the tile's outputs and the diagonal sum's overhang fit the columns");   // 128 of 128
 constexpr int kExEpw = (kExOuts + kExWaves - 1) / kExWaves + 1;   // epilogue lanes per wave: its share of the outputs + its left neighbour's last
 static_assert(kExTile == kExTileRows, "kernels.hip.h marks the bitmap in tiles of kExTileRows rows");
-constexpr int kExGStride = 168;                 // floats per row of G in LDS: 4 rows further = 32 banks further (the two half-waves of a C/D register)
+constexpr int kExGStride = 136;                 // floats per row of G in LDS: 4 rows further = 32 banks further (the two half-waves of a C/D register)
 constexpr int kExWords = kExBmWords;            // bitmap words per tile (<= 96 channels)
 
 struct ExactParams {
@@ -56,20 +57,17 @@ struct ExactParams {
     int nch;
 };
 
-constexpr int exact_dpad(int D) { return (D + 3) / 4 * 4; }      // floats per lane of a channel's A operand (16-byte reads)
-// LDS: the staged span (32 D samples per wave), reused once the B operands are in registers for A (two buffers) and G (two buffers); + the arctangent table
-constexpr size_t exact_lds_main(int D)
-{
-    const size_t stage = (size_t)kExWaves * 32 * D * 8, ops = (size_t)2 * (64 * exact_dpad(D) + 2 * kExQB * kExGStride) * 4;
-    return ((stage > ops ? stage : ops) + 15) / 16 * 16;
-}
-inline size_t exact_lds_bytes(int D) { return exact_lds_main(D) + 260 * sizeof(float); }
-inline int exact_ntiles(long long G) { return (int)((G + kExTile - 1) / kExTile); }
+constexpr int exact_dpad(int D) { return (D + 3) / 4 * 4; }      // steps of a channel's A operand, padded to whole 16-byte groups
+constexpr int kExGSize = 2 * kExQB * kExGStride;                 // floats of one G buffer
+// LDS: two G buffers + the arctangent table -- 38.7 KB: FOUR workgroups per CU.  (Neither operand goes through LDS: B comes straight
+// from the stream into registers, once per tile; A from the L1 / L2, where the 13 KB of a channel's taps stay resident.)
+inline size_t exact_lds_bytes(int) { return (size_t)2 * kExGSize * sizeof(float) + 260 * sizeof(float); }
+inline int exact_ntiles(long long G) { return (int)((G + kExSlotRows - 1) / kExSlotRows) * kExSlotTiles; }
 
-// tapsA from a direct-form bank's reversed taps [nch][ntp][2] (design.h FilterBank): out[(c * 64 + l) * dpad + r] = the A operand of
-// step r for lane l -- row l & 31 = 2 q + (re: 0, im: 1), k = l >> 5: (tr, -ti) for a re row, (ti, tr) for an im row; zero beyond the
-// filter, in rows 2 QB .. 31 and in the pad
-inline void exact_pack_taps(const float *taps, int nch, int ntp, int D, float *out /* [nch][64][exact_dpad(D)] */)
+// tapsA from a direct-form bank's reversed taps [nch][ntp][2] (design.h FilterBank): out[((c * (dpad / 4) + i) * 64 + l) * 4 + e] = the A
+// operand of step r = 4 i + e for lane l -- row l & 31 = 2 q + (re: 0, im: 1), k = l >> 5: (tr, -ti) for a re row, (ti, tr) for an im
+// row; zero beyond the filter, in rows 2 QB .. 31 and in the pad.  One 16-byte load per lane and four steps, 1 KB contiguous per wave.
+inline void exact_pack_taps(const float *taps, int nch, int ntp, int D, float *out /* [nch][dpad / 4][64][4] */)
 {
     const int DP = exact_dpad(D);
     for (int c = 0; c < nch; c++)
@@ -78,28 +76,25 @@ inline void exact_pack_taps(const float *taps, int nch, int ntp, int D, float *o
                 const int row = l & 31, kh = l >> 5, q = row >> 1, im = row & 1, j = q * D + r;
                 float tr = 0.f, ti = 0.f;
                 if (r < D && q < kExQB && j < ntp) { tr = taps[((size_t)c * ntp + j) * 2]; ti = taps[((size_t)c * ntp + j) * 2 + 1]; }
-                out[((size_t)c * 64 + l) * DP + r] = im ? (kh ? tr : ti) : (kh ? -ti : tr);
+                out[(((size_t)c * (DP / 4) + r / 4) * 64 + l) * 4 + (r & 3)] = im ? (kh ? tr : ti) : (kh ? -ti : tr);
             }
 }
 inline size_t exact_taps_floats(int nch, int D) { return (size_t)nch * 64 * exact_dpad(D); }
 
-// Choreography of one tile: the five waves stage their 32 columns each (coalesced loads -> LDS -> D registers per lane: the B
-// operand for every channel of the tile), then per channel ONE barrier:
-//     [loads of the NEXT channel's A in flight]  D MFMAs over As[n & 1]  ->  G to Gs[n & 1]  ->  next A to As[~n & 1]  ->  barrier
+// Choreography of one tile: every wave fetches its 32 columns straight into D registers per lane (the B operand for every channel
+// of the tile; strided 4-byte loads, once per tile), then per channel ONE barrier:
+//     D MFMAs, the A operand streaming in from the L1 / L2 three 16-byte loads ahead  ->  G to Gs[n & 1]  ->  barrier
 //     ->  epilogue of channel n: diagonal sums, de-rotation, demodulator, stores  (while other waves are already in channel n + 1's MFMAs)
-// Epilogue lanes: wave w takes outputs 26 w - 1 .. 26 w + 25 on its lanes 0 .. 26 (lane 0 only supplies its right neighbour's
-// predecessor), so that y[t - 1] is one shuffle away and all five waves share the work.
+// Epilogue lanes: wave w takes outputs 29 w - 1 .. 29 w + 28 on its lanes 0 .. 29 (lane 0 only supplies its right neighbour's
+// predecessor), so that y[t - 1] is one shuffle away and all four waves share the work.
 template <int D>
-__global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
+__global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
 {
     HIP_DYNAMIC_SHARED(float2, lds)
     constexpr int NS = 32 * D;                                     // samples per wave
-    constexpr int DP = exact_dpad(D), NA4 = 64 * DP / 4;           // float4 of one channel's A
-    constexpr int NPF = (NA4 + kExThreads - 1) / kExThreads;       // ... per thread
-    constexpr int GSZ = 2 * kExQB * kExGStride;
-    float *atab = (float *)((char *)lds + exact_lds_main(D));
-    float4 *As4 = (float4 *)lds;                                   // [2][NA4]
-    float *Gs = (float *)lds + 2 * 64 * DP;                        // [2][GSZ]
+    constexpr int NI = exact_dpad(D) / 4;                          // 16-byte groups of a channel's A per lane
+    float *Gs = (float *)lds;                                      // [2][kExGSize]
+    float *atab = Gs + 2 * kExGSize;
     const int tid = (int)threadIdx.x, lane = tid & 63;
 #if defined(__HIP_DEVICE_COMPILE__)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,6 +102,9 @@ __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p
     const int wave = tid >> 6;
 #endif
     for (int i = tid; i < 257; i += kExThreads) atab[i] = p.atan_tab[i];
+    // the epilogue's lane: output u of the tile (u = 0: the halo), -1 where the lane has none
+    const int u = (lane < kExEpw) ? (kExEpw - 1) * wave + lane - 1 : -1;
+    const bool u_ok = u >= 0 && u < kExOuts;
     for (int tile = (int)blockIdx.x; tile < p.ntiles; tile += (int)gridDim.x) {
         uint32_t bm[kExWords];
         uint32_t any = 0;
@@ -122,77 +120,53 @@ __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p
             for (int wi = 0; wi < kExWords; wi++) if (c >= 0 && (c >> 5) == wi) bm[wi] &= bm[wi] - 1;   // (static indices: a run-time one put bm in scratch memory)
             return c;
         };
-        float4 apf[NPF];
-        auto load_a = [&](int c) {
-            const float4 *ta = (const float4 *)p.tapsA + (size_t)c * NA4;
-#pragma unroll
-            for (int i = 0; i < NPF; i++) { const int j = tid + i * kExThreads; apf[i] = ta[j < NA4 ? j : NA4 - 1]; }
-        };
-        auto store_a = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < NPF; i++) { const int j = tid + i * kExThreads; if (j < NA4) As4[buf * NA4 + j] = apf[i]; }
-        };
-        int c_cur = next_channel();
-        load_a(c_cur);                                             // (in flight under the staging)
-        const long long g0 = (long long)tile * kExTile - 1;        // grid row of output 0
+        const long long g0 = exact_tile_row0(tile) - 1;            // grid row of output 0
+        const int nout = (int)(((tile + 1) % kExSlotTiles == 0 ? (long long)(tile / kExSlotTiles + 1) * kExSlotRows : exact_tile_row0(tile + 1)) - g0);   // outputs of this tile incl. the halo (115, or 111 for a slot's last)
         const long long sb = p.first0 + g0 * D + (long long)wave * NS;
-        __syncthreads();                                           // the previous tile's buffers are consumed
-        // ---- the wave's 32 columns: coalesced loads, LDS, then one column half per lane ----
-        {
-            float2 *xs = lds + wave * NS;
-            constexpr int NL = (NS + 63) / 64;
-            float2 v[NL];
-            if (sb >= 0 && sb + NS <= p.x_len) {
-                const float2 *xb = x + sb;
-#pragma unroll
-                for (int i = 0; i < NL; i++) { const int n = lane + 64 * i; v[i] = xb[n < NS ? n : NS - 1]; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NL; i++) {
-                    const long long a = sb + lane + 64 * i;
-                    const float2 t = x[a < 0 ? 0 : (a < p.x_len ? a : p.x_len - 1)];
-                    v[i] = (a >= 0 && a < p.x_len) ? t : make_float2(0.f, 0.f);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NL; i++) { const int n = lane + 64 * i; if (n < NS) xs[n] = v[i]; }
-        }
-        __syncthreads();
+        // ---- B: lane (column m = lane & 31, half kh = lane >> 5) holds the re (kh = 0) or im (kh = 1) parts of its column's D samples ----
         float B[D];
         {
-            const float *xf = (const float *)(lds + wave * NS) + 2 * D * (lane & 31) + (lane >> 5);
+            const long long s0 = sb + (long long)D * (lane & 31);
+            if (sb >= 0 && sb + NS <= p.x_len) {                   // uniform: the wave's span lies inside the stream
+                const float *xf = (const float *)(x + s0) + (lane >> 5);
 #pragma unroll
-            for (int r = 0; r < D; r++) B[r] = xf[2 * r];
+                for (int r = 0; r < D; r++) B[r] = xf[2 * r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < D; r++) {
+                    const long long a = s0 + r;
+                    const float2 t = x[a < 0 ? 0 : (a < p.x_len ? a : p.x_len - 1)];
+                    B[r] = (a >= 0 && a < p.x_len) ? ((lane >> 5) ? t.y : t.x) : 0.f;
+                }
+            }
         }
-        __syncthreads();                                           // every wave has its operands: the span is free
-        store_a(0);
-        __syncthreads();
-        // the epilogue's lane: output u of the tile (u = 0: the halo), -1 where the lane has none
-        const int u = (lane < kExEpw) ? (kExEpw - 1) * wave + lane - 1 : -1;
-        const bool u_ok = u >= 0 && u < kExOuts;
         const long long g = g0 + (u_ok ? u : 0);
+        int c_cur = next_channel();
+        const float4 *ap = (const float4 *)p.tapsA + (size_t)c_cur * NI * 64 + lane;
+        float4 q0 = ap[0], q1 = ap[NI > 1 ? 64 : 0], q2 = ap[NI > 2 ? 128 : 0];
+        __syncthreads();                                           // (the previous tile's last epilogue has read its G buffer)
         for (int n = 0; c_cur >= 0; n++) {
             const int c_nxt = next_channel();
-            if (c_nxt >= 0) load_a(c_nxt);
             float2 rt = make_float2(1.f, 0.f);
             if (u_ok && g >= 0) rt = p.rot[(size_t)c_cur * p.Qr + (int)(g % p.Qr)];
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.f;
-            {
-                const float4 *ap = As4 + (n & 1) * NA4 + lane * (DP / 4);
-                float4 a = ap[0];
 #pragma unroll
-                for (int i = 0; i < DP / 4; i++) {
-                    const float4 an = ap[i + 1 < DP / 4 ? i + 1 : i];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, B[4 * i], acc, 0, 0, 0);
-                    if (4 * i + 1 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, B[4 * i + 1 < D ? 4 * i + 1 : 0], acc, 0, 0, 0);
-                    if (4 * i + 2 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, B[4 * i + 2 < D ? 4 * i + 2 : 0], acc, 0, 0, 0);
-                    if (4 * i + 3 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, B[4 * i + 3 < D ? 4 * i + 3 : 0], acc, 0, 0, 0);
-                    a = an;
-                }
+            for (int i = 0; i < NI; i++) {
+                const float4 a = q0;
+                q0 = q1; q1 = q2;
+                if (i + 3 < NI) q2 = ap[(i + 3) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, B[4 * i], acc, 0, 0, 0);
+                if (4 * i + 1 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, B[4 * i + 1 < D ? 4 * i + 1 : 0], acc, 0, 0, 0);
+                if (4 * i + 2 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, B[4 * i + 2 < D ? 4 * i + 2 : 0], acc, 0, 0, 0);
+                if (4 * i + 3 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, B[4 * i + 3 < D ? 4 * i + 3 : 0], acc, 0, 0, 0);
             }
-            float *Gn = Gs + (n & 1) * GSZ;
+            if (c_nxt >= 0) {                                      // the next channel's first groups land under this one's epilogue
+                ap = (const float4 *)p.tapsA + (size_t)c_nxt * NI * 64 + lane;
+                q0 = ap[0]; q1 = ap[NI > 1 ? 64 : 0]; q2 = ap[NI > 2 ? 128 : 0];
+            }
+            float *Gn = Gs + (n & 1) * kExGSize;
             {
                 const int col = 32 * wave + (lane & 31), rb = 4 * (lane >> 5);
 #pragma unroll
@@ -201,7 +175,6 @@ __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p
                     if (row < 2 * kExQB) Gn[row * kExGStride + col] = acc[i];
                 }
             }
-            if (c_nxt >= 0) store_a((n + 1) & 1);
             __syncthreads();
             // ---- epilogue of channel c_cur ----
             float2 y = make_float2(0.f, 0.f);
@@ -218,7 +191,7 @@ __global__ __launch_bounds__(kExThreads, 2) void exact_rows_kernel(ExactParams p
             }
             float2 yp;                                             // y[u - 1]: the left neighbour's
             yp.x = __shfl_up(y.x, 1, 64); yp.y = __shfl_up(y.y, 1, 64);
-            if (u_ok && lane >= 1 && u >= 1 && g >= 1 && g < p.G) {
+            if (u_ok && lane >= 1 && u >= 1 && u < nout && g >= 1 && g < p.G) {
                 const float dv = demod_one(atab, p.gain, y, yp);
                 p.d[(size_t)g * p.drow + c_cur] = dv;
                 if (p.dcol) { const unsigned int gq = (unsigned int)g, tq = gq / 25u; p.dcol[(size_t)(gq + 25u * (79u * tq + (unsigned int)c_cur))] = dv; }

@@ -537,14 +537,27 @@ __device__ __forceinline__ int ver_rows_of(const WindowParams &p, int span)
 }
 
 // ---- exact rows: which (channel, time tile) pairs are recomputed through the reference's own arithmetic (exact.hip.h) ----
-// bitmap[tile][kExWords]: bit c of tile j = grid rows [kExTile j, kExTile (j + 1)) of channel c.  A slot is a whole number of tiles
-// (1250 rows = 10 tiles at every rate with a shared grid), a batch begins with a slot: which rows are exact does not depend on how
-// the stream is cut into batches or ranks, nor on what the first slot is called.
-constexpr int kExTileRows = 125;     // = exact.hip.h kExTile
+// bitmap[tile][kExWords]: bit c of tile t.  Tiles never straddle a slot: a slot's 1250 rows (at every rate with a shared grid) are
+// eleven tiles -- ten of 114 rows and one of 110 -- and a batch begins with a slot, so which rows are exact does not depend on how the
+// stream is cut into batches or ranks, nor on what the first slot is called.  (114 + the diagonal sum's 13 + the demodulator's halo
+// = 128 polyphase columns = four waves, one per SIMD.)
+constexpr int kExTileRows = 114;     // = exact.hip.h kExTile
+constexpr int kExSlotRows = 1250, kExSlotTiles = 11;
 constexpr int kExBmWords = 3;        // bitmap words per tile (<= 96 channels)
+__host__ __device__ __forceinline__ int exact_tile_of(long long g)         // the tile that holds grid row g
+{
+    const long long k = g / kExSlotRows;
+    const int j = (int)(g - k * kExSlotRows) / kExTileRows;
+    return (int)k * kExSlotTiles + (j < kExSlotTiles ? j : kExSlotTiles - 1);
+}
+__host__ __device__ __forceinline__ long long exact_tile_row0(int t)      // its first row; exact_tile_row0(t + 1) is one past its last
+{
+    const int k = t / kExSlotTiles, j = t - k * kExSlotTiles;
+    return (long long)k * kExSlotRows + (long long)j * kExTileRows;      // (j = 11 of slot k = row 1254 > 1250: never asked -- t + 1 of a slot's last tile is j = 0 of the next)
+}
 __device__ __forceinline__ void exact_mark(uint32_t *bm, const uint32_t *skip, int ntiles, long long g_lo, long long g_hi, int c, unsigned int *stat)
 {
-    int t0 = (int)(g_lo / kExTileRows), t1 = (int)((g_hi - 1) / kExTileRows);
+    int t0 = exact_tile_of(g_lo), t1 = exact_tile_of(g_hi - 1);
     if (t1 >= ntiles) t1 = ntiles - 1;
     const uint32_t bit = 1u << (c & 31);
     int n = 0;
@@ -558,10 +571,10 @@ __device__ __forceinline__ void exact_mark(uint32_t *bm, const uint32_t *skip, i
 // rows of window (k, c), from its first row on, that the bitmap covers without a gap
 __device__ __forceinline__ int exact_covered_rows(const uint32_t *bm, int ntiles, long long g_lo, int c)
 {
-    int t = (int)(g_lo / kExTileRows);
+    int t = exact_tile_of(g_lo);
     const uint32_t bit = 1u << (c & 31);
     while (t < ntiles && (bm[(size_t)t * kExBmWords + (c >> 5)] & bit)) t++;
-    const long long cov = (long long)t * kExTileRows - g_lo;
+    const long long cov = exact_tile_row0(t) - g_lo;
     return cov > 0 ? (cov > 0x3fffffff ? 0x3fffffff : (int)cov) : 0;
 }
 

@@ -73,7 +73,7 @@ for case in range(a.cases):
     tot["other_product"] += d["other_gpu"]; tot["other_oracle"] += d["other_ref"]
     tot["other_only_product"] += d["other_only_gpu"]; tot["other_only_oracle"] += d["other_only_ref"]
     tot["packets"] += len(meta); tot["windows"] += c["n_slots"] * (o.high_ch - o.low_ch + 1)
-    tot["tasks"] += int(vc[0]) + int(vc[3]); tot["task_rows"] += 125 * (int(vc[4]) + int(vc[5]))   # busy windows + second-run windows; exact rows computed
+    tot["tasks"] += int(vc[0]) + int(vc[3]); tot["task_rows"] += 1250 * (int(vc[4]) + int(vc[5])) // 11   # busy windows + second-run windows; exact rows computed
     tot["planted_%dM" % round(fs / 1e6)] += d["planted_ref"]
     nsym_dev_max = max(nsym_dev_max, d["planted_nsym_max_abs_dev"])
     # which packet each of the oracle's planted records belongs to: level band and constellation
@@ -107,6 +107,6 @@ for case in range(a.cases):
         print("case %5d fs %3.0fM sniffer %d le %d sq %2.0f packets %3d  planted %3d one-sided %d/%d nsym-dev %2d  adverts %d/%d  other %d/%d one-sided %d/%d  tasks %d rows %d"
               % (case, fs / 1e6, c["sniffer"], le, c["squelch"], len(meta), d["planted_ref"], d["planted_only_gpu"], d["planted_only_ref"],
                  d["planted_nsym_max_abs_dev"], sum(ga.values()), sum(wa.values()), d["other_gpu"], d["other_ref"], d["other_only_gpu"], d["other_only_ref"],
-                 int(vc[0]) + int(vc[3]), 125 * (int(vc[4]) + int(vc[5]))), flush=True)
+                 int(vc[0]) + int(vc[3]), 1250 * (int(vc[4]) + int(vc[5])) // 11), flush=True)
 out = dict(tot); out["nsym_dev_max"] = nsym_dev_max; out["seed"] = a.seed; out["rates"] = a.rates; out["min_snr_db"] = a.min_snr; out["wide"] = a.wide
 print("TOTAL " + json.dumps(out))

@@ -115,7 +115,8 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(exact_rows_kernel<D>, dim3(p.ntiles), dim3(kExThreads), lds, 0, p, d_x);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        for (int i = 0; i < reps; i++) hipLaunchKernelGGL(exact_rows_kernel<D>, dim3(p.ntiles), dim3(kExThreads), lds, 0, p, d_x);
+        const int grid = getenv("UB_GRID") ? atoi(getenv("UB_GRID")) : p.ntiles;
+        for (int i = 0; i < reps; i++) hipLaunchKernelGGL(exact_rows_kernel<D>, dim3(grid), dim3(kExThreads), lds, 0, p, d_x);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         if (ms) { CK(hipEventElapsedTime(ms, e0, e1)); *ms /= (float)(reps > 0 ? reps : 1); }
         CK(hipFree(d_tapsA)); CK(hipFree(d_atab)); CK(hipFree(d_rot)); CK(hipFree(d_bm));
@@ -174,7 +175,9 @@ int main(int argc, char **argv)
             CK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice));
         }
         CK(hipMalloc(&d_d, (size_t)G * 80 * 4)); CK(hipMalloc(&d_dcol, ((size_t)G / 25 + 1) * 2000 * 4));
+        const int only_mode = argc > 3 ? atoi(argv[3]) : -1;
         for (int mode = 0; mode < 3; mode++) {
+            if (only_mode >= 0 && mode != only_mode) continue;
             // 0: per_tile channels in every tile; 1: the same number of (channel, tile) pairs bunched into a quarter of the tiles; 2: one channel per tile
             std::vector<uint32_t> bm((size_t)exact_ntiles(G) * kExWords, 0);
             long long pairs = 0;
@@ -185,7 +188,7 @@ int main(int argc, char **argv)
             }
             float ms = 0.f;
             run(G, bm, x_len, d_x, d_d, d_dcol, nullptr, 5, &ms);
-            const double rows = (double)pairs * kExTile, fl = rows * 2.0 * 4.0 * 667.0;
+            const double rows = (double)pairs * kExSlotRows / kExSlotTiles, fl = rows * 2.0 * 4.0 * 667.0;
             printf("mode %d: %lld (channel, tile) pairs, %.2f M rows: %.3f ms = %.2f G rows/s, %.1f TFLOP/s of useful multiply-adds, input %.2f TB/s\n", mode, pairs,
                    rows * 1e-6, ms, rows / ms * 1e-6, fl / ms * 1e-9, (double)exact_ntiles(G) * (mode == 1 ? 0.25 : 1.0) * kExCols * D * 8.0 / ms * 1e-9);
         }

@@ -733,7 +733,7 @@ extern "C" long emu_verify_check(double fs, double fc, int mode, double squelch_
     for (int t = 0; t < fast_tiles; t++)
         for (int c = 0; c < nch; c++) {
             if (!(((b1[(size_t)t * kExBmWords + (c >> 5)] | b2[(size_t)t * kExBmWords + (c >> 5)]) >> (c & 31)) & 1u)) continue;
-            for (long long g = std::max<long long>(1, (long long)t * kExTile); g < (long long)(t + 1) * kExTile && g < fast.G; g++) {
+            for (long long g = std::max<long long>(1, exact_tile_row0(t)); exact_tile_of(g) == t && g < fast.G; g++) {
                 const float a = fast.d[(size_t)g * fast.drow + c], b = exact.d[(size_t)g * exact.drow + c];
                 checked++;
                 if (std::memcmp(&a, &b, 4) != 0) {

@@ -852,13 +852,13 @@ def test_exact_stage_rows_equal_the_direct_path(pkg, synth, fs, fc, nsl):
     bm = (bm[:tiles * 3] | bm[tiles * 3:]).reshape(tiles, 3)             # presence's marks | the second run's
     rows_checked = pairs = 0
     for c in range(nch):
-        marked = [t for t in range(min(tiles, (G + 124) // 125)) if (int(bm[t, c >> 5]) >> (c & 31)) & 1]
+        marked = [t for t in range(min(tiles, 11 * ((G + 1249) // 1250))) if (int(bm[t, c >> 5]) >> (c & 31)) & 1]
         if not marked:
             continue
         a = fast.debug_fetch(1, d.low_channel + c, 0, 1 << 24)
         b = exact.debug_fetch(1, d.low_channel + c, 0, 1 << 24)
         for t in marked:
-            lo, hi = max(1, 125 * t), min(125 * (t + 1), G)
+            lo = 1250 * (t // 11) + 114 * (t % 11); hi = min(1250 * (t // 11 + 1), lo + 114, G); lo = max(1, lo)    # eleven tiles per slot: ten of 114 rows, one of 110
             assert np.array_equal(a[lo:hi], b[lo:hi]), (c, t)
             rows_checked += hi - lo; pairs += 1
     assert pairs >= 8
