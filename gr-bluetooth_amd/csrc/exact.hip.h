@@ -36,7 +36,7 @@ constexpr int kExQB = 14;                       // tap blocks: ceil(ntaps / D) (
 constexpr int kExTile = 114;                    // new demodulated rows per full tile; a SLOT (1250 rows) is ten of those and one of 110 (kernels.hip.h exact_tile_of)
 constexpr int kExOuts = kExTile + 1;            // outputs per tile; output 0 is the halo of the demodulator
 static_assert(kExOuts + kExQB - 1 <= kExCols, "the tile's outputs and the diagonal sum's overhang fit the columns");   // 128 of 128
-constexpr int kExEpw = (kExOuts + kExWaves - 1) / kExWaves + 1;   // epilogue lanes per wave: its share of the outputs + its left neighbour's last
+static_assert(kExOuts <= 2 * 63 + 1, "two waves hold a tile's outputs");
 static_assert(kExTile == kExTileRows, "kernels.hip.h marks the bitmap in tiles of kExTileRows rows");
 constexpr int kExGStride = 136;                 // floats per row of G in LDS: 4 rows further = 32 banks further (the two half-waves of a C/D register)
 constexpr int kExWords = kExBmWords;            // bitmap words per tile (<= 96 channels)
@@ -55,6 +55,7 @@ struct ExactParams {
     float *dcol;                  // nullptr, or the tile-blocked copy [G / 25][80][25]
     float2 *ydbg; long long ystride;   // diagnostics: nullptr, or the de-rotated y [nch][ystride]
     int nch;
+    int dbg;                      // timing experiments (scripts/ubench/exact_mfma.hip): 1 no stores, 2 no demodulator
 };
 
 constexpr int exact_dpad(int D) { return (D + 3) / 4 * 4; }      // steps of a channel's A operand, padded to whole 16-byte groups
@@ -85,8 +86,13 @@ inline size_t exact_taps_floats(int nch, int D) { return (size_t)nch * 64 * exac
 // of the tile; strided 4-byte loads, once per tile), then per channel ONE barrier:
 //     D MFMAs, the A operand streaming in from the L1 / L2 three 16-byte loads ahead  ->  G to Gs[n & 1]  ->  barrier
 //     ->  epilogue of channel n: diagonal sums, de-rotation, demodulator, stores  (while other waves are already in channel n + 1's MFMAs)
-// Epilogue lanes: wave w takes outputs 29 w - 1 .. 29 w + 28 on its lanes 0 .. 29 (lane 0 only supplies its right neighbour's
-// predecessor), so that y[t - 1] is one shuffle away and all four waves share the work.
+// F12 (round 6, scripts/ubench/mfma_overlap.hip, mfma_shadow.hip): v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate because it runs ON
+// the SIMD's vector lanes: nothing else of that SIMD -- of the same wave or of another -- issues in its shadow, and a kernel's time
+// is its matrix time PLUS every other instruction's issue time (workgroups with matrix waves and epilogue waves side by side, one to
+// four workgroups per CU, operands through LDS or from the L1: all within 10 % of each other).  What is left is to issue FEW other
+// instructions: per channel the epilogue runs on TWO waves with every lane busy (waves 0, 1 for even channels of the tile, 2, 3 for
+// odd ones: lanes 0 .. 63 of the first take outputs -1 .. 62, of the second 62 .. 125; y[t - 1] is one shuffle away), its row
+// indices are formed once per tile.
 template <int D>
 __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
 {
@@ -102,8 +108,8 @@ __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p
     const int wave = tid >> 6;
 #endif
     for (int i = tid; i < 257; i += kExThreads) atab[i] = p.atan_tab[i];
-    // the epilogue's lane: output u of the tile (u = 0: the halo), -1 where the lane has none
-    const int u = (lane < kExEpw) ? (kExEpw - 1) * wave + lane - 1 : -1;
+    // the epilogue's lane: output u of the tile (u = 0: the halo)
+    const int u = (wave & 1) ? 62 + lane : lane - 1;
     const bool u_ok = u >= 0 && u < kExOuts;
     for (int tile = (int)blockIdx.x; tile < p.ntiles; tile += (int)gridDim.x) {
         uint32_t bm[kExWords];
@@ -141,14 +147,22 @@ __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p
             }
         }
         const long long g = g0 + (u_ok ? u : 0);
+        // this lane's row in the two streams and its phase in the rotator's period, once per tile (a 64-bit division per channel was
+        // a third of the epilogue's instructions)
+        const bool row_ok = u_ok && (wave & 1 ? lane >= 1 : lane >= 2) && u < nout && g >= 1 && g < p.G;      // (lane 0 of a wave, and u = 0, only feed their neighbour)
+        const unsigned int gq = (unsigned int)(g > 0 ? g : 0);
+        const unsigned int rot_i = gq % (unsigned int)p.Qr;
+        float *drow_p = p.d + (size_t)gq * p.drow;
+        float *dcol_p = p.dcol ? p.dcol + (size_t)(gq + 25u * 79u * (gq / 25u)) : nullptr;
         int c_cur = next_channel();
         const float4 *ap = (const float4 *)p.tapsA + (size_t)c_cur * NI * 64 + lane;
         float4 q0 = ap[0], q1 = ap[NI > 1 ? 64 : 0], q2 = ap[NI > 2 ? 128 : 0];
         __syncthreads();                                           // (the previous tile's last epilogue has read its G buffer)
         for (int n = 0; c_cur >= 0; n++) {
             const int c_nxt = next_channel();
+            const bool my_turn = ((wave >> 1) & 1) == (n & 1);       // uniform: this wave is one of the channel's two epilogue waves
             float2 rt = make_float2(1.f, 0.f);
-            if (u_ok && g >= 0) rt = p.rot[(size_t)c_cur * p.Qr + (int)(g % p.Qr)];
+            if (my_turn && u_ok && g >= 0) rt = p.rot[(size_t)c_cur * p.Qr + rot_i];
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -177,6 +191,7 @@ __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p
             }
             __syncthreads();
             // ---- epilogue of channel c_cur ----
+            if (my_turn) {
             float2 y = make_float2(0.f, 0.f);
             if (u_ok) {
                 float yr = Gn[u], yi = Gn[kExGStride + u];
@@ -191,10 +206,13 @@ __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p
             }
             float2 yp;                                             // y[u - 1]: the left neighbour's
             yp.x = __shfl_up(y.x, 1, 64); yp.y = __shfl_up(y.y, 1, 64);
-            if (u_ok && lane >= 1 && u >= 1 && u < nout && g >= 1 && g < p.G) {
+            if (row_ok && !(p.dbg & 2)) {
                 const float dv = demod_one(atab, p.gain, y, yp);
-                p.d[(size_t)g * p.drow + c_cur] = dv;
-                if (p.dcol) { const unsigned int gq = (unsigned int)g, tq = gq / 25u; p.dcol[(size_t)(gq + 25u * (79u * tq + (unsigned int)c_cur))] = dv; }
+                if (!(p.dbg & 1)) {
+                    drow_p[c_cur] = dv;
+                    if (dcol_p) dcol_p[25 * c_cur] = dv;
+                }
+            }
             }
             c_cur = c_nxt;
         }

@@ -108,7 +108,7 @@ int main(int argc, char **argv)
         CK(hipMalloc(&d_bm, bitmap.size() * 4)); CK(hipMemcpy(d_bm, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice));
         ExactParams p{};
         p.x_len = (long long)x_len; p.first0 = 0; p.G = G; p.tapsA = d_tapsA; p.rot = d_rot; p.Qr = Qr; p.atan_tab = d_atab; p.gain = 1.0f;
-        p.bitmap = d_bm; p.ntiles = exact_ntiles(G); p.d = d_d; p.drow = 80; p.dcol = d_dcol; p.ydbg = d_y; p.ystride = G; p.nch = nch;
+        p.bitmap = d_bm; p.ntiles = exact_ntiles(G); p.dbg = getenv("UB_DBG") ? atoi(getenv("UB_DBG")) : 0; p.d = d_d; p.drow = 80; p.dcol = d_dcol; p.ydbg = d_y; p.ystride = G; p.nch = nch;
         const size_t lds = exact_lds_bytes(D);
         CK(hipFuncSetAttribute((const void *)exact_rows_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -161,7 +161,7 @@ int main(int argc, char **argv)
         }
         printf("exact_rows_kernel<50> vs the C restatement of its order: %lld outputs checked, %lld differ\n", checked, bad);
         CK(hipFree(d_x)); CK(hipFree(d_y)); CK(hipFree(d_d));
-        if (bad) return 1;
+        if (bad && !getenv("UB_DBG")) return 1;
     }
     // ---- 3. rate ----
     {

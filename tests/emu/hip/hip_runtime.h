@@ -37,6 +37,7 @@ namespace emu {
 extern thread_local dim3 t_idx, b_idx, b_dim, g_dim;
 extern char dyn_lds[160 * 1024];
 void barrier();
+void wave_barrier();
 void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 }  // namespace emu
 
@@ -97,11 +98,11 @@ template <class T> static inline T __shfl_up(T v, int off, int width = 64)
     static_assert(sizeof(T) <= 16, "exchange slot");
     const unsigned tid = threadIdx.x;
     std::memcpy(emu::xchg[tid], &v, sizeof(T));
-    emu::barrier();
+    emu::wave_barrier();
     T r = v;
     const unsigned lane = tid % (unsigned)width;
     if (lane >= (unsigned)off) std::memcpy(&r, emu::xchg[tid - off], sizeof(T));
-    emu::barrier();
+    emu::wave_barrier();
     return r;
 }
 static inline unsigned long long __ballot(int pred)
@@ -123,7 +124,7 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
 {
     const unsigned tid = threadIdx.x, w0 = tid & ~63u, lane = tid & 63u;
     std::memcpy(emu::xchg[tid], &a, 4); std::memcpy(emu::xchg[tid] + 4, &b, 4);
-    emu::barrier();
+    emu::wave_barrier();
     const unsigned col = lane & 31u;
     for (unsigned i = 0; i < 16; i++) {
         const unsigned row = (i & 3u) + 8u * (i >> 2) + 4u * (lane >> 5);
@@ -135,6 +136,6 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
         }
         c[i] = acc;
     }
-    emu::barrier();
+    emu::wave_barrier();
     return c;
 }
