@@ -16,11 +16,15 @@ torchrun (WORLD_SIZE / RANK / LOCAL_RANK in the environment) each process is one
 plainly with --gpus N > 1 this script spawns its own N ranks, one device each, and FAILS if it
 cannot see N devices.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`,
-`cpu_baseline`, `parity` and (N = 1) `block_config` objects added.  `parity` is a differential of the
-records of one step against the CPU oracle run on all host cores over the first --parity-slots slots
-of the same capture (tests/paritylib.py); `block_config` = the same K steps with the flags the drop-in
-C++ block sets (LE pass, symbols, header sweep), with its own differential.
+Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is measured in the configuration of the
+drop-in block, gr::bluetooth::multi_sniffer::work (lib/multi_sniffer_impl.cc:107-149): classic search, LE pass,
+the symbols of every hit handed over with the GPU header sweep -- BTGPU_FLAG_LE | HEADERS (what host/blocks.cc
+sets).  Added objects: `roofline` (the step's dominant kernel: since round 6 exact_rows_kernel on the fp32 matrix
+pipe), `roofline_bank` (the channel bank against the HBM roofline, rounds 1-5's `roofline`), `cpu_baseline`,
+`parity` (a differential of the records of one step against the CPU oracle run on all host cores over the first
+--parity-slots slots of the same capture, tests/paritylib.py), and at N = 1 `classic_only` (the same K steps
+without LE pass and symbols: rounds 1-5's headline), `c8` (BASELINE configs[1], 8 channels at 8 Msps, the
+headline's flags), `verify` (exact rows per step, the A/B without them), `host_fed`.
 """
 import argparse
 import collections
@@ -71,12 +75,14 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--all-on-device0", action="store_true", help="dry run of the N > 1 path on a 1-GPU box (use with --backend gloo)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
-    ap.add_argument("--headers", action="store_true", help="also export hit symbols and run the GPU header sweep (BTGPU_FLAG_HEADERS), as the C++ multi_sniffer block does")
+    ap.add_argument("--headers", action="store_true", help="(default since round 6) export hit symbols and run the GPU header sweep (BTGPU_FLAG_HEADERS), as the C++ multi_sniffer block does")
+    ap.add_argument("--classic-only", action="store_true", help="the headline region WITHOUT the LE pass and the symbol hand-over (rounds 1-5's headline; now the extra key classic_only)")
+    ap.add_argument("--no-c8", action="store_true", help="skip the short run of BASELINE configs[1] (8 channels, 8 Msps) that fills the c8 object")
     ap.add_argument("--synth-device", default=None, help="where the synthetic capture is generated (default: the GPU).  'cpu': torch CPU ops + one "
                     "upload -- for the rocprofv3 --pmc passes of the C8 workload, which crash inside torch's own randn launches")
     ap.add_argument("--exact-payload", action="store_true", help="with --headers: BTGPU_FLAG_EXACT_PAYLOAD, as the C++ multi_sniffer block sets it")
     ap.add_argument("--le", action="store_true", help="also run the le_packet::sniff_aa pass (BTGPU_FLAG_LE), as the C++ multi_sniffer block does")
-    ap.add_argument("--no-block-config", action="store_true", help="skip the second timed region in the drop-in block's configuration (LE | HEADERS)")
+    ap.add_argument("--no-block-config", action="store_true", help="skip the second timed region (the classic-only configuration)")
     ap.add_argument("--full-timing", action="store_true", help="HIP events around every kernel in the headline region too (kernel_avg_ms of all kernels)")
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP events (BTGPU_FLAG_TIMING off): kernel traces without event records; roofline then has no kernel time")
     ap.add_argument("--gather-every", type=int, default=4, help="N > 1: batches per record-gather round (one fixed-size all_gather every that "
@@ -200,7 +206,7 @@ def run_rank(args):
 
     base_flags = 0 if args.sync else pkg.FLAG_ASYNC
     # HIP events in the timed region: around the channel-bank kernel only (the roofline's kernel; two records per batch) in
-    # the headline region, around every kernel (--full-timing, and always in the block_config region: eleven records per
+    # the headline region, around every kernel (--full-timing, and always in the classic_only region: eleven records per
     # batch, measured at 2-3 % of the step)
     head_timing = 0 if args.no_timing else (pkg.FLAG_TIMING if args.full_timing else pkg.FLAG_TIMING_BANK)
 
@@ -208,6 +214,10 @@ def run_rank(args):
         return pkg.multi_sniffer(fs, fc, args.squelch, False, device=local_rank, max_batch_slots=S,
                                  channelizer=args.channelizer, squelch=args.squelch_mode,
                                  flags=base_flags | extra | (head_timing if timing is None else timing))
+    # The headline is what gr::bluetooth::multi_sniffer::work does (lib/multi_sniffer_impl.cc:107-149): the LE pass after the classic
+    # one, the symbols of every hit handed to the packet handlers -- the flags host/blocks.cc creates its handle with.
+    if not args.classic_only:
+        args.le = args.headers = args.exact_payload = True
     head_flags = (pkg.FLAG_HEADERS if args.headers else 0) | (pkg.FLAG_LE if args.le else 0) | (pkg.FLAG_EXACT_PAYLOAD if args.exact_payload else 0)
     blk = make_block(head_flags)
     des = blk.design
@@ -328,7 +338,9 @@ def run_rank(args):
     elapsed, ints, snr, marks, fence_ms, kernel_ms, kernel_launches = timed_region(blk)
     # the exact stage re-runs every window that can carry a packet's record through the direct-form arithmetic:
     # 4 * ntaps multiply-adds per recomputed demodulated row
+    blk_stats, blk_long = dict(blk._verify_stats), dict(blk._long_stats)
     verify_obj = dict(blk._verify_stats)
+    verify_obj["second_run"] = dict(blk._long_stats)
     verify_obj["enabled"] = bool(verify_obj["windows_per_step"] > 0 or os.environ.get("BTGPU_VERIFY", "1") != "0")
     verify_obj["gfma_per_step"] = round(verify_obj["rows_per_step"] * 4.0 * ((des.ntaps_channel + 7) // 8 * 8) / 1e9, 3)
     rank_elapsed = [elapsed]
@@ -361,41 +373,65 @@ def run_rank(args):
                                       "records_equal_on_6_fields": bool(len(a_ints) == len(ints) and np.array_equal(a_ints[:, :6], ints[:, :6]))}
         verify_obj["cost_frac_of_step"] = round(1.0 - a_el / elapsed, 4)
 
+    # ---- the classic-only configuration (N = 1): rounds 1-5's headline -- no LE pass, no symbol hand-over: the LAP list alone ----
     block_cfg = None
-    if world == 1 and not args.no_block_config and not (args.le and args.headers):
+    if world == 1 and not args.no_block_config and not args.classic_only:
         blk.close()
-        # `value` with the event records of the headline region (one pair per batch, around the bank); the kernel breakdown from a
-        # second pass with records around every kernel (eleven per batch: ~5 % slower, reported as ms_per_step_full_timing)
-        # (round 5: host/blocks.cc also sets BTGPU_FLAG_EXACT_PAYLOAD -- the symbols it decodes are exact to the end of each packet;
-        # `without_exact_payload` is the same region without it, round 4's block configuration)
-        BF = pkg.FLAG_LE | pkg.FLAG_HEADERS | pkg.FLAG_EXACT_PAYLOAD
-        blk = make_block(pkg.FLAG_LE | pkg.FLAG_HEADERS, timing=head_timing)
-        n_el, n_ints, _ns, _m, _f, _k1, _k2 = timed_region(blk, gather=False)
-        blk.close()
-        blk = make_block(BF, timing=head_timing)
+        blk = make_block(0, timing=pkg.FLAG_TIMING)
         b_el, b_ints, b_snr, _m, _f, b_kms, b_kl = timed_region(blk, gather=False)
         b_ints, b_snr = one_copy(b_ints, b_snr)
-        b_verify = dict(blk._verify_stats); b_verify["exact_payload"] = dict(blk._long_stats)
-        b_el_full = None
-        if not args.no_timing and head_timing != pkg.FLAG_TIMING:
-            blk.close()
-            blk = make_block(BF, timing=pkg.FLAG_TIMING)
-            b_el_full, _i, _s, _m, _f, b_kms, b_kl = timed_region(blk, gather=False)
-        block_cfg = {"flags": "BTGPU_FLAG_LE | BTGPU_FLAG_HEADERS | BTGPU_FLAG_EXACT_PAYLOAD (what host/blocks.cc sets for multi_sniffer)",
-                     "without_exact_payload": {"value": round(float(S) * slot * args.steps / n_el / 1e6, 3), "ms_per_step": round(n_el / args.steps * 1e3, 3),
-                                               "hits": int(len(one_copy(n_ints, _ns)[0]))},
+        head_ac = ints[ints[:, 2] == 0]
+        block_cfg = {"flags": "ASYNC|TIMING (no LE pass, no symbols: the classic LAP list; every kernel bracketed, ~3 % slower than the light form)",
                      "value": round(float(S) * slot * args.steps / b_el / 1e6, 3), "unit": "Msamples/s",
                      "ms_per_step": round(b_el / args.steps * 1e3, 3), "hits": int(len(b_ints)),
-                     "ms_per_step_full_timing": round(b_el_full / args.steps * 1e3, 3) if b_el_full else None,
-                     "hits_ac": int((b_ints[:, 2] == 0).sum()) if len(b_ints) else 0,
-                     "hits_aa": int((b_ints[:, 2] == 1).sum()) if len(b_ints) else 0,
                      "kernel_avg_ms": {pkg.KERNEL_NAMES[i]: round(float(b_kms[i] / b_kl[i]), 4) if b_kl[i] else 0.0
                                        for i in range(len(pkg.KERNEL_NAMES))},
-                     "verify": b_verify,
-                     # all seven columns / the six key fields: the header keeps 58 more symbols of a task exact, so the continuation that
-                     # produces nsym (column seven) takes over at another row -- the records themselves are the same
-                     "ac_records_equal_headline": bool(np.array_equal(b_ints[b_ints[:, 2] == 0], ints[ints[:, 2] == 0])) if not args.le else None,
-                     "ac_records_equal_headline_on_6_fields": bool(np.array_equal(b_ints[b_ints[:, 2] == 0][:, :6], ints[ints[:, 2] == 0][:, :6])) if not args.le else None}
+                     "verify": dict(blk._verify_stats),
+                     "ac_records_equal_headline": bool(np.array_equal(b_ints, head_ac)),
+                     "ac_records_equal_headline_on_6_fields": bool(len(b_ints) == len(head_ac) and np.array_equal(b_ints[:, :6], head_ac[:, :6]))}
+
+    # ---- BASELINE configs[1] (N = 1): 8 channels at 8 Msps, the same flags, driver-timed ----
+    c8 = None
+    if world == 1 and not args.no_c8 and args.workload == "c79":
+        blk.close()
+        w8 = WORKLOADS["c8"]
+        S8 = 16384
+        b8 = pkg.multi_sniffer(w8["sample_rate"], w8["center_freq"], args.squelch, False, device=local_rank, max_batch_slots=S8,
+                               flags=base_flags | head_flags | head_timing)
+        d8 = b8.design
+        m8 = d8.left_margin
+        seg8, truth8 = synth.make_segment_torch(w8["sample_rate"], w8["center_freq"], 0, S8, args.synth_device or device, left_pad=d8.history - 1 + m8, **gen)
+        seg8 = seg8.to(device).contiguous()
+        torch.cuda.synchronize()
+        def step8(last):
+            b8.process_device(seg8.data_ptr(), seg8.shape[0], 0, S8, left_margin=m8)
+            if last:
+                b8.flush()
+            return bdist.struct_to_arrays(b8.poll_arrays())
+        for i in range(6):
+            step8(i == 5)
+        torch.cuda.synchronize()
+        tm0 = b8.timing()
+        K8 = max(10, 2 * args.steps)
+        t0 = time.perf_counter()
+        n8 = 0
+        for i in range(K8):
+            n8 += len(step8(i == K8 - 1)[0])
+        torch.cuda.synchronize()
+        el8 = time.perf_counter() - t0
+        tm1 = b8.timing()
+        k8, l8 = tdiff(tm0, tm1)
+        bank8 = float(k8[0] / l8[0]) if l8[0] else 0.0
+        ex8 = float(k8[7] / l8[7]) if l8[7] else 0.0
+        c8 = {"workload": w8["name"], "flags": "the headline's", "slots_per_step": S8, "steps": K8,
+              "value": round(float(S8) * d8.samples_per_slot * K8 / el8 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(el8 / K8 * 1e3, 3),
+              "hits_per_step": n8 // K8,
+              "bank_ms": round(bank8, 4), "bank_frac_of_hbm_roofline": round(8.0 * S8 * d8.samples_per_slot / (bank8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if bank8 > 0 else None,
+              "exact_ms": round(ex8, 4),
+              "exact_rows_per_step": round((tm1.verify_rows - tm0.verify_rows) / K8, 1), "busy_windows_per_step": round((tm1.verify_windows - tm0.verify_windows) / K8, 1)}
+        b8.close()
+        del seg8
+        blk = make_block(head_flags)                       # (something to close at the end)
 
     # ---- the host-fed rate (N = 1): what btrx_amd and the GNU Radio block see -- the batch lies in HOST memory and goes through
     # btgpu_process_host (PCIe-inclusive; never `value`).  Source page-locked (a block can register the scheduler's buffer once):
@@ -466,7 +502,9 @@ def run_rank(args):
         # the dominant kernel is looked for on the critical path: in pipelined mode the tail
         # (finish_kernel) of batch n runs on its own stream underneath batch n+1
         crit = [i for i in range(NK) if not (names[i] in ("finish", "verify") and not args.sync)]
-        dom = max(crit, key=lambda i: avg[i])                  # (light timing: only ddc_channel is non-zero -- it is the dominant one)
+        dom_all = max(crit, key=lambda i: avg[i])              # (light timing: the channel bank and the exact rows' kernel are bracketed)
+        bank_like = [i for i in crit if names[i] != "exact"]
+        dom = max(bank_like, key=lambda i: avg[i])             # the HBM-side figure: the dominant STREAMING kernel (the channel bank)
         bytes_per_launch = 8.0 * S * slot                      # 8 B per complex input sample, read once
         ach = bytes_per_launch / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         # algorithmic FMA per input sample of the direct-form banks
@@ -478,7 +516,7 @@ def run_rank(args):
                 "avg_launch_ms": round(avg[dom], 4),
                 "kernel_avg_ms": {names[i]: round(avg[i], 4) for i in range(NK)},
                 "note": "ddc_channel = channel bank (+ noise stage 1 when fused); ddc_noise = 0 then; without --full-timing only "
-                        "ddc_channel is bracketed in the headline region (block_config.kernel_avg_ms has every kernel)"}
+                        "ddc_channel and exact are bracketed in the headline region (classic_only.kernel_avg_ms has every kernel)"}
         direct = (names[dom] == "ddc_channel" and int(des.channelizer) == 1) or \
                  (names[dom] == "ddc_noise" and int(des.squelch) == 1)
         if direct:                                  # direct-form banks are ALU-bound: report the fp32 rate too
@@ -521,6 +559,22 @@ def run_rank(args):
             except Exception as e:                      # (no disassembler on the box, ...: traffic stays null)
                 roof["traffic_note"] = "no PMC summary of this build; device-code match not possible: %r" % (e,)
 
+        # The dominant kernel of the step since round 6 is exact_rows_kernel (the reference's direct-form DDC on the fp32 matrix pipe
+        # over every busy window's rows): MFMA-bound.  Algorithmic flops per launch = rows recomputed in line x 4 real multiply-adds
+        # per tap x ntaps x 2; peak = the dense f32-MFMA rate (MI355X_MICROARCH.md: 157.3 TFLOP/s).  The channel bank's HBM figure
+        # (rounds 1-5's `roofline`) stays beside it as roofline_bank.
+        roof_bank = roof
+        if names[dom_all] == "exact" and avg[dom_all] > 0:
+            rows_inline = float(blk_stats["rows_per_step"] - blk_long["rows_per_step"])
+            fl = rows_inline * 8.0 * des.ntaps_channel
+            roof = {"bound": "mfma", "kernel": "exact (exact_rows_kernel<%d>)" % des.decimation, "achieved": round(fl / (avg[dom_all] * 1e-3) / 1e12, 3),
+                    "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (avg[dom_all] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 5), "traffic": None,
+                    "algorithmic_flops_per_launch": fl, "rows_per_launch": rows_inline, "avg_launch_ms": round(avg[dom_all], 4),
+                    "executed_tflops": round(fl / (avg[dom_all] * 1e-3) / 1e12 / (28.0 / 32.0 * des.ntaps_channel / (14.0 * des.decimation) * 1250.0 / (11 * 128)), 3),
+                    "note": "executed = the matrix pipe's own rate: 28 of 32 rows, 667 of 700 taps, 1250 of 1408 columns carry results (DESIGN.md 4.4); "
+                            "F12: the f32 MFMA runs on the SIMD's vector lanes -- its time and every other instruction's add up",
+                    "build_id": roof_bank.get("build_id")}
+
         # ---- cpu_baseline + parity: the oracle (a port, NOT the upstream binary) ----
         cpu = None
         parity = {"note": "truth_detected / truth_expected is the recall of the synthetic ground truth; the misses are the "
@@ -537,7 +591,7 @@ def run_rank(args):
             import paritylib
             # with the block configuration measured, the oracle runs its LE pass too (one run serves both differentials:
             # the LE pass only adds access-address records, lib/multi_sniffer_impl.cc:129-149)
-            le_on = bool(args.le or block_cfg is not None)
+            le_on = bool(args.le)
             o = po.Oracle(fs, fc, args.squelch, po.MODE_SNIFFER, le=le_on)
             ncores = os.cpu_count() or 1
             P = max(2, min(S, args.parity_slots)) if args.parity_slots > 0 else 0
@@ -575,12 +629,13 @@ def run_rank(args):
                 parity["differential"] = paritylib.differential(gi, oi, tr)
                 if block_cfg is not None:
                     bi = b_ints[b_ints[:, 0] < P]
-                    block_cfg["differential"] = paritylib.differential(bi, oi_all, tr)
-                    ga = collections.Counter(tuple(int(v) for v in r[[0, 1, 3, 4]]) for r in bi if r[2] == 1)
+                    block_cfg["differential"] = paritylib.differential(bi, oi_all[oi_all[:, 2] == 0], tr)
+                if args.le:
+                    ga = collections.Counter(tuple(int(v) for v in r[[0, 1, 3, 4]]) for r in gi if r[2] == 1)
                     ra = collections.Counter(tuple(int(v) for v in r[[0, 1, 3, 4]]) for r in oi_all if r[2] == 1)
-                    block_cfg["aa_records"] = {"gpu": int(sum(ga.values())), "ref": int(sum(ra.values())),
-                                               "common": int(sum((ga & ra).values())),
-                                               "note": "access-address records of a classic-only capture are born from noise symbols"}
+                    parity["aa_records"] = {"gpu": int(sum(ga.values())), "ref": int(sum(ra.values())),
+                                            "common": int(sum((ga & ra).values())),
+                                            "note": "access-address records of a classic-only capture are born from noise symbols"}
                 parity["lap_list_equal_ref"] = ("planted records identical" if parity["differential"]["planted_identical"]
                                                 else "PLANTED RECORDS DIFFER") + \
                     "; %d / %d other records on one side only" % (
@@ -604,12 +659,14 @@ def run_rank(args):
                        "channelizer": {1: "direct", 2: "polyphase"}[int(des.channelizer)],
                        "squelch_filter": {1: "direct", 2: "staged"}[int(des.squelch)]},
             "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed],
-            "block_config": block_cfg,
+            "classic_only": block_cfg,
+            "c8": c8,
             "verify": verify_obj,
             "host_fed": host_fed,
             "fence_ms": round(fence_ms, 3),
             "step_enqueue_ms": [round(float(v), 3) for v in np.percentile(np.diff(np.array(marks)) * 1e3, [0, 50, 100])],
             "roofline": roof,
+            "roofline_bank": roof_bank,
             "cpu_baseline": cpu,
             "parity": parity,
         }

@@ -66,7 +66,7 @@ class Hit(ctypes.Structure):
 
 
 K_DDC_CHANNEL, K_DEMOD_ENERGY, K_DDC_NOISE, K_NOISE_ENERGY, K_WINDOW = 0, 1, 2, 3, 4
-KERNEL_NAMES = ["ddc_channel", "demod_energy", "ddc_noise", "noise_energy", "window", "finish", "verify"]
+KERNEL_NAMES = ["ddc_channel", "demod_energy", "ddc_noise", "noise_energy", "window", "finish", "verify", "exact"]
 
 
 class Timing(ctypes.Structure):

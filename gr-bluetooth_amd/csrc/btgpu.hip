@@ -260,7 +260,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     DevBuf &d_winfin = t.d_winfin, &d_symbits = t.d_symbits;
     t.S = S; t.abs_first_slot = abs_first_slot;
     // BTGPU_FLAG_TIMING: every mark; BTGPU_FLAG_TIMING_BANK alone: only the two around the channel bank
-    auto mark = [&](int k, hipStream_t s_) -> hipError_t { return (timing_on && (timing_full || k <= 1)) ? hipEventRecord(ev[k], s_) : hipSuccess; };
+    auto mark = [&](int k, hipStream_t s_) -> hipError_t { return (timing_on && (timing_full || k <= 1 || k >= 12)) ? hipEventRecord(ev[k], s_) : hipSuccess; };   // (light form: the bank and the exact rows)
 
     // =========================== FRONT (stream `st`): the banks ===========================
     // (The post stage runs behind it on the same stream unless BTGPU_PIPE=1, see btgpu_create.)
@@ -406,7 +406,6 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                                  bitmap, vb.bm_tiles, (float *)d_d.p, drow, (float *)(use_dcol ? t.d_dcol.p : nullptr), stat);
         hipLaunchKernelGGL(ex_kern, dim3((unsigned)vb.bm_tiles), dim3(kExThreads), ex_lds, s_, ep, d_x);
     };
-    HIPCHK(this, mark(12, ps));
     if (verify && p.verify == 1) {
         // presence's last-resort noise reference: each channel's quietest full tile of the batch
         HIPCHK(this, hipMemsetAsync(t.d_chanfloor.p, 0x7f, 81 * sizeof(float), ps));       // (0x7f7f7f7f = 3.4e38: no tile yet)
@@ -423,9 +422,10 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
         else if (drow == 20) launch_presence(WinLayout<12, 20, 5>{});
         else if (drow == 8) launch_presence(WinLayout<32, 8, 2>{});
         else launch_presence(WinLayout<64, 4, 1>{});
+        HIPCHK(this, mark(12, ps));
         launch_exact_rows(vb.bm1, vb.vcount + 4, ps);
-    }
-    HIPCHK(this, mark(13, ps));
+        HIPCHK(this, mark(13, ps));
+    } else { HIPCHK(this, mark(12, ps)); HIPCHK(this, mark(13, ps)); }
     HIPCHK(this, mark(5, qs));
     // tile sums -> block sums: as extra rows of the squelch stage-2 launch where both exist (a kernel of its own costs 0.05 ms
     // of launch ramp and tail for microseconds of work; on a side stream it saved those and cost 0.4 ms per step in
@@ -661,7 +661,7 @@ int btgpu_handle::harvest(TailCtx &t)
             timing.kernel_ms[i] += ms;
             timing.kernel_launches[i] += 1;
         }
-        if (timing_full && verify) { HIPCHK(this, hipEventElapsedTime(&ms, t.ev[12], t.ev[13])); timing.kernel_ms[6] += ms; }   // (+ presence and the exact rows in line)
+        { HIPCHK(this, hipEventElapsedTime(&ms, t.ev[12], t.ev[13])); timing.kernel_ms[BTGPU_K_EXACT] += ms; timing.kernel_launches[BTGPU_K_EXACT] += 1; }   // exact_rows_kernel over presence's marks, in line
         if (timing_full) { HIPCHK(this, hipEventElapsedTime(&ms, t.ev[0], t.ev[10])); timing.total_ms += ms; }
     }
     timing.batches += 1;

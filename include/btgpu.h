@@ -71,25 +71,24 @@ extern "C" {
 
 #define BTGPU_FLAG_TIMING    0x20       /* bracket the kernels of every batch with HIP events for btgpu_last_timing
                                            (off by default: eleven event records per batch are not free)     */
-#define BTGPU_FLAG_TIMING_BANK 0x80      /* the light form: events only around the channel-bank kernel (BTGPU_K_DDC_CHANNEL);
-                                           what bench.py's timed region uses for its roofline figure                */
+#define BTGPU_FLAG_TIMING_BANK 0x80      /* the light form: events only around the channel-bank kernel (BTGPU_K_DDC_CHANNEL) and the exact
+                                           rows' kernel (BTGPU_K_EXACT); what bench.py's timed region uses for its roofline figures */
 #define BTGPU_FLAG_NO_NSYM   0x40       /* LAP-list consumers (multi_LAP prints the LAP only, lib/multi_LAP_impl.cc:93-110):
                                            skip the clock-recovery continuation over the rest of a hit window that
                                            only produces hit.nsym; nsym is then -1 unless the window ended inside
                                            the 693-symbol detection span.  Ignored with BTGPU_FLAG_SYMBOLS / HEADERS */
 
-#define BTGPU_FLAG_NO_VERIFY 0x100      /* polyphase channelizer only: do NOT re-run the windows that can carry a packet's record (a classic
-                                           hit, or burst energy inside the detection span) through the bit-exact direct-form
-                                           arithmetic.  By default they are (exact confirmation): their records
-                                           then equal the CPU reference's in slot, channel, kind, offset, LAP and ac_errors; with this
-                                           flag ~1.4e-4 of them come out a symbol apart or on one side only (the round-3 behaviour) */
+#define BTGPU_FLAG_NO_VERIFY 0x100      /* polyphase channelizer only: do NOT recompute the demodulated rows of the busy windows (energy
+                                           anywhere in the detection span: "presence") through the bit-exact direct-form arithmetic.  By
+                                           default they are (exact rows, DESIGN.md sections 4.4 and 5): the records then equal the CPU
+                                           reference's in slot, channel, kind, offset, LAP and ac_errors, and the symbols handed to the
+                                           host layer are the reference's to the end of each packet; with this flag ~1e-4 .. 2e-2 of the
+                                           records (by traffic) come out a symbol apart or on one side only (the round-3 behaviour) */
 
-#define BTGPU_FLAG_EXACT_PAYLOAD 0x200   /* with SYMBOLS / HEADERS on the polyphase channelizer: the symbols a record hands to the host layer are the
-                                           reference's own arithmetic to the END OF THE PACKET, not only through access code and header: the
-                                           direct-form DDC is also run over the rows behind the header, up to where the burst's energy ends, and
-                                           the clock-recovery continuation reads those.  What every payload decode and CRC of the host layer
-                                           sees (lib/packet_impl.cc:1066-1160) then equals the CPU reference's.  Costs the direct-form filter
-                                           over the air time of every detected packet; the gr::bluetooth::multi_sniffer mirror sets it */
+#define BTGPU_FLAG_EXACT_PAYLOAD 0x200   /* accepted; ALWAYS ON since round 6.  The symbols a record hands to the host layer are the reference's
+                                           own arithmetic to the END OF THE PACKET: a packet's air time is busy, so its rows are exact rows
+                                           anyway (no separate pass).  What every payload decode and CRC of the host layer sees
+                                           (lib/packet_impl.cc:1066-1160) equals the CPU reference's */
 
 #define BTGPU_KIND_AC 0
 #define BTGPU_KIND_AA 1
@@ -150,7 +149,8 @@ typedef struct btgpu_hit {
 #define BTGPU_K_NOISE_ENERGY  3   /* noise |Y|^2 per-slot sums                           */
 #define BTGPU_K_WINDOW        4   /* squelch + M&M + slicer + access-code search         */
 #define BTGPU_K_FINISH        5   /* M&M continuation of the windows that reported hits  */
-#define BTGPU_K_VERIFY        6   /* exact confirmation: direct-form DDC of the handed-over windows + their window kernel */
+#define BTGPU_K_VERIFY        6   /* the second run (tail stream): exact rows under the first run's uncovered hits, fill, window kernel over those windows */
+#define BTGPU_K_EXACT         7   /* exact_rows_kernel over presence's marks, in line before the window kernel (bracketed with BTGPU_FLAG_TIMING_BANK too) */
 #define BTGPU_K_COUNT         8
 typedef struct btgpu_timing {
     float    kernel_ms[BTGPU_K_COUNT];        /* summed over launches                  */
@@ -159,12 +159,12 @@ typedef struct btgpu_timing {
     uint32_t batches;
     uint64_t samples;                         /* new complex samples consumed          */
     uint64_t slots;
-    uint64_t verify_windows;                  /* windows re-run through the exact stage (always counted)                 */
-    uint64_t verify_rows;                     /* demodulated rows recomputed by the direct-form DDC, in 127-row tiles    */
-    uint64_t verify_turned_away;              /* windows that should have been re-run but found the task list full       */
-    uint64_t long_tasks;                      /* BTGPU_FLAG_EXACT_PAYLOAD: windows whose rows behind the header were recomputed to the end of the burst */
-    uint64_t long_rows;                       /* ... the rows of those, in 127-row tiles                                  */
-    uint64_t long_turned_away;                /* ... windows that found the long-task lists full (their payload symbols: the polyphase continuation) */
+    uint64_t verify_windows;                  /* busy windows (presence) + windows of the second run (always counted)    */
+    uint64_t verify_rows;                     /* demodulated rows recomputed by exact_rows_kernel (both launches), in tiles of 1250 / 11 rows */
+    uint64_t verify_turned_away;              /* windows that should have gone to the second run but found its list full */
+    uint64_t long_tasks;                      /* windows of the second run (a classic hit on rows presence had not covered) */
+    uint64_t long_rows;                       /* ... the rows recomputed for them                                         */
+    uint64_t long_turned_away;                /* (unused since round 6)                                                   */
 } btgpu_timing;
 
 /* ---- host-only helpers (no GPU needed) ---- */

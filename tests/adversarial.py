@@ -145,3 +145,76 @@ def judge_r04_nearfar_case(mode, seed, want_case):
             synth.add_burst(iq, b2, st2, fs, fc, ch2, r2, cfo_hz=cfo, amplitude=10 ** ((a + up) / 20))
             truth.append(dict(slot=st2 // slot, channel=ch2, lap=lap2))
     return fs, fc, nsl, sq, iq, truth
+
+
+SEAMLESS_KINDS = ("seam-gfsk", "seam-cw", "seam-noise", "ramp")
+
+
+def judge_r05_seamless_case(mode, seed, want_case, kinds=SEAMLESS_KINDS):
+    """The capture of case `want_case` of scripts/experiments/judge_r05_seamless_emu.py <mode> <cases> <seed> (the round-5 judge's
+    generator, replayed draw for draw): packets that show NO STEP in the channel's energy where they begin -- behind a GFSK emitter, an
+    unmodulated carrier or a noise burst of their own level on the same channel ("seam-*"), or with their amplitude raised over
+    10..80 us ("ramp"); kinds=("weak-beside",): packets 2.5..7 dB over the noise beside a long packet 20..35 dB up on the channel
+    below.  Returns (fs, fc, n_slots, squelch, iq, truth, meta).  Round 5's edge-based selection lost three of its records:
+    `mix 470 103` case 469 (a 0-error packet 17 us behind an equal-level emitter), `mix 823 103` case 822 (behind a carrier 1.2 dB
+    stronger), `mix 1617 101` case 1616 (a slow ramp, handed to the wrong window)."""
+    synth = _synth()
+    rng = np.random.default_rng(seed)
+    rates = {"100": [(100e6, 2441e6)], "8": [(8e6, 2476.5e6)], "20": [(20e6, 2441e6)], "mix": [(8e6, 2476.5e6), (8e6, 2476.5e6), (20e6, 2441e6)]}[mode]
+    for case in range(want_case + 1):
+        fs, fc = rates[int(rng.integers(0, len(rates)))]
+        nsl = int(rng.integers(9, 13)); sq = float(rng.choice([5.0, 10.0])); cseed = int(rng.integers(0, 1 << 30))
+        npk = int(rng.integers(30, 70)) if fs == 100e6 else int(rng.integers(6, 16))
+        laps = tuple(int(x) for x in rng.integers(0, 1 << 24, 5))
+    sps = int(round(fs / 1e6)); slot = 625 * sps; lo, hi = synth.visible_channels(fs, fc)
+    r2 = np.random.default_rng(cseed); truth, meta = [], []
+    iq, _ = synth.make_capture(fs, fc, nsl, laps=laps, seed=cseed, snr_db=TOP_DB, occupancy=0.0)      # noise: unit amplitude = 43 dB over it
+    reach = int((nsl - 6.4) * slot)
+    used = {}
+
+    def put(bb, start, ch, f_off, ph):
+        f = (synth.BASE_FREQUENCY + ch * 1e6 - fc) + f_off
+        start = int(start)
+        if start < 0:
+            bb = bb[-start:]; start = 0
+        m = np.arange(len(bb))
+        bb = bb * np.exp(1j * (2 * np.pi * f / fs * m + ph))
+        end = min(start + len(bb), len(iq))
+        if end > start:
+            iq[start:end] += bb[:end - start].astype(np.complex64)
+
+    for _ in range(npk):
+        kind = str(r2.choice(kinds)); lap = int(r2.choice(laps)); ch = int(r2.integers(lo, hi + 1))
+        level = float(r2.uniform(10.0, 40.0)); start = int(r2.integers(1600 * sps, max(reach, 1601 * sps)))
+        if any(abs(start - s) < 4000 * sps for s in used.get(ch, [])):          # keep the constellations apart on a channel
+            continue
+        used.setdefault(ch, []).append(start)
+        amp = 10 ** ((level - TOP_DB) / 20); cfo = float(r2.uniform(-60e3, 60e3))
+        bits = synth.packet_bits(lap, r2, int(r2.choice([0, int(r2.integers(0, 241)), int(r2.integers(0, 1201))])))
+        bb = synth.gfsk_baseband(bits, sps) * amp
+        gap = d = None
+        if kind == "weak-beside":
+            level = float(r2.uniform(2.5, 7.0)); amp = 10 ** ((level - TOP_DB) / 20); bb = synth.gfsk_baseband(bits, sps) * amp
+            if ch > lo:
+                nbits = synth.packet_bits(int(r2.choice(laps)), r2, 2745)
+                put(synth.gfsk_baseband(nbits, sps) * 10 ** ((float(r2.uniform(20, 35)) - TOP_DB) / 20), start - int(r2.integers(400, 1400)) * sps, ch - 1,
+                    float(r2.uniform(-60e3, 60e3)), float(r2.uniform(0, 2 * np.pi)))
+        elif kind == "ramp":
+            n = int(r2.uniform(10, 80) * sps); w = 0.5 - 0.5 * np.cos(np.pi * np.arange(n) / n)
+            bb[:n] = bb[:n] * w
+        else:
+            d = float(r2.uniform(-1.5, 1.5)); a2 = amp * 10 ** (d / 20); dur = int(r2.integers(300, 1500)) * sps
+            gap = int(r2.uniform(-5, 20) * sps) if kind == "seam-gfsk" else int(r2.uniform(-2, 2) * sps)
+            if kind == "seam-gfsk":
+                fb = synth.gfsk_baseband(r2.integers(0, 2, dur // sps, dtype=np.uint8), sps) * a2
+                put(fb, start - gap - len(fb), ch, float(r2.uniform(-60e3, 60e3)), float(r2.uniform(0, 2 * np.pi)))
+            elif kind == "seam-cw":
+                put(np.full(dur, a2, np.complex128), start - gap - dur, ch, float(r2.uniform(-150e3, 150e3)), float(r2.uniform(0, 2 * np.pi)))
+            else:
+                nz = (r2.standard_normal(dur) + 1j * r2.standard_normal(dur)) / np.sqrt(2.0)
+                k = np.sinc((np.arange(-4 * sps, 4 * sps + 1)) / sps) * np.hanning(8 * sps + 1); k /= np.sqrt(np.sum(k * k))
+                put(np.convolve(nz, k, mode="same") * a2, start - gap - dur, ch, 0.0, 0.0)
+        put(bb, start, ch, cfo, float(r2.uniform(0, 2 * np.pi)))
+        truth.append(dict(slot=start // slot, channel=ch, lap=lap))
+        meta.append(dict(kind=kind, level=level, start=start, channel=ch, lap=lap, gap_us=(gap / sps if gap is not None else None), delta_db=d))
+    return fs, fc, nsl, sq, iq, truth, meta
