@@ -61,7 +61,7 @@ struct VerifyTask {
     int32_t n_exact;          // demodulated rows [0, n_exact) of the window are exact by the time the second run reads them
     double  snr;              // the window's squelch figure (the second run goes beside the next batch, whose sums reuse P / Qn)
     int32_t emit_from;        // the first run has already emitted this window's classic records at offsets below this one (from exact rows)
-    int32_t pad_;
+    int32_t le_emit_from;     // ... and its access-address records at offsets below this one
 };
 constexpr int kVerRows = 1416;    // rows of a window the exact stage's clock recovery can reach in 693 symbols (693 * 2.01 + 8), rounded up
 constexpr int kVerTile = 127;     // new demodulated rows per tile of verify_ddc_kernel (128 outputs, the first is the demod halo)
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
     const int k = blockIdx.x * kWinSlots + sl;                   // slot (VER: pseudo-slot) whose rows this lane reads
     // the window the lane stands for: (k, c) itself, or the task's
     int kq = k, cq = c;
-    int emit_from = 0;                               // VER: classic records below this offset left in the first run
+    int emit_from = 0, le_emit_from = 0;             // VER: classic / access-address records below these offsets left in the first run
     bool lane_ok = sl < kWinSlots && k < p.S;
     if (VER) {
         unsigned int ntask = p.vcount[0];
@@ -786,6 +786,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         const int wr = lane_ok ? p.vtasks[q].w : 0;
         kq = wr / nch; cq = wr - kq * nch;
         emit_from = lane_ok ? p.vtasks[q].emit_from : 0;
+        le_emit_from = lane_ok ? p.vtasks[q].le_emit_from : 0;
     }
     const long long w = (long long)kq * nch + cq;
     int nmax = 0;                                    // symbols this lane will produce in phase 1
@@ -1076,7 +1077,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         const long long g_lo = (long long)kq * p.outs_per_slot;
         exact_mark(p.bm2, p.bm1, p.bm_tiles, g_lo, g_lo + rows, cq, &p.vcount[1]);
         VerifyTask t_;
-        t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr; t_.emit_from = first_uncov; t_.pad_ = 0;
+        t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr; t_.emit_from = first_uncov; t_.le_emit_from = 0;
         p.vtasks[vslot] = t_;
         return;
     }
@@ -1095,6 +1096,7 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
         const uint8_t *phl = le_hdr + (access ? 0 : 512), *phm = phl + 256;
         const uint32_t wmask = le_whiten_g[le_index];
         int le_resume = 0;
+        int le_uncov = -1;                                       // first run: the first access-address hit that stands on rows exact.hip.h has not covered
         uint32_t q0 = mybits[0], q1 = mybits[kWinThreads], q2;
         for (int b = 0; b * 32 < le_limit; b++) {
             q2 = mybits[(b + 2) * kWinThreads];
@@ -1136,7 +1138,23 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                 int maxd = 0;
                 if (access) { dist += __popc(aa ^ 0x8e89bed6u); maxd = 2; }
                 if (dist <= maxd) {
-                    const unsigned int slot_h = atomicAdd(hit_count, 1u);
+                    // An access-address hit outside the exact rows -- in practice one born from noise symbols: a real advert's air time
+                    // is busy -- is a claim like a classic one: the window goes to the second run, which settles it on exact rows
+                    // (the records of the product's side then are the reference's wherever the product saw anything at all; what only
+                    // the reference's noise shows stays on its side: ~1 % of the noise-born records, bench.py parity.aa_records).
+                    bool emit = !(VER && cpos < le_emit_from);
+                    if (!VER && p.verify) {
+                        const int span_ = cpos + 40 + 16 + 8;        // preamble + address, the header bits the test reads, margin
+                        if (le_uncov >= 0 || ver_rows(span_) > cov_rows) {
+                            if (le_uncov < 0) {
+                                const unsigned int s_ = atomicAdd(&p.vcount[0], 1u);
+                                if (s_ < (unsigned int)p.vcap) { vslot = (int)s_; le_uncov = cpos; }
+                                else atomicAdd(&p.vcount[2], 1u);
+                            }
+                            if (vslot >= 0) { vspan = span_ > vspan ? span_ : vspan; emit = false; }
+                        }
+                    }
+                    const unsigned int slot_h = emit ? atomicAdd(hit_count, 1u) : 0xffffffffu;
                     if (slot_h < (unsigned int)p.max_hits) {
                         DeviceHit h;
                         h.slot = (uint32_t)kq; h.channel_idx = cq; h.offset = cpos;
@@ -1148,6 +1166,16 @@ __global__ __launch_bounds__(kWinThreads) void window_kernel(
                 }
             }
             q0 = q1; q1 = q2;
+        }
+        if (vslot >= 0) {
+            // (reserved by the LE pass: every classic record of this window has left already -- all stood on exact rows)
+            const int rows = ver_rows(vspan);
+            const long long g_lo = (long long)kq * p.outs_per_slot;
+            exact_mark(p.bm2, p.bm1, p.bm_tiles, g_lo, g_lo + rows, cq, &p.vcount[1]);
+            VerifyTask t_;
+            t_.w = (int32_t)w; t_.n_exact = rows; t_.snr = snr; t_.emit_from = 0x3fffffff; t_.le_emit_from = le_uncov;
+            p.vtasks[vslot] = t_;
+            return;
         }
     }
     if (nhits > 0) {

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the time partition + hit gather
+"""N > 1 path on CPU: world_size-2 and world_size-8 gloo runs of the time partition + hit gather
 (gr_bluetooth_amd/dist.py).  The per-rank processor here is the oracle (checker standing in
 for the GPU, which does not exist in this container); the partition, halo and gather logic is
 the product's and must reproduce the single-process hit list."""
@@ -28,7 +28,7 @@ def test_partition_and_segment_bounds(pkg):
     assert d.segment_bounds(0, 0, 31601, 5000)[1] == 0
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, total=18):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -41,7 +41,7 @@ def _worker(rank, world, port, tmp):
     synth = importlib.import_module("gr_bluetooth_amd.synth")
     import pyoracle as po
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    fs, fc, total = 8e6, 2476.5e6, 18
+    fs, fc = 8e6, 2476.5e6
     iq, _ = synth.make_capture(fs, fc, total, laps=(0x24D952, 0x4831DD), seed=21, snr_db=24, occupancy=0.5)
     o = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER)
     H, slot = o.history, o.slot
@@ -63,7 +63,7 @@ def _worker(rank, world, port, tmp):
     g.post(ints[half:], snr[half:])
     b_i, b_s = g.collect(drain=True)
     gi, gs = bd.sort_hits(np.concatenate([a_i, b_i], axis=0), np.concatenate([a_s, b_s], axis=0))
-    assert g.rounds >= 3
+    assert g.rounds >= 3                                             # (the busiest rank's records / capacity: every rank runs every round)
     # ... and in one round with room for everything: the same records
     g2 = bd.HitGatherer(cap=4096, device="cpu")
     g2.hold(ints[:half], snr[:half])                                 # (a cadence of several batches: held, then posted together)
@@ -103,4 +103,22 @@ def test_two_rank_time_partition_matches_single_process(pkg, po, synth, tmp_path
     bd = importlib.import_module("gr_bluetooth_amd.dist")
     wi, _ = bd.sort_hits(*bd.hits_to_arrays(want))
     assert len(want) > 0
+    assert np.array_equal(gi, wi)
+
+
+def test_eight_rank_time_partition_and_gather(pkg, po, synth, tmp_path):
+    """The node's real shape: EIGHT ranks, 40 slots -- five per rank, halo and gather as above, spill rounds and
+    the two-in-flight cadence with eight senders per collective -- against the single-process oracle."""
+    import importlib
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(8, port, str(tmp_path), 40), nprocs=8, join=True)
+    gi = np.load(os.path.join(str(tmp_path), "gathered.npy"))
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 40, laps=(0x24D952, 0x4831DD), seed=21, snr_db=24, occupancy=0.5)
+    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER).run_stream(iq, threads=4)
+    bd = importlib.import_module("gr_bluetooth_amd.dist")
+    wi, _ = bd.sort_hits(*bd.hits_to_arrays(want))
+    assert len(want) > 20
     assert np.array_equal(gi, wi)
