@@ -536,6 +536,7 @@ def run_rank(args):
                 if pj.get("build_id") == roof["build_id"] and pj.get("slots") == S:
                     args.pmc_json = cand
                     break
+        pmc_loaded = None
         if args.pmc_json:
             # HBM bytes of the dominant kernel from rocprofv3 PMC passes of the SAME build and batch size
             # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; scripts/collect_profiles.sh stamps the build id)
@@ -543,6 +544,7 @@ def run_rank(args):
             if pmc.get("build_id") != roof["build_id"] or pmc.get("slots") != S:
                 raise SystemExit("--pmc-json %s was collected on build %s / %s slots, this run is build %s / %d slots"
                                  % (args.pmc_json, pmc.get("build_id"), pmc.get("slots"), roof["build_id"], S))
+            pmc_loaded = pmc
             key = {"ddc_channel": "pfb", "window": "window_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
             match = [k for k in pmc["kernels"] if key and k.startswith(key)]
             # (the small-M banks run the same kernel template twice -- channel bank and squelch stage 1: the channel bank is the one
@@ -574,6 +576,10 @@ def run_rank(args):
                     "note": "executed = the matrix pipe's own rate: 28 of 32 rows, 667 of 700 taps, 1250 of 1408 columns carry results (DESIGN.md 4.4); "
                             "F12: the f32 MFMA runs on the SIMD's vector lanes -- its time and every other instruction's add up",
                     "build_id": roof_bank.get("build_id")}
+            if pmc_loaded is not None:                  # (PMC passes run one step with --sync: the first launch of exact_rows_kernel, over presence's marks, is the larger one)
+                ex = sorted((v["hbm_bytes"] * v.get("launches", 1) for k, v in pmc_loaded["kernels"].items() if k.startswith("exact_rows")), reverse=True)
+                if ex:                                  # (both launches of the step: the second run's is ~1 % of it)
+                    roof["traffic"] = ex[0]; roof["traffic_source"] = os.path.basename(args.pmc_json)
 
         # ---- cpu_baseline + parity: the oracle (a port, NOT the upstream binary) ----
         cpu = None
