@@ -74,6 +74,16 @@ int multi_block::run_work(int noutput_items, gr_vector_const_void_star &input_it
         abort();
     }
     drain(d_gpu);
+    {
+        // the second run's list (hits on rows presence had not made exact) holds 32 768 windows per batch: a window that found it full
+        // kept the polyphase path's record -- said once, not silently
+        btgpu_timing tm{};
+        if (!d_warned_turned_away && btgpu_last_timing(d_gpu, &tm) == BTGPU_OK && tm.verify_turned_away > 0) {
+            d_warned_turned_away = true;
+            fprintf(stderr, "Warning: %llu windows kept records from rows that are not the reference's arithmetic (the second run's list was full; "
+                            "smaller batches: btgpu_config.max_batch_slots)\n", (unsigned long long)tm.verify_turned_away);
+        }
+    }
     d_cumulative_count += consumed;
     return (int)consumed;
 }

@@ -29,6 +29,7 @@ protected:
     double d_sample_rate = 0, d_center_freq = 0, d_target_snr = 0;
     int d_mode = 0;
     bool d_headers = false;               // records come with symbols and the header sweep
+    bool d_warned_turned_away = false;    // the "second run's list was full" warning has been printed
 
     // forwards one scheduler call to btgpu_work(); returns the number of items consumed
     int run_work(int noutput_items, gr_vector_const_void_star &input_items);
