@@ -77,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed load before the warm-up steps (clock ramp)")
     ap.add_argument("--headers", action="store_true", help="(default since round 6) export hit symbols and run the GPU header sweep (BTGPU_FLAG_HEADERS), as the C++ multi_sniffer block does")
     ap.add_argument("--classic-only", action="store_true", help="the headline region WITHOUT the LE pass and the symbol hand-over (rounds 1-5's headline; now the extra key classic_only)")
+    ap.add_argument("--no-exact-all", action="store_true", help="skip the short region with BTGPU_FLAG_EXACT_ALL (no selection: every row of every channel exact)")
     ap.add_argument("--no-c8", action="store_true", help="skip the short run of BASELINE configs[1] (8 channels, 8 Msps) that fills the c8 object")
     ap.add_argument("--synth-device", default=None, help="where the synthetic capture is generated (default: the GPU).  'cpu': torch CPU ops + one "
                     "upload -- for the rocprofv3 --pmc passes of the C8 workload, which crash inside torch's own randn launches")
@@ -390,6 +391,24 @@ def run_rank(args):
                      "ac_records_equal_headline": bool(np.array_equal(b_ints, head_ac)),
                      "ac_records_equal_headline_on_6_fields": bool(len(b_ints) == len(head_ac) and np.array_equal(b_ints[:, :6], head_ac[:, :6]))}
 
+    # ---- no selection at all (N = 1): BTGPU_FLAG_EXACT_ALL -- every row of every channel through the reference's arithmetic on the
+    # matrix pipe; every field of every record then equals the oracle's (nsym and the noise-born records included) ----
+    exact_all = None
+    x_ints = None
+    if world == 1 and not args.no_exact_all and not args.classic_only:
+        blk.close()
+        blk = make_block(head_flags | pkg.FLAG_EXACT_ALL)
+        keep_steps, keep_warm = args.steps, args.warmup
+        args.steps, args.warmup = max(3, args.steps // 4), 1
+        x_el, x_ints, x_snr, _m, _f, x_kms, x_kl = timed_region(blk, gather=False)
+        x_ints, x_snr = one_copy(x_ints, x_snr)
+        exact_all = {"flags": "the headline's + BTGPU_FLAG_EXACT_ALL", "steps": args.steps,
+                     "value": round(float(S) * slot * args.steps / x_el / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(x_el / args.steps * 1e3, 3),
+                     "hits": int(len(x_ints)), "exact_ms": round(float(x_kms[7] / x_kl[7]), 3) if x_kl[7] else None,
+                     "rows_per_step": blk._verify_stats["rows_per_step"],
+                     "records_equal_headline_on_6_fields_where_planted": None}
+        args.steps, args.warmup = keep_steps, keep_warm
+
     # ---- BASELINE configs[1] (N = 1): 8 channels at 8 Msps, the same flags, driver-timed ----
     c8 = None
     if world == 1 and not args.no_c8 and args.workload == "c79":
@@ -633,6 +652,10 @@ def run_rank(args):
                 tr = [t for t in truth if t["slot"] < P]
                 parity["oracle_slots"] = P
                 parity["differential"] = paritylib.differential(gi, oi, tr)
+                if exact_all is not None:
+                    xi = x_ints[x_ints[:, 0] < P]
+                    exact_all["differential"] = paritylib.differential(xi, oi_all, tr)
+                    exact_all["records_identical_all_fields"] = bool(exact_all["differential"]["records_identical_all_fields"])
                 if block_cfg is not None:
                     bi = b_ints[b_ints[:, 0] < P]
                     block_cfg["differential"] = paritylib.differential(bi, oi_all[oi_all[:, 2] == 0], tr)
@@ -667,6 +690,7 @@ def run_rank(args):
             "ms_per_step_by_rank": [round(v / args.steps * 1e3, 3) for v in rank_elapsed],
             "classic_only": block_cfg,
             "c8": c8,
+            "exact_all": exact_all,
             "verify": verify_obj,
             "host_fed": host_fed,
             "fence_ms": round(fence_ms, 3),

@@ -33,6 +33,7 @@ CORRELATOR_AUTO, CORRELATOR_INTREE, CORRELATOR_BTBB = 0, 1, 2   # multi_LAP defa
 FLAG_LE, FLAG_DEBUG_Y, FLAG_ASYNC, FLAG_SYMBOLS, FLAG_HEADERS, FLAG_TIMING, FLAG_NO_NSYM, FLAG_TIMING_BANK = 1, 2, 4, 8, 16, 32, 64, 128
 FLAG_NO_VERIFY = 256      # polyphase path without the exact confirmation of its records (A/B)
 FLAG_EXACT_PAYLOAD = 512  # exported symbols exact to the end of the packet (include/btgpu.h)
+FLAG_EXACT_ALL = 1024     # no selection: every row of every channel exact (include/btgpu.h)
 KIND_AC, KIND_AA = 0, 1
 
 

@@ -87,7 +87,8 @@ struct btgpu_handle {
         // stage 2, 8 window; tail 9 start, 10 end
         // ... 11 exact stage done (tail)
         // ... 12 / 13 around presence + the exact rows in line (post)
-        hipEvent_t ev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        // ... 14: squelch stage 2 done (on its side stream, beside presence and the exact rows)
+        hipEvent_t ev[15] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         hipEvent_t front_done = nullptr, detect_done = nullptr, tail_done = nullptr, squelch_done = nullptr, exact_done = nullptr, floor_done = nullptr;
         int S = 0;
         uint64_t abs_first_slot = 0;
@@ -102,6 +103,7 @@ struct btgpu_handle {
     int verify = 0;                  // exact rows under the polyphase path's records (exact.hip.h): 0 off, 1 presence + uncovered hits, 2 uncovered hits only
     int vcap = 0, bm_tiles = 0;
     ExactRowsKernel ex_kern = nullptr; size_t ex_lds = 0;
+    bool exact_all = false;          // BTGPU_FLAG_EXACT_ALL: every row of every channel is recomputed (no presence)
     std::vector<const void *> lds_opted;   // bank kernels that have been granted > 48 KiB of dynamic LDS on this handle's device
     DevBuf d_tapsA;                  // the direct-form channel bank's taps as exact_rows_kernel's A operand (exact_pack_taps)
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
@@ -260,7 +262,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     DevBuf &d_winfin = t.d_winfin, &d_symbits = t.d_symbits;
     t.S = S; t.abs_first_slot = abs_first_slot;
     // BTGPU_FLAG_TIMING: every mark; BTGPU_FLAG_TIMING_BANK alone: only the two around the channel bank
-    auto mark = [&](int k, hipStream_t s_) -> hipError_t { return (timing_on && (timing_full || k <= 1 || k >= 12)) ? hipEventRecord(ev[k], s_) : hipSuccess; };   // (light form: the bank and the exact rows)
+    auto mark = [&](int k, hipStream_t s_) -> hipError_t { return (timing_on && (timing_full || k <= 1 || k == 12 || k == 13)) ? hipEventRecord(ev[k], s_) : hipSuccess; };   // (light form: the bank and the exact rows)
 
     // =========================== FRONT (stream `st`): the banks ===========================
     // (The post stage runs behind it on the same stream unless BTGPU_PIPE=1, see btgpu_create.)
@@ -379,8 +381,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     if (pipelined) HIPCHK(this, hipStreamWaitEvent(ps, t.front_done, 0));
     // deferred squelch: the sums, stage 2 and the per-window SNR go to the side stream (behind this batch's banks), the window
     // kernel follows the banks directly on `ps`
-    hipStream_t qs = deferred ? sq_stream : ps;
-    if (deferred) HIPCHK(this, hipStreamWaitEvent(qs, t.front_done, 0));
+    // (round 6) squelch stage 2 + block sums on the side stream as well where presence and the exact rows stand between the banks and
+    // the window kernel: they do not depend on each other, and the exact rows' kernel leaves a fifth of the issue cycles idle
+    static const bool side_sq_off = getenv("BTGPU_SQ_INLINE") != nullptr;        // (A/B)
+    const bool side_sq = !deferred && !pipelined && verify == 1 && use_pfb && use_staged && !side_sq_off;
+    hipStream_t qs = (deferred || side_sq) ? sq_stream : ps;
+    if (deferred || side_sq) HIPCHK(this, hipStreamWaitEvent(qs, t.front_done, 0));
     // ---- window parameters, and the exact stage's burst scan right behind the banks (round 5) ----
     WindowParams p = make_window_params(des, S, nb, ystride, max_hits, want_syms, (const uint64_t *)d_pcol.p);
     { static const int ws = getenv("BTGPU_WIN_STOP") ? atoi(getenv("BTGPU_WIN_STOP")) : 0; p.dbg_stop = ws; }
@@ -406,7 +412,12 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                                  bitmap, vb.bm_tiles, (float *)d_d.p, drow, (float *)(use_dcol ? t.d_dcol.p : nullptr), stat);
         hipLaunchKernelGGL(ex_kern, dim3((unsigned)vb.bm_tiles), dim3(kExThreads), ex_lds, s_, ep, d_x);
     };
-    if (verify && p.verify == 1) {
+    if (verify && exact_all) {
+        hipLaunchKernelGGL(exact_mark_all_kernel, dim3((unsigned)((vb.bm_tiles * kExBmWords + 255) / 256)), dim3(256), 0, ps, vb.bm1, vb.bm_tiles, nch);
+        HIPCHK(this, mark(12, ps));
+        launch_exact_rows(vb.bm1, vb.vcount + 4, ps);
+        HIPCHK(this, mark(13, ps));
+    } else if (verify && p.verify == 1) {
         // presence's last-resort noise reference: each channel's quietest full tile of the batch
         HIPCHK(this, hipMemsetAsync(t.d_chanfloor.p, 0x7f, 81 * sizeof(float), ps));       // (0x7f7f7f7f = 3.4e38: no tile yet)
         const int full_tiles = (G % p.tile_outs) ? p.ptile_stride - 1 : p.ptile_stride;    // (the batch's last tile may be a partial one: ADVICE r5)
@@ -448,7 +459,9 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                            (const float2 *)t.d_Z.p, zstride, ns.outs, ns.nw, ns.L3, (const float *)d_h3.p,
                            (const double *)d_w.p, (double *)d_Q.p, S, bsa);
     }
-    HIPCHK(this, mark(7, qs));
+    HIPCHK(this, mark(14, qs));
+    if (side_sq) { HIPCHK(this, hipEventRecord(t.squelch_done, qs)); HIPCHK(this, hipStreamWaitEvent(ps, t.squelch_done, 0)); }
+    HIPCHK(this, mark(7, deferred ? qs : ps));
 
     // ---- K3: squelch + M&M + slicer + access-code search ----
     {
@@ -655,7 +668,7 @@ int btgpu_handle::harvest(TailCtx &t)
         const bool blk = use_pfb;
         // (deferred squelch: the window kernel starts behind the banks' last mark, not behind stage 2, which runs beside it)
         hipEvent_t a[7] = {t.ev[0], blk ? t.ev[5] : t.ev[1], t.ev[2], use_staged ? t.ev[6] : t.ev[3], deferred ? t.ev[4] : t.ev[7], t.ev[11], verify ? t.ev[8] : t.ev[9]};   // (the exact stage from the end of the window kernel: its DDC runs in line, before the tail's first mark -- ADVICE r4)
-        hipEvent_t e[7] = {t.ev[1], blk ? t.ev[6] : t.ev[2], t.ev[3], use_staged ? t.ev[7] : t.ev[4], t.ev[8], t.ev[10], t.ev[11]};
+        hipEvent_t e[7] = {t.ev[1], blk ? t.ev[6] : t.ev[2], t.ev[3], use_staged ? t.ev[14] : t.ev[4], t.ev[8], t.ev[10], t.ev[11]};
         for (int i = 0; i < (timing_full ? 7 : 1); i++) {
             HIPCHK(this, hipEventElapsedTime(&ms, a[i], e[i]));
             timing.kernel_ms[i] += ms;
@@ -1069,6 +1082,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
                   getenv("BTGPU_DEFER") && atoi(getenv("BTGPU_DEFER")) == 1;
     h->want_hdrs = (cfg->flags & BTGPU_FLAG_HEADERS) != 0;
     h->want_syms = (cfg->flags & BTGPU_FLAG_SYMBOLS) != 0 || h->want_hdrs;
+    h->exact_all = h->verify && (cfg->flags & BTGPU_FLAG_EXACT_ALL) != 0;
     // (BTGPU_FLAG_EXACT_PAYLOAD: accepted, and always on since round 6 -- a packet's air time is busy, so its rows are exact to its end)
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != BTGPU_OK) { int c__ = rc__; std::string m__ = h->err; \

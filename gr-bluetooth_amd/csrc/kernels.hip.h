@@ -708,6 +708,15 @@ __global__ __launch_bounds__(kWinThreads) void presence_kernel(WindowParams p)
     if (threadIdx.x == 0 && s_cnt[0]) { atomicAdd(&p.vcount[3], s_cnt[0]); atomicAdd(&p.vcount[1], s_cnt[1]); }   // (statistics: busy windows, pairs marked)
 }
 
+// BTGPU_FLAG_EXACT_ALL: no selection -- every (channel, tile) pair is marked
+__global__ void exact_mark_all_kernel(uint32_t *__restrict__ bm, int ntiles, int nch)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= ntiles * kExBmWords) return;
+    const int w = i % kExBmWords, lo = 32 * w;
+    bm[i] = nch >= lo + 32 ? 0xffffffffu : (nch > lo ? (1u << (nch - lo)) - 1u : 0u);
+}
+
 // The quietest tile of every channel over the whole batch (with a predecessor that holds signal too, like the scan's own minimum),
 // and in out[kChanFloorAll] the quietest of all channels: presence's noise reference of last resort.  gridDim.y = channels,
 // gridDim.x workgroups share a channel's tiles and meet in an atomic minimum on the float's bits (positive floats order like their

@@ -344,7 +344,10 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
     };
     auto launch_window = [&](auto lay) {
         using LAY = decltype(lay);
-        if (verify && p.verify == 1) {
+        if (verify && getenv("EMU_EXACT_ALL")) {                   // BTGPU_FLAG_EXACT_ALL: no selection, every row exact
+            emu::launch(dim3((unsigned)((vb.bm_tiles * kExBmWords + 255) / 256)), dim3(256), [&]() { exact_mark_all_kernel(vb.bm1, vb.bm_tiles, nch); });
+            run_exact(vb.bm1, &vcount[4]);
+        } else if (verify && p.verify == 1) {
             const int full_tiles = (G % p.tile_outs) ? p.ptile_stride - 1 : p.ptile_stride;
             emu::launch(dim3(2u, (unsigned)nch), dim3(256), [&]() { channel_floor_kernel(p.ptile, p.ptile_stride, std::max(1, full_tiles), chan_floor.data()); });
             p.chan_floor = getenv("EMU_NO_FLOOR") ? nullptr : chan_floor.data();

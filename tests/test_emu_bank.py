@@ -736,6 +736,20 @@ def test_judge_r04_nearfar_case_35_is_found(emu, po, synth):     # (synth: the f
     assert d["planted_ref"] >= 20 and d["planted_identical"] and d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, d
 
 
+@pytest.mark.parametrize("fs,fc,nsl", [(8e6, 2476.5e6, 12), (100e6, 2441e6, 8)])
+def test_exact_all_every_field_of_every_record_is_the_oracles(emu, po, synth, fs, fc, nsl):
+    """BTGPU_FLAG_EXACT_ALL on the emulator: no selection at all -- every row of every channel recomputed by exact_rows_kernel -- gives
+    the oracle's records in EVERY field, nsym (the run length through the noise behind each packet) and the records born from noise
+    included: the polyphase front end then only supplies the squelch's energies."""
+    iq, truth = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=17, snr_db=20, occupancy=0.5, cfo_hz=30e3, max_payload_bits=1500)
+    os.environ["EMU_EXACT_ALL"] = "1"
+    try:
+        got, wi, tasks, o = _front_m(emu, po, fs, fc, iq, nsl, 10.0, le=True)
+    finally:
+        del os.environ["EMU_EXACT_ALL"]
+    assert len(wi) >= 3 and got.tolist() == wi.tolist()
+
+
 @pytest.mark.parametrize("mode,seed,case,key,what", [
     ("mix", 103, 469, (9, 76, 0, 443, 0x225d22, 0), "8 Msps: a 32.7 dB packet that begins 17 us after a GFSK emitter of its own level (+0.4 dB) on its channel ends -- ZERO access-code errors"),
     ("mix", 103, 822, None, "20 Msps: a 30.8 dB packet where an unmodulated carrier 1.2 dB stronger ends (1.4 us of overlap)"),

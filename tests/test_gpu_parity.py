@@ -993,6 +993,24 @@ def test_judge_r04_nearfar_case_35_on_the_device(pkg, po, synth):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fs,fc,nsl", [(100e6, 2441e6, 12), (8e6, 2476.5e6, 30), (20e6, 2441e6, 14)])
+def test_exact_all_flag_every_field_of_every_record(pkg, po, synth, fs, fc, nsl):
+    """BTGPU_FLAG_EXACT_ALL on the MI355X: no selection -- every row of every channel recomputed by exact_rows_kernel on the matrix pipe:
+    the records equal the oracle's in EVERY field (slot, channel, kind, offset, LAP, ac_errors AND nsym), the ones born from noise
+    included, on the polyphase front end."""
+    iq, _ = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=23, snr_db=20, occupancy=0.6, cfo_hz=30e3, max_payload_bits=1500)
+    want, _ = po.Oracle(fs, fc, 10.0, po.MODE_SNIFFER, le=True).run_stream(iq, threads=os.cpu_count() or 1)
+    blk = pkg.multi_sniffer(fs, fc, 10.0, False, le=True, flags=pkg.FLAG_EXACT_ALL, max_batch_slots=5)
+    assert blk.design.channelizer == pkg.CHANNELIZER_POLYPHASE
+    blk.push(iq)
+    got = blk.poll()
+    tm = blk.timing()
+    blk.close()
+    assert len(want) >= 6 and [h.key() for h in got] == [h.key() for h in want]
+    assert tm.long_tasks == 0                                   # nothing left for a second run: every row was exact already
+
+
+@pytest.mark.gpu
 def test_judge_r05_seamless_cases_on_the_device(pkg, po, synth):
     """VERDICT r5 weak 1 on the MI355X: the three captures whose records round 5's edge-based selection lost (a packet 17 us behind an
     equal-level emitter, one behind a carrier 1.2 dB stronger, one that ramps up over tens of microseconds), a slice of the judge's
