@@ -399,7 +399,7 @@ def run_rank(args):
         blk.close()
         blk = make_block(head_flags | pkg.FLAG_EXACT_ALL)
         keep_steps, keep_warm = args.steps, args.warmup
-        args.steps, args.warmup = max(3, args.steps // 4), 1
+        args.steps, args.warmup = max(4, args.steps // 2), 2
         x_el, x_ints, x_snr, _m, _f, x_kms, x_kl = timed_region(blk, gather=False)
         x_ints, x_snr = one_copy(x_ints, x_snr)
         exact_all = {"flags": "the headline's + BTGPU_FLAG_EXACT_ALL", "steps": args.steps,
