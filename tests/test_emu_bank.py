@@ -736,15 +736,17 @@ def test_judge_r04_nearfar_case_35_is_found(emu, po, synth):     # (synth: the f
     assert d["planted_ref"] >= 20 and d["planted_identical"] and d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, d
 
 
-@pytest.mark.parametrize("fs,fc,nsl", [(8e6, 2476.5e6, 12), (100e6, 2441e6, 8)])
-def test_exact_all_every_field_of_every_record_is_the_oracles(emu, po, synth, fs, fc, nsl):
+@pytest.mark.parametrize("fs,fc,nsl,sniff", [(8e6, 2476.5e6, 12, True), (100e6, 2441e6, 3, False)])
+def test_exact_all_every_field_of_every_record_is_the_oracles(emu, po, synth, fs, fc, nsl, sniff):
     """BTGPU_FLAG_EXACT_ALL on the emulator: no selection at all -- every row of every channel recomputed by exact_rows_kernel -- gives
     the oracle's records in EVERY field, nsym (the run length through the noise behind each packet) and the records born from noise
     included: the polyphase front end then only supplies the squelch's energies."""
-    iq, truth = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=17, snr_db=20, occupancy=0.5, cfo_hz=30e3, max_payload_bits=1500)
+    iq, truth = synth.make_capture(fs, fc, nsl, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=17, snr_db=20, occupancy=0.5 if sniff else 2.0, cfo_hz=30e3,
+                                   max_payload_bits=1500 if sniff else 200)
     os.environ["EMU_EXACT_ALL"] = "1"
     try:
-        got, wi, tasks, o = _front_m(emu, po, fs, fc, iq, nsl, 10.0, le=True)
+        # (100 Msps: multi_LAP -- three short windows, 79 channels x 35 tiles through the emulated matrix pipe)
+        got, wi, tasks, o = _front_m(emu, po, fs, fc, iq, nsl, 10.0, po.MODE_SNIFFER if sniff else po.MODE_LAP, le=sniff)
     finally:
         del os.environ["EMU_EXACT_ALL"]
     assert len(wi) >= 3 and got.tolist() == wi.tolist()
@@ -848,11 +850,11 @@ def test_presence_on_its_thresholds(emu, po, synth, name):
 
 
 def test_adversarial_fuzz_slice_emulated(emu):
-    """Thirty captures of scripts/emu_fuzz_adversarial.py (8 / 20 Msps; per-packet levels 3..43 dB, random instants, +-75 kHz, payloads
+    """Twenty captures of scripts/emu_fuzz_adversarial.py (8 / 20 Msps; per-packet levels 3..43 dB, random instants, +-75 kHz, payloads
     to 2745 bits, near-far / back-to-back / on-top constellations, LE adverts, three squelch levels, both blocks): every planted record
     identical on the six key fields, none on one side only.  (The 1.2e5-record run of the same script: profiles/r05_*.)"""
     import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_fuzz_adversarial.py"), "30", "905", "--rates", "8,8,20", "--quiet"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_fuzz_adversarial.py"), "20", "905", "--rates", "8,8,20", "--quiet"],
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
@@ -867,7 +869,7 @@ def test_adversarial_fuzz_slice_wide_generator_other_rates(emu):
     40 / 50 Msps: the burst scan's other tile geometries.  (The long runs: profiles/r05_emu_fuzz_adversarial_more.txt; on the device
     profiles/r05_p_*.)"""
     import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_fuzz_adversarial.py"), "16", "906", "--rates", "4,10,16,40,50", "--quiet", "--wide"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "emu_fuzz_adversarial.py"), "9", "906", "--rates", "4,10,16,40,50", "--quiet", "--wide"],
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     tot = json.loads(r.stdout.strip().splitlines()[-1][len("TOTAL "):])
