@@ -40,7 +40,11 @@ cd $R
 if [ "$MODE" = "full" ]; then
   python bench.py --gpus 2 --all-on-device0 --backend gloo --slots 1152 --no-cpu --no-c8 > "$OUT/two_rank_on_one_device_bench.json" 2> "$OUT/two_rank.err"
   python bench.py --gpus 1 --force-gather --backend nccl --no-cpu --no-block-config --no-c8 --no-ab --no-host-fed 2> "$OUT/one_rank_rccl.err" | head -1 > "$OUT/one_rank_rccl_gather_bench.json"
-  timeout 1500 python scripts/gpu_fuzz_adversarial.py 300 31001 > "$OUT/fuzz_adversarial_300_seed31001.txt" 2>&1; tail -1 "$OUT/fuzz_adversarial_300_seed31001.txt"
+  timeout 1500 python scripts/gpu_fuzz_adversarial.py 1000 31001 > "$OUT/fuzz_adversarial_1000_seed31001.txt" 2>&1; tail -1 "$OUT/fuzz_adversarial_1000_seed31001.txt"
+  timeout 900 python scripts/gpu_fuzz_adversarial.py 400 31002 --wide --rates 4,10,16,40,50,100 > "$OUT/fuzz_adversarial_wide_400_seed31002.txt" 2>&1; tail -1 "$OUT/fuzz_adversarial_wide_400_seed31002.txt"
+  timeout 1200 python scripts/gpu_judge_seamless.py 1500 32001 > "$OUT/judge_seamless_mix_1500_seed32001.txt" 2>&1; tail -1 "$OUT/judge_seamless_mix_1500_seed32001.txt"
+  timeout 900 python scripts/gpu_judge_seamless.py 150 32002 --mode 100 > "$OUT/judge_seamless_100M_150_seed32002.txt" 2>&1; tail -1 "$OUT/judge_seamless_100M_150_seed32002.txt"
+  timeout 600 python scripts/gpu_judge_seamless.py 600 32003 --weak > "$OUT/judge_weak_beside_600_seed32003.txt" 2>&1; tail -1 "$OUT/judge_weak_beside_600_seed32003.txt"
   timeout 900 python scripts/gpu_fuzz_parity.py 200 > "$OUT/fuzz_parity_200.txt" 2>&1; tail -1 "$OUT/fuzz_parity_200.txt"
   timeout 1200 python scripts/gpu_text_parity.py 60 2000 > "$OUT/text_parity_60.txt" 2>&1; tail -2 "$OUT/text_parity_60.txt"
 fi
