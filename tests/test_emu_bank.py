@@ -736,7 +736,7 @@ def test_judge_r04_nearfar_case_35_is_found(emu, po, synth):     # (synth: the f
     assert d["planted_ref"] >= 20 and d["planted_identical"] and d["planted_only_gpu"] == 0 and d["planted_only_ref"] == 0, d
 
 
-@pytest.mark.parametrize("fs,fc,nsl,sniff", [(8e6, 2476.5e6, 12, True), (100e6, 2441e6, 3, False)])
+@pytest.mark.parametrize("fs,fc,nsl,sniff", [(8e6, 2476.5e6, 12, True), (20e6, 2441e6, 4, False)])       # (100 Msps: tests/test_gpu_parity.py, on the device)
 def test_exact_all_every_field_of_every_record_is_the_oracles(emu, po, synth, fs, fc, nsl, sniff):
     """BTGPU_FLAG_EXACT_ALL on the emulator: no selection at all -- every row of every channel recomputed by exact_rows_kernel -- gives
     the oracle's records in EVERY field, nsym (the run length through the noise behind each packet) and the records born from noise
@@ -745,7 +745,7 @@ def test_exact_all_every_field_of_every_record_is_the_oracles(emu, po, synth, fs
                                    max_payload_bits=1500 if sniff else 200)
     os.environ["EMU_EXACT_ALL"] = "1"
     try:
-        # (100 Msps: multi_LAP -- three short windows, 79 channels x 35 tiles through the emulated matrix pipe)
+        # (20 Msps: multi_LAP -- four short windows, 20 channels through the emulated matrix pipe)
         got, wi, tasks, o = _front_m(emu, po, fs, fc, iq, nsl, 10.0, po.MODE_SNIFFER if sniff else po.MODE_LAP, le=sniff)
     finally:
         del os.environ["EMU_EXACT_ALL"]
