@@ -595,10 +595,15 @@ def run_rank(args):
                     "note": "executed = the matrix pipe's own rate: 28 of 32 rows, 667 of 700 taps, 1250 of 1408 columns carry results (DESIGN.md 4.4); "
                             "F12: the f32 MFMA runs on the SIMD's vector lanes -- its time and every other instruction's add up",
                     "build_id": roof_bank.get("build_id")}
-            if pmc_loaded is not None:                  # (PMC passes run one step with --sync: the first launch of exact_rows_kernel, over presence's marks, is the larger one)
-                ex = sorted((v["hbm_bytes"] * v.get("launches", 1) for k, v in pmc_loaded["kernels"].items() if k.startswith("exact_rows")), reverse=True)
-                if ex:                                  # (both launches of the step: the second run's is ~1 % of it)
-                    roof["traffic"] = ex[0]; roof["traffic_source"] = os.path.basename(args.pmc_json)
+            if pmc_loaded is not None:
+                # HBM bytes of the step's exact_rows_kernel launches (two per step: over presence's marks, then the second run's ~4 %):
+                # per-launch average x its launches / the steps of the PMC run (= launches of the channel bank)
+                ks = pmc_loaded["kernels"]
+                ex = [v for k, v in ks.items() if k.startswith("exact_rows")]
+                bank = [v for k, v in ks.items() if k.startswith("pfb")]
+                if ex and bank and bank[0].get("launches"):
+                    roof["traffic"] = round(sum(v["hbm_bytes"] * v.get("launches", 1) for v in ex) / max(v.get("launches", 1) for v in bank), 1)
+                    roof["traffic_source"] = os.path.basename(args.pmc_json)
 
         # ---- cpu_baseline + parity: the oracle (a port, NOT the upstream binary) ----
         cpu = None

@@ -6,7 +6,7 @@
 #    the two-rank dry run, the one-rank RCCL gather, the device fuzz slices
 set -u
 TAG=${1:-r06_x}
-MODE=${3:-full}
+MODE=${3:-full}    # full | quick (no fuzz, no N > 1 runs) | pmc (kernel stats + PMC passes + the bench line with traffic only)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -15,16 +15,16 @@ if [ "${2:-tests}" = "tests" ]; then
   python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -3 "$OUT/pytest_gpu.log"
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log"
 fi
-for u in exact_mfma mfma_rate mfma_overlap mfma_shadow; do [ -x scripts/ubench/$u ] && ./scripts/ubench/$u > "$OUT/ubench_$u.txt" 2>&1; done
+if [ "$MODE" != "pmc" ]; then for u in exact_mfma mfma_rate mfma_overlap mfma_shadow; do [ -x scripts/ubench/$u ] && ./scripts/ubench/$u > "$OUT/ubench_$u.txt" 2>&1; done; fi
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+[ "$MODE" = "pmc" ] || python $R/bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 KRE='_kernel'   # counters only on the library's kernels (all named *_kernel)
 n=c79; slots=2304
 rm -rf /tmp/kt_$n /tmp/p1_$n /tmp/p2_$n /tmp/p3_$n /tmp/p4_$n /tmp/p5_$n
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$n -o kt -- python $R/bench.py --no-cpu --no-block-config --no-c8 --no-ab --no-host-fed --no-timing > "$OUT/${n}_bench_under_rocprof.json" 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$n -o kt -- python $R/bench.py --no-cpu --no-block-config --no-c8 --no-exact-all --no-ab --no-host-fed --no-timing > "$OUT/${n}_bench_under_rocprof.json" 2>> "$OUT/bench.err"
 python $R/scripts/summarize_rocprof.py "$(find /tmp/kt_$n -name '*kernel_stats.csv' | head -1)" "$OUT/${n}_kernel_stats.csv"
 python $R/scripts/timeline.py "$(find /tmp/kt_$n -name '*kernel_trace.csv' | head -1)" 30 > "$OUT/${n}_timeline.txt" 2>&1
-PM="python $R/bench.py --steps 1 --warmup 0 --prewarm-ms 0 --no-cpu --no-block-config --no-c8 --no-ab --no-host-fed --sync"
+PM="python $R/bench.py --steps 1 --warmup 0 --prewarm-ms 0 --no-cpu --no-block-config --no-c8 --no-exact-all --no-ab --no-host-fed --sync"
 rocprofv3 --kernel-include-regex "$KRE" --pmc FETCH_SIZE --output-format csv -d /tmp/p1_$n -o p -- $PM > /dev/null 2>> "$OUT/bench.err"
 rocprofv3 --kernel-include-regex "$KRE" --pmc WRITE_SIZE --output-format csv -d /tmp/p2_$n -o p -- $PM > /dev/null 2>> "$OUT/bench.err"
 python $R/scripts/pmc_hbm_json.py "$(find /tmp/p1_$n -name '*counter_collection.csv' | head -1)" "$(find /tmp/p2_$n -name '*counter_collection.csv' | head -1)" $slots > "$OUT/${n}_pmc_hbm.json"
@@ -35,7 +35,7 @@ python $R/scripts/pmc_table.py "$(find /tmp/p4_$n -name '*counter_collection.csv
 rocprofv3 --kernel-include-regex "$KRE" --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA --output-format csv -d /tmp/p5_$n -o p -- $PM > /dev/null 2>> "$OUT/bench.err"
 python $R/scripts/pmc_table.py "$(find /tmp/p5_$n -name '*counter_collection.csv' | head -1)" > "$OUT/${n}_pmc_mfma.txt" 2>> "$OUT/bench.err"
 # the bench line again with the traffic of this very build
-python $R/bench.py --no-cpu --no-block-config --no-c8 --no-ab --no-host-fed --pmc-json "$OUT/c79_pmc_hbm.json" > "$OUT/bench_with_traffic.json" 2>> "$OUT/bench.err"
+python $R/bench.py --no-cpu --no-block-config --no-c8 --no-exact-all --no-ab --no-host-fed --pmc-json "$OUT/c79_pmc_hbm.json" > "$OUT/bench_with_traffic.json" 2>> "$OUT/bench.err"
 cd $R
 if [ "$MODE" = "full" ]; then
   python bench.py --gpus 2 --all-on-device0 --backend gloo --slots 1152 --no-cpu --no-c8 > "$OUT/two_rank_on_one_device_bench.json" 2> "$OUT/two_rank.err"
@@ -51,7 +51,7 @@ fi
 echo "== $n"; head -12 "$OUT/${n}_kernel_stats.csv"; cat "$OUT/${n}_pmc_sq.txt" "$OUT/${n}_pmc_stall.txt" "$OUT/${n}_pmc_mfma.txt" | head -40
 python -c "import json; d=json.load(open('$OUT/${n}_pmc_hbm.json')); [print(k, {a: round(b/1e6,1) for a,b in v.items()}) for k,v in d['kernels'].items()]"
 for f in bench bench_with_traffic two_rank_on_one_device_bench one_rank_rccl_gather_bench; do [ -f "$OUT/$f.json" ] && { echo "== $f"; tail -1 "$OUT/$f.json" | cut -c1-330; }; done
-python - "$OUT/bench.json" <<'PY'
+[ -f "$OUT/bench.json" ] && python - "$OUT/bench.json" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
 for k in ("roofline", "roofline_bank", "verify", "host_fed", "classic_only", "c8", "cpu_baseline"): print(k, d.get(k))
