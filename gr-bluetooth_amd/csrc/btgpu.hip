@@ -78,8 +78,8 @@ struct btgpu_handle {
         DevBuf d_bm;                                            // exact rows' bitmaps bm1 | bm2, [2][bm_tiles][kExBmWords] (presence / the first run's uncovered hits)
         DevBuf d_chanfloor;                                     // presence's last-resort noise reference: each channel's quietest tile of the batch, [80] the quietest of all
         DevBuf d_eon, d_eoff, d_snr;          // E_on, E_off, SNR per window (window_kernel, or squelch_kernel when the squelch is deferred)   // exact confirmation (verify.hip.h): task list, exact rows, task stream
-        HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first kEagerFin hits
-        uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first kEagerFin hit windows
+        HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first eager_hdr hits (records_out_kernel)
+        uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first eager_fin hit windows (records_out_kernel)
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records, -, -, verify tasks, verify tiles, turned away, -}
         DeviceHit *h_hits = nullptr;          // pinned: first kEagerHits records, copied by the tail stream
         // timing events (recorded only with BTGPU_FLAG_TIMING): front 0 start, 1 channel bank, 2 demod / energy (direct
@@ -109,11 +109,43 @@ struct btgpu_handle {
     bool pipelined = false;          // front writes per-context buffers only: front(n+1) may overlap post(n)
     hipStream_t copy_stream = nullptr;
     hipStream_t spill_stream = nullptr;          // harvest: records beyond the eager copies (never behind an input copy)
+    // ... which land in PAGE-LOCKED buffers kept by the handle (grown on demand).  A device-to-host copy into pageable memory is
+    // not an asynchronous copy: with three batches queued the call came back only when the device had drained -- 26 ms per five
+    // batches at C8 (11 068 hit windows per batch, 2876 beyond the eager copy): the pipeline emptied every fifth call, 7.2 ms per
+    // step for 4.0 ms of kernels (profiles/r06_q_c8_*)
+    void *h_spill[3] = {nullptr, nullptr, nullptr}; size_t h_spill_cap[3] = {0, 0, 0};     // hits | symbols | headers
+    void *spill_buf(int k, size_t bytes)
+    {
+        if (bytes <= h_spill_cap[k]) return h_spill[k];
+        if (h_spill[k]) { (void)hipHostFree(h_spill[k]); h_spill[k] = nullptr; h_spill_cap[k] = 0; }
+        const size_t cap = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+        if (hipHostMalloc(&h_spill[k], cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h_spill[k] = nullptr; return nullptr; }
+        h_spill_cap[k] = cap;
+        return h_spill[k];
+    }
     static constexpr unsigned kEagerHits = 65536;
     static constexpr unsigned kEagerFin = 8192;
+    unsigned eager_fin = kEagerFin, eager_hdr = kEagerFin;      // capacity (records) of the page-locked h_sym / h_hdr of a context: records_out_kernel fills them
     bool want_syms = false, want_hdrs = false;
+    // The host queue: records of harvested batches in emission order, consumed from the front (qhead).  Flat arenas -- a record
+    // costs one memcpy of its symbols, no allocation (a vector per record was 5 ms of host time per 11 000-record batch at C8:
+    // twice the batch's kernels, profiles/r06_q_c8_*).
     std::vector<btgpu_header> qhdr;              // header sweep per queued hit (BTGPU_FLAG_HEADERS)
-    std::vector<std::vector<uint32_t>> qbits;    // packed symbols per queued hit (BTGPU_FLAG_SYMBOLS)
+    std::vector<uint32_t> qbits;                 // packed symbols per queued hit [n][kSymWords] (BTGPU_FLAG_SYMBOLS)
+    std::vector<uint8_t> qhas;                   // ... and whether the record has any (a window the tail did not finish has none)
+    size_t qhead = 0;                            // first record not yet polled
+    size_t pending_records() const { return queue.size() - qhead; }
+    void pop_records(size_t n)
+    {
+        qhead += n;
+        if (qhead == queue.size()) { queue.clear(); qhdr.clear(); qbits.clear(); qhas.clear(); qhead = 0; }
+        else if (qhead >= 8192 && 2 * qhead >= queue.size()) {                     // (amortised: at most one move per record)
+            queue.erase(queue.begin(), queue.begin() + qhead);
+            if (want_hdrs) qhdr.erase(qhdr.begin(), qhdr.begin() + qhead);
+            if (want_syms) { qbits.erase(qbits.begin(), qbits.begin() + qhead * kSymWords); qhas.erase(qhas.begin(), qhas.begin() + qhead); }
+            qhead = 0;
+        }
+    }
     std::string err;
     int sticky = BTGPU_OK;
 
@@ -190,6 +222,7 @@ struct btgpu_handle {
             if (t.h_count) { (void)hipHostFree(t.h_count); t.h_count = nullptr; }
             if (t.h_hits) { (void)hipHostFree(t.h_hits); t.h_hits = nullptr; }
         }
+        for (int k = 0; k < 3; k++) if (h_spill[k]) { (void)hipHostFree(h_spill[k]); h_spill[k] = nullptr; h_spill_cap[k] = 0; }
         for (int k = 0; k < 2; k++) {
             if (h_stage[k]) { (void)hipHostFree(h_stage[k]); h_stage[k] = nullptr; }
             if (ev_copied[k]) { (void)hipEventDestroy(ev_copied[k]); ev_copied[k] = nullptr; }
@@ -410,7 +443,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     auto launch_exact_rows = [&](const uint32_t *bitmap, unsigned int *stat, hipStream_t s_) {
         const ExactParams ep = make_exact_params(des, x_len, w0, G, (const float *)d_tapsA.p, (const float2 *)d_rot_ch.p, (const float *)d_atan.p,
                                                  bitmap, vb.bm_tiles, (float *)d_d.p, drow, (float *)(use_dcol ? t.d_dcol.p : nullptr), stat);
-        hipLaunchKernelGGL(ex_kern, dim3((unsigned)vb.bm_tiles), dim3(kExThreads), ex_lds, s_, ep, d_x);
+        hipLaunchKernelGGL(ex_kern, dim3((unsigned)vb.bm_tiles), dim3(kExThreads), ex_lds, s_, ep, d_x, (const float4 *)ep.tapsA);
     };
     if (verify && exact_all) {
         hipLaunchKernelGGL(exact_mark_all_kernel, dim3((unsigned)((vb.bm_tiles * kExBmWords + 255) / 256)), dim3(256), 0, ps, vb.bm1, vb.bm_tiles, nch);
@@ -553,17 +586,15 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                    (const unsigned int *)d_hitcount.p, max_hits, (const uint32_t *)d_symbits.p,
                                    (const uint32_t *)d_wh18.p, dd.correlator == BTGPU_CORRELATOR_BTBB ? 68 : 72,
                                    (HeaderRec *)t.d_hdr.p);
-                HIPCHK(this, hipMemcpyAsync(t.h_hdr, t.d_hdr.p, std::min<size_t>((size_t)max_hits, (size_t)kEagerFin) * sizeof(HeaderRec),
-                                         hipMemcpyDeviceToHost, tail_stream));
             }
-            if (want_syms)
-                HIPCHK(this, hipMemcpyAsync(t.h_sym, d_symbits.p, (size_t)kEagerFin * kSymWords * sizeof(uint32_t),
-                                         hipMemcpyDeviceToHost, tail_stream));
-            // records travel to pinned host memory on the tail stream too: harvesting a batch is
-            // then pure host work and never waits on the other streams
+            // records travel to page-locked host memory on the tail stream too -- through a kernel that knows the counts (the
+            // first eager_fin hit windows' symbols, eager_hdr sweeps, kEagerHits records; beyond: harvest's spill copies) --
+            // harvesting a batch is then pure host work and never waits on the other streams
             HIPCHK(this, hipMemcpyAsync(t.h_count, d_hitcount.p, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
-            const size_t eager = std::min<size_t>((size_t)max_hits, (size_t)kEagerHits);
-            HIPCHK(this, hipMemcpyAsync(t.h_hits, d_hits.p, eager * sizeof(DeviceHit), hipMemcpyDeviceToHost, tail_stream));
+            hipLaunchKernelGGL(records_out_kernel, dim3(128), dim3(256), 0, tail_stream, (const unsigned int *)d_hitcount.p, max_hits,
+                               (const uint4 *)(want_syms ? d_symbits.p : nullptr), (uint4 *)(want_syms ? t.h_sym : nullptr), eager_fin,
+                               (const uint2 *)(want_hdrs ? t.d_hdr.p : nullptr), (uint2 *)(want_hdrs ? t.h_hdr : nullptr), eager_hdr,
+                               (const uint4 *)d_hits.p, (uint4 *)t.h_hits, std::min<unsigned>((unsigned)max_hits, kEagerHits));
         }
     }
     HIPCHK(this, mark(10, tail_stream));
@@ -693,34 +724,52 @@ int btgpu_handle::harvest(TailCtx &t)
     int rc = BTGPU_OK;
     if (count > (unsigned)max_hits) { count = (unsigned)max_hits; rc = BTGPU_EOVERFLOW; sticky = rc; set_error("hit buffer overflow"); }
     if (count) {
-        std::vector<DeviceHit> hh(t.h_hits, t.h_hits + std::min<unsigned>(count, kEagerHits));
-        if (count > kEagerHits) {             // rare: more records than the eager copy carries
-            hh.resize(count);
-            HIPCHK(this, hipMemcpyAsync(hh.data() + kEagerHits, (const DeviceHit *)t.d_hits.p + kEagerHits,
-                                     sizeof(DeviceHit) * (count - kEagerHits), hipMemcpyDeviceToHost, spill_stream));
-            HIPCHK(this, hipStreamSynchronize(spill_stream));
-        }
-        // what the eager copies do not carry (more than kEagerFin hit windows / records in one batch: dense captures
-        // at the small rates) comes over in ONE bulk copy each -- not record by record with a synchronise apiece
-        std::vector<uint32_t> sym_spill;
-        std::vector<HeaderRec> hdr_spill;
+        // what the eager copies do not carry (more than kEagerHits records, more than kEagerFin hit windows in one batch: dense
+        // captures at the small rates) comes over in ONE bulk copy each, into page-locked memory, and one wait for the three
         const unsigned nfin = t.h_count[1];
-        if (want_syms && nfin > kEagerFin) {
-            sym_spill.resize((size_t)(nfin - kEagerFin) * kSymWords);
-            HIPCHK(this, hipMemcpyAsync(sym_spill.data(), (const uint32_t *)t.d_symbits.p + (size_t)kEagerFin * kSymWords,
-                                     sym_spill.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, spill_stream));
+        const size_t n_hit_spill = count > kEagerHits ? count - kEagerHits : 0;
+        const size_t n_sym_spill = (want_syms && nfin > eager_fin) ? (size_t)(nfin - eager_fin) : 0;
+        const size_t n_hdr_spill = (want_hdrs && count > eager_hdr) ? (size_t)(count - eager_hdr) : 0;
+        const DeviceHit *hit_spill = nullptr; const uint32_t *sym_spill = nullptr; const HeaderRec *hdr_spill = nullptr;
+        if (n_hit_spill) {
+            void *b = spill_buf(0, n_hit_spill * sizeof(DeviceHit));
+            if (!b) { set_error("hipHostMalloc (record spill)"); return BTGPU_ENOMEM; }
+            HIPCHK(this, hipMemcpyAsync(b, (const DeviceHit *)t.d_hits.p + kEagerHits, n_hit_spill * sizeof(DeviceHit), hipMemcpyDeviceToHost, spill_stream));
+            hit_spill = (const DeviceHit *)b;
         }
-        if (want_hdrs && count > kEagerFin) {
-            hdr_spill.resize(count - kEagerFin);
-            HIPCHK(this, hipMemcpyAsync(hdr_spill.data(), (const HeaderRec *)t.d_hdr.p + kEagerFin,
-                                     hdr_spill.size() * sizeof(HeaderRec), hipMemcpyDeviceToHost, spill_stream));
+        if (n_sym_spill) {
+            void *b = spill_buf(1, n_sym_spill * kSymWords * sizeof(uint32_t));
+            if (!b) { set_error("hipHostMalloc (symbol spill)"); return BTGPU_ENOMEM; }
+            HIPCHK(this, hipMemcpyAsync(b, (const uint32_t *)t.d_symbits.p + (size_t)eager_fin * kSymWords, n_sym_spill * kSymWords * sizeof(uint32_t), hipMemcpyDeviceToHost, spill_stream));
+            sym_spill = (const uint32_t *)b;
         }
-        if (!sym_spill.empty() || !hdr_spill.empty()) HIPCHK(this, hipStreamSynchronize(spill_stream));
-        size_t q0 = queue.size();
-        size_t hi = 0;
-        for (const DeviceHit &x : hh) {
-            const size_t hit_index = hi++;
+        if (n_hdr_spill) {
+            void *b = spill_buf(2, n_hdr_spill * sizeof(HeaderRec));
+            if (!b) { set_error("hipHostMalloc (header spill)"); return BTGPU_ENOMEM; }
+            HIPCHK(this, hipMemcpyAsync(b, (const HeaderRec *)t.d_hdr.p + eager_hdr, n_hdr_spill * sizeof(HeaderRec), hipMemcpyDeviceToHost, spill_stream));
+            hdr_spill = (const HeaderRec *)b;
+        }
+        if (n_hit_spill || n_sym_spill || n_hdr_spill) HIPCHK(this, hipStreamSynchronize(spill_stream));
+        auto hit_at = [&](size_t i) -> const DeviceHit & { return i < kEagerHits ? t.h_hits[i] : hit_spill[i - kEagerHits]; };
+        // the order the reference's loops print in -- slot, channel, kind, offset -- formed FIRST, on packed keys; the records then go
+        // to the queue's arenas in that order, once
+        std::vector<std::pair<uint64_t, uint32_t>> order;
+        order.reserve(count);
+        for (size_t i = 0; i < count; i++) {
+            const DeviceHit &x = hit_at(i);
             if (x.kind < 0) continue;                              // deferred squelch: the window failed it, the reference never looked
+            const uint64_t key = ((uint64_t)(uint32_t)x.slot << 40) | ((uint64_t)((uint32_t)x.channel_idx & 0xffu) << 32) |
+                                 ((uint64_t)((uint32_t)x.kind & 0xffu) << 24) | (uint64_t)((uint32_t)x.offset & 0xffffffu);
+            order.emplace_back(key, (uint32_t)i);
+        }
+        std::sort(order.begin(), order.end());
+        const size_t q0 = queue.size(), n = order.size();
+        queue.resize(q0 + n);
+        if (want_syms) { qbits.resize((q0 + n) * kSymWords); qhas.resize(q0 + n); }
+        if (want_hdrs) qhdr.resize(q0 + n);
+        for (size_t k = 0; k < n; k++) {
+            const size_t hit_index = order[k].second;
+            const DeviceHit &x = hit_at(hit_index);
             btgpu_hit o{};
             o.slot = t.abs_first_slot + x.slot;
             o.channel = d.low_channel + x.channel_idx;
@@ -730,49 +779,21 @@ int btgpu_handle::harvest(TailCtx &t)
             o.kind = x.kind;
             o.nsym = x.nsym;
             o.snr_db = x.snr;
-            queue.push_back(o);
+            queue[q0 + k] = o;
             if (want_syms) {
-                std::vector<uint32_t> bits;
+                const uint32_t *src = nullptr;
                 if (x.sym >= 0) {
-                    bits.resize(kSymWords);
-                    if ((unsigned)x.sym < kEagerFin) std::memcpy(bits.data(), t.h_sym + (size_t)x.sym * kSymWords, kSymWords * sizeof(uint32_t));
-                    else if ((size_t)((unsigned)x.sym - kEagerFin + 1) * kSymWords <= sym_spill.size())
-                        std::memcpy(bits.data(), sym_spill.data() + (size_t)((unsigned)x.sym - kEagerFin) * kSymWords, kSymWords * sizeof(uint32_t));
+                    if ((unsigned)x.sym < eager_fin) src = t.h_sym + (size_t)x.sym * kSymWords;
+                    else if ((size_t)((unsigned)x.sym - eager_fin) < n_sym_spill) src = sym_spill + (size_t)((unsigned)x.sym - eager_fin) * kSymWords;
                 }
-                qbits.push_back(std::move(bits));
+                qhas[q0 + k] = src != nullptr;
+                if (src) std::memcpy(&qbits[(q0 + k) * kSymWords], src, kSymWords * sizeof(uint32_t));
             }
             if (want_hdrs) {
-                btgpu_header hd;
+                btgpu_header &hd = qhdr[q0 + k];
                 std::memset(&hd, 0, sizeof hd);
-                HeaderRec r;
-                if (hit_index < kEagerFin) r = t.h_hdr[hit_index];
-                else r = hdr_spill[hit_index - kEagerFin];
+                const HeaderRec &r = hit_index < eager_hdr ? t.h_hdr[hit_index] : hdr_spill[hit_index - eager_hdr];
                 std::memcpy(hd.uap, r.uap, 64); std::memcpy(hd.type, r.type, 64); hd.fec13_ok = r.fec13_ok;
-                qhdr.push_back(hd);
-            }
-        }
-        auto less = [](const btgpu_hit &a, const btgpu_hit &b) {
-            if (a.slot != b.slot) return a.slot < b.slot;
-            if (a.channel != b.channel) return a.channel < b.channel;
-            if (a.kind != b.kind) return a.kind < b.kind;
-            return a.offset < b.offset;
-        };
-        if (!want_syms) std::sort(queue.begin() + q0, queue.end(), less);
-        else {
-            const size_t n = queue.size() - q0;
-            std::vector<size_t> idx(n);
-            for (size_t i = 0; i < n; i++) idx[i] = i;
-            std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return less(queue[q0 + a], queue[q0 + b]); });
-            std::vector<btgpu_hit> qs(n);
-            std::vector<std::vector<uint32_t>> bs(n);
-            std::vector<btgpu_header> hs(want_hdrs ? n : 0);
-            for (size_t i = 0; i < n; i++) {
-                qs[i] = queue[q0 + idx[i]]; bs[i] = std::move(qbits[q0 + idx[i]]);
-                if (want_hdrs) hs[i] = qhdr[q0 + idx[i]];
-            }
-            for (size_t i = 0; i < n; i++) {
-                queue[q0 + i] = qs[i]; qbits[q0 + i] = std::move(bs[i]);
-                if (want_hdrs) qhdr[q0 + i] = hs[i];
             }
         }
     }
@@ -1183,7 +1204,8 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         std::vector<float> ta(exact_taps_floats(nch, d.decimation));
         exact_pack_taps(des.channel.taps.data(), nch, des.channel.ntp, d.decimation, ta.data());
         TRY(h->upload(h->d_tapsA, ta.data(), ta.size() * sizeof(float)));
-        h->ex_kern = exact_rows_pick(d.decimation); h->ex_lds = exact_lds_bytes(d.decimation);
+        static const bool ex_small_off = getenv("BTGPU_EXACT_SMALL") && atoi(getenv("BTGPU_EXACT_SMALL")) == 0;      // (A/B: the matrix form at D <= 4 too)
+        h->ex_kern = exact_rows_pick(d.decimation, !ex_small_off); h->ex_lds = exact_lds_bytes(d.decimation);
         h->bm_tiles = exact_ntiles(h->ystride + 64);
         (void)hipFuncSetAttribute((const void *)h->ex_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(h->ex_lds, 64 * 1024));
     }
@@ -1223,8 +1245,11 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     }
     for (int i = 0; i < h->nctx; i++) {
         auto &t = h->tc[i];
-        if (h->want_hdrs && hipHostMalloc((void **)&t.h_hdr, (size_t)btgpu_handle::kEagerFin * sizeof(HeaderRec), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
-        if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)btgpu_handle::kEagerFin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
+        // (one record per hit window / per hit: as many as a batch can hold, within 64 Ki -- 31 MB of symbols and 9 MB of sweeps per context)
+        h->eager_fin = (unsigned)std::min<size_t>(std::max<size_t>((size_t)S * nch, 1024), 65536);
+        h->eager_hdr = (unsigned)std::min<size_t>(std::max<size_t>((size_t)h->max_hits, 1024), 65536);
+        if (h->want_hdrs && hipHostMalloc((void **)&t.h_hdr, (size_t)h->eager_hdr * sizeof(HeaderRec), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
+        if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)h->eager_fin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_count, 12 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         std::memset(t.h_count, 0, 12 * sizeof(unsigned int));
         if (hipHostMalloc((void **)&t.h_hits, (size_t)btgpu_handle::kEagerHits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
@@ -1389,7 +1414,7 @@ int btgpu_pending(const btgpu_handle *h)
 {
     if (!h) return BTGPU_EINVAL;
     (void)const_cast<btgpu_handle *>(h)->harvest_all(false);      // take batches whose tail has finished
-    return (int)h->queue.size();
+    return (int)h->pending_records();
 }
 
 int btgpu_flush(btgpu_handle *h)
@@ -1410,12 +1435,10 @@ int btgpu_poll(btgpu_handle *h, btgpu_hit *out, int max_hits)
 {
     if (!h || (!out && max_hits > 0) || max_hits < 0) return BTGPU_EINVAL;
     (void)h->harvest_all(false);
-    int n = (int)std::min<size_t>((size_t)max_hits, h->queue.size());
+    int n = (int)std::min<size_t>((size_t)max_hits, h->pending_records());
     if (n > 0) {
-        std::memcpy(out, h->queue.data(), sizeof(btgpu_hit) * n);
-        h->queue.erase(h->queue.begin(), h->queue.begin() + n);
-        if (h->want_syms) h->qbits.erase(h->qbits.begin(), h->qbits.begin() + n);
-        if (h->want_hdrs) h->qhdr.erase(h->qhdr.begin(), h->qhdr.begin() + n);
+        std::memcpy(out, h->queue.data() + h->qhead, sizeof(btgpu_hit) * n);
+        h->pop_records((size_t)n);
     }
     return n;
 }
@@ -1426,26 +1449,23 @@ static int poll_symbols_impl(btgpu_handle *h, btgpu_hit *out, btgpu_header *hdr,
     if (!h || (!out && max_hits > 0) || max_hits < 0 || sym_cap < 0 || (!symbols && sym_cap > 0)) return BTGPU_EINVAL;
     if (!h->want_syms || (hdr && !h->want_hdrs)) return BTGPU_EUNSUPPORTED;
     (void)h->harvest_all(false);
-    int n = (int)std::min<size_t>((size_t)max_hits, h->queue.size());
+    int n = (int)std::min<size_t>((size_t)max_hits, h->pending_records());
     for (int i = 0; i < n; i++) {
-        out[i] = h->queue[i];
-        if (hdr) hdr[i] = h->qhdr[i];
-        const std::vector<uint32_t> &bits = h->qbits[i];
+        const size_t qi = h->qhead + (size_t)i;
+        out[i] = h->queue[qi];
+        if (hdr) hdr[i] = h->qhdr[qi];
+        const uint32_t *bits = &h->qbits[qi * kSymWords];
         // what the reference hands to ac()/aa(): &symp[i], len - i  (one symbol per byte, air order)
-        int avail = bits.empty() ? 0 : out[i].nsym;
+        int avail = h->qhas[qi] ? out[i].nsym : 0;
         if (avail > sym_cap) avail = sym_cap;
         const int first = out[i].offset;
-        const int limit = (int)bits.size() * 32 - first;
+        const int limit = kSymWords * 32 - first;
         if (avail > limit) avail = limit < 0 ? 0 : limit;
         uint8_t *dst = symbols + (size_t)i * sym_cap;
         for (int s = 0; s < avail; s++) { const int b = first + s; dst[s] = (uint8_t)((bits[b >> 5] >> (b & 31)) & 1u); }
         if (sym_len) sym_len[i] = avail;
     }
-    if (n > 0) {
-        h->queue.erase(h->queue.begin(), h->queue.begin() + n);
-        h->qbits.erase(h->qbits.begin(), h->qbits.begin() + n);
-        if (h->want_hdrs) h->qhdr.erase(h->qhdr.begin(), h->qhdr.begin() + n);
-    }
+    if (n > 0) h->pop_records((size_t)n);
     return n;
 }
 

@@ -184,38 +184,28 @@ __global__ __launch_bounds__(256) void ddc_direct_kernel(
 // ------------------------------------------------------------------------------------
 // gr::fast_atan2f [EXT GNU Radio 3.7], table in LDS/global (257 floats)
 // ------------------------------------------------------------------------------------
+// Straight-line form (no divergent branch: a wave whose lanes fall on both sides of |y| < |x| ran BOTH divisions, a third of the
+// exact rows' epilogue): the same operations on the same operands as the reference's branches, so the same bits --
+//   z = min / max by the reference's own comparison;  base = z or the table's interpolation;
+//   |x| > |y|:  x >= 0: +-base,  else +-(pi - base);   otherwise: +-(pi/2 -+ base)       (the outer sign is y's; -(a - b) == b - a exactly)
 __device__ __forceinline__ float fast_atan2f_dev(const float *__restrict__ tab, float y, float x)
 {
     const float TAN_MAP_RES = 0.003921569f;
     const float TAN_MAP_SIZE = 255.0f;
-    float y_abs = fabsf(y), x_abs = fabsf(x), z, base_angle, angle;
-    if (!((y_abs > 0.0f) || (x_abs > 0.0f))) return 0.0f;
-    if (y_abs < x_abs) z = __fdiv_rn(y_abs, x_abs); else z = __fdiv_rn(x_abs, y_abs);
-    if (z < TAN_MAP_RES) {
-        base_angle = z;
-    } else {
-        float alpha = z * TAN_MAP_SIZE;
-        int index = ((int)alpha) & 0xff;
-        alpha -= (float)index;
-        base_angle = tab[index];
-        base_angle = base_angle + ((tab[index + 1] - tab[index]) * alpha);
-    }
-    if (x_abs > y_abs) {
-        if (x >= 0.0f) angle = (y >= 0.0f) ? base_angle : -base_angle;
-        else {
-            angle = 3.14159265358979323846f;
-            angle = (y >= 0.0f) ? (angle - base_angle) : (base_angle - angle);
-        }
-    } else {
-        if (y >= 0.0f) {
-            angle = 1.57079632679489661923f;
-            angle = (x >= 0.0f) ? (angle - base_angle) : (angle + base_angle);
-        } else {
-            angle = -1.57079632679489661923f;
-            angle = (x >= 0.0f) ? (angle + base_angle) : (angle - base_angle);
-        }
-    }
-    return angle;
+    const float y_abs = fabsf(y), x_abs = fabsf(x);
+    const bool lt = y_abs < x_abs;
+    const float z = __fdiv_rn(lt ? y_abs : x_abs, lt ? x_abs : y_abs);       // (0 / 0 only where the result below is discarded)
+    float alpha = z * TAN_MAP_SIZE;
+    const int index = ((int)alpha) & 0xff;
+    alpha -= (float)index;
+    const float t0 = tab[index], t1 = tab[index + 1];
+    const float base_angle = z < TAN_MAP_RES ? z : t0 + ((t1 - t0) * alpha);
+    const bool xg = x_abs > y_abs, xp = x >= 0.0f;
+    const float off = xg ? (xp ? 0.0f : 3.14159265358979323846f) : 1.57079632679489661923f;
+    const float sb = (xg == xp) ? base_angle : -base_angle;                  // + base: (|x| > |y|, x >= 0) and (|x| <= |y|, x < 0)
+    float angle = (xg && xp) ? base_angle : off + sb;
+    angle = (y >= 0.0f) ? angle : -angle;
+    return ((y_abs > 0.0f) || (x_abs > 0.0f)) ? angle : 0.0f;
 }
 
 __device__ __forceinline__ float demod_one(const float *__restrict__ atab, float gain, float2 a, float2 b)
@@ -1473,6 +1463,35 @@ __global__ __launch_bounds__(64) void header_sweep_kernel(
         o->uap[lane] = (uint8_t)(__brev(hec) >> 24);
         o->type[lane] = (uint8_t)((plain >> 3) & 0xfu);
         if (lane == 0) { o->fec13_ok = be < 18 / 4 ? 1 : 0; o->pad_ = 0; }
+    }
+}
+
+// A batch's records leave for the host through THIS kernel: it knows the counts, the host does not when it enqueues the batch.  It
+// writes the first min(count, cap) records of each kind -- the packed symbols of the hit windows, the header sweeps, the hit records
+// themselves -- straight into page-locked host memory (device-visible), 16 bytes per lane.  Before: fixed-size copies sized for 8192
+// hit windows and a second, synchronous copy for the rest -- which, at C8's 11 068 hit windows per batch, waited behind every
+// kernel queued on the stream its hardware queue was shared with: 20 ms in every fifth call (profiles/r06_s_c8_*).
+__global__ __launch_bounds__(256) void records_out_kernel(const unsigned int *__restrict__ counts /* [0] records, [1] hit windows */, int max_hits,
+                                                          const uint4 *__restrict__ symbits, uint4 *__restrict__ h_sym, unsigned int cap_sym,
+                                                          const uint2 *__restrict__ hdr, uint2 *__restrict__ h_hdr, unsigned int cap_hdr,
+                                                          const uint4 *__restrict__ hits, uint4 *__restrict__ h_hits, unsigned int cap_hits)
+{
+    static_assert(kSymWords % 4 == 0 && sizeof(HeaderRec) % 8 == 0 && sizeof(DeviceHit) % 16 == 0, "whole 16- / 8-byte pieces per record");
+    unsigned int n = counts[0];
+    n = n > (unsigned int)max_hits ? (unsigned int)max_hits : n;
+    const unsigned int nfin = counts[1];
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h_sym) {
+        const size_t m = (size_t)(nfin < cap_sym ? nfin : cap_sym) * (kSymWords / 4);
+        for (size_t i = i0; i < m; i += stride) h_sym[i] = symbits[i];
+    }
+    if (h_hdr) {
+        const size_t m = (size_t)(n < cap_hdr ? n : cap_hdr) * (sizeof(HeaderRec) / 8);
+        for (size_t i = i0; i < m; i += stride) h_hdr[i] = hdr[i];
+    }
+    if (h_hits) {
+        const size_t m = (size_t)(n < cap_hits ? n : cap_hits) * (sizeof(DeviceHit) / 16);
+        for (size_t i = i0; i < m; i += stride) h_hits[i] = hits[i];
     }
 }
 

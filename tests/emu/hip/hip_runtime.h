@@ -30,6 +30,8 @@
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) uint2 { unsigned int x, y; };
+struct alignas(16) uint4 { unsigned int x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
