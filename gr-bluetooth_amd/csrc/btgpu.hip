@@ -443,7 +443,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
     auto launch_exact_rows = [&](const uint32_t *bitmap, unsigned int *stat, hipStream_t s_) {
         const ExactParams ep = make_exact_params(des, x_len, w0, G, (const float *)d_tapsA.p, (const float2 *)d_rot_ch.p, (const float *)d_atan.p,
                                                  bitmap, vb.bm_tiles, (float *)d_d.p, drow, (float *)(use_dcol ? t.d_dcol.p : nullptr), stat);
-        hipLaunchKernelGGL(ex_kern, dim3((unsigned)vb.bm_tiles), dim3(kExThreads), ex_lds, s_, ep, d_x, (const float4 *)ep.tapsA);
+        hipLaunchKernelGGL(ex_kern, dim3((unsigned)vb.bm_tiles), dim3(kExThreads), ex_lds, s_, ep, d_x);
     };
     if (verify && exact_all) {
         hipLaunchKernelGGL(exact_mark_all_kernel, dim3((unsigned)((vb.bm_tiles * kExBmWords + 255) / 256)), dim3(256), 0, ps, vb.bm1, vb.bm_tiles, nch);
@@ -1204,8 +1204,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         std::vector<float> ta(exact_taps_floats(nch, d.decimation));
         exact_pack_taps(des.channel.taps.data(), nch, des.channel.ntp, d.decimation, ta.data());
         TRY(h->upload(h->d_tapsA, ta.data(), ta.size() * sizeof(float)));
-        static const bool ex_small_off = getenv("BTGPU_EXACT_SMALL") && atoi(getenv("BTGPU_EXACT_SMALL")) == 0;      // (A/B: the matrix form at D <= 4 too)
-        h->ex_kern = exact_rows_pick(d.decimation, !ex_small_off); h->ex_lds = exact_lds_bytes(d.decimation);
+        h->ex_kern = exact_rows_pick(d.decimation); h->ex_lds = exact_lds_bytes(d.decimation);
         h->bm_tiles = exact_ntiles(h->ystride + 64);
         (void)hipFuncSetAttribute((const void *)h->ex_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(h->ex_lds, 64 * 1024));
     }

@@ -95,7 +95,7 @@ inline size_t exact_taps_floats(int nch, int D) { return (size_t)nch * 64 * exac
 // odd ones: lanes 0 .. 63 of the first take outputs -1 .. 62, of the second 62 .. 125; y[t - 1] is one shuffle away), its row
 // indices are formed once per tile.
 template <int D>
-__global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x, const float4 *__restrict__ /* p.tapsA: the vector form's scalar loads */)
+__global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
 {
     HIP_DYNAMIC_SHARED(float2, lds)
     constexpr int NS = 32 * D;                                     // samples per wave
@@ -135,6 +135,8 @@ __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p
         {
             const long long s0 = sb + (long long)D * (lane & 31);
             if (sb >= 0 && sb + NS <= p.x_len) {                   // uniform: the wave's span lies inside the stream
+                // (16-byte loads -- two samples, the lane keeps its half -- cost the texture unit a quarter of this form's work per tile and
+                // measured the same: 2.09 ms against 2.07, profiles/r06_u_*)
                 const float *xf = (const float *)(x + s0) + (lane >> 5);
 #pragma unroll
                 for (int r = 0; r < D; r++) B[r] = xf[2 * r];
@@ -220,120 +222,13 @@ __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p
     }
 }
 
-// ---- the small decimations (D <= 4: 4, 6, 8 Msps) on the VECTOR lanes ----
-// At D = 4 a channel's tile is FOUR matrix instructions per wave (256 cycles) against ~100 other instructions, a 16 KB trip through LDS
-// and a workgroup barrier: exact_rows_kernel<4> ran at 15 % of the matrix pipe's rate, bound by its synchronisation (C8: 2.2 ms for
-// 119 M rows, profiles/r06_q_c8_*).  Here a lane IS an output row: its 14 D input samples stay in registers for every marked channel of
-// the tile, the taps come in as scalar operands (the same tapsA array: lane 2 q of step group 0 holds tr[0..3] of block q, lane 2 q + 1
-// ti[0..3] -- one uniform 32-byte load per block), 8 D 14 fused multiply-adds per row in the matrix instruction's own order (block
-// chains from +0 over r: re fmaf(tr, xr, .), fmaf(-ti, xi, .); im fmaf(ti, xr, .), fmaf(tr, xi, .); block sums ascending), then the
-// same epilogue.  No LDS traffic per channel, no barrier per channel: waves 0, 1 take the even marked channels of the tile, waves
-// 2, 3 the odd ones, and meet once per tile where the input span is staged.  Same tiles, same bitmap, same bits as the matrix form
-// (tests/test_emu_bank.py, scripts/ubench/exact_mfma.hip check one against the other).
-template <int D>
-__global__ __launch_bounds__(kExThreads, 3) void exact_rows_small_kernel(ExactParams p, const float2 *__restrict__ x, const float4 *__restrict__ taps4 /* = p.tapsA: a kernel argument of its own, restrict const, so that the uniform tap loads become scalar loads */)
+typedef void (*ExactRowsKernel)(ExactParams, const float2 *);
+// the instantiations: D = fs / 2 MHz for the rates the polyphase banks serve (4 .. 50 Msps: D = 2 .. 25; 100 Msps: D = 50)
+// (Round 6 also built a vector-lane form for D <= 4 -- a lane = an output row, its 14 D samples in registers, the taps as scalar
+// operands, no LDS and no barrier per channel -- bit-identical to this kernel on 164 M rows and SLOWER: 2.58 ms against 2.05 for
+// 145 M rows at D = 4 (profiles/r06_t_ubench_exact.txt); removed.)
+inline ExactRowsKernel exact_rows_pick(int D)
 {
-    static_assert(D >= 1 && D <= 4, "one 16-byte group of taps per block");
-    HIP_DYNAMIC_SHARED(float2, lds)
-    constexpr int NX = kExCols * D;                                // samples of a tile's span
-    float2 *xs = lds;                                              // [NX]
-    float *atab = (float *)(xs + NX);
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#else
-    const int wave = tid >> 6;
-#endif
-    for (int i = tid; i < 257; i += kExThreads) atab[i] = p.atan_tab[i];
-    const int u = (wave & 1) ? 62 + lane : lane - 1;               // output of the tile (0: the demodulator's halo), as in the matrix form
-    const bool u_ok = u >= 0 && u < kExOuts;
-    for (int tile = (int)blockIdx.x; tile < p.ntiles; tile += (int)gridDim.x) {
-        uint32_t bm[kExWords];
-        uint32_t any = 0;
-#pragma unroll
-        for (int i = 0; i < kExWords; i++) { bm[i] = p.bitmap[(size_t)tile * kExWords + i]; any |= bm[i]; }
-        if (!any) continue;                                        // uniform
-        if (p.stat && tid == 0) { unsigned int n = 0; for (int i = 0; i < kExWords; i++) n += (unsigned int)__popc(bm[i]); atomicAdd(p.stat, n); }
-        auto next_channel = [&]() {                                // uniform: the lowest channel left in bm, -1 when none
-            int c = -1;
-#pragma unroll
-            for (int wi = kExWords - 1; wi >= 0; wi--) if (bm[wi]) c = 32 * wi + __ffs(bm[wi]) - 1;
-#pragma unroll
-            for (int wi = 0; wi < kExWords; wi++) if (c >= 0 && (c >> 5) == wi) bm[wi] &= bm[wi] - 1;
-            return c;
-        };
-        const long long g0 = exact_tile_row0(tile) - 1;            // grid row of output 0
-        const int nout = (int)(((tile + 1) % kExSlotTiles == 0 ? (long long)(tile / kExSlotTiles + 1) * kExSlotRows : exact_tile_row0(tile + 1)) - g0);
-        const long long sb = p.first0 + g0 * D;
-        __syncthreads();                                           // (the previous tile's lanes have taken their samples)
-        for (int i = tid; i < NX; i += kExThreads) {
-            const long long a = sb + i;
-            const float2 t = x[a < 0 ? 0 : (a < p.x_len ? a : p.x_len - 1)];
-            xs[i] = (a >= 0 && a < p.x_len) ? t : make_float2(0.f, 0.f);
-        }
-        __syncthreads();
-        float2 X[kExQB * D];                                       // this row's samples: columns u .. u + 13
-        {
-            const float2 *xu = xs + (u_ok ? u : 0) * D;
-#pragma unroll
-            for (int i = 0; i < kExQB * D; i++) X[i] = xu[i];
-        }
-        const long long g = g0 + (u_ok ? u : 0);
-        const bool row_ok = u_ok && (wave & 1 ? lane >= 1 : lane >= 2) && u < nout && g >= 1 && g < p.G;
-        const unsigned int gq = (unsigned int)(g > 0 ? g : 0);
-        const unsigned int rot_i = gq % (unsigned int)p.Qr;
-        float *drow_p = p.d + (size_t)gq * p.drow;
-        float *dcol_p = p.dcol ? p.dcol + (size_t)(gq + 25u * 79u * (gq / 25u)) : nullptr;
-        int c_cur;
-        for (int n = 0; (c_cur = next_channel()) >= 0; n++) {
-            if ((n & 1) != (wave >> 1)) continue;                  // uniform: the other pair of waves has this channel
-            const float4 *__restrict__ tp = taps4 + (size_t)c_cur * 64;            // exact_dpad(D) = 4: one group
-            float2 rt = make_float2(1.f, 0.f);
-            if (u_ok && g >= 0) rt = p.rot[(size_t)c_cur * p.Qr + rot_i];
-            float yr = 0.f, yi = 0.f;
-#pragma unroll
-            for (int q = 0; q < kExQB; q++) {
-                const float4 tr4 = tp[2 * q], ti4 = tp[2 * q + 1];
-                const float tr[4] = {tr4.x, tr4.y, tr4.z, tr4.w}, ti[4] = {ti4.x, ti4.y, ti4.z, ti4.w};
-                float gr = 0.f, gi = 0.f;
-#pragma unroll
-                for (int r = 0; r < D; r++) {
-                    const float2 v = X[q * D + r];
-                    gr = fmaf(tr[r], v.x, gr); gr = fmaf(-ti[r], v.y, gr);
-                    gi = fmaf(ti[r], v.x, gi); gi = fmaf(tr[r], v.y, gi);
-                }
-                yr = q ? yr + gr : gr;
-                yi = q ? yi + gi : gi;
-            }
-            float2 y = make_float2(0.f, 0.f);
-            if (u_ok) {
-                y.x = fmaf(-yi, rt.y, yr * rt.x);
-                y.y = fmaf(yi, rt.x, yr * rt.y);
-                if (p.ydbg && g >= 0 && g < p.G) p.ydbg[(size_t)c_cur * p.ystride + g] = y;
-            }
-            float2 yp;
-            yp.x = __shfl_up(y.x, 1, 64); yp.y = __shfl_up(y.y, 1, 64);
-            if (row_ok && !(p.dbg & 2)) {
-                const float dv = demod_one(atab, p.gain, y, yp);
-                if (!(p.dbg & 1)) {
-                    drow_p[c_cur] = dv;
-                    if (dcol_p) dcol_p[25 * c_cur] = dv;
-                }
-            }
-        }
-    }
-}
-
-typedef void (*ExactRowsKernel)(ExactParams, const float2 *, const float4 *);
-// the instantiations: D = fs / 2 MHz for the rates the polyphase banks serve (4 .. 50 Msps: D = 2 .. 25; 100 Msps: D = 50).
-// small = false: the matrix form at every D (A/B, and the check of one form against the other)
-inline ExactRowsKernel exact_rows_pick(int D, bool small = true)
-{
-    if (small) switch (D) {
-        case 2: return exact_rows_small_kernel<2>;
-        case 3: return exact_rows_small_kernel<3>;
-        case 4: return exact_rows_small_kernel<4>;
-    }
     switch (D) {
 #define BTGPU_EX(n) case n: return exact_rows_kernel<n>;
         BTGPU_EX(2) BTGPU_EX(3) BTGPU_EX(4) BTGPU_EX(5) BTGPU_EX(6) BTGPU_EX(7) BTGPU_EX(8) BTGPU_EX(9) BTGPU_EX(10) BTGPU_EX(11) BTGPU_EX(12) BTGPU_EX(13)
@@ -343,7 +238,5 @@ inline ExactRowsKernel exact_rows_pick(int D, bool small = true)
     }
     return nullptr;
 }
-// (the small form needs 8 NX + 1 KB; both forms are launched with the matrix form's size -- the vector form is bound by its
-// registers, three waves per SIMD, long before LDS)
 
 }  // namespace btgpu

@@ -112,11 +112,11 @@ int main(int argc, char **argv)
         const size_t lds = exact_lds_bytes(D);
         CK(hipFuncSetAttribute((const void *)exact_rows_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(exact_rows_kernel<D>, dim3(p.ntiles), dim3(kExThreads), lds, 0, p, d_x, (const float4 *)p.tapsA);
+        hipLaunchKernelGGL(exact_rows_kernel<D>, dim3(p.ntiles), dim3(kExThreads), lds, 0, p, d_x);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         const int grid = getenv("UB_GRID") ? atoi(getenv("UB_GRID")) : p.ntiles;
-        for (int i = 0; i < reps; i++) hipLaunchKernelGGL(exact_rows_kernel<D>, dim3(grid), dim3(kExThreads), lds, 0, p, d_x, (const float4 *)p.tapsA);
+        for (int i = 0; i < reps; i++) hipLaunchKernelGGL(exact_rows_kernel<D>, dim3(grid), dim3(kExThreads), lds, 0, p, d_x);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         if (ms) { CK(hipEventElapsedTime(ms, e0, e1)); *ms /= (float)(reps > 0 ? reps : 1); }
         CK(hipFree(d_tapsA)); CK(hipFree(d_atab)); CK(hipFree(d_rot)); CK(hipFree(d_bm));
@@ -194,7 +194,7 @@ int main(int argc, char **argv)
         }
         CK(hipFree(d_x)); CK(hipFree(d_d)); CK(hipFree(d_dcol));
     }
-    // ---- 4. D = 4 (8 Msps, configs[1]): the vector form (exact_rows_small_kernel<4>) against the matrix form -- the same bits, and both rates ----
+    // ---- 4. D = 4 (8 Msps, configs[1]): the rate where a channel's tile is four matrix instructions per wave ----
     {
         constexpr int D4 = 4;
         const int nch4 = 8, ntaps4 = 53, ntp4 = 56, S4 = argc > 4 ? atoi(argv[4]) : 16384;
@@ -209,10 +209,9 @@ int main(int argc, char **argv)
         const size_t x_len = (size_t)G * D4 + 700;
         std::vector<float> xh(x_len * 2);
         for (size_t i = 0; i < xh.size(); i++) xh[i] = 1e-2f * (float)((int)(mix(19, (uint32_t)i, 0) % 2001u) - 1000);
-        float2 *d_x; float *d_da, *d_db, *d_tapsA, *d_atab; float2 *d_rot; uint32_t *d_bm;
+        float2 *d_x; float *d_da, *d_tapsA, *d_atab; float2 *d_rot; uint32_t *d_bm;
         CK(hipMalloc(&d_x, x_len * 8)); CK(hipMemcpy(d_x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice));
-        CK(hipMalloc(&d_da, (size_t)G * 8 * 4)); CK(hipMalloc(&d_db, (size_t)G * 8 * 4));
-        CK(hipMemset(d_da, 0, (size_t)G * 8 * 4)); CK(hipMemset(d_db, 0, (size_t)G * 8 * 4));
+        CK(hipMalloc(&d_da, (size_t)G * 8 * 4)); CK(hipMemset(d_da, 0, (size_t)G * 8 * 4));
         CK(hipMalloc(&d_tapsA, tapsA4.size() * 4)); CK(hipMemcpy(d_tapsA, tapsA4.data(), tapsA4.size() * 4, hipMemcpyHostToDevice));
         CK(hipMalloc(&d_atab, 257 * 4)); CK(hipMemcpy(d_atab, atab.data(), 257 * 4, hipMemcpyHostToDevice));
         CK(hipMalloc(&d_rot, rot.size() * 4)); CK(hipMemcpy(d_rot, rot.data(), rot.size() * 4, hipMemcpyHostToDevice));
@@ -222,29 +221,21 @@ int main(int argc, char **argv)
         CK(hipMalloc(&d_bm, bm.size() * 4)); CK(hipMemcpy(d_bm, bm.data(), bm.size() * 4, hipMemcpyHostToDevice));
         ExactParams p{};
         p.x_len = (long long)x_len; p.first0 = 0; p.G = G; p.tapsA = d_tapsA; p.rot = d_rot; p.Qr = Qr; p.atan_tab = d_atab; p.gain = 1.0f;
-        p.bitmap = d_bm; p.ntiles = exact_ntiles(G); p.drow = 8; p.dcol = nullptr; p.nch = nch4;
+        p.bitmap = d_bm; p.ntiles = exact_ntiles(G); p.drow = 8; p.dcol = nullptr; p.nch = nch4; p.d = d_da;
+        p.dbg = getenv("UB_DBG") ? atoi(getenv("UB_DBG")) : 0;
         const size_t lds = exact_lds_bytes(D4);
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        float ms[2] = {0.f, 0.f};
-        for (int form = 0; form < 2; form++) {
-            ExactRowsKernel k = exact_rows_pick(D4, form == 1);
-            CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            p.d = form ? d_db : d_da;
-            hipLaunchKernelGGL(k, dim3(p.ntiles), dim3(kExThreads), lds, 0, p, d_x, (const float4 *)p.tapsA);
-            CK(hipDeviceSynchronize());
-            CK(hipEventRecord(e0));
-            for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k, dim3(p.ntiles), dim3(kExThreads), lds, 0, p, d_x, (const float4 *)p.tapsA);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            CK(hipEventElapsedTime(&ms[form], e0, e1)); ms[form] /= 5.f;
-        }
-        std::vector<float> da((size_t)G * 8), db((size_t)G * 8);
-        CK(hipMemcpy(da.data(), d_da, da.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(db.data(), d_db, db.size() * 4, hipMemcpyDeviceToHost));
-        long long differ = 0, nonzero = 0;
-        for (size_t i = 0; i < da.size(); i++) { if (memcmp(&da[i], &db[i], 4)) differ++; if (da[i] != 0.f) nonzero++; }
+        float ms = 0.f;
+        ExactRowsKernel k = exact_rows_pick(D4);
+        CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3(p.ntiles), dim3(kExThreads), lds, 0, p, d_x);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k, dim3(p.ntiles), dim3(kExThreads), lds, 0, p, d_x);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5.f;
         const double rows = (double)pairs * kExSlotRows / kExSlotTiles, fl = rows * 8.0 * ntaps4;
-        printf("D = 4, 8 channels, %lld (channel, tile) pairs, %.1f M rows: matrix form %.3f ms (%.1f TFLOP/s), vector form %.3f ms (%.1f TFLOP/s); %lld of %zu demodulated rows differ between the forms (%lld nonzero)\n",
-               pairs, rows * 1e-6, ms[0], fl / ms[0] * 1e-9, ms[1], fl / ms[1] * 1e-9, differ, da.size(), nonzero);
-        if (differ) return 1;
+        printf("D = 4, 8 channels, %lld (channel, tile) pairs, %.1f M rows: %.3f ms = %.1f G rows/s, %.1f TFLOP/s of useful multiply-adds\n", pairs, rows * 1e-6, ms, rows / ms * 1e-6, fl / ms * 1e-9);
     }
     return 0;
 }

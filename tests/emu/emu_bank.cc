@@ -333,15 +333,14 @@ static int run_detect(const Design &des, int S, int nb, int nch, int drow, long 
         if (tapsA.empty()) { tapsA.resize(exact_taps_floats(nch, D)); exact_pack_taps(des.channel.taps.data(), nch, des.channel.ntp, D, tapsA.data()); }
         const ExactParams ep = make_exact_params(des, (size_t)ve->x_len, 0, G, tapsA.data(), (const float2 *)des.channel.rot.data(), des.atan_tab,
                                                  bitmap, vb.bm_tiles, const_cast<float *>(d), drow, const_cast<float *>(dcol_p), stat);
-        static const bool small_off = getenv("EMU_EXACT_SMALL") && atoi(getenv("EMU_EXACT_SMALL")) == 0;          // (the matrix form at D <= 4 too: one form against the other)
-        const ExactRowsKernel kern = exact_rows_pick(D, !small_off);
+        const ExactRowsKernel kern = exact_rows_pick(D);
         if (exact_lds_bytes(D) > sizeof emu::dyn_lds) { std::fprintf(stderr, "emu: LDS %zu\n", exact_lds_bytes(D)); std::abort(); }
         bool any = false;
         for (size_t i = 0; i < (size_t)vb.bm_tiles * kExBmWords; i++) any = any || bitmap[i];
         if (!any) return;
         std::memset(emu::dyn_lds, 0xff, sizeof emu::dyn_lds);
         // (ONE emulated workgroup strides over all the tiles, as the kernel allows: the fibers are set up once)
-        emu::launch(dim3(1), dim3(kExThreads), [&]() { kern(ep, ve->x, (const float4 *)ep.tapsA); });
+        emu::launch(dim3(1), dim3(kExThreads), [&]() { kern(ep, ve->x); });
     };
     auto launch_window = [&](auto lay) {
         using LAY = decltype(lay);
