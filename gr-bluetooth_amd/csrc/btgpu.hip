@@ -125,7 +125,7 @@ struct btgpu_handle {
     }
     static constexpr unsigned kEagerHits = 65536;
     static constexpr unsigned kEagerFin = 8192;
-    unsigned eager_fin = kEagerFin, eager_hdr = kEagerFin;      // capacity (records) of the page-locked h_sym / h_hdr of a context: records_out_kernel fills them
+    unsigned eager_fin = kEagerFin, eager_hdr = kEagerFin, eager_hits = kEagerHits;   // capacity (records) of the page-locked h_sym / h_hdr / h_hits of a context: records_out_kernel fills them
     bool want_syms = false, want_hdrs = false;
     // The host queue: records of harvested batches in emission order, consumed from the front (qhead).  Flat arenas -- a record
     // costs one memcpy of its symbols, no allocation (a vector per record was 5 ms of host time per 11 000-record batch at C8:
@@ -594,7 +594,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
             hipLaunchKernelGGL(records_out_kernel, dim3(128), dim3(256), 0, tail_stream, (const unsigned int *)d_hitcount.p, max_hits,
                                (const uint4 *)(want_syms ? d_symbits.p : nullptr), (uint4 *)(want_syms ? t.h_sym : nullptr), eager_fin,
                                (const uint2 *)(want_hdrs ? t.d_hdr.p : nullptr), (uint2 *)(want_hdrs ? t.h_hdr : nullptr), eager_hdr,
-                               (const uint4 *)d_hits.p, (uint4 *)t.h_hits, std::min<unsigned>((unsigned)max_hits, kEagerHits));
+                               (const uint4 *)d_hits.p, (uint4 *)t.h_hits, std::min<unsigned>((unsigned)max_hits, eager_hits));
         }
     }
     HIPCHK(this, mark(10, tail_stream));
@@ -727,14 +727,14 @@ int btgpu_handle::harvest(TailCtx &t)
         // what the eager copies do not carry (more than kEagerHits records, more than kEagerFin hit windows in one batch: dense
         // captures at the small rates) comes over in ONE bulk copy each, into page-locked memory, and one wait for the three
         const unsigned nfin = t.h_count[1];
-        const size_t n_hit_spill = count > kEagerHits ? count - kEagerHits : 0;
+        const size_t n_hit_spill = count > eager_hits ? count - eager_hits : 0;
         const size_t n_sym_spill = (want_syms && nfin > eager_fin) ? (size_t)(nfin - eager_fin) : 0;
         const size_t n_hdr_spill = (want_hdrs && count > eager_hdr) ? (size_t)(count - eager_hdr) : 0;
         const DeviceHit *hit_spill = nullptr; const uint32_t *sym_spill = nullptr; const HeaderRec *hdr_spill = nullptr;
         if (n_hit_spill) {
             void *b = spill_buf(0, n_hit_spill * sizeof(DeviceHit));
             if (!b) { set_error("hipHostMalloc (record spill)"); return BTGPU_ENOMEM; }
-            HIPCHK(this, hipMemcpyAsync(b, (const DeviceHit *)t.d_hits.p + kEagerHits, n_hit_spill * sizeof(DeviceHit), hipMemcpyDeviceToHost, spill_stream));
+            HIPCHK(this, hipMemcpyAsync(b, (const DeviceHit *)t.d_hits.p + eager_hits, n_hit_spill * sizeof(DeviceHit), hipMemcpyDeviceToHost, spill_stream));
             hit_spill = (const DeviceHit *)b;
         }
         if (n_sym_spill) {
@@ -750,7 +750,7 @@ int btgpu_handle::harvest(TailCtx &t)
             hdr_spill = (const HeaderRec *)b;
         }
         if (n_hit_spill || n_sym_spill || n_hdr_spill) HIPCHK(this, hipStreamSynchronize(spill_stream));
-        auto hit_at = [&](size_t i) -> const DeviceHit & { return i < kEagerHits ? t.h_hits[i] : hit_spill[i - kEagerHits]; };
+        auto hit_at = [&](size_t i) -> const DeviceHit & { return i < eager_hits ? t.h_hits[i] : hit_spill[i - eager_hits]; };
         // the order the reference's loops print in -- slot, channel, kind, offset -- formed FIRST, on packed keys; the records then go
         // to the queue's arenas in that order, once
         std::vector<std::pair<uint64_t, uint32_t>> order;
@@ -1247,6 +1247,10 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         // (one record per hit window / per hit: as many as a batch can hold, within 64 Ki -- 31 MB of symbols and 9 MB of sweeps per context)
         h->eager_fin = (unsigned)std::min<size_t>(std::max<size_t>((size_t)S * nch, 1024), 65536);
         h->eager_hdr = (unsigned)std::min<size_t>(std::max<size_t>((size_t)h->max_hits, 1024), 65536);
+        if (const char *e = getenv("BTGPU_EAGER_CAP")) {      // tests: a small capacity, so that a small capture takes the spill path
+            const unsigned v = (unsigned)std::max(1, atoi(e));
+            h->eager_fin = std::min(h->eager_fin, v); h->eager_hdr = std::min(h->eager_hdr, v); h->eager_hits = std::min(h->eager_hits, v);
+        }
         if (h->want_hdrs && hipHostMalloc((void **)&t.h_hdr, (size_t)h->eager_hdr * sizeof(HeaderRec), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)h->eager_fin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_count, 12 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);

@@ -515,6 +515,33 @@ def test_header_sweep_equals_try_clock(pkg, po, synth):
             assert [int(x) for x in hd["type"]] == [w[1] for w in want]
 
 
+def test_records_beyond_the_page_locked_capacity_take_the_spill_path_unchanged(pkg, synth, monkeypatch):
+    """records_out_kernel writes the first `capacity` hit records, symbol rows and header sweeps of a batch into page-locked memory
+    (csrc/btgpu.hip harvest); what a batch holds beyond that comes over in spill copies.  With the capacity forced down to 3
+    (BTGPU_EAGER_CAP) a small capture takes that path: records, sweeps and symbols equal the default handle's, whether polled in one
+    call or five records at a time (the queue's head index and its compaction)."""
+    fs, fc = 8e6, 2476.5e6
+    iq, _ = synth.make_capture(fs, fc, 40, laps=(0x24D952, 0x4831DD, 0x9E8B33), seed=72, snr_db=24, occupancy=0.6)
+    def run(chunk):
+        blk = pkg.multi_sniffer(fs, fc, 10.0, False, flags=pkg.FLAG_HEADERS | pkg.FLAG_LE, max_batch_slots=16)
+        blk.push(iq)
+        parts = []
+        while True:
+            hits, hdrs, syms, lens = blk.poll_headers(sym_cap=3125, max_hits=chunk)
+            if len(hits) == 0:
+                break
+            parts.append((hits.copy(), hdrs.copy(), syms.copy(), lens.copy()))
+        blk.close()
+        return [np.concatenate([q[i] for q in parts]) for i in range(4)]
+    want = run(1 << 16)
+    assert len(want[0]) > 12
+    monkeypatch.setenv("BTGPU_EAGER_CAP", "3")
+    for chunk in (1 << 16, 5):
+        got = run(chunk)
+        for a, b in zip(got, want):
+            assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
 def test_hit_buffer_overflow_is_reported_not_silent(pkg, po, synth):
     """max_hits smaller than the number of records: BTGPU_EOVERFLOW comes back from the call that
     produced them, exactly max_hits records are kept, every one of them a record of the full
