@@ -81,7 +81,7 @@ struct btgpu_handle {
         HeaderRec *h_hdr = nullptr;           // pinned: sweeps of the first eager_hdr hits (records_out_kernel)
         uint32_t *h_sym = nullptr;            // pinned: packed symbols of the first eager_fin hit windows (records_out_kernel)
         unsigned int *h_count = nullptr;      // pinned: {hits, finish records, -, -, verify tasks, verify tiles, turned away, -}
-        DeviceHit *h_hits = nullptr;          // pinned: first kEagerHits records, copied by the tail stream
+        DeviceHit *h_hits = nullptr;          // pinned: first eager_hits records (records_out_kernel)
         // timing events (recorded only with BTGPU_FLAG_TIMING): front 0 start, 1 channel bank, 2 demod / energy (direct
         // form), 3 noise stage 1 / direct noise bank, 4 direct noise energy; post 5 start, 6 block sums, 7 squelch
         // stage 2, 8 window; tail 9 start, 10 end
@@ -588,7 +588,7 @@ int btgpu_handle::process_batch(const float2 *d_x, size_t x_len, long long w0, u
                                    (HeaderRec *)t.d_hdr.p);
             }
             // records travel to page-locked host memory on the tail stream too -- through a kernel that knows the counts (the
-            // first eager_fin hit windows' symbols, eager_hdr sweeps, kEagerHits records; beyond: harvest's spill copies) --
+            // first eager_fin hit windows' symbols, eager_hdr sweeps, eager_hits records; beyond: harvest's spill copies) --
             // harvesting a batch is then pure host work and never waits on the other streams
             HIPCHK(this, hipMemcpyAsync(t.h_count, d_hitcount.p, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, tail_stream));
             hipLaunchKernelGGL(records_out_kernel, dim3(128), dim3(256), 0, tail_stream, (const unsigned int *)d_hitcount.p, max_hits,
@@ -724,7 +724,7 @@ int btgpu_handle::harvest(TailCtx &t)
     int rc = BTGPU_OK;
     if (count > (unsigned)max_hits) { count = (unsigned)max_hits; rc = BTGPU_EOVERFLOW; sticky = rc; set_error("hit buffer overflow"); }
     if (count) {
-        // what the eager copies do not carry (more than kEagerHits records, more than kEagerFin hit windows in one batch: dense
+        // what the eager copies do not carry (more records, sweeps or hit windows in one batch than the page-locked buffers hold: dense
         // captures at the small rates) comes over in ONE bulk copy each, into page-locked memory, and one wait for the three
         const unsigned nfin = t.h_count[1];
         const size_t n_hit_spill = count > eager_hits ? count - eager_hits : 0;
@@ -1247,6 +1247,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         // (one record per hit window / per hit: as many as a batch can hold, within 64 Ki -- 31 MB of symbols and 9 MB of sweeps per context)
         h->eager_fin = (unsigned)std::min<size_t>(std::max<size_t>((size_t)S * nch, 1024), 65536);
         h->eager_hdr = (unsigned)std::min<size_t>(std::max<size_t>((size_t)h->max_hits, 1024), 65536);
+        h->eager_hits = (unsigned)std::min<size_t>(std::max<size_t>((size_t)h->max_hits, 1024), btgpu_handle::kEagerHits);
         if (const char *e = getenv("BTGPU_EAGER_CAP")) {      // tests: a small capacity, so that a small capture takes the spill path
             const unsigned v = (unsigned)std::max(1, atoi(e));
             h->eager_fin = std::min(h->eager_fin, v); h->eager_hdr = std::min(h->eager_hdr, v); h->eager_hits = std::min(h->eager_hits, v);
@@ -1255,7 +1256,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         if (h->want_syms && hipHostMalloc((void **)&t.h_sym, (size_t)h->eager_fin * kSymWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         if (hipHostMalloc((void **)&t.h_count, 12 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
         std::memset(t.h_count, 0, 12 * sizeof(unsigned int));
-        if (hipHostMalloc((void **)&t.h_hits, (size_t)btgpu_handle::kEagerHits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
+        if (hipHostMalloc((void **)&t.h_hits, (size_t)h->eager_hits * sizeof(DeviceHit), hipHostMallocDefault) != hipSuccess) return fail(BTGPU_ENOMEM);
     }
 #undef TRY
     // allow > 48 KiB of dynamic LDS for the FIR tiles
