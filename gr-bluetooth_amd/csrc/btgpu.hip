@@ -1050,8 +1050,12 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
             // (the tails of consecutive batches alternate between these streams: the same mask on all of them -- ADVICE r4)
             for (auto &te : h->tail_extra) if (hipExtStreamCreateWithCUMask(&te, 8, mask) != hipSuccess) return fail(BTGPU_EDEVICE);
         } else {
-            if (hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
-            for (auto &te : h->tail_extra) if (hipStreamCreateWithPriority(&te, hipStreamNonBlocking, hi) != hipSuccess) return fail(BTGPU_EDEVICE);
+            // BTGPU_TAIL_PRIO=lo|mid (A/B): the tail at the lowest / the default stream priority -- measured (round 6, profiles/r06_y_tail_prio_ab.txt):
+            // hi 32.9 / 32.7, mid 32.1 / 32.6, lo 32.0 / 32.2 Gsamples/s: the highest stays
+            const char *tp = getenv("BTGPU_TAIL_PRIO");
+            const int tprio = tp && !strcmp(tp, "lo") ? lo : tp && !strcmp(tp, "mid") ? 0 : hi;
+            if (hipStreamCreateWithPriority(&h->tail_stream, hipStreamNonBlocking, tprio) != hipSuccess) return fail(BTGPU_EDEVICE);
+            for (auto &te : h->tail_extra) if (hipStreamCreateWithPriority(&te, hipStreamNonBlocking, tprio) != hipSuccess) return fail(BTGPU_EDEVICE);
         }
     }
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
