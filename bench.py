@@ -409,9 +409,10 @@ def run_rank(args):
             if last:
                 b8.flush()
             return bdist.struct_to_arrays(b8.poll_arrays())
-        # the headline's regime (timed_region): no cyclic-GC pass inside the timed loop -- with 11 068 records per step coming back as
-        # arrays the collector's generation-2 sweeps (tens of ms each with torch loaded) made this leg read 15 G where the same block
-        # measures 19 G under --workload c8 -- and prewarm_ms of load, then W steps, in front of it
+        # the headline's regime (timed_region): no cyclic-GC pass inside the timed loop, prewarm_ms of load and W steps in front of it.
+        # (This leg still reads 14.8-15.1 G where the same block measures 19.0-19.2 G under --workload c8, in a process of its own: as the
+        # second handle of a process every throughput kernel of it runs 25-40 % longer in steady state -- not the warm-up, not the
+        # collector, not torch's cached blocks, not the number of hardware queues (profiles/r06_z_c8_leg_*); cause not found.)
         gc.collect()
         gc.disable()
         t_pre = time.perf_counter()
