@@ -125,7 +125,8 @@ def traffic_by_device_code(key, S):
         match = sorted([k for k in pj["kernels"] if key and k.startswith(key)], key=lambda k: -pj["kernels"][k]["hbm_bytes"])
         want_id = pj["kernel_code_sha"].get(match[0]) if match else None
         if want_id and want_id == dci.lookup(ids, match[0]):
-            return {"traffic": pj["kernels"][match[0]]["hbm_bytes"], "traffic_source": os.path.basename(cand),
+            return {"_summary": pj, "_kernel": match[0],
+                    "traffic": pj["kernels"][match[0]]["hbm_bytes"], "traffic_source": os.path.basename(cand),
                     "traffic_basis": "PMC passes ran on build %s; %s is instruction-identical in this build (device code id %s, "
                                      "scripts/device_code_ids.py)" % (pj.get("build_id"), match[0], want_id)}
     return None
@@ -410,9 +411,9 @@ def run_rank(args):
                 b8.flush()
             return bdist.struct_to_arrays(b8.poll_arrays())
         # the headline's regime (timed_region): no cyclic-GC pass inside the timed loop, prewarm_ms of load and W steps in front of it.
-        # (This leg still reads 14.8-15.1 G where the same block measures 19.0-19.2 G under --workload c8, in a process of its own: as the
-        # second handle of a process every throughput kernel of it runs 25-40 % longer in steady state -- not the warm-up, not the
-        # collector, not torch's cached blocks, not the number of hardware queues (profiles/r06_z_c8_leg_*); cause not found.)
+        # (Until the library kept a destroyed handle's streams for the next one -- btgpu.hip g_stream_pool -- this leg read 14.8-15.1 G where
+        # the same block measures 19-20 G in a process of its own: streams created after others were destroyed ran every kernel 4-19 %
+        # longer, profiles/r06_z_c8_leg_*, r06_zz_second_handle.txt.)
         gc.collect()
         gc.disable()
         t_pre = time.perf_counter()
@@ -586,7 +587,9 @@ def run_rank(args):
             # no summary of this very build: one of another build counts for the dominant kernel on an equal device-code id
             key = {"ddc_channel": "pfb", "window": "window_kernel", "noise_energy": "noise_stage2_kernel"}.get(names[dom])
             try:
-                roof.update(traffic_by_device_code(key, S) or {})
+                tb = traffic_by_device_code(key, S) or {}
+                tb.pop("_summary", None); tb.pop("_kernel", None)
+                roof.update(tb)
             except Exception as e:                      # (no disassembler on the box, ...: traffic stays null)
                 roof["traffic_note"] = "no PMC summary of this build; device-code match not possible: %r" % (e,)
 
@@ -605,6 +608,15 @@ def run_rank(args):
                     "note": "executed = the matrix pipe's own rate: 28 of 32 rows, 667 of 700 taps, 1250 of 1408 columns carry results (DESIGN.md 4.4); "
                             "F12: the f32 MFMA runs on the SIMD's vector lanes -- its time and every other instruction's add up",
                     "build_id": roof_bank.get("build_id")}
+            pmc_basis = None
+            if pmc_loaded is None:
+                # no summary of this very build: one whose exact_rows_kernel AND channel bank are instruction-identical to this build's
+                try:
+                    te, tk = traffic_by_device_code("exact_rows", S), traffic_by_device_code("pfb", S)
+                    if te and tk and te["traffic_source"] == tk["traffic_source"]:
+                        pmc_loaded, pmc_basis, args.pmc_json = te["_summary"], te["traffic_basis"], te["traffic_source"]
+                except Exception:
+                    pass
             if pmc_loaded is not None:
                 # HBM bytes of the step's exact_rows_kernel launches (two per step: over presence's marks, then the second run's ~4 %):
                 # per-launch average x its launches / the steps of the PMC run (= launches of the channel bank)
@@ -614,6 +626,8 @@ def run_rank(args):
                 if ex and bank and bank[0].get("launches"):
                     roof["traffic"] = round(sum(v["hbm_bytes"] * v.get("launches", 1) for v in ex) / max(v.get("launches", 1) for v in bank), 1)
                     roof["traffic_source"] = os.path.basename(args.pmc_json)
+                    if pmc_basis:
+                        roof["traffic_basis"] = pmc_basis
 
         # ---- cpu_baseline + parity: the oracle (a port, NOT the upstream binary) ----
         cpu = None

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -41,6 +42,13 @@ struct DevBuf {
 }  // namespace
 
 constexpr int kCtxMax = 3;
+// The eight streams of a destroyed handle are kept and handed to the next handle on the same device.  Streams created
+// after others were destroyed measured slower: the SECOND handle of a process ran every kernel 4-19 % longer (C8 14.8 against
+// 19.8 Gsamples/s, profiles/r06_zz_second_handle.txt); with the first handle's streams it runs like the first.  BTGPU_STREAM_POOL=0: off.
+struct StreamSet { int device; hipStream_t s[8]; };
+static std::mutex g_stream_pool_mu;
+static std::vector<StreamSet> g_stream_pool;
+
 struct btgpu_handle {
     Design des;
     FastPath fp;
@@ -229,9 +237,17 @@ struct btgpu_handle {
             if (ev_consumed[k]) { (void)hipEventDestroy(ev_consumed[k]); ev_consumed[k] = nullptr; }
             if (ev_vdone[k]) { (void)hipEventDestroy(ev_vdone[k]); ev_vdone[k] = nullptr; }
         }
+        if (streams_poolable && stream && post_stream && tail_stream && copy_stream && spill_stream && tail_extra[0] && tail_extra[1] && sq_stream) {
+            StreamSet ss; ss.device = device;
+            hipStream_t *all[8] = {&stream, &post_stream, &tail_stream, &copy_stream, &spill_stream, &tail_extra[0], &tail_extra[1], &sq_stream};
+            for (int k = 0; k < 8; k++) { (void)hipStreamSynchronize(*all[k]); ss.s[k] = *all[k]; *all[k] = nullptr; }
+            std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+            g_stream_pool.push_back(ss);
+        }
         for (hipStream_t *st : {&stream, &post_stream, &tail_stream, &copy_stream, &spill_stream, &tail_extra[0], &tail_extra[1], &sq_stream})
             if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     }
+    bool streams_poolable = false;
 
     BankBuffers bank_buffers(const float2 *d_x, const TailCtx &t, bool with_dcol = false) const
     {
@@ -1033,6 +1049,20 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
     h->nb_max = (int)((G + ops - 1) / ops);
     h->in_cap = (size_t)d.history + (size_t)(S - 1) * d.samples_per_slot;
 
+    bool from_pool = false;
+    if (!(getenv("BTGPU_STREAM_POOL") && atoi(getenv("BTGPU_STREAM_POOL")) == 0) && !getenv("BTGPU_TAIL_CUS") && !getenv("BTGPU_TAIL_PRIO") && !getenv("BTGPU_POST_PRIO")) {
+        h->streams_poolable = true;
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); i++) if (g_stream_pool[i].device == h->device) {
+            const StreamSet ss = g_stream_pool[i];
+            g_stream_pool.erase(g_stream_pool.begin() + i);
+            hipStream_t *all[8] = {&h->stream, &h->post_stream, &h->tail_stream, &h->copy_stream, &h->spill_stream, &h->tail_extra[0], &h->tail_extra[1], &h->sq_stream};
+            for (int k = 0; k < 8; k++) *all[k] = ss.s[k];
+            from_pool = true;
+            break;
+        }
+    }
+    if (!from_pool) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(BTGPU_EDEVICE);
     {
         // the tail (a few dozen latency-bound waves) gets the highest stream priority so that it is
@@ -1068,6 +1098,7 @@ int btgpu_create(const btgpu_config *cfg, btgpu_handle **out)
         const int pp = getenv("BTGPU_POST_PRIO") ? atoi(getenv("BTGPU_POST_PRIO")) : 0;       // 1 high, 0 normal, -1 low
         if (hipStreamCreateWithPriority(&h->post_stream, hipStreamNonBlocking, pp > 0 ? hi : pp < 0 ? lo : 0) != hipSuccess) return fail(BTGPU_EDEVICE);
     }
+    }   // (!from_pool)
     for (auto &t : h->tc) {
         for (auto &e : t.ev) if (hipEventCreate(&e) != hipSuccess) return fail(BTGPU_EDEVICE);
         for (hipEvent_t *e : {&t.front_done, &t.detect_done, &t.tail_done, &t.squelch_done, &t.exact_done, &t.floor_done})

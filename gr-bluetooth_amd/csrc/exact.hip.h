@@ -94,8 +94,13 @@ inline size_t exact_taps_floats(int nch, int D) { return (size_t)nch * 64 * exac
 // instructions: per channel the epilogue runs on TWO waves with every lane busy (waves 0, 1 for even channels of the tile, 2, 3 for
 // odd ones: lanes 0 .. 63 of the first take outputs -1 .. 62, of the second 62 .. 125; y[t - 1] is one shuffle away), its row
 // indices are formed once per tile.
+#ifndef BTGPU_EX_FULLA
+#define BTGPU_EX_FULLA 1
+#endif
+// (experiment) the whole A operand of the NEXT channel in registers while this one's matrix instructions run: 52 registers at D = 50, three workgroups per CU
+constexpr bool exact_full_a(int D) { return BTGPU_EX_FULLA && D > 25; }
 template <int D>
-__global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
+__global__ __launch_bounds__(kExThreads, exact_full_a(D) ? 3 : 4) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
 {
     HIP_DYNAMIC_SHARED(float2, lds)
     constexpr int NS = 32 * D;                                     // samples per wave
@@ -158,14 +163,86 @@ __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p
         float *drow_p = p.d + (size_t)gq * p.drow;
         float *dcol_p = p.dcol ? p.dcol + (size_t)(gq + 25u * 79u * (gq / 25u)) : nullptr;
         int c_cur = next_channel();
+        // everything of a channel behind its matrix instructions: G to LDS, the barrier, the epilogue on this channel's two waves
+        auto finish_channel = [&](const f32x16 &acc, int n, int c, float2 rt) {
+            const bool my_turn = ((wave >> 1) & 1) == (n & 1);       // uniform: this wave is one of the channel's two epilogue waves
+            float *Gn = Gs + (n & 1) * kExGSize;
+            {
+                // register group j of the C/D layout = rows 8 j + 4 (lane >> 5) + (0 .. 3) of column lane & 31: four 16-byte writes, no
+                // predicate (rows 28 .. 31 are zero taps: written, never read)
+                float4 *gw = (float4 *)(Gn + (32 * wave + (lane & 31)) * kExRS + 4 * (lane >> 5));
+#pragma unroll
+                for (int j = 0; j < 4; j++) gw[2 * j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+            }
+            __syncthreads();
+            // ---- epilogue of channel c ----
+            if (my_turn) {
+            float2 y = make_float2(0.f, 0.f);
+            if (u_ok) {
+                const float *gu = Gn + u * kExRS;                  // block q of output u: column u + q, rows 2 q (re), 2 q + 1 (im)
+                float2 gq[kExQB];
+#pragma unroll
+                for (int q = 0; q < kExQB; q++) gq[q] = *(const float2 *)(gu + q * (kExRS + 2));
+                float yr = gq[0].x, yi = gq[0].y;
+#pragma unroll
+                for (int q = 1; q < kExQB; q++) { yr = yr + gq[q].x; yi = yi + gq[q].y; }
+                y.x = fmaf(-yi, rt.y, yr * rt.x);
+                y.y = fmaf(yi, rt.x, yr * rt.y);
+                if (p.ydbg && g >= 0 && g < p.G) p.ydbg[(size_t)c * p.ystride + g] = y;
+            }
+            float2 yp;                                             // y[u - 1]: the left neighbour's
+            yp.x = __shfl_up(y.x, 1, 64); yp.y = __shfl_up(y.y, 1, 64);
+            if (row_ok && !(p.dbg & 2)) {
+                const float dv = demod_one(atab, p.gain, y, yp);
+                if (!(p.dbg & 1)) {
+                    drow_p[c] = dv;
+                    if (dcol_p) dcol_p[25 * c] = dv;
+                }
+            }
+            }
+        };
+        auto rot_of = [&](int n, int c) {
+            float2 rt = make_float2(1.f, 0.f);
+            if (((wave >> 1) & 1) == (n & 1) && u_ok && g >= 0) rt = p.rot[(size_t)c * p.Qr + rot_i];
+            return rt;
+        };
+        if constexpr (exact_full_a(D)) {
+            // a rotating copy of the whole A operand: group i is consumed by its four matrix instructions and at once re-fetched for the
+            // NEXT channel -- every tap load is a whole channel (D matrix instructions, 64 cycles each) ahead of its use
+            float4 q[NI];
+            {
+                const float4 *ap = (const float4 *)p.tapsA + (size_t)c_cur * NI * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < NI; i++) q[i] = ap[i * 64];
+            }
+            __syncthreads();                                       // (the previous tile's last epilogue has read its G buffer)
+            for (int n = 0; c_cur >= 0; n++) {
+                const int c_nxt = next_channel();
+                const float4 *an = (const float4 *)p.tapsA + (size_t)(c_nxt >= 0 ? c_nxt : c_cur) * NI * 64 + lane;
+                const float2 rt = rot_of(n, c_cur);
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const float4 a = q[i];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, B[4 * i], acc, 0, 0, 0);
+                    if (4 * i + 1 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, B[4 * i + 1 < D ? 4 * i + 1 : 0], acc, 0, 0, 0);
+                    if (4 * i + 2 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, B[4 * i + 2 < D ? 4 * i + 2 : 0], acc, 0, 0, 0);
+                    if (4 * i + 3 < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, B[4 * i + 3 < D ? 4 * i + 3 : 0], acc, 0, 0, 0);
+                    q[i] = an[i * 64];                             // (after the tile's last channel: that channel's own taps again, unused)
+                    __builtin_amdgcn_sched_barrier(0);             // (keep the re-fetch HERE: the scheduler sinks all of them behind the chain otherwise)
+                }
+                finish_channel(acc, n, c_cur, rt);
+                c_cur = c_nxt;
+            }
+        } else {
         const float4 *ap = (const float4 *)p.tapsA + (size_t)c_cur * NI * 64 + lane;
         float4 q0 = ap[0], q1 = ap[NI > 1 ? 64 : 0], q2 = ap[NI > 2 ? 128 : 0];
         __syncthreads();                                           // (the previous tile's last epilogue has read its G buffer)
         for (int n = 0; c_cur >= 0; n++) {
             const int c_nxt = next_channel();
-            const bool my_turn = ((wave >> 1) & 1) == (n & 1);       // uniform: this wave is one of the channel's two epilogue waves
-            float2 rt = make_float2(1.f, 0.f);
-            if (my_turn && u_ok && g >= 0) rt = p.rot[(size_t)c_cur * p.Qr + rot_i];
+            const float2 rt = rot_of(n, c_cur);
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -183,41 +260,9 @@ __global__ __launch_bounds__(kExThreads, 4) void exact_rows_kernel(ExactParams p
                 ap = (const float4 *)p.tapsA + (size_t)c_nxt * NI * 64 + lane;
                 q0 = ap[0]; q1 = ap[NI > 1 ? 64 : 0]; q2 = ap[NI > 2 ? 128 : 0];
             }
-            float *Gn = Gs + (n & 1) * kExGSize;
-            {
-                // register group j of the C/D layout = rows 8 j + 4 (lane >> 5) + (0 .. 3) of column lane & 31: four 16-byte writes, no
-                // predicate (rows 28 .. 31 are zero taps: written, never read)
-                float4 *gw = (float4 *)(Gn + (32 * wave + (lane & 31)) * kExRS + 4 * (lane >> 5));
-#pragma unroll
-                for (int j = 0; j < 4; j++) gw[2 * j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
-            }
-            __syncthreads();
-            // ---- epilogue of channel c_cur ----
-            if (my_turn) {
-            float2 y = make_float2(0.f, 0.f);
-            if (u_ok) {
-                const float *gu = Gn + u * kExRS;                  // block q of output u: column u + q, rows 2 q (re), 2 q + 1 (im)
-                float2 gq[kExQB];
-#pragma unroll
-                for (int q = 0; q < kExQB; q++) gq[q] = *(const float2 *)(gu + q * (kExRS + 2));
-                float yr = gq[0].x, yi = gq[0].y;
-#pragma unroll
-                for (int q = 1; q < kExQB; q++) { yr = yr + gq[q].x; yi = yi + gq[q].y; }
-                y.x = fmaf(-yi, rt.y, yr * rt.x);
-                y.y = fmaf(yi, rt.x, yr * rt.y);
-                if (p.ydbg && g >= 0 && g < p.G) p.ydbg[(size_t)c_cur * p.ystride + g] = y;
-            }
-            float2 yp;                                             // y[u - 1]: the left neighbour's
-            yp.x = __shfl_up(y.x, 1, 64); yp.y = __shfl_up(y.y, 1, 64);
-            if (row_ok && !(p.dbg & 2)) {
-                const float dv = demod_one(atab, p.gain, y, yp);
-                if (!(p.dbg & 1)) {
-                    drow_p[c_cur] = dv;
-                    if (dcol_p) dcol_p[25 * c_cur] = dv;
-                }
-            }
-            }
+            finish_channel(acc, n, c_cur, rt);
             c_cur = c_nxt;
+        }
         }
     }
 }

@@ -182,7 +182,9 @@ const char *btgpu_version(void);
 
 /* ---- block lifetime ---- */
 int  btgpu_create(const btgpu_config *cfg, btgpu_handle **out);
-void btgpu_destroy(btgpu_handle *h);
+void btgpu_destroy(btgpu_handle *h);          /* frees the handle's memory; its eight HIP streams are kept by the library and handed
+                                                 to the next btgpu_create on the same device (streams created after others were
+                                                 destroyed measured 25 % slower steps; BTGPU_STREAM_POOL=0 in the environment: off) */
 int  btgpu_get_design(const btgpu_handle *h, btgpu_design *out);
 int  btgpu_history(const btgpu_handle *h);
 int  btgpu_device(const btgpu_handle *h);     /* HIP ordinal the handle lives on (what device = -1 resolved to) */
