@@ -370,6 +370,30 @@ def test_async_pipeline_equals_sync(pkg, po, synth):
     blk.close()
 
 
+def test_handle_after_handle_on_the_previous_handles_streams(pkg, synth, monkeypatch):
+    """btgpu_destroy keeps the handle's streams for the next btgpu_create on the device (btgpu.hip g_stream_pool: streams created after
+    others were destroyed serialise -- 25 % longer steps, profiles/r06_zz_second_handle.txt).  Three handles in a row, the default path,
+    asynchronous, with and without the pool: the same records every time, at two rates (another geometry on the same streams)."""
+    def run(fs, fc, nslots, seed):
+        iq, _ = synth.make_capture(fs, fc, nslots, laps=(0x24D952, 0x4831DD), seed=seed, snr_db=25, occupancy=0.5)
+        b = pkg.multi_sniffer(fs, fc, 10.0, False, flags=pkg.FLAG_ASYNC | pkg.FLAG_LE | pkg.FLAG_HEADERS, max_batch_slots=8)
+        b.push(iq)
+        b.flush()
+        keys = _keys(b.poll())
+        b.close()
+        return keys
+    monkeypatch.delenv("BTGPU_STREAM_POOL", raising=False)
+    first8, first20 = run(8e6, 2476.5e6, 24, 21), run(20e6, 2441e6, 12, 22)      # (the second one already runs on the first one's streams)
+    assert len(first8) > 0 and len(first20) > 0
+    for _ in range(2):
+        assert run(8e6, 2476.5e6, 24, 21) == first8
+        assert run(20e6, 2441e6, 12, 22) == first20
+    monkeypatch.setenv("BTGPU_STREAM_POOL", "0")
+    assert run(8e6, 2476.5e6, 24, 21) == first8
+    monkeypatch.delenv("BTGPU_STREAM_POOL")
+    assert run(20e6, 2441e6, 12, 22) == first20                                   # (from the pool again, after a handle that did not use it)
+
+
 def test_fast_path_ragged_pushes_equal_one_shot(pkg, synth):
     """Fast path (staged squelch reads `left_margin` samples before each batch): chunked pushes,
     small internal batches and the one-shot push give the same records, bit for bit."""
