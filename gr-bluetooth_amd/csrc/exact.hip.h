@@ -19,9 +19,9 @@
 // and GNU Radio is not in the image (parity of the float half is unpinned upstream): the order is this repository's to fix.
 //
 // One workgroup = one time tile of 128 columns = 115 outputs (the first is the demodulator's halo) + the diagonal sum's 13: four waves, wave w owns
-// columns [32 w, 32 w + 32) -- its 32 D input samples go through LDS once and stay in D registers per lane as the B operand for
-// EVERY channel the bitmap names for the tile; the channel's T (2 QB x 2 D floats, lane-major, 12.8 KB at D = 50) is streamed
-// through LDS as the A operand.  Per channel and wave: D MFMAs (64 cycles each) and nothing else on the critical path.
+// columns [32 w, 32 w + 32) -- its 32 D input samples go straight from the stream into D registers per lane and stay there as the B
+// operand for EVERY channel the bitmap names for the tile; the channel's T (2 QB x 2 D floats, lane-major, 12.8 KB at D = 50) comes
+// from the L1 / L2 as the A operand.  Per channel and wave: D MFMAs (64 cycles each) and nothing else on the critical path.
 #pragma once
 #include "kernels.hip.h"
 
@@ -97,7 +97,11 @@ inline size_t exact_taps_floats(int nch, int D) { return (size_t)nch * 64 * exac
 #ifndef BTGPU_EX_FULLA
 #define BTGPU_EX_FULLA 1
 #endif
-// (experiment) the whole A operand of the NEXT channel in registers while this one's matrix instructions run: 52 registers at D = 50, three workgroups per CU
+// D = 50: the A operand as a rotating register copy -- a 16-byte group is consumed by its four matrix instructions and at once re-fetched
+// for the tile's NEXT channel, every tap load a whole channel ahead of its use: 158 VGPRs, three workgroups per CU.  Against three groups
+// ahead in 122 VGPRs and four workgroups (-DBTGPU_EX_FULLA=0, and what D <= 25 keeps): the kernel alone 2.18 -> 2.11 ms at nine channels
+// per tile, 3.89 -> 3.72 at twenty, 1.21 -> 1.20 at four; in the bench's step 2.14 -> 2.04 ms, records identical
+// (profiles/r06_zz_ubench_exact_full_a_ab.txt, r06_zz_exact_full_a_ab_bench.txt).
 constexpr bool exact_full_a(int D) { return BTGPU_EX_FULLA && D > 25; }
 template <int D>
 __global__ __launch_bounds__(kExThreads, exact_full_a(D) ? 3 : 4) void exact_rows_kernel(ExactParams p, const float2 *__restrict__ x)
